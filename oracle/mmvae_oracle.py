@@ -1,0 +1,468 @@
+"""CPU oracle: a from-scratch PyTorch-CPU fp32 restatement of the reference's per-step training path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under multimodal_vae_comparison_amd/ may import this module; only
+tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg use it, and only as the checker /
+the timed CPU baseline.  The product path has no CPU fallback.
+
+Parity pinning: every function below is checked against golden vectors produced by importing the
+reference itself (gabinsane/multimodal-vae-comparison @ 2025-05-23) under tests/golden/ref_harness.py
+in the build container (tests/golden/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).
+The reference's own tests hold no numeric vectors for this path.
+
+Third-party arithmetic restated here (not vendored by the reference): PyTorch's nn.Conv2d /
+nn.ConvTranspose2d / nn.Linear / nn.MultiheadAttention / nn.TransformerEncoderLayer /
+nn.TransformerDecoderLayer (post-norm, exact-erf GELU, LayerNorm eps 1e-5) / nn.Embedding /
+torch.distributions.Normal + kl_divergence.  The reference pins "PyTorch 1.12.1" in prose only
+(/root/reference/README.md:48); the fixtures were generated with torch 2.10.0.
+
+All file:line citations are relative to /root/reference/multimodal_compare/.
+
+Conventions
+-----------
+* `params`: dict {reference state_dict key: tensor}.  Key names are the reference's, including the
+  `.module.` segment that its nn.DataParallel wrappers add (models/decoders.py:58-69).
+* `eps`: list of standard-normal tensors consumed in the order the reference draws them
+  (one `Normal.rsample` each); the reference's own generator is never used here.
+* dropout: the reference trains with p=0.1 dropout (PositionalEncoding + every transformer sub-layer).
+  `train=False` (default) is the parity mode (dropout off == reference .eval()).  `train=True`
+  applies torch CPU dropout at the same sites and exists only so that the timed CPU baseline does the
+  same work as a reference training step.
+"""
+import itertools
+import math
+
+import torch
+import torch.nn.functional as F
+
+ETA = 1e-6          # utils.py:254  Constants.eta
+DROPOUT_P = 0.1     # models/encoders.py:790, models/decoders.py:669 (ctor defaults)
+LN_EPS = 1e-5       # torch.nn.LayerNorm default
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter inventory (reference key names)
+# ----------------------------------------------------------------------------------------------
+def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
+    """Shapes of every learnable tensor of one VAE, keyed like the reference's state_dict.
+
+    models/vae.py:121-170 (VAE ctor), models/encoders.py:163-200,790-826, models/decoders.py:35-69,668-706.
+    """
+    Dp = n_latents + (private or 0)
+    s = {}
+    if enc == "CNN2":
+        s[f"{prefix}.enc.conv1.weight"] = (32, 3, 4, 4)
+        s[f"{prefix}.enc.conv1.bias"] = (32,)
+        for i in (2, 3, 4):
+            s[f"{prefix}.enc.conv{i}.weight"] = (32, 32, 4, 4)
+            s[f"{prefix}.enc.conv{i}.bias"] = (32,)
+        s[f"{prefix}.enc.lin1.weight"] = (512, 512)
+        s[f"{prefix}.enc.lin1.bias"] = (512,)
+        s[f"{prefix}.enc.mu_layer.weight"] = (Dp, 512)
+        s[f"{prefix}.enc.mu_layer.bias"] = (Dp,)
+        s[f"{prefix}.enc.logvar_layer.weight"] = (Dp, 512)
+        s[f"{prefix}.enc.logvar_layer.bias"] = (Dp,)
+    elif enc == "TxtTransformer":
+        feats = data_dim[-1] * data_dim[-2]        # njoints*nfeats, encoders.py:805-815
+        d = feats * 2
+        L = f"{prefix}.enc.seqTransEncoder.layers.0"
+        s[f"{prefix}.enc.embedding.weight"] = (feats, 2)
+        s[f"{L}.self_attn.in_proj_weight"] = (3 * d, d)
+        s[f"{L}.self_attn.in_proj_bias"] = (3 * d,)
+        s[f"{L}.self_attn.out_proj.weight"] = (d, d)
+        s[f"{L}.self_attn.out_proj.bias"] = (d,)
+        s[f"{L}.linear1.weight"] = (128, d)
+        s[f"{L}.linear1.bias"] = (128,)
+        s[f"{L}.linear2.weight"] = (d, 128)
+        s[f"{L}.linear2.bias"] = (d,)
+        for n in ("norm1", "norm2"):
+            s[f"{L}.{n}.weight"] = (d,)
+            s[f"{L}.{n}.bias"] = (d,)
+        s[f"{prefix}.enc.mu_layer.module.weight"] = (Dp, d)
+        s[f"{prefix}.enc.mu_layer.module.bias"] = (Dp,)
+        s[f"{prefix}.enc.logvar_layer.module.weight"] = (Dp, d)
+        s[f"{prefix}.enc.logvar_layer.module.bias"] = (Dp,)
+    else:
+        raise NotImplementedError(enc)
+    if dec == "CNN":
+        s[f"{prefix}.dec.lin1.module.weight"] = (512, Dp)
+        s[f"{prefix}.dec.lin1.module.bias"] = (512,)
+        for n in ("lin2", "lin3"):
+            s[f"{prefix}.dec.{n}.module.weight"] = (512, 512)
+            s[f"{prefix}.dec.{n}.module.bias"] = (512,)
+        for n in ("convT_64", "convT1", "convT2"):
+            s[f"{prefix}.dec.{n}.module.weight"] = (32, 32, 4, 4)
+            s[f"{prefix}.dec.{n}.module.bias"] = (32,)
+        s[f"{prefix}.dec.convT3.module.weight"] = (32, 3, 4, 4)
+        s[f"{prefix}.dec.convT3.module.bias"] = (3,)
+    elif dec == "TxtTransformer":
+        d = Dp
+        feats = data_dim[1] * (data_dim[2] if len(data_dim) > 2 else 1)   # decoders.py:683-694
+        L = f"{prefix}.dec.seqTransDecoder.layers.0"
+        for a in ("self_attn", "multihead_attn"):
+            s[f"{L}.{a}.in_proj_weight"] = (3 * d, d)
+            s[f"{L}.{a}.in_proj_bias"] = (3 * d,)
+            s[f"{L}.{a}.out_proj.weight"] = (d, d)
+            s[f"{L}.{a}.out_proj.bias"] = (d,)
+        s[f"{L}.linear1.weight"] = (128, d)
+        s[f"{L}.linear1.bias"] = (128,)
+        s[f"{L}.linear2.weight"] = (d, 128)
+        s[f"{L}.linear2.bias"] = (d,)
+        for n in ("norm1", "norm2", "norm3"):
+            s[f"{L}.{n}.weight"] = (d,)
+            s[f"{L}.{n}.bias"] = (d,)
+        s[f"{prefix}.dec.finallayer.module.weight"] = (feats, d)
+        s[f"{prefix}.dec.finallayer.module.bias"] = (feats,)
+    else:
+        raise NotImplementedError(dec)
+    return s
+
+
+def model_param_shapes(mods, n_latents):
+    """All trainable tensors of a multimodal model.  `mods` = list of dicts with keys
+    enc, dec, data_dim, (private).  Trainable prior theta = `_pz_params.1` (models/mmvae_base.py:35-38)."""
+    s = {}
+    for i, m in enumerate(mods):
+        s.update(tower_param_shapes(f"vaes.mod_{i + 1}", m["enc"], m["dec"], m["data_dim"], n_latents,
+                                    m.get("private")))
+    s["_pz_params.1"] = (1, n_latents)
+    return s
+
+
+# ----------------------------------------------------------------------------------------------
+# towers
+# ----------------------------------------------------------------------------------------------
+def process_output(h, w_mu, b_mu, w_lv, b_lv):
+    """models/encoders.py:49-54: mu = linear; "logvar" = softmax(linear, -1) + eta."""
+    return F.linear(h, w_mu, b_mu), F.softmax(F.linear(h, w_lv, b_lv), dim=-1) + ETA
+
+
+def enc_cnn2(p, pre, x):
+    """Enc_CNN2.forward, models/encoders.py:202-223: 4x [Conv2d(k4,s2,p1)+SiLU], flatten, Linear, heads."""
+    o = x.float()
+    for i in (1, 2, 3, 4):
+        o = F.silu(F.conv2d(o, p[f"{pre}.enc.conv{i}.weight"], p[f"{pre}.enc.conv{i}.bias"], stride=2, padding=1))
+    o = o.reshape(o.shape[0], -1)
+    o = F.linear(o, p[f"{pre}.enc.lin1.weight"], p[f"{pre}.enc.lin1.bias"])
+    return process_output(o, p[f"{pre}.enc.mu_layer.weight"], p[f"{pre}.enc.mu_layer.bias"],
+                          p[f"{pre}.enc.logvar_layer.weight"], p[f"{pre}.enc.logvar_layer.bias"])
+
+
+def dec_cnn(p, pre, z, data_dim=(64, 64, 3)):
+    """Dec_CNN.forward, models/decoders.py:71-98.  z (K,B,D') -> recon (K*B, 64,64,3)-*viewed* NCHW memory."""
+    if z.dim() == 2:
+        z = z.unsqueeze(0)
+    K, B = z.shape[0], z.shape[1]
+    x = z
+    for n in ("lin1", "lin2", "lin3"):
+        x = torch.relu(F.linear(x, p[f"{pre}.dec.{n}.module.weight"], p[f"{pre}.dec.{n}.module.bias"]))
+    x = x.reshape(B * K, 32, 4, 4)
+    for n in ("convT_64", "convT1", "convT2"):
+        x = torch.relu(F.conv_transpose2d(x, p[f"{pre}.dec.{n}.module.weight"], p[f"{pre}.dec.{n}.module.bias"],
+                                          stride=2, padding=1))
+    x = F.conv_transpose2d(x, p[f"{pre}.dec.convT3.module.weight"], p[f"{pre}.dec.convT3.module.bias"],
+                           stride=2, padding=1)
+    d = torch.sigmoid(x.reshape(K, B, *data_dim)).clamp(ETA, 1 - ETA)   # decoders.py:96-97 (view, no permute)
+    return d.reshape(-1, *data_dim)
+
+
+def positional_table(d_model, n, dtype=torch.float32):
+    """PositionalEncoding buffer rows [0, n): models/nn_modules.py:422-428.  Returns (n, d_model)."""
+    pe = torch.zeros(n, d_model, dtype=dtype)
+    position = torch.arange(0, n, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)[:, : d_model // 2]
+    return pe
+
+
+def _dropout(x, train):
+    return F.dropout(x, DROPOUT_P, True) if train else x
+
+
+def mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, kpm=None, train=False):
+    """torch.nn.MultiheadAttention forward (seq-first).  q_in (L,N,E), kv_in (S,N,E), kpm (N,S) True=ignore."""
+    L, N, E = q_in.shape
+    S = kv_in.shape[0]
+    hd = E // nhead
+    q = F.linear(q_in, w_in[:E], b_in[:E])
+    k = F.linear(kv_in, w_in[E:2 * E], b_in[E:2 * E])
+    v = F.linear(kv_in, w_in[2 * E:], b_in[2 * E:])
+    q = q.reshape(L, N * nhead, hd).transpose(0, 1) * (1.0 / math.sqrt(hd))
+    k = k.reshape(S, N * nhead, hd).transpose(0, 1)
+    v = v.reshape(S, N * nhead, hd).transpose(0, 1)
+    att = torch.bmm(q, k.transpose(1, 2))                      # (N*h, L, S)
+    if kpm is not None:
+        att = att.reshape(N, nhead, L, S).masked_fill(kpm[:, None, None, :], float("-inf")).reshape(N * nhead, L, S)
+    att = _dropout(F.softmax(att, dim=-1), train)
+    o = torch.bmm(att, v).transpose(0, 1).reshape(L, N, E)
+    return F.linear(o, w_out, b_out)
+
+
+def transformer_encoder_layer(x, p, L, nhead, kpm, train=False):
+    """torch.nn.TransformerEncoderLayer, norm_first=False, activation gelu (exact)."""
+    sa = mha(x, x, p[f"{L}.self_attn.in_proj_weight"], p[f"{L}.self_attn.in_proj_bias"],
+             p[f"{L}.self_attn.out_proj.weight"], p[f"{L}.self_attn.out_proj.bias"], nhead, kpm, train)
+    x = F.layer_norm(x + _dropout(sa, train), x.shape[-1:], p[f"{L}.norm1.weight"], p[f"{L}.norm1.bias"], LN_EPS)
+    ff = F.linear(_dropout(F.gelu(F.linear(x, p[f"{L}.linear1.weight"], p[f"{L}.linear1.bias"])), train),
+                  p[f"{L}.linear2.weight"], p[f"{L}.linear2.bias"])
+    return F.layer_norm(x + _dropout(ff, train), x.shape[-1:], p[f"{L}.norm2.weight"], p[f"{L}.norm2.bias"], LN_EPS)
+
+
+def transformer_decoder_layer(x, mem, p, L, nhead, tgt_kpm, train=False):
+    """torch.nn.TransformerDecoderLayer, norm_first=False, activation gelu."""
+    sa = mha(x, x, p[f"{L}.self_attn.in_proj_weight"], p[f"{L}.self_attn.in_proj_bias"],
+             p[f"{L}.self_attn.out_proj.weight"], p[f"{L}.self_attn.out_proj.bias"], nhead, tgt_kpm, train)
+    x = F.layer_norm(x + _dropout(sa, train), x.shape[-1:], p[f"{L}.norm1.weight"], p[f"{L}.norm1.bias"], LN_EPS)
+    ca = mha(x, mem, p[f"{L}.multihead_attn.in_proj_weight"], p[f"{L}.multihead_attn.in_proj_bias"],
+             p[f"{L}.multihead_attn.out_proj.weight"], p[f"{L}.multihead_attn.out_proj.bias"], nhead, None, train)
+    x = F.layer_norm(x + _dropout(ca, train), x.shape[-1:], p[f"{L}.norm2.weight"], p[f"{L}.norm2.bias"], LN_EPS)
+    ff = F.linear(_dropout(F.gelu(F.linear(x, p[f"{L}.linear1.weight"], p[f"{L}.linear1.bias"])), train),
+                  p[f"{L}.linear2.weight"], p[f"{L}.linear2.bias"])
+    return F.layer_norm(x + _dropout(ff, train), x.shape[-1:], p[f"{L}.norm3.weight"], p[f"{L}.norm3.bias"], LN_EPS)
+
+
+def enc_txt_transformer(p, pre, data, mask, train=False):
+    """Enc_TxtTransformer.forward, models/encoders.py:828-837, with PositionalEncoding's two branches
+    (models/nn_modules.py:430-438).
+
+    data (B,T,V) one-hot float, mask (B,T) bool or None.  Returns mu, lv (B, D').
+    """
+    B, T, V = data.shape
+    if mask is None:
+        mask = torch.ones(B, T, dtype=torch.bool)
+    emb = p[f"{pre}.enc.embedding.weight"]
+    x = emb[data.long()]                                        # (B,T,V,2): rows 0/1 of the table only
+    pe = positional_table(2, 1000)[:B].reshape(B, 1, 2)         # self.pe[:x.shape[0]]  (B,1,2)
+    if B == T or B == 1:
+        # `x + pe[:B]` broadcasts: pe's first axis lines up with x's T axis; no permute happens
+        x = x + pe
+    else:
+        # except-branch: permute to (T,B,V,2) then add pe[:B] (B,1,2) -> indexed by *batch* index
+        x = x.permute(1, 0, 2, 3) + pe
+    x = _dropout(x, train).contiguous()
+    x = x.view(T, B, -1)                                        # encoders.py:835: nframes, bs
+    x = transformer_encoder_layer(x, p, f"{pre}.enc.seqTransEncoder.layers.0", 2, ~mask, train)
+    z = x.mean(dim=0)                                           # includes padded steps
+    return process_output(z, p[f"{pre}.enc.mu_layer.module.weight"], p[f"{pre}.enc.mu_layer.module.bias"],
+                          p[f"{pre}.enc.logvar_layer.module.weight"], p[f"{pre}.enc.logvar_layer.module.bias"])
+
+
+def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
+    """Dec_TxtTransformer.forward, models/decoders.py:708-723.  z (K,B,D') is the *memory* (length K)."""
+    if z.dim() == 2:
+        z = z.unsqueeze(0)
+    B, D = z.shape[1], z.shape[-1]
+    if mask is None:
+        mask = torch.ones(B, data_dim[0], dtype=torch.bool)
+    T = mask.shape[1]
+    tq = torch.zeros(T, B, D) + positional_table(D, T).reshape(T, 1, D)
+    tq = _dropout(tq, train)
+    out = transformer_decoder_layer(tq, z, p, f"{pre}.dec.seqTransDecoder.layers.0", 2, ~mask, train)
+    out = F.linear(out, p[f"{pre}.dec.finallayer.module.weight"], p[f"{pre}.dec.finallayer.module.bias"])
+    return out.permute(1, 0, 2) * mask.unsqueeze(-1).float()    # (B,T,V), zero at padding
+
+
+_ENC = {"CNN2": lambda p, pre, d, train: enc_cnn2(p, pre, d["data"]),
+        "TxtTransformer": lambda p, pre, d, train: enc_txt_transformer(p, pre, d["data"], d["masks"], train)}
+
+
+def encode(p, mods, i, inp, train=False):
+    return _ENC[mods[i]["enc"]](p, f"vaes.mod_{i + 1}", inp, train)
+
+
+def decode(p, mods, i, z, mask, train=False):
+    m = mods[i]
+    pre = f"vaes.mod_{i + 1}"
+    if m["dec"] == "CNN":
+        return dec_cnn(p, pre, z, tuple(m["data_dim"]))
+    if m["dec"] == "TxtTransformer":
+        return dec_txt_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
+    raise NotImplementedError(m["dec"])
+
+
+# ----------------------------------------------------------------------------------------------
+# fusion, KL, reconstruction losses
+# ----------------------------------------------------------------------------------------------
+def product_of_experts(mu, logvar):
+    """TorchMMVAE.product_of_experts, models/mmvae_base.py:203-222.  Returns (mu, VARIANCE)."""
+    var = torch.exp(logvar) + 1e-8
+    T = 1.0 / var
+    return torch.sum(mu * T, dim=0) / torch.sum(T, dim=0), 1.0 / torch.sum(T, dim=0)
+
+
+def mopoe_subsets(n_mods):
+    """MoPOE.set_subsets, models/mmvae_models.py:279-294: non-empty subsets in combinations() order."""
+    idx = list(range(n_mods))
+    return [c for n in range(1, n_mods + 1) for c in itertools.combinations(idx, n)]
+
+
+def chunk_bounds(n_comp, n_samples):
+    """MoPOE.mixture_component_selection, models/mmvae_models.py:396-410 with uniform float32 weights
+    (`:345`, renormalised `:377-378`)."""
+    w = (1 / float(n_comp)) * torch.ones(n_comp)
+    w = w / w.sum()
+    bounds = [0]
+    for k in range(n_comp):
+        if k == n_comp - 1:
+            bounds.append(n_samples)
+        else:
+            bounds.append(bounds[-1] + int(torch.floor(n_samples * w[k])))
+    return bounds
+
+
+def prior_sigma(theta):
+    """pz_params property, models/mmvae_models.py:274-276: softmax(theta, dim=1) * D."""
+    return F.softmax(theta, dim=1) * theta.size(-1)
+
+
+def kl_normal(mu_q, sig_q, mu_p, sig_p):
+    """torch.distributions.kl._kl_normal_normal (called from utils.py:399-402)."""
+    var_ratio = (sig_q / sig_p).pow(2)
+    t1 = ((mu_q - mu_p) / sig_p).pow(2)
+    return 0.5 * (var_ratio + t1 - 1 - var_ratio.log())
+
+
+def recon_bce(x_hat, target):
+    """ReconLoss.bce, models/objectives.py:392-406; target reshaped to the output's (viewed) shape
+    (`:120`).  Returns (B, F) positive loss."""
+    B = target.shape[0]
+    return F.binary_cross_entropy(x_hat, target.float().reshape(x_hat.shape).detach(), reduction="none").reshape(B, -1)
+
+
+def recon_category_ce(logits, target):
+    """ReconLoss.category_ce, models/objectives.py:486-500: CrossEntropyLoss over dim 1 (= time) with
+    probability targets.  logits/target (B,T,V) -> (B,V)."""
+    lsm = F.log_softmax(logits, dim=1)
+    return -(target.float().detach() * lsm).sum(dim=1)
+
+
+_RECON = {"bce": recon_bce, "category_ce": recon_category_ce}
+
+
+def recon_loss(ltype, out, target):
+    """BaseObjective.recon_loss_fn, models/objectives.py:30-52: slice to the mask length, positive loss."""
+    if target["masks"] is not None:
+        out = out[:, : target["masks"].shape[1]]
+    return _RECON[ltype](out, target["data"])
+
+
+# ----------------------------------------------------------------------------------------------
+# objectives
+# ----------------------------------------------------------------------------------------------
+def mopoe_forward(p, mods, batch, eps, n_latents, train=False):
+    """MoPOE.modality_mixing + forward, models/mmvae_models.py:322-370 (all modalities present)."""
+    M = len(mods)
+    enc = [encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in range(M)]
+    B = enc[0][0].shape[0]
+    subs = mopoe_subsets(M)
+    s_mu, s_var = [], []
+    for S in subs:
+        mus = torch.stack([enc[i][0] for i in S])
+        lvs = torch.stack([enc[i][1] for i in S])
+        if len(S) == M:                                          # prior expert only in the full subset, :386-389
+            mus = torch.cat((mus, torch.zeros(1, B, n_latents)), dim=0)
+            lvs = torch.cat((lvs, torch.zeros(1, B, n_latents)), dim=0)
+        m_, v_ = product_of_experts(mus, lvs)
+        s_mu.append(m_)
+        s_var.append(v_)
+    # moe_fusion / mixture_component_selection, :380-410.  The reference stacks the subset posteriors as
+    # (n_subsets, 1, B, D) (poe_fusion unsqueezes, then `:343` unsqueezes again), so the "batch-chunk
+    # selection" runs over the SINGLETON axis 1: num_samples == 1, every chunk but the last is empty and the
+    # joint posterior is the LAST subset (= PoE of all modalities + prior expert) for every sample
+    # [verified on the reference, tests/golden/make_golden.py].  Restated literally:
+    mus = torch.stack([m_.unsqueeze(0) for m_ in s_mu])          # (n, 1, B, D)
+    vrs = torch.stack([v_.unsqueeze(0) for v_ in s_var])
+    bounds = chunk_bounds(mus.shape[0], mus.shape[1])
+    j_mu = torch.cat([mus[k, bounds[k]:bounds[k + 1], :] for k in range(len(subs))]).squeeze(0)
+    j_var = torch.cat([vrs[k, bounds[k]:bounds[k + 1], :] for k in range(len(subs))]).squeeze(0)
+    zs, recons = [], []
+    for i in range(M):
+        z = j_mu + j_var * eps[i].reshape(-1, B, n_latents)      # Normal(mu, VAR-as-sigma).rsample([K]), :365-366
+        zs.append(z)
+        recons.append(decode(p, mods, i, z, batch[f"mod_{i + 1}"]["masks"], train))
+    return {"enc": enc, "subsets": dict(zip(subs, zip(s_mu, s_var))), "bounds": bounds,
+            "joint": (j_mu, j_var), "z": zs, "recon": recons}
+
+
+def mopoe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+    """MoPOE.objective, models/mmvae_models.py:296-320 + weighted_group_kld, models/objectives.py:184-201."""
+    M = len(mods)
+    fw = mopoe_forward(p, mods, batch, eps, n_latents, train)
+    sig_p = prior_sigma(p["_pz_params.1"])
+    dists = list(fw["enc"]) + [fw["joint"]]
+    klds = [kl_normal(mu, sig, 0.0, sig_p) for (mu, sig) in dists]
+    w = (1 / len(dists)) * torch.ones(len(dists))
+    group = (torch.stack(klds).sum(-1).mean(1) * w).sum()
+    lpx_zs = []
+    for i in range(M):
+        scale = float(mods[i].get("llik_scaling", 1.0))
+        lpx = -recon_loss(mods[i]["ltype"], fw["recon"][i], batch[f"mod_{i + 1}"]) * scale
+        lpx_zs.append(lpx.sum(-1))
+    lpx = torch.stack(lpx_zs).sum(0).mean()
+    loss = -(lpx - beta * group)
+    rec = [-m / float(mods[i].get("llik_scaling", 1.0)) for i, m in enumerate(lpx_zs)]
+    return {"loss": loss, "kld": group, "reconstruction_loss": rec, "_fw": fw, "_klds": klds}
+
+
+def poe_subset_order(n_mods, order=None):
+    """utils.subsample_input_modalities, utils.py:86-112.  Within one subset size the reference iterates
+    a Python `set` of tuples of str => order depends on PYTHONHASHSEED; pass the recorded order."""
+    if order is not None:
+        return [tuple(o) for o in order]
+    idx = list(range(n_mods))
+    return [c for n in range(1, n_mods + 1) for c in itertools.combinations(idx, n)]
+
+
+def poe_objective(p, mods, batch, eps, n_latents, beta=1.0, order=None, train=False):
+    """POE.objective / forward / modality_mixing, models/mmvae_models.py:159-232."""
+    M = len(mods)
+    B = next(batch[f"mod_{i + 1}"]["data"].shape[0] for i in range(M) if batch[f"mod_{i + 1}"]["data"] is not None)
+    sig_p = prior_sigma(p["_pz_params.1"])
+    lpx_rec = [[] for _ in range(M)]
+    klds, losses, inter = [], [], []
+    for s_idx, S in enumerate(poe_subset_order(M, order)):
+        mus = [torch.zeros(1, B, n_latents)]                     # prior expert: mu 0, logvar log(1), :222,246-247
+        lvs = [torch.zeros(1, B, n_latents)]
+        for i in range(M):
+            if i in S:
+                m_, l_ = encode(p, mods, i, batch[f"mod_{i + 1}"], train)
+                mus.append(m_.unsqueeze(0))
+                lvs.append(l_.unsqueeze(0))
+        j_mu, j_var = product_of_experts(torch.cat(mus), torch.cat(lvs))
+        z = j_mu + j_var * eps[s_idx].reshape(-1, B, n_latents)  # ONE shared rsample, :200-201
+        kld = kl_normal(j_mu, j_var, 0.0, sig_p).sum(-1)
+        klds.append(kld)
+        loc = []
+        for i in range(M):
+            mask = batch[f"mod_{i + 1}"]["masks"] if i in S else None   # absent modality: masks None, utils.py:104-106
+            rec = decode(p, mods, i, z, mask, train)
+            lpx = (-recon_loss(mods[i]["ltype"], rec, batch[f"mod_{i + 1}"]) * float(mods[i].get("llik_scaling", 1.0))).sum(-1)
+            loc.append(lpx)
+            if i == s_idx:
+                lpx_rec[i].append(lpx)
+        lpx_sum = torch.stack(loc).sum(0)
+        losses.append(-(lpx_sum.sum(-1) - beta * kld.sum()).sum())
+        inter.append({"joint": (j_mu, j_var), "z": z})
+    rec = [-torch.stack(m).sum() / float(mods[i].get("llik_scaling", 1.0)) for i, m in enumerate(lpx_rec)]
+    return {"loss": torch.stack(losses).sum(), "reconstruction_loss": rec,
+            "kld": torch.stack(klds).mean(0).sum(), "_inter": inter}
+
+
+OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective}
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser
+# ----------------------------------------------------------------------------------------------
+def adam_amsgrad_step(params, grads, state, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam(amsgrad=True) single-tensor update (models/trainer.py:79-81); `step` is 1-based.
+    state: dict name -> (m, v, vmax) updated in place; params updated in place."""
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    for k, g in grads.items():
+        m, v, vmax = state[k]
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        torch.maximum(vmax, v, out=vmax)
+        denom = (vmax.sqrt() / math.sqrt(bc2)).add_(eps)
+        params[k].data.addcdiv_(m, denom, value=-lr / bc1)

@@ -1,0 +1,156 @@
+"""Generate golden input/output vectors by running the REFERENCE itself (build container only).
+
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py
+
+Imports /root/reference/multimodal_compare under tests/golden/ref_harness.py, loads the deterministic
+weights of oracle/golden_weights.py into the reference's own model classes, runs `objective()` +
+`backward()` + one Adam(amsgrad) step with the noise draws recorded, and writes tests/golden/<case>.npz.
+The fixtures are data only (inputs, noise, expected outputs / gradient summaries); no reference source
+is copied.  The oracle (oracle/mmvae_oracle.py) and the HIP path are both tested against these files.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import ref_harness
+
+ref_harness.install()
+import models  # noqa: E402  (the reference package)
+from models.vae import VAE  # noqa: E402
+
+from oracle import golden_weights as gw  # noqa: E402
+from oracle import mmvae_oracle as orc  # noqa: E402
+
+MODS = [
+    {"enc": "CNN2", "dec": "CNN", "data_dim": [64, 64, 3], "ltype": "bce", "llik_scaling": 1.0},
+    {"enc": "TxtTransformer", "dec": "TxtTransformer", "data_dim": [45, 27, 1], "ltype": "category_ce",
+     "llik_scaling": 1.0},
+]
+
+CASES = [
+    # name, mixing, B, T, D, lengths (None = ragged random), mode, beta
+    ("mopoe_b6_t5_d8", "mopoe", 6, 5, 8, [5, 3, 4, 2, 5, 1], "eval", 1.0),
+    ("mopoe_b5_t5_d8_BeqT", "mopoe", 5, 5, 8, [5, 2, 4, 3, 1], "eval", 1.0),
+    ("mopoe_b4_t6_d16_full", "mopoe", 4, 6, 16, [6, 6, 6, 6], "eval", 2.5),
+    ("mopoe_b7_t9_d32_trainp0", "mopoe", 7, 9, 32, [9, 4, 7, 1, 3, 9, 5], "train_p0", 1.0),
+    ("poe_b4_t5_d8", "poe", 4, 5, 8, [5, 2, 3, 4], "eval", 1.0),
+    ("poe_b4_t4_d16_BeqT", "poe", 4, 4, 16, [4, 1, 3, 2], "eval", 0.5),
+]
+
+
+def build_reference(mixing, D, beta):
+    vaes = {}
+    for i, m in enumerate(MODS):
+        vaes[f"mod_{i + 1}"] = VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], None, obj_fn="elbo", beta=beta,
+                                   id_name=f"mod_{i + 1}", llik_scaling=m["llik_scaling"])
+    return getattr(models, mixing)(nn.ModuleDict(vaes), D, {"obj": "elbo", "beta": beta, "K": 1}, {})
+
+
+def make_batch(B, T, lengths, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, 64, 64, generator=g)
+    ids = torch.randint(0, 27, (B, T), generator=g)
+    lens = torch.tensor(lengths)
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    onehot = torch.nn.functional.one_hot(ids, 27).float() * mask[..., None]
+    return img, onehot, mask
+
+
+def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
+    model = build_reference(mixing, D, beta)
+    shapes = orc.model_param_shapes(MODS, D)
+    ref_sd = model.state_dict()
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    assert trainable == set(shapes), (trainable ^ set(shapes))
+    for k, s in shapes.items():
+        assert tuple(ref_sd[k].shape) == tuple(s), (k, ref_sd[k].shape, s)
+    params = gw.make_params(shapes, seed)
+    missing = model.load_state_dict(params, strict=False)
+    assert not missing.unexpected_keys
+    if mode == "eval":
+        model.eval()
+    else:                                   # train mode with every dropout p forced to 0
+        model.train()
+        for mod in model.modules():
+            if isinstance(mod, nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, nn.MultiheadAttention):
+                mod.dropout = 0.0
+    img, onehot, mask = make_batch(B, T, lengths, seed + 1)
+    batch = {"mod_1": {"data": img, "masks": None, "categorical": False},
+             "mod_2": {"data": onehot, "masks": mask, "categorical": True}}
+
+    out = {"img": img.numpy(), "onehot": onehot.numpy(), "mask": mask.numpy()}
+    meta = {"name": name, "mixing": mixing, "B": B, "T": T, "D": D, "beta": beta, "seed": seed, "mode": mode,
+            "mods": MODS, "lr": 1e-4}
+
+    order = None
+    if mixing == "poe":                     # record the hash-seed dependent subset order (utils.py:98)
+        from utils import subsample_input_modalities
+        subs = subsample_input_modalities(batch)
+        order = [[i for i in range(len(MODS)) if s[f"mod_{i + 1}"]["data"] is not None] for s in subs]
+        meta["order"] = order
+
+    torch.manual_seed(seed + 2)
+    with ref_harness.EpsTape() as tape:
+        res = model.objective(batch)
+    res["loss"].backward()
+    for i, e in enumerate(tape.draws):
+        out[f"eps_{i}"] = e.numpy()
+    meta["n_eps"] = len(tape.draws)
+    out["loss"] = res["loss"].detach().numpy()
+    out["kld"] = res["kld"].detach().numpy()
+    for i, r in enumerate(res["reconstruction_loss"]):
+        out[f"rec_{i}"] = r.detach().numpy()
+
+    # intermediates straight from the reference's own methods (deterministic in this mode)
+    with torch.no_grad():
+        if mixing == "mopoe":
+            lat = model.modality_mixing(batch)
+            for i in range(len(MODS)):
+                mu, lv = lat["modalities"][f"mod_{i + 1}"]["shared"]
+                out[f"enc_mu_{i}"], out[f"enc_lv_{i}"] = mu.numpy(), lv.numpy()
+            out["joint_mu"], out["joint_var"] = lat["joint"][0].numpy(), lat["joint"][1].numpy()
+            for k, (mu, var) in lat["subsets"].items():
+                out[f"subset_mu/{k}"], out[f"subset_var/{k}"] = mu.squeeze(0).numpy(), var.squeeze(0).numpy()
+            with ref_harness.EpsTape(replay=tape.draws):
+                fw = model.forward(batch)
+            for i in range(len(MODS)):
+                o = fw.mods[f"mod_{i + 1}"]
+                out[f"z_{i}"] = o.latent_samples["latents"].numpy()
+                out[f"recon_{i}"] = gw.summarize(o.decoder_dist.loc, 256)
+        else:
+            for i in range(len(MODS)):
+                mu, lv = model.vaes[f"mod_{i + 1}"].enc(batch[f"mod_{i + 1}"])
+                out[f"enc_mu_{i}"], out[f"enc_lv_{i}"] = mu.numpy(), lv.numpy()
+
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, k
+            out[f"g/{k}"] = gw.summarize(p.grad)
+    # one optimiser step exactly as models/trainer.py:79-81
+    opt = torch.optim.Adam(filter(lambda q: q.requires_grad, model.parameters()), lr=meta["lr"], amsgrad=True)
+    opt.step()
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            out[f"a/{k}"] = gw.summarize(p.data)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={float(res['loss']):.6f} kld={float(res['kld']):.6f} order={order} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0 (PoE subset order, utils.py:98)"
+    for c in CASES:
+        run_case(*c)

@@ -1,0 +1,86 @@
+"""The oracle (oracle/mmvae_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerances: fp32, relative 2e-5 on scalars (the reference's
+own reduction order differs), 1e-4 relative-to-norm on gradient summaries."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from oracle import golden_weights as gw
+from oracle import mmvae_oracle as orc
+
+
+def _batch(g):
+    return {"mod_1": {"data": torch.from_numpy(g["img"]), "masks": None, "categorical": False},
+            "mod_2": {"data": torch.from_numpy(g["onehot"]), "masks": torch.from_numpy(g["mask"]), "categorical": True}}
+
+
+def _run(meta, g):
+    shapes = orc.model_param_shapes(meta["mods"], meta["D"])
+    p = gw.make_params(shapes, meta["seed"], requires_grad=True)
+    eps = [torch.from_numpy(g[f"eps_{i}"]) for i in range(meta["n_eps"])]
+    kw = {"order": meta["order"]} if meta["mixing"] == "poe" else {}
+    out = orc.OBJECTIVES[meta["mixing"]](p, meta["mods"], _batch(g), eps, meta["D"], beta=meta["beta"], **kw)
+    return p, out
+
+
+def _close(a, b, rtol, what, floor=1e-30):
+    """max|a-b| <= rtol * max(max|b|, floor).  `floor` absorbs analytically-zero gradients (e.g. a bias that
+    shifts all logits of a time-softmax equally) whose computed value is pure rounding noise (~1e-7)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), floor)
+    assert err <= rtol, f"{what}: rel err {err:.3e} > {rtol}"
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_objective_matches_reference(name):
+    meta, g = load_golden(name)
+    p, out = _run(meta, g)
+    _close(out["loss"].item(), g["loss"], 2e-5, "loss")
+    _close(out["kld"].item(), g["kld"], 2e-5, "kld")
+    for i, r in enumerate(out["reconstruction_loss"]):
+        _close(r.detach().numpy(), g[f"rec_{i}"], 2e-5, f"rec_{i}")
+    if meta["mixing"] == "mopoe":
+        fw = out["_fw"]
+        for i in range(len(meta["mods"])):
+            _close(fw["enc"][i][0].detach(), g[f"enc_mu_{i}"], 1e-5, f"enc_mu_{i}")
+            _close(fw["enc"][i][1].detach(), g[f"enc_lv_{i}"], 1e-5, f"enc_lv_{i}")
+            _close(fw["z"][i].detach(), g[f"z_{i}"], 1e-5, f"z_{i}")
+            _close(gw.summarize(fw["recon"][i], 256), g[f"recon_{i}"], 1e-5, f"recon_{i}")
+        _close(fw["joint"][0].detach(), g["joint_mu"], 1e-5, "joint_mu")
+        _close(fw["joint"][1].detach(), g["joint_var"], 1e-5, "joint_var")
+        for S, (mu, var) in fw["subsets"].items():
+            key = "_".join(f"mod_{i + 1}" for i in S)
+            _close(mu.detach(), g[f"subset_mu/{key}"], 1e-5, f"subset_mu/{key}")
+            _close(var.detach(), g[f"subset_var/{key}"], 1e-5, f"subset_var/{key}")
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_gradients_and_adam_match_reference(name):
+    meta, g = load_golden(name)
+    p, out = _run(meta, g)
+    out["loss"].backward()
+    for k, t in p.items():
+        assert t.grad is not None, k
+        _close(gw.summarize(t.grad), g[f"g/{k}"], 1e-4, f"grad {k}", floor=0.02)
+    state = {k: (torch.zeros_like(t), torch.zeros_like(t), torch.zeros_like(t)) for k, t in p.items()}
+    orc.adam_amsgrad_step(p, {k: t.grad for k, t in p.items()}, state, meta["lr"], 1)
+    # Step 1 of Adam moves every element by ~lr*sign(g): elements whose gradient is ~0 (masked keys, unused
+    # embedding rows) are ill-conditioned, so pin the update on the bulk of the sampled elements.
+    for k, t in p.items():
+        a, b = gw.summarize(t.data)[3:], g[f"a/{k}"][3:]
+        gref = np.abs(g[f"g/{k}"][3:])
+        well = gref > 1e-3 * max(gref.max(), 1e-30)
+        bad = (np.abs(a - b) > 1e-6 * np.maximum(np.abs(b), 1e-3)) & well
+        assert well.any() and not bad.any(), f"adam {k}: {bad.sum()}/{well.sum()} well-conditioned elements differ"
+        assert np.abs(a - b).max() <= 2.0 * meta["lr"] * 1.001, f"adam {k}: step larger than 2*lr"
+
+
+def test_chunk_bounds():
+    # mixture_component_selection arithmetic (models/mmvae_models.py:396-410) on a real batch axis ...
+    assert orc.chunk_bounds(3, 128) == [0, 42, 84, 128]
+    b = orc.chunk_bounds(7, 128)
+    assert [b[i + 1] - b[i] for i in range(7)] == [18] * 6 + [20]
+    # ... and on the singleton axis the reference actually hands it: everything goes to the last subset
+    assert orc.chunk_bounds(3, 1) == [0, 0, 0, 1]
+    assert orc.chunk_bounds(7, 1) == [0] * 7 + [1]
