@@ -1,0 +1,267 @@
+/*
+ * mmvae_hip.h — C ABI of the MI355X (gfx950) hot-path library for the multimodal-VAE training step.
+ *
+ * The reference (gabinsane/multimodal-vae-comparison) has no native code and no FFI: every "kernel" it
+ * runs is a stock PyTorch op reached through torch.nn.  The entry points below are the op
+ * sequences of its per-step path, each citing the reference lines it replaces.  Paths are
+ * relative to /root/reference/multimodal_compare/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated; no torch types, no allocation,
+ *     no host synchronisation; every call only enqueues work on `stream` (graph-capturable, re-entrant
+ *     per stream);
+ *   - return value: 0 = ok, MMVAE_ERR_* otherwise (the Python binding raises RuntimeError);
+ *   - `ws` = caller-provided workspace; the number of floats needed is returned by the matching
+ *     *_ws_floats() query (0 => may be NULL);
+ *   - `accumulate` != 0: results are ADDED to the destination (gradient accumulation into a flat grad
+ *     buffer), else they overwrite it.
+ */
+#ifndef MMVAE_HIP_H
+#define MMVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmvae_stream_t; /* hipStream_t */
+
+enum {
+  MMVAE_OK = 0,
+  MMVAE_ERR_ARG = 1,         /* null pointer / non-positive size */
+  MMVAE_ERR_UNSUPPORTED = 2, /* shape outside what the kernels are built for */
+  MMVAE_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after launch */
+};
+
+/* input transform applied to an operand while it is staged into LDS */
+enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_SILU = 1, MMVAE_ACT_RELU = 2, MMVAE_ACT_GELU = 3 };
+/* epilogue applied to the accumulator before the store; `aux` has the output's shape */
+enum {
+  MMVAE_EP_NONE = 0,
+  MMVAE_EP_RELU = 1,          /* y = max(acc + bias, 0)                                           */
+  MMVAE_EP_MUL_RELU_MASK = 2, /* y = acc * (aux > 0)        (dgrad through a ReLU, aux = saved u or y) */
+  MMVAE_EP_MUL_SILU_GRAD = 3, /* y = acc * silu'(aux)       (dgrad through a SiLU, aux = saved u)   */
+  MMVAE_EP_GELU = 4,          /* y = gelu(acc + bias); aux (if non-null) RECEIVES acc + bias        */
+  MMVAE_EP_MUL_GELU_GRAD = 5, /* y = acc * gelu'(aux)                                              */
+  MMVAE_EP_SIGMOID_CLAMP = 6  /* y = clamp(sigmoid(acc + bias), 1e-6, 1 - 1e-6)                     */
+};
+
+int mmvae_version(void);
+const char* mmvae_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------------
+ * 4x4 / stride 2 / padding 1 convolutions, NCHW fp32, square maps  (a2, a3 of SURVEY 8(a))
+ *   conv2d      : torch.nn.Conv2d(k=4,s=2,p=1)          models/encoders.py:186-191,214-217
+ *   convT2d     : torch.nn.ConvTranspose2d(k=4,s=2,p=1)  models/decoders.py:62-69,91-95
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 / 16x16x4_f32, im2col tiles staged through LDS.
+ * Supported channel pairs: (3|32) -> 32 for the "gather" form, 32 -> (32|3) for the "scatter" form.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* y[b,o,oh,ow] = ep( bias[o] + sum_{c,kh,kw} act(x[b,c,2oh-1+kh,2ow-1+kw]) * w[o,c,kh,kw] )
+ * x (B,Cin,Hin,Hin) -> y (B,Cout,Hin/2,Hin/2); w (Cout,Cin,4,4).  bias/aux may be NULL. */
+int mmvae_conv2d_k4s2_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y,
+                          int B, int Cin, int Cout, int Hin, int in_act, int ep_mode, mmvae_stream_t stream);
+
+/* dx[b,c,ih,iw] = ep( sum_{o,kh,kw: ih=2oh-1+kh, iw=2ow-1+kw} dy[b,o,oh,ow] * w[o,c,kh,kw] )
+ * dy (B,Cout,Hout,Hout) -> dx (B,Cin,2Hout,2Hout); w (Cout,Cin,4,4).  ep: MUL_* with aux = saved input. */
+int mmvae_conv2d_k4s2_dgrad(const float* dy, const float* w, const float* aux, float* dx,
+                            int B, int Cin, int Cout, int Hout, int ep_mode, mmvae_stream_t stream);
+
+/* dw[o,c,kh,kw] (+)= sum_{b,oh,ow} dy[b,o,oh,ow] * act(x[b,c,2oh-1+kh,2ow-1+kw]);  db[o] (+)= sum dy.
+ * ws: mmvae_conv_wgrad_ws_floats(B,Cin,Cout,Hout) floats. */
+int mmvae_conv2d_k4s2_wgrad(const float* dy, const float* x, float* dw, float* db, float* ws,
+                            int B, int Cin, int Cout, int Hout, int x_act, int accumulate, mmvae_stream_t stream);
+
+/* y[b,o,oh,ow] = ep( bias[o] + sum_{c,kh,kw: oh=2ih-1+kh, ow=2iw-1+kw} act(x[b,c,ih,iw]) * w[c,o,kh,kw] )
+ * x (B,Cin,Hin,Hin) -> y (B,Cout,2Hin,2Hin); w (Cin,Cout,4,4). */
+int mmvae_convT2d_k4s2_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y,
+                           int B, int Cin, int Cout, int Hin, int in_act, int ep_mode, mmvae_stream_t stream);
+
+/* dx[b,c,ih,iw] = ep( sum_{o,kh,kw} dy[b,o,2ih-1+kh,2iw-1+kw] * w[c,o,kh,kw] );  dy (B,Cout,2Hin,2Hin) */
+int mmvae_convT2d_k4s2_dgrad(const float* dy, const float* w, const float* aux, float* dx,
+                             int B, int Cin, int Cout, int Hin, int ep_mode, mmvae_stream_t stream);
+
+/* dw[c,o,kh,kw] (+)= sum_{b,ih,iw} act(x[b,c,ih,iw]) * dy[b,o,2ih-1+kh,2iw-1+kw];  db[o] (+)= sum dy. */
+int mmvae_convT2d_k4s2_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws,
+                             int B, int Cin, int Cout, int Hin, int x_act, int accumulate, mmvae_stream_t stream);
+
+size_t mmvae_conv_wgrad_ws_floats(int B, int Csmall, int Clarge, int Hsmall);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense layers: torch.nn.Linear and the projections inside nn.MultiheadAttention /
+ * nn.Transformer*Layer  (models/encoders.py:194,43-54,825-826; models/decoders.py:58-60,86-88,705)
+ * One strided fp32 MFMA GEMM:  C[M,N] = ep( bias + act(A)[M,K] * B[K,N] )
+ *   A(m,k) at A[m*sam + k*sak],  B(k,n) at Bm[k*sbk + n*sbn],  C row-major with leading dim ldc.
+ *   bias: per column n, or NULL.  a_rowsum (optional, length M): (+)= sum_k act(A)(m,k)
+ *   (the bias gradient when A = dy^T).  splitk > 1 needs ws of mmvae_gemm_ws_floats() floats and
+ *   allows neither bias nor epilogue (partials are summed by mmvae_reduce_rows).
+ * ---------------------------------------------------------------------------------------------- */
+int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias, const float* aux, float* C,
+                   float* a_rowsum, float* ws, int M, int N, int K, long sam, long sak, long sbk, long sbn,
+                   long ldc, int a_act, int b_act, int ep_mode, int accumulate, int splitk,
+                   mmvae_stream_t stream);
+size_t mmvae_gemm_ws_floats(int M, int N, int splitk);
+
+/* y = ep(x W^T + b): x (M,K) ld ldx, W (N,K), y (M,N).  F.linear */
+int mmvae_linear_fwd(const float* x, const float* w, const float* b, float* aux, float* y, int M, int N, int K,
+                     long ldx, int x_act, int ep_mode, mmvae_stream_t stream);
+/* dx = ep(dy W): dy (M,N), W (N,K), dx (M,K) */
+int mmvae_linear_bwd_data(const float* dy, const float* w, const float* aux, float* dx, int M, int N, int K,
+                          int ep_mode, int accumulate, mmvae_stream_t stream);
+/* dW (+)= dy^T act(x), db (+)= colsum(dy); dW (N,K).  ws: mmvae_linear_bwd_weight_ws_floats(M,N,K) */
+int mmvae_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, float* ws, int M, int N, int K,
+                            long ldx, int x_act, int accumulate, mmvae_stream_t stream);
+size_t mmvae_linear_bwd_weight_ws_floats(int M, int N, int K);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder heads: VaeComponent.process_output, models/encoders.py:49-54
+ *   h (B, 2D) = [mu | pre-softmax]  ->  lv = softmax(h[:, D:], -1) + 1e-6, written in place.
+ * bwd: dh[:, D:] = softmax backward of dlv (in place on dh, which holds [dmu | dlv]).
+ * ---------------------------------------------------------------------------------------------- */
+int mmvae_head_softmax_fwd(float* h, int B, int D, mmvae_stream_t stream);
+int mmvae_head_softmax_bwd(const float* h, float* dh, int B, int D, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused latent op: product of experts -> reparameterised samples -> analytic KL
+ *   TorchMMVAE.product_of_experts   models/mmvae_base.py:203-222   (returns VARIANCE, used as sigma)
+ *   MoPOE.poe_fusion / forward      models/mmvae_models.py:385-394,351-370
+ *   POE.modality_mixing / forward   models/mmvae_models.py:189-232
+ *   weighted_group_kld / kl_normal  models/objectives.py:184-201, utils.py:399-402
+ *   model prior sigma = softmax(theta)*D  models/mmvae_models.py:274-276
+ *
+ * experts: E pointers (device array of E device pointers is NOT used; pass up to 8 pointers by value)
+ *   mu[e], lv[e] : (B,D) each with row stride ld_in (2D when they are the halves of a packed head output;
+ *                  dmu/dlv use the same stride); lv is the encoder's softmax output, used as log-variance
+ *                  inside PoE.  eps, z, dz are contiguous (B,D).
+ *   with_prior   : add the N(0,1) expert (mu 0, logvar 0).
+ *   n_z draws    : z[i] = mu_J + var_J * eps[i]   (eps[i], z[i] : (B,D))
+ *   kl (n_kl,B)  : row j < E: sum_d KL(N(mu_j, sigma=lv_j) || p) if kl_mask bit j set;
+ *                  row E    : sum_d KL(N(mu_J, sigma=var_J) || p) if kl_mask bit E set; p = N(0, softmax(theta)*D)
+ *   joint (2,B,D): mu_J, var_J (always written).
+ * bwd: dz[i] (B,D), dkl (E+1,B)  ->  dmu[e], dlv[e] (B,D), dtheta (D) (+)=; ws: mmvae_poe_ws_floats(B,D).
+ * ---------------------------------------------------------------------------------------------- */
+#define MMVAE_MAX_EXPERTS 8
+typedef struct {
+  const float* mu[MMVAE_MAX_EXPERTS];
+  const float* lv[MMVAE_MAX_EXPERTS];
+  const float* eps[MMVAE_MAX_EXPERTS];
+  float* z[MMVAE_MAX_EXPERTS];
+} mmvae_poe_fwd_args;
+typedef struct {
+  const float* mu[MMVAE_MAX_EXPERTS];
+  const float* lv[MMVAE_MAX_EXPERTS];
+  const float* eps[MMVAE_MAX_EXPERTS];
+  const float* dz[MMVAE_MAX_EXPERTS];
+  float* dmu[MMVAE_MAX_EXPERTS];
+  float* dlv[MMVAE_MAX_EXPERTS];
+} mmvae_poe_bwd_args;
+int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl, int E,
+                             int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
+                             mmvae_stream_t stream);
+int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl, float* dtheta,
+                             float* ws, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
+                             int accumulate, mmvae_stream_t stream);
+size_t mmvae_poe_ws_floats(int B, int D);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reconstruction losses (per-sample sums), ReconLoss.* in models/objectives.py
+ * ---------------------------------------------------------------------------------------------- */
+/* bce (objectives.py:392-406) on x_hat = clamp(sigmoid(logit),1e-6,1-1e-6) (decoders.py:96-97):
+ *   row_loss[b] = sum_f -[t log xh + (1-t) log(1-xh)];  x_hat (B,F) given (already clamped). */
+int mmvae_bce_rowsum_fwd(const float* x_hat, const float* target, float* row_loss, int B, int F,
+                         mmvae_stream_t stream);
+/* dlogit[b,f] = g[b] * (xh - t) * [1e-6 < xh < 1-1e-6]  (gradient through sigmoid+clamp+bce) */
+int mmvae_bce_sigmoid_clamp_bwd(const float* x_hat, const float* target, const float* g_row, float* dlogit,
+                                int B, int F, mmvae_stream_t stream);
+/* true gradient wrt x_hat: dxh[b,f] = g[b] * (xh - t) / max(xh (1 - xh), 1e-12)  (torch's bce backward) */
+int mmvae_bce_rowsum_bwd(const float* x_hat, const float* target, const float* g_row, float* dxhat, int B, int F,
+                         mmvae_stream_t stream);
+/* backward of y = clamp(sigmoid(l), 1e-6, 1-1e-6): dl = dy * y (1 - y) * [1e-6 < y < 1-1e-6] */
+int mmvae_sigmoid_clamp_bwd(const float* dy, const float* y, float* dl, long n, mmvae_stream_t stream);
+/* elementwise bce (B,F) for the ReconLoss.bce API */
+int mmvae_bce_elem_fwd(const float* x_hat, const float* target, float* loss, long n, mmvae_stream_t stream);
+
+/* category_ce (objectives.py:486-500): softmax over TIME.  logits/target (B,T,V) ->
+ *   loss (B,V) = -sum_t tgt * log_softmax_t(logits);  row_loss[b] = sum_v loss[b,v]  (either may be NULL) */
+int mmvae_ce_over_time_fwd(const float* logits, const float* target, float* loss, float* row_loss, int B, int T,
+                           int V, mmvae_stream_t stream);
+/* dlogits[b,t,v] = g[b,v] * (softmax_t(logits)[t] * sum_t' tgt[t'] - tgt[t]);  g (B,V) or g_row (B) */
+int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float* g, const float* g_row,
+                           float* dlogits, int B, int T, int V, mmvae_stream_t stream);
+
+/* out[k] = sum_n W[k,n] * sum_b V[n,b]   (ELBO assembly: BaseObjective.elbo objectives.py:54-67,
+ * MoPOE.objective mmvae_models.py:315-319).  W is passed by value (<= 4 x 16 host floats). */
+int mmvae_lincomb_rows_fwd(const float* V, const float* W_host, float* out, int n_rows, int B, int n_out,
+                           mmvae_stream_t stream);
+int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, int n_rows, int B, int n_out,
+                           mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Text towers (Enc_TxtTransformer / Dec_TxtTransformer, models/encoders.py:790-837, decoders.py:668-723)
+ * ---------------------------------------------------------------------------------------------- */
+/* Embedding(one-hot.long()) + PositionalEncoding quirk (models/nn_modules.py:430-438, encoders.py:833-835).
+ *   onehot (B,T,V) 0/1 floats, emb (V,2) [only rows 0/1 are read], pe (>= max(B,T), 2) = the module's
+ *   sin/cos buffer (host-computed once), x (T*B, 2V) = the (nframes,bs,-1) view.
+ *   mode 0 (B != T, B != 1): x[t,b,v,e] = emb[oh[b,t,v],e] + pe[b,e]
+ *   mode 1 (B == T or B == 1): memory (B,T,2V) with pe[t] (pe[0] if B == 1), relabelled as (T,B,2V). */
+int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T, int V,
+                       int mode, mmvae_stream_t stream);
+int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V, int mode,
+                       int accumulate, mmvae_stream_t stream);
+size_t mmvae_embed_ws_floats(int B, int T, int V);
+
+/* Scaled-dot-product attention with key padding mask for L,S <= 64 (nn.MultiheadAttention core).
+ *   q (L*N, ldq) rows r = l*N+n, head h at columns [h*hd,(h+1)*hd); k, v (S*N, ld) likewise.
+ *   kpm (N,S) bytes, 1 = ignore key (may be NULL).  out (L*N, E=H*hd).  probs (N,H,L,S) saved for bwd. */
+int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out, float* probs,
+                   int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv, mmvae_stream_t stream);
+int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                   float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
+                   long ldv, mmvae_stream_t stream);
+
+/* y = LayerNorm(x + r) * gamma + beta (eps 1e-5); r may be NULL, same-shape (r_rows = 0) or broadcast over time
+ * (r_rows = N: row index = row % N).  xhat (rows,d) and rstd (rows) are saved for the backward.
+ * bwd: dsum = grad wrt (x + r); dgamma/dbeta (+)= through ws (mmvae_layernorm_ws_floats). */
+int mmvae_layernorm_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                                 float* xhat, float* rstd, int rows, int d, int r_rows, mmvae_stream_t stream);
+int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                                 float* dsum, float* dgamma, float* dbeta, float* ws, int rows, int d,
+                                 int accumulate, mmvae_stream_t stream);
+size_t mmvae_layernorm_ws_floats(int rows, int d);
+
+/* mean over the leading (time) axis: x (L,N,d) -> y (N,d)  (encoders.py:836); bwd: dx = dy / L broadcast */
+int mmvae_mean_over_time_fwd(const float* x, float* y, int L, int N, int d, mmvae_stream_t stream);
+int mmvae_mean_over_time_bwd(const float* dy, float* dx, int L, int N, int d, mmvae_stream_t stream);
+
+/* rows of (L,N,d) summed over time into (N,d): used for the broadcast cross-attention gradient */
+int mmvae_sum_over_time(const float* x, float* y, int L, int N, int d, mmvae_stream_t stream);
+
+/* y[r, :] = x[r, :] * m[r]  with rows r = (t,b) of a (T,B,V) tensor written as (B,T,V): the decoder's
+ * permute(1,0,2) * mask (decoders.py:722).  in (T*B, V) -> out (B,T,V);  bwd is the inverse scatter. */
+int mmvae_permute_mask_fwd(const float* x, const uint8_t* mask, float* y, int T, int B, int V,
+                           mmvae_stream_t stream);
+int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, float* dx, int T, int B, int V,
+                           mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser + utilities
+ * ---------------------------------------------------------------------------------------------- */
+/* torch.optim.Adam(amsgrad=True) over one flat buffer (models/trainer.py:79-81); step is 1-based and is
+ * read from *step_dev (device int) when step_dev != NULL, so that a captured hipGraph replays with the
+ * right bias correction (mmvae_step_inc bumps it on the stream).  g is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce); zero_grad != 0 clears g. */
+int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
+                            float beta2, float eps, int step, const int* step_dev, float grad_scale,
+                            int zero_grad, mmvae_stream_t stream);
+int mmvae_step_inc(int* step_dev, mmvae_stream_t stream);
+/* dst[i] (+)= sum_r src[r*stride + i],  i < len */
+int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long len, long stride, int accumulate,
+                      mmvae_stream_t stream);
+int mmvae_fill(float* p, long n, float value, mmvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVAE_HIP_H */

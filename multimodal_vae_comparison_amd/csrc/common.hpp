@@ -1,0 +1,77 @@
+// Shared device helpers for the gfx950 kernels.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mmvae_hip.h"
+
+#define MMVAE_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MMVAE_CHECK_ARG(cond) \
+  do {                        \
+    if (!(cond)) return MMVAE_ERR_ARG; \
+  } while (0)
+
+static inline int mmvae_launch_status() { return hipGetLastError() == hipSuccess ? MMVAE_OK : MMVAE_ERR_LAUNCH; }
+
+__device__ __forceinline__ float dev_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dev_silu(float x) { return x * dev_sigmoid(x); }
+__device__ __forceinline__ float dev_silu_grad(float x) {
+  float s = dev_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+// exact (erf) GELU, torch.nn.functional.gelu default
+__device__ __forceinline__ float dev_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dev_gelu_grad(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float apply_in_act(float v, int act) {
+  switch (act) {
+    case MMVAE_ACT_SILU: return dev_silu(v);
+    case MMVAE_ACT_RELU: return fmaxf(v, 0.0f);
+    case MMVAE_ACT_GELU: return dev_gelu(v);
+    default: return v;
+  }
+}
+
+// epilogue: v = acc (+bias already added by the caller); aux_v = value of aux at the same location (or 0)
+__device__ __forceinline__ float apply_epilogue(float v, float aux_v, int ep) {
+  switch (ep) {
+    case MMVAE_EP_RELU: return fmaxf(v, 0.0f);
+    case MMVAE_EP_MUL_RELU_MASK: return aux_v > 0.0f ? v : 0.0f;
+    case MMVAE_EP_MUL_SILU_GRAD: return v * dev_silu_grad(aux_v);
+    case MMVAE_EP_GELU: return dev_gelu(v);
+    case MMVAE_EP_MUL_GELU_GRAD: return v * dev_gelu_grad(aux_v);
+    case MMVAE_EP_SIGMOID_CLAMP: return fminf(fmaxf(dev_sigmoid(v), 1e-6f), 1.0f - 1e-6f);
+    default: return v;
+  }
+}
+__host__ __device__ __forceinline__ bool ep_reads_aux(int ep) {
+  return ep == MMVAE_EP_MUL_RELU_MASK || ep == MMVAE_EP_MUL_SILU_GRAD || ep == MMVAE_EP_MUL_GELU_GRAD;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// sum over a 256-thread block; result valid in every thread.  `red` = >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}

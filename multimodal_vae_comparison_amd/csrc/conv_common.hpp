@@ -1,0 +1,35 @@
+// Shared pieces of the 4x4 / stride-2 / pad-1 implicit-GEMM convolution kernels (gfx950).
+#pragma once
+#include "common.hpp"
+
+#define CONV_CO 32   // MFMA N tile = all 32 output channels of the towers
+#define CONV_CC 8    // input channels staged per LDS chunk (K = 128 per chunk)
+
+__host__ __device__ __forceinline__ int ilog2i(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// Geometry of one workgroup's macro tile: `nr` consecutive global rows (row = b*H + h) of an H x H map.
+// Either a slice of rows inside one image (nr <= H) or `nimg` whole images (nr = nimg * H).
+struct MacroTile {
+  int b0;     // first image
+  int h0;     // first row inside the image (0 when whole images)
+  int nrow;   // rows per image in this tile
+  int nimg;   // images in this tile
+};
+__device__ __forceinline__ MacroTile macro_tile(int first_row, int nr, int H) {
+  MacroTile t;
+  t.b0 = first_row / H;
+  if (nr <= H) {
+    t.h0 = first_row - t.b0 * H;
+    t.nrow = nr;
+    t.nimg = 1;
+  } else {
+    t.h0 = 0;
+    t.nrow = H;
+    t.nimg = nr / H;
+  }
+  return t;
+}

@@ -1,0 +1,240 @@
+// Strided fp32 GEMM on v_mfma_f32_32x32x2_f32 for the small dense layers of the towers
+// (nn.Linear fwd / dgrad / wgrad, attention projections, FFN).  gfx950 only.
+//
+//   C[M,N] = ep( bias + act(A)[M,K] * B[K,N] )
+//
+// Workgroup = 4 wavefronts.  Two tilings share one body:
+//   KSPLIT = 1 : 128 x 32 output tile, wave w owns rows [32w, 32w+32), K staged 32 deep;
+//   KSPLIT = 4 : 32 x 32 output tile, the four waves split every 128-deep K stage four ways and the
+//                partial accumulators are summed through LDS (used when M*N is too small to fill the
+//                chip: batch-128 linears, weight gradients).
+// A and B tiles are staged global -> registers -> LDS as [k][m] / [k][n] (row pitch odd => both the
+// transposing store and the per-lane fragment read are bank-conflict free), with the next stage's global
+// loads issued before the current stage's MFMAs.  MFMA operand layout (32x32x2 f32): lane l supplies
+// A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; accumulator register r of lane l is
+// C[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+// gridDim.z > 1 = split-K across workgroups: raw partial tiles go to `ws` ([z][M][N] then [z][M] row sums)
+// and are summed by mmvae_reduce_rows (deterministic, no atomics).
+#include "common.hpp"
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  const float* bias;
+  float* aux;  // read for MUL_* epilogues, written (pre-activation) for EP_GELU
+  float* C;
+  float* a_rowsum;
+  float* ws;
+  int M, N, K;
+  long sam, sak, sbk, sbn, ldc;
+  int a_act, b_act, ep, accumulate, kper;
+};
+
+template <int KSPLIT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int BM = KSPLIT == 1 ? 128 : 32;
+  constexpr int BN = 32;
+  constexpr int BK = KSPLIT == 1 ? 32 : 128;
+  constexpr int AP = BM + 1;  // LDS row pitch of As (odd)
+  constexpr int BP = BN + 1;
+  constexpr int A_PER_T = BM * BK / 256;  // 16
+  constexpr int B_PER_T = BK * BN / 256;  // 4 or 16
+  __shared__ float As[BK * AP];
+  __shared__ float Bs[BK * BP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.kper;
+  const int kend = min(g.K, kbeg + g.kper);
+  const bool a_kmajor = (g.sak == 1);
+  const bool b_kmajor = (g.sbk == 1 && g.sbn != 1);
+
+  float ra[A_PER_T], rb[B_PER_T];
+
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int e = i * 256 + tid;
+      int ml, kl;
+      if (a_kmajor) { kl = e % BK; ml = e / BK; } else { ml = e % BM; kl = e / BM; }
+      const int m = m0 + ml, k = k0 + kl;
+      float v = 0.f;
+      if (m < g.M && k < kend) v = apply_in_act(g.A[(long)m * g.sam + (long)k * g.sak], g.a_act);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int e = i * 256 + tid;
+      int nl, kl;
+      if (b_kmajor) { kl = e % BK; nl = e / BK; } else { nl = e % BN; kl = e / BN; }
+      const int n = n0 + nl, k = k0 + kl;
+      float v = 0.f;
+      if (n < g.N && k < kend) v = apply_in_act(g.B[(long)k * g.sbk + (long)n * g.sbn], g.b_act);
+      rb[i] = v;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int e = i * 256 + tid;
+      int ml, kl;
+      if (a_kmajor) { kl = e % BK; ml = e / BK; } else { ml = e % BM; kl = e / BM; }
+      As[kl * AP + ml] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int e = i * 256 + tid;
+      int nl, kl;
+      if (b_kmajor) { kl = e % BK; nl = e / BK; } else { nl = e % BN; kl = e / BN; }
+      Bs[kl * BP + nl] = rb[i];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float asum = 0.f;
+
+  const int a_off = (KSPLIT == 1 ? wave * 32 : 0) + li;   // m within the staged tile
+  const int k_off = (KSPLIT == 1 ? 0 : wave * 32) + lh;   // k within the staged tile
+
+  if (kbeg < kend) load_stage(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    store_stage();
+    __syncthreads();
+    if (k0 + BK < kend) load_stage(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = As[(k_off + kk) * AP + a_off];
+      const float b = Bs[(k_off + kk) * BP + li];
+      asum += a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool partial = gridDim.z > 1;
+  float* Cout = partial ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+  const long ldc = partial ? g.N : g.ldc;
+  float* rs_out = partial ? g.ws + (size_t)gridDim.z * g.M * g.N + (size_t)blockIdx.z * g.M : g.a_rowsum;
+  const int ep = partial ? MMVAE_EP_NONE : g.ep;
+  const bool acc_out = !partial && g.accumulate;
+
+  asum += __shfl_xor(asum, 32, 64);
+
+  auto emit = [&](int row, int col, float v) {
+    if (row < g.M && col < g.N) {
+      if (!partial && g.bias) v += g.bias[col];
+      const long o = (long)row * ldc + col;
+      float av = 0.f;
+      if (ep_reads_aux(ep)) av = g.aux[o];
+      if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
+      v = apply_epilogue(v, av, ep);
+      Cout[o] = acc_out ? Cout[o] + v : v;
+    }
+  };
+
+  if (KSPLIT == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) emit(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, acc[r]);
+    if (g.a_rowsum && blockIdx.x == 0 && lh == 0) {
+      const int row = m0 + wave * 32 + li;
+      if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + asum : asum;
+    }
+  } else {
+    float* red = As;  // 4 waves x 16 regs x 64 lanes = 4096 floats <= BK*AP
+    float* rsr = Bs;  // 4 x 32 row sums
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    if (lh == 0) rsr[wave * 32 + li] = asum;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 4 + q;
+      const float v = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] +
+                      red[(3 * 16 + r) * 64 + lane];
+      emit(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, v);
+    }
+    if (g.a_rowsum && blockIdx.x == 0 && wave == 0 && lh == 0) {
+      const int row = m0 + li;
+      const float v = rsr[li] + rsr[32 + li] + rsr[64 + li] + rsr[96 + li];
+      if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + v : v;
+    }
+  }
+}
+
+extern "C" size_t mmvae_gemm_ws_floats(int M, int N, int splitk) {
+  return splitk > 1 ? (size_t)splitk * ((size_t)M * N + M) : 0;
+}
+
+extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias, const float* aux, float* C,
+                              float* a_rowsum, float* ws, int M, int N, int K, long sam, long sak, long sbk, long sbn,
+                              long ldc, int a_act, int b_act, int ep_mode, int accumulate, int splitk,
+                              mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(A && Bm && C && M > 0 && N > 0 && K > 0);
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && (!ws || bias || ep_mode != MMVAE_EP_NONE)) return MMVAE_ERR_ARG;
+  if (ep_reads_aux(ep_mode) && !aux) return MMVAE_ERR_ARG;
+  GemmArgs g;
+  g.A = A; g.B = Bm; g.bias = bias; g.aux = const_cast<float*>(aux); g.C = C; g.a_rowsum = a_rowsum; g.ws = ws;
+  g.M = M; g.N = N; g.K = K; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
+  g.a_act = a_act; g.b_act = b_act; g.ep = ep_mode; g.accumulate = accumulate;
+  const int ntn = (N + 31) / 32;
+  // enough 128x32 tiles to give every CU one => big-tile kernel; otherwise the intra-workgroup K-split tile
+  const bool big = (long)((M + 127) / 128) * ntn >= 256;
+  const int bk = big ? 32 : 128;
+  int kper = (K + splitk - 1) / splitk;
+  kper = (kper + bk - 1) / bk * bk;
+  const int nz = (K + kper - 1) / kper;
+  g.kper = kper;
+  if (nz > 1 && !ws) return MMVAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (big)
+    hipLaunchKernelGGL(gemm_kernel<1>, dim3(ntn, (M + 127) / 128, nz), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(gemm_kernel<4>, dim3(ntn, (M + 31) / 32, nz), dim3(256), 0, st, g);
+  int rc = mmvae_launch_status();
+  if (rc) return rc;
+  if (nz > 1) {
+    rc = mmvae_reduce_rows(ws, C, nz, (long)M * N, (long)M * N, accumulate, stream);
+    if (rc) return rc;
+    if (a_rowsum) rc = mmvae_reduce_rows(ws + (size_t)nz * M * N, a_rowsum, nz, M, M, accumulate, stream);
+  }
+  return rc;
+}
+
+// ---- nn.Linear wrappers ---------------------------------------------------------------------------
+extern "C" int mmvae_linear_fwd(const float* x, const float* w, const float* b, float* aux, float* y, int M, int N,
+                                int K, long ldx, int x_act, int ep_mode, mmvae_stream_t stream) {
+  // y[m,n] = sum_k x[m,k] w[n,k]: A = x (sam = ldx, sak = 1), B(k,n) = w[n*K + k]
+  return mmvae_gemm_f32(x, w, b, aux, y, nullptr, nullptr, M, N, K, ldx, 1, 1, K, N, x_act, MMVAE_ACT_NONE, ep_mode, 0,
+                        1, stream);
+}
+extern "C" int mmvae_linear_bwd_data(const float* dy, const float* w, const float* aux, float* dx, int M, int N,
+                                     int K, int ep_mode, int accumulate, mmvae_stream_t stream) {
+  // dx[m,k] = sum_n dy[m,n] w[n,k]: A = dy (M x N), B(n,k) = w[n*K + k]
+  return mmvae_gemm_f32(dy, w, nullptr, aux, dx, nullptr, nullptr, M, K, N, N, 1, K, 1, K, MMVAE_ACT_NONE, MMVAE_ACT_NONE,
+                        ep_mode, accumulate, 1, stream);
+}
+static int wgrad_splitk(int M, int N, int K) {
+  // reduction length is M (rows); output N x K.  Split so that tiles * splits ~ 512 workgroups.
+  const long tiles = (long)((N + 31) / 32) * ((K + 31) / 32);
+  int s = (int)(512 / (tiles > 0 ? tiles : 1));
+  const int maxs = (M + 127) / 128;
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+extern "C" size_t mmvae_linear_bwd_weight_ws_floats(int M, int N, int K) {
+  return mmvae_gemm_ws_floats(N, K, wgrad_splitk(M, N, K));
+}
+extern "C" int mmvae_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, float* ws, int M, int N,
+                                       int K, long ldx, int x_act, int accumulate, mmvae_stream_t stream) {
+  // dw[n,k] = sum_m dy[m,n] act(x[m,k]): "A"(n,m) = dy[m*N + n] (sam = 1, sak = N), "B"(m,k) = x[m*ldx + k];
+  // db[n] = row sum of "A".
+  const int sk = wgrad_splitk(M, N, K);
+  return mmvae_gemm_f32(dy, x, nullptr, nullptr, dw, db, ws, N, K, M, 1, N, ldx, 1, K, MMVAE_ACT_NONE, x_act,
+                        MMVAE_EP_NONE, accumulate, sk, stream);
+}

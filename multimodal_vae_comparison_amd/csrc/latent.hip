@@ -1,0 +1,273 @@
+// Encoder heads + fused latent op (product of experts -> reparameterise -> analytic KL) for gfx950.
+// Elementwise / small-reduction work over (experts x B x D) with D <= 256: one wavefront per sample,
+// lanes over the latent dimension, wave-shuffle reductions; no LDS, no atomics (deterministic).
+#include "common.hpp"
+
+#define POE_MAX_WAVES 128
+#define POE_SLOTS 4  // D <= 64 * POE_SLOTS
+
+// ---------------------------------------------------------------------------------------------
+// VaeComponent.process_output (models/encoders.py:49-54): lv = softmax(u, -1) + 1e-6 on h[:, D:2D]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_softmax_fwd_kernel(float* __restrict__ h, int B, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float* u = h + (size_t)b * 2 * D + D;
+  float mx = -INFINITY;
+  for (int d = lane; d < D; d += 64) mx = fmaxf(mx, u[d]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += expf(u[d] - mx);
+  s = wave_sum(s);
+  const float inv = 1.0f / s;
+  for (int d = lane; d < D; d += 64) u[d] = expf(u[d] - mx) * inv + 1e-6f;
+}
+
+// dh[:, D:] <- s * (dlv - sum(s * dlv)),  s = lv - 1e-6
+__global__ __launch_bounds__(256) void head_softmax_bwd_kernel(const float* __restrict__ h, float* __restrict__ dh,
+                                                               int B, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* lv = h + (size_t)b * 2 * D + D;
+  float* g = dh + (size_t)b * 2 * D + D;
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) dot += (lv[d] - 1e-6f) * g[d];
+  dot = wave_sum(dot);
+  for (int d = lane; d < D; d += 64) g[d] = (lv[d] - 1e-6f) * (g[d] - dot);
+}
+
+extern "C" int mmvae_head_softmax_fwd(float* h, int B, int D, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(h && B > 0 && D > 0);
+  hipLaunchKernelGGL(head_softmax_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, B, D);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_head_softmax_bwd(const float* h, float* dh, int B, int D, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(h && dh && B > 0 && D > 0);
+  hipLaunchKernelGGL(head_softmax_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, dh, B, D);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// prior sigma: softmax(theta) * D   (models/mmvae_models.py:274-276), computed per wave
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void prior_sigma(const float* __restrict__ theta, int D, int lane, float sp[POE_SLOTS],
+                                            float sm[POE_SLOTS]) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    int d = lane + 64 * s;
+    if (d < D) mx = fmaxf(mx, theta[d]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    int d = lane + 64 * s;
+    sm[s] = d < D ? expf(theta[d] - mx) : 0.f;
+    sum += sm[s];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    sm[s] = sm[s] / sum;
+    sp[s] = sm[s] * (float)D;
+  }
+}
+
+__device__ __forceinline__ float kl_elem(float mu, float s, float sp) {
+  float r = s / sp, m = mu / sp;
+  float vr = r * r;
+  return 0.5f * (vr + m * m - 1.0f - logf(vr));
+}
+
+__global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, const float* __restrict__ theta,
+                                                      float* __restrict__ joint, float* __restrict__ kl, int E,
+                                                      int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  float sp[POE_SLOTS], sm[POE_SLOTS];
+  prior_sigma(theta, D, lane, sp, sm);
+  for (int b = wave; b < B; b += nwaves) {
+    float klacc[MMVAE_MAX_EXPERTS + 1];
+#pragma unroll
+    for (int j = 0; j <= MMVAE_MAX_EXPERTS; ++j) klacc[j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < POE_SLOTS; ++s) {
+      const int d = lane + 64 * s;
+      if (d < D) {
+      const size_t o = (size_t)b * D + d;    // contiguous (B,D) tensors
+      const size_t oi = (size_t)b * ld + d;  // strided expert tensors
+      float P = 0.f, S = 0.f;
+#pragma unroll
+      for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e) {
+        if (e >= E) continue;
+        const float mu = a.mu[e][oi], lv = a.lv[e][oi];
+        const float T = 1.0f / (expf(lv) + 1e-8f);
+        P += T;
+        S += mu * T;
+        if (kl_mask & (1u << e)) klacc[e] += kl_elem(mu, lv, sp[s]);
+      }
+      if (with_prior) P += 1.0f / (1.0f + 1e-8f);
+      const float muJ = S / P, varJ = 1.0f / P;
+      joint[o] = muJ;
+      joint[(size_t)B * D + o] = varJ;
+      if (kl_mask & (1u << E)) klacc[E] += kl_elem(muJ, varJ, sp[s]);
+#pragma unroll
+      for (int i = 0; i < MMVAE_MAX_EXPERTS; ++i) {
+        if (i >= n_z) continue;
+        a.z[i][o] = muJ + varJ * a.eps[i][o];
+      }
+      }
+    }
+    if (kl) {
+#pragma unroll
+      for (int j = 0; j <= MMVAE_MAX_EXPERTS; ++j) {
+        if (j > E) continue;
+        float v = wave_sum(klacc[j]);
+        if (lane == 0) kl[(size_t)j * B + b] = v;
+      }
+    }
+  }
+}
+
+// Backward.  Per element (all for fixed b,d):
+//   G_mu  = sum_i dz_i            + gk_J * muJ / sp^2
+//   G_var = sum_i dz_i * eps_i    + gk_J * (varJ / sp^2 - 1 / varJ)
+//   dmu_e = G_mu * T_e * varJ                                  + gk_e * mu_e / sp^2
+//   dlv_e = [G_mu (mu_e - muJ) varJ - G_var varJ^2] * (-exp(lv_e) T_e^2)  + gk_e * (lv_e / sp^2 - 1 / lv_e)
+//   dsp  += sum_j gk_j * (1 - (s_j^2 + mu_j^2) / sp^2) / sp
+__global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, const float* __restrict__ theta,
+                                                      const float* __restrict__ dkl, float* __restrict__ ws, int E,
+                                                      int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  float sp[POE_SLOTS], sm[POE_SLOTS], dsp[POE_SLOTS];
+  prior_sigma(theta, D, lane, sp, sm);
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) dsp[s] = 0.f;
+  for (int b = wave; b < B; b += nwaves) {
+    float gk[MMVAE_MAX_EXPERTS + 1];
+#pragma unroll
+    for (int j = 0; j <= MMVAE_MAX_EXPERTS; ++j)
+      gk[j] = (j <= E && dkl && (kl_mask & (1u << j))) ? dkl[(size_t)j * B + b] : 0.f;
+#pragma unroll
+    for (int s = 0; s < POE_SLOTS; ++s) {
+      const int d = lane + 64 * s;
+      if (d < D) {
+      const size_t o = (size_t)b * D + d;    // contiguous (B,D) tensors
+      const size_t oi = (size_t)b * ld + d;  // strided expert tensors
+      const float isp2 = 1.0f / (sp[s] * sp[s]);
+      float mu[MMVAE_MAX_EXPERTS], lv[MMVAE_MAX_EXPERTS], T[MMVAE_MAX_EXPERTS];
+      float P = 0.f, S = 0.f;
+#pragma unroll
+      for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e) {
+        if (e >= E) continue;
+        mu[e] = a.mu[e][oi];
+        lv[e] = a.lv[e][oi];
+        T[e] = 1.0f / (expf(lv[e]) + 1e-8f);
+        P += T[e];
+        S += mu[e] * T[e];
+      }
+      if (with_prior) P += 1.0f / (1.0f + 1e-8f);
+      const float muJ = S / P, varJ = 1.0f / P;
+      float Gmu = 0.f, Gvar = 0.f;
+#pragma unroll
+      for (int i = 0; i < MMVAE_MAX_EXPERTS; ++i) {
+        if (i >= n_z) continue;
+        const float g = a.dz[i][o];
+        Gmu += g;
+        Gvar += g * a.eps[i][o];
+      }
+      float dspe = 0.f;
+      if (gk[E] != 0.f) {
+        Gmu += gk[E] * muJ * isp2;
+        Gvar += gk[E] * (varJ * isp2 - 1.0f / varJ);
+        dspe += gk[E] * (1.0f - (varJ * varJ + muJ * muJ) * isp2) / sp[s];
+      }
+#pragma unroll
+      for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e) {
+        if (e >= E) continue;
+        float dmu = Gmu * T[e] * varJ;
+        float dT = Gmu * (mu[e] - muJ) * varJ - Gvar * varJ * varJ;
+        float dlv = dT * (-expf(lv[e]) * T[e] * T[e]);
+        if (gk[e] != 0.f) {
+          dmu += gk[e] * mu[e] * isp2;
+          dlv += gk[e] * (lv[e] * isp2 - 1.0f / lv[e]);
+          dspe += gk[e] * (1.0f - (lv[e] * lv[e] + mu[e] * mu[e]) * isp2) / sp[s];
+        }
+        a.dmu[e][oi] = dmu;
+        a.dlv[e][oi] = dlv;
+      }
+      dsp[s] += dspe;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    const int d = lane + 64 * s;
+    if (d < D) ws[(size_t)wave * D + d] = dsp[s];
+  }
+}
+
+// dtheta_d (+)= D * s_d * (dsp_d - sum_k s_k dsp_k), dsp = sum over the per-wave partial rows
+__global__ __launch_bounds__(64) void poe_theta_kernel(const float* __restrict__ theta, const float* __restrict__ ws,
+                                                       float* __restrict__ dtheta, int nrows, int D, int accumulate) {
+  const int lane = threadIdx.x;
+  float sp[POE_SLOTS], sm[POE_SLOTS], dsp[POE_SLOTS];
+  prior_sigma(theta, D, lane, sp, sm);
+  float dot = 0.f;
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    const int d = lane + 64 * s;
+    float acc = 0.f;
+    if (d < D)
+      for (int r = 0; r < nrows; ++r) acc += ws[(size_t)r * D + d];
+    dsp[s] = acc;
+    dot += acc * sm[s];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    const int d = lane + 64 * s;
+    if (d < D) {
+      float g = (float)D * sm[s] * (dsp[s] - dot);
+      dtheta[d] = accumulate ? dtheta[d] + g : g;
+    }
+  }
+}
+
+static inline int poe_blocks(int B) {
+  int waves = B < POE_MAX_WAVES ? B : POE_MAX_WAVES;
+  return (waves + 3) / 4;
+}
+
+extern "C" size_t mmvae_poe_ws_floats(int B, int D) { return (size_t)poe_blocks(B) * 4 * D; }
+
+extern "C" int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl,
+                                        int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
+                                        mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(a && theta && joint && B > 0 && D > 0 && E > 0 && ld_in >= D);
+  if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
+  if (kl_mask && !kl) return MMVAE_ERR_ARG;
+  hipLaunchKernelGGL(poe_fwd_kernel, dim3(poe_blocks(B)), dim3(256), 0, (hipStream_t)stream, *a, theta, joint, kl, E,
+                     with_prior, n_z, kl_mask, B, D, ld_in);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl,
+                                        float* dtheta, float* ws, int E, int with_prior, int n_z, unsigned kl_mask,
+                                        int B, int D, int ld_in, int accumulate, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(a && theta && ws && B > 0 && D > 0 && E > 0 && ld_in >= D);
+  if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
+  const int nb = poe_blocks(B);
+  hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
+                     n_z, kl_mask, B, D, ld_in);
+  if (dtheta)
+    hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
+                       accumulate);
+  return mmvae_launch_status();
+}

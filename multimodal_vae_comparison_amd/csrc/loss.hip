@@ -1,0 +1,248 @@
+// Reconstruction losses and ELBO assembly for gfx950.  HBM-bound streaming kernels: 16-byte loads,
+// one wave-shuffle + LDS reduction per row, no atomics.
+#include "common.hpp"
+
+#define BCE_ETA 1e-6f
+
+__device__ __forceinline__ float bce_term(float x, float t) {
+  // torch.nn.functional.binary_cross_entropy clamps each log at -100 (ReconLoss.bce, objectives.py:405)
+  float lx = fmaxf(logf(x), -100.0f), l1x = fmaxf(logf(1.0f - x), -100.0f);
+  return -(t * lx + (1.0f - t) * l1x);
+}
+
+// one 256-thread block per sample row
+__global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
+                                                         float* __restrict__ row, int F) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * F;
+  float acc = 0.f;
+  if ((F & 3) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(xh + base);
+    const float4* t4 = reinterpret_cast<const float4*>(tg + base);
+    for (int i = threadIdx.x; i < F / 4; i += 256) {
+      float4 x = x4[i], t = t4[i];
+      acc += bce_term(x.x, t.x) + bce_term(x.y, t.y) + bce_term(x.z, t.z) + bce_term(x.w, t.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < F; i += 256) acc += bce_term(xh[base + i], tg[base + i]);
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) row[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void bce_elem_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
+                                                       float* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  for (; i < n; i += stride) out[i] = bce_term(xh[i], tg[i]);
+}
+
+// d/dlogit of bce(clamp(sigmoid(logit))) = (xh - t) where the clamp is inactive, else 0
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
+                                                      const float* __restrict__ grow, float* __restrict__ dl, int F) {
+  const size_t base = (size_t)blockIdx.y * F;
+  const float g = grow[blockIdx.y];
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < F && (F & 3) == 0) {
+    float4 x = *reinterpret_cast<const float4*>(xh + base + i);
+    float4 t = *reinterpret_cast<const float4*>(tg + base + i);
+    float4 o;
+    o.x = (x.x > BCE_ETA && x.x < 1.0f - BCE_ETA) ? g * (x.x - t.x) : 0.f;
+    o.y = (x.y > BCE_ETA && x.y < 1.0f - BCE_ETA) ? g * (x.y - t.y) : 0.f;
+    o.z = (x.z > BCE_ETA && x.z < 1.0f - BCE_ETA) ? g * (x.z - t.z) : 0.f;
+    o.w = (x.w > BCE_ETA && x.w < 1.0f - BCE_ETA) ? g * (x.w - t.w) : 0.f;
+    *reinterpret_cast<float4*>(dl + base + i) = o;
+  } else {
+    for (int j = i; j < F && j < i + 4; ++j) {
+      float x = xh[base + j];
+      dl[base + j] = (x > BCE_ETA && x < 1.0f - BCE_ETA) ? g * (x - tg[base + j]) : 0.f;
+    }
+  }
+}
+
+// true gradient wrt x_hat (torch: grad * (x - t) / max((1 - x) * x, 1e-12))
+__global__ __launch_bounds__(256) void bce_rowsum_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
+                                                             const float* __restrict__ grow, float* __restrict__ dx,
+                                                             int F) {
+  const size_t base = (size_t)blockIdx.y * F;
+  const float g = grow[blockIdx.y];
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < F; j += gridDim.x * 256) {
+    const float x = xh[base + j];
+    dx[base + j] = g * (x - tg[base + j]) / fmaxf((1.0f - x) * x, 1e-12f);
+  }
+}
+__global__ __launch_bounds__(256) void sigmoid_clamp_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                float* __restrict__ dl, long n) {
+  const long gs = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
+    const float v = y[i];
+    dl[i] = (v > BCE_ETA && v < 1.0f - BCE_ETA) ? dy[i] * v * (1.0f - v) : 0.f;
+  }
+}
+extern "C" int mmvae_bce_rowsum_bwd(const float* x_hat, const float* target, const float* g_row, float* dxhat, int B,
+                                    int F, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && g_row && dxhat && B > 0 && F > 0);
+  int bx = (F + 255) / 256;
+  if (bx > 16) bx = 16;
+  hipLaunchKernelGGL(bce_rowsum_bwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x_hat, target, g_row, dxhat,
+                     F);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_sigmoid_clamp_bwd(const float* dy, const float* y, float* dl, long n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && y && dl && n > 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sigmoid_clamp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, dl, n);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_bce_rowsum_fwd(const float* x_hat, const float* target, float* row_loss, int B, int F,
+                                    mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && row_loss && B > 0 && F > 0);
+  hipLaunchKernelGGL(bce_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x_hat, target, row_loss, F);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_bce_elem_fwd(const float* x_hat, const float* target, float* loss, long n,
+                                  mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && loss && n > 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bce_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_hat, target, loss,
+                     n);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_bce_sigmoid_clamp_bwd(const float* x_hat, const float* target, const float* g_row,
+                                           float* dlogit, int B, int F, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && g_row && dlogit && B > 0 && F > 0);
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((F + 1023) / 1024, B), dim3(256), 0, (hipStream_t)stream, x_hat, target,
+                     g_row, dlogit, F);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// category_ce: softmax over TIME (objectives.py:499-500).  One 64-thread block per
+// sample; lanes over the vocabulary (coalesced rows of V floats), serial loop over T (<= a few hundred).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ce_time_fwd_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
+                                                         float* __restrict__ loss, float* __restrict__ row, int T,
+                                                         int V) {
+  const int b = blockIdx.x;
+  const float* L = lg + (size_t)b * T * V;
+  const float* Tg = tg + (size_t)b * T * V;
+  float rsum = 0.f;
+  for (int v = threadIdx.x; v < V; v += 64) {
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, L[t * V + v]);
+    float se = 0.f, dot = 0.f, ts = 0.f;
+    for (int t = 0; t < T; ++t) {
+      float l = L[t * V + v], g = Tg[t * V + v];
+      se += expf(l - mx);
+      dot += g * l;
+      ts += g;
+    }
+    float lse = mx + logf(se);
+    float ls = lse * ts - dot;
+    if (loss) loss[(size_t)b * V + v] = ls;
+    rsum += ls;
+  }
+  rsum = wave_sum(rsum);
+  if (row && threadIdx.x == 0) row[b] = rsum;
+}
+
+__global__ __launch_bounds__(64) void ce_time_bwd_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
+                                                         const float* __restrict__ g, const float* __restrict__ grow,
+                                                         float* __restrict__ dl, int T, int V) {
+  const int b = blockIdx.x;
+  const float* L = lg + (size_t)b * T * V;
+  const float* Tg = tg + (size_t)b * T * V;
+  float* D = dl + (size_t)b * T * V;
+  for (int v = threadIdx.x; v < V; v += 64) {
+    const float gv = g ? g[(size_t)b * V + v] : grow[b];
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, L[t * V + v]);
+    float se = 0.f, ts = 0.f;
+    for (int t = 0; t < T; ++t) {
+      se += expf(L[t * V + v] - mx);
+      ts += Tg[t * V + v];
+    }
+    const float inv = 1.0f / se;
+    for (int t = 0; t < T; ++t) D[t * V + v] = gv * (expf(L[t * V + v] - mx) * inv * ts - Tg[t * V + v]);
+  }
+}
+
+extern "C" int mmvae_ce_over_time_fwd(const float* logits, const float* target, float* loss, float* row_loss, int B,
+                                      int T, int V, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(logits && target && (loss || row_loss) && B > 0 && T > 0 && V > 0);
+  hipLaunchKernelGGL(ce_time_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss, row_loss, T,
+                     V);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float* g, const float* g_row,
+                                      float* dlogits, int B, int T, int V, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(logits && target && (g || g_row) && dlogits && B > 0 && T > 0 && V > 0);
+  hipLaunchKernelGGL(ce_time_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, g, g_row, dlogits,
+                     T, V);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ELBO assembly: out[k] = sum_n W[k,n] * sum_b V[n,b]
+// ---------------------------------------------------------------------------------------------
+#define LC_MAX_ROWS 16
+#define LC_MAX_OUT 4
+struct lincomb_w {
+  float w[LC_MAX_OUT * LC_MAX_ROWS];
+};
+
+__global__ __launch_bounds__(256) void lincomb_fwd_kernel(const float* __restrict__ V, lincomb_w W,
+                                                          float* __restrict__ out, int n_rows, int B, int n_out) {
+  __shared__ float red[4];
+  __shared__ float rs[LC_MAX_ROWS];
+  for (int n = 0; n < n_rows; ++n) {
+    float a = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) a += V[(size_t)n * B + b];
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) rs[n] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < n_out) {
+    float o = 0.f;
+    for (int n = 0; n < n_rows; ++n) o += W.w[threadIdx.x * LC_MAX_ROWS + n] * rs[n];
+    out[threadIdx.x] = o;
+  }
+}
+__global__ __launch_bounds__(256) void lincomb_bwd_kernel(const float* __restrict__ gout, lincomb_w W,
+                                                          float* __restrict__ dV, int n_rows, int B, int n_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows * B) return;
+  const int n = i / B;
+  float g = 0.f;
+  for (int k = 0; k < n_out; ++k) g += gout[k] * W.w[k * LC_MAX_ROWS + n];
+  dV[i] = g;
+}
+
+static int pack_w(const float* W_host, int n_rows, int n_out, lincomb_w* w) {
+  if (n_rows > LC_MAX_ROWS || n_out > LC_MAX_OUT) return MMVAE_ERR_UNSUPPORTED;
+  for (int k = 0; k < n_out; ++k)
+    for (int n = 0; n < n_rows; ++n) w->w[k * LC_MAX_ROWS + n] = W_host[k * n_rows + n];
+  return MMVAE_OK;
+}
+extern "C" int mmvae_lincomb_rows_fwd(const float* V, const float* W_host, float* out, int n_rows, int B, int n_out,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(V && W_host && out && n_rows > 0 && B > 0 && n_out > 0);
+  lincomb_w w;
+  int rc = pack_w(W_host, n_rows, n_out, &w);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lincomb_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, V, w, out, n_rows, B, n_out);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, int n_rows, int B, int n_out,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(gout && W_host && dV && n_rows > 0 && B > 0 && n_out > 0);
+  lincomb_w w;
+  int rc = pack_w(W_host, n_rows, n_out, &w);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lincomb_bwd_kernel, dim3((n_rows * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gout, w,
+                     dV, n_rows, B, n_out);
+  return mmvae_launch_status();
+}

@@ -1,0 +1,116 @@
+// Flat-buffer Adam(amsgrad) + partial-sum reduction + fill, gfx950.  Pure HBM streaming: 16-byte
+// accesses, grid capped at 2048 blocks with a grid-stride loop.
+#include "common.hpp"
+
+// torch.optim.Adam(amsgrad=True) (reference: models/trainer.py:79-81), torch's single-tensor formula:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; vmax = max(vmax, v)
+//   p -= (lr / bc1) * m / (sqrt(vmax) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ vmax, long n, float lr,
+                                                           int step, const int* __restrict__ step_dev, float b1,
+                                                           float b2, float eps, float gscale, int zero_grad) {
+  // bias corrections from the step count; the count lives in device memory when the launch is replayed
+  // from a captured graph (kernel arguments are frozen at capture time).
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const int st = step_dev ? *step_dev : step;
+    const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
+    bc[0] = (float)((double)lr / bc1);
+    bc[1] = (float)(1.0 / sqrt(bc2));
+  }
+  __syncthreads();
+  const float lr_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
+    float4 X = reinterpret_cast<float4*>(vmax)[i];
+    float* pp = &P.x;
+    float* gg = &G.x;
+    float* mm = &M.x;
+    float* vv = &Vv.x;
+    float* xx = &X.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gscale;
+      mm[k] = b1 * mm[k] + (1.0f - b1) * gr;
+      vv[k] = b2 * vv[k] + (1.0f - b2) * gr * gr;
+      xx[k] = fmaxf(xx[k], vv[k]);
+      pp[k] -= lr_bc1 * mm[k] / (sqrtf(xx[k]) * inv_sqrt_bc2 + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = Vv;
+    reinterpret_cast<float4*>(vmax)[i] = X;
+    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // tail
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float gr = g[i] * gscale;
+    float mi = b1 * m[i] + (1.0f - b1) * gr;
+    float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
+    float xi = fmaxf(vmax[i], vi);
+    p[i] -= lr_bc1 * mi / (sqrtf(xi) * inv_sqrt_bc2 + eps);
+    m[i] = mi;
+    v[i] = vi;
+    vmax[i] = xi;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+extern "C" int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr,
+                                       float beta1, float beta2, float eps, int step, const int* step_dev,
+                                       float grad_scale, int zero_grad, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(p && g && m && v && vmax && n > 0 && (step > 0 || step_dev));
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) != 0) return MMVAE_ERR_ARG;
+  long blocks = ((n >> 2) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
+                     n, lr, step, step_dev, beta1, beta2, eps, grad_scale, zero_grad);
+  return mmvae_launch_status();
+}
+
+// dst[i] (+)= sum_r src[r*stride + i]
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int n_rows, long len, long stride, int accumulate) {
+  const long gs = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += gs) {
+    float a = accumulate ? dst[i] : 0.f;
+    for (int r = 0; r < n_rows; ++r) a += src[(size_t)r * stride + i];
+    dst[i] = a;
+  }
+}
+extern "C" int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long len, long stride, int accumulate,
+                                 mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(src && dst && n_rows > 0 && len > 0);
+  long blocks = (len + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n_rows,
+                     len, stride, accumulate);
+  return mmvae_launch_status();
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float value) {
+  const long gs = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) p[i] = value;
+}
+extern "C" int mmvae_fill(float* p, long n, float value, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(p && n > 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  return mmvae_launch_status();
+}
+
+__global__ void step_inc_kernel(int* s) { *s += 1; }
+extern "C" int mmvae_step_inc(int* step_dev, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(step_dev);
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_version(void) { return 1; }
+extern "C" const char* mmvae_arch(void) { return "gfx950"; }

@@ -1,0 +1,437 @@
+// Text-tower kernels for gfx950: embedding + positional-encoding quirk, masked softmax attention for
+// sequences <= 64, residual LayerNorm, time reductions, decoder output permute+mask.
+// All of these are tiny (T <= 64, d <= 64): one wavefront per row / per (sample, head), wave-shuffle
+// reductions, LDS only for the attention tiles.  No atomics: parameter gradients go through per-block
+// partial rows + mmvae_reduce_rows.
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// Embedding(one-hot.long()) + PositionalEncoding (models/encoders.py:833-835, nn_modules.py:430-438)
+//   mode 0: out[((t*B+b)*V+v)*2+e] = emb[oh[b,t,v]][e] + pe[b][e]
+//   mode 1: out[((b*T+t)*V+v)*2+e] = emb[oh[b,t,v]][e] + pe[B==1 ? 0 : t][e]      (memory relabelled as (T,B,2V))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const float* __restrict__ oh, const float* __restrict__ emb,
+                                                           const float* __restrict__ pe, float* __restrict__ out, int B,
+                                                           int T, int V, int mode) {
+  const int n = B * T * V;
+  const float e00 = emb[0], e01 = emb[1], e10 = emb[2], e11 = emb[3];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int v = i % V, bt = i / V, t = bt % T, b = bt / T;
+    const bool one = oh[i] != 0.f;  // .long() of a 0/1 float
+    const int pos = mode == 0 ? b : (B == 1 ? 0 : t);
+    const size_t o = mode == 0 ? (((size_t)t * B + b) * V + v) * 2 : (size_t)i * 2;
+    float2 r;
+    r.x = (one ? e10 : e00) + pe[pos * 2];
+    r.y = (one ? e11 : e01) + pe[pos * 2 + 1];
+    *reinterpret_cast<float2*>(out + o) = r;
+  }
+}
+
+// per-block partial of demb rows 0/1: ws[block][4] = {sum dx0 | oh=0, sum dx1 | oh=0, sum dx0 | oh=1, sum dx1 | oh=1}
+__global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restrict__ oh, const float* __restrict__ dx,
+                                                           float* __restrict__ ws, int B, int T, int V, int mode) {
+  __shared__ float red[4];
+  const int n = B * T * V;
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int v = i % V, bt = i / V, t = bt % T, b = bt / T;
+    const size_t o = mode == 0 ? (((size_t)t * B + b) * V + v) * 2 : (size_t)i * 2;
+    const float2 g = *reinterpret_cast<const float2*>(dx + o);
+    if (oh[i] != 0.f) { a10 += g.x; a11 += g.y; } else { a00 += g.x; a01 += g.y; }
+  }
+  a00 = block_sum_256(a00, red);
+  a01 = block_sum_256(a01, red);
+  a10 = block_sum_256(a10, red);
+  a11 = block_sum_256(a11, red);
+  if (threadIdx.x == 0) {
+    float* w = ws + (size_t)blockIdx.x * 4;
+    w[0] = a00; w[1] = a01; w[2] = a10; w[3] = a11;
+  }
+}
+
+static inline int embed_blocks(int B, int T, int V) {
+  long n = (long)B * T * V;
+  long b = (n + 255) / 256;
+  return (int)(b > 256 ? 256 : (b < 1 ? 1 : b));
+}
+extern "C" size_t mmvae_embed_ws_floats(int B, int T, int V) { return (size_t)embed_blocks(B, T, V) * 4; }
+
+extern "C" int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T,
+                                  int V, int mode, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(onehot && emb && pe && x && B > 0 && T > 0 && V > 1);
+  hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(embed_blocks(B, T, V)), dim3(256), 0, (hipStream_t)stream, onehot, emb,
+                     pe, x, B, T, V, mode);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V,
+                                  int mode, int accumulate, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(onehot && dx && demb && ws && B > 0 && T > 0 && V > 1);
+  const int nb = embed_blocks(B, T, V);
+  hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, onehot, dx, ws, B, T, V, mode);
+  int rc = mmvae_launch_status();
+  if (rc) return rc;
+  if (!accumulate && V > 2) {
+    rc = mmvae_fill(demb + 4, (long)(V - 2) * 2, 0.f, stream);  // rows >= 2 are never looked up
+    if (rc) return rc;
+  }
+  return mmvae_reduce_rows(ws, demb, nb, 4, 4, accumulate, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention core of nn.MultiheadAttention, one wavefront per (sample n, head h); lane = query index.
+// ---------------------------------------------------------------------------------------------
+#define ATT_MAX 64
+#define ATT_HD 32  // head_dim <= 32 (27 encoder, D/2 decoder)
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const uint8_t* __restrict__ kpm,
+                                                      float* __restrict__ out, float* __restrict__ probs, int L, int S,
+                                                      int N, int H, int hd, long ldq, long ldk, long ldv) {
+  __shared__ float sk[ATT_MAX * (ATT_HD + 1)];
+  __shared__ float sv[ATT_MAX * (ATT_HD + 1)];
+  __shared__ float smask[ATT_MAX];
+  const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int HP = ATT_HD + 1;
+  for (int e = lane; e < S * hd; e += 64) {
+    const int s = e / hd, d = e - s * hd;
+    sk[s * HP + d] = k[((size_t)s * N + n) * ldk + h * hd + d];
+    sv[s * HP + d] = v[((size_t)s * N + n) * ldv + h * hd + d];
+  }
+  if (lane < S) smask[lane] = (kpm && kpm[(size_t)n * S + lane]) ? 1.f : 0.f;
+  __syncthreads();
+  if (lane >= L) return;
+  const float scale = 1.0f / sqrtf((float)hd);
+  float qr[ATT_HD];
+#pragma unroll
+  for (int d = 0; d < ATT_HD; ++d) qr[d] = d < hd ? q[((size_t)lane * N + n) * ldq + h * hd + d] * scale : 0.f;
+  float mx = -INFINITY;
+  for (int s = 0; s < S; ++s) {
+    float sc = 0.f;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) sc += qr[d] * sk[s * HP + d];
+    if (smask[s] != 0.f) sc = -INFINITY;
+    mx = fmaxf(mx, sc);
+  }
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float sc = 0.f;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) sc += qr[d] * sk[s * HP + d];
+    if (smask[s] != 0.f) sc = -INFINITY;
+    sum += expf(sc - mx);
+  }
+  const float inv = 1.0f / sum;
+  float o[ATT_HD];
+#pragma unroll
+  for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
+  float* prow = probs + (((size_t)n * H + h) * L + lane) * S;
+  for (int s = 0; s < S; ++s) {
+    float sc = 0.f;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) sc += qr[d] * sk[s * HP + d];
+    if (smask[s] != 0.f) sc = -INFINITY;
+    const float p = expf(sc - mx) * inv;
+    prow[s] = p;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) o[d] += p * sv[s * HP + d];
+  }
+  float* orow = out + ((size_t)lane * N + n) * ((size_t)H * hd) + h * hd;
+#pragma unroll
+  for (int d = 0; d < ATT_HD; ++d)
+    if (d < hd) orow[d] = o[d];
+}
+
+// dV[s] = sum_l P[l,s] dO[l];  dP[l,s] = dO[l].V[s];  dS = P (dP - sum_s P dP);
+// dQ[l] = scale * sum_s dS[l,s] K[s];  dK[s] = scale * sum_l dS[l,s] Q[l]
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const float* __restrict__ probs,
+                                                      const float* __restrict__ dout, float* __restrict__ dq,
+                                                      float* __restrict__ dk, float* __restrict__ dv, int L, int S,
+                                                      int N, int H, int hd, long ldq, long ldk, long ldv) {
+  constexpr int HP = ATT_HD + 1, SP = ATT_MAX + 1;
+  __shared__ float sq[ATT_MAX * HP];
+  __shared__ float sk[ATT_MAX * HP];
+  __shared__ float sv[ATT_MAX * HP];
+  __shared__ float sdo[ATT_MAX * HP];
+  __shared__ float sp[ATT_MAX * SP];
+  __shared__ float sds[ATT_MAX * SP];
+  const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const size_t E = (size_t)H * hd;
+  for (int e = lane; e < S * hd; e += 64) {
+    const int s = e / hd, d = e - s * hd;
+    sk[s * HP + d] = k[((size_t)s * N + n) * ldk + h * hd + d];
+    sv[s * HP + d] = v[((size_t)s * N + n) * ldv + h * hd + d];
+  }
+  for (int e = lane; e < L * hd; e += 64) {
+    const int l = e / hd, d = e - l * hd;
+    sq[l * HP + d] = q[((size_t)l * N + n) * ldq + h * hd + d];
+    sdo[l * HP + d] = dout[((size_t)l * N + n) * E + h * hd + d];
+  }
+  const float* P = probs + ((size_t)n * H + h) * L * S;
+  for (int e = lane; e < L * S; e += 64) {
+    const int l = e / S, s = e - l * S;
+    sp[l * SP + s] = P[e];
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (lane < L) {
+    const int l = lane;
+    float delta = 0.f;
+    for (int s = 0; s < S; ++s) {
+      float dp = 0.f;
+      for (int d = 0; d < hd; ++d) dp += sdo[l * HP + d] * sv[s * HP + d];
+      sds[l * SP + s] = dp;
+      delta += sp[l * SP + s] * dp;
+    }
+    for (int s = 0; s < S; ++s) sds[l * SP + s] = sp[l * SP + s] * (sds[l * SP + s] - delta);
+    for (int d = 0; d < hd; ++d) {
+      float a = 0.f;
+      for (int s = 0; s < S; ++s) a += sds[l * SP + s] * sk[s * HP + d];
+      dq[((size_t)l * N + n) * ldq + h * hd + d] = a * scale;
+    }
+  }
+  __syncthreads();
+  if (lane < S) {
+    const int s = lane;
+    for (int d = 0; d < hd; ++d) {
+      float av = 0.f, ak = 0.f;
+      for (int l = 0; l < L; ++l) {
+        av += sp[l * SP + s] * sdo[l * HP + d];
+        ak += sds[l * SP + s] * sq[l * HP + d];
+      }
+      dv[((size_t)s * N + n) * ldv + h * hd + d] = av;
+      dk[((size_t)s * N + n) * ldk + h * hd + d] = ak * scale;
+    }
+  }
+}
+
+extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out,
+                              float* probs, int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv,
+                              mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
+  if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L, S, N,
+                     H, hd, ldq, ldk, ldv);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                              float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
+                              long ldv, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
+  if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk, dv,
+                     L, S, N, H, hd, ldq, ldk, ldv);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = LayerNorm(x + r) (torch.nn.LayerNorm, eps 1e-5, biased variance); one wavefront per row.
+// r: NULL, same shape, or broadcast over time (r_rows = N rows, row index = row % N).
+// ---------------------------------------------------------------------------------------------
+#define LN_SLOTS 4  // d <= 256
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* __restrict__ xhat,
+                                                     float* __restrict__ rstd, int rows, int d, int r_rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * d;
+  const float* rr = r ? r + (size_t)(r_rows > 0 ? row % r_rows : row) * d : nullptr;
+  float vals[LN_SLOTS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_SLOTS; ++i) {
+    const int c = lane + 64 * i;
+    float v = 0.f;
+    if (c < d) v = xr[c] + (rr ? rr[c] : 0.f);
+    vals[i] = v;
+    s += v;
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_SLOTS; ++i) {
+    const int c = lane + 64 * i;
+    const float dv = c < d ? vals[i] - mean : 0.f;
+    ss += dv * dv;
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)d + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < LN_SLOTS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) {
+      const float xh = (vals[i] - mean) * rs;
+      xhat[(size_t)row * d + c] = xh;
+      y[(size_t)row * d + c] = xh * gamma[c] + beta[c];
+    }
+  }
+  if (lane == 0) rstd[row] = rs;
+}
+
+// dsum = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partials of dgamma, dbeta
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     float* __restrict__ dsum, float* __restrict__ ws, int rows, int d,
+                                                     int rows_per_block) {
+  __shared__ float sg[4][2 * 64 * LN_SLOTS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[LN_SLOTS], db[LN_SLOTS];
+#pragma unroll
+  for (int i = 0; i < LN_SLOTS; ++i) dg[i] = db[i] = 0.f;
+  const int row_beg = blockIdx.x * rows_per_block;
+  const int row_end = min(rows, row_beg + rows_per_block);
+  for (int row = row_beg + wave; row < row_end; row += 4) {
+    float g[LN_SLOTS], xh[LN_SLOTS];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_SLOTS; ++i) {
+      const int c = lane + 64 * i;
+      g[i] = xh[i] = 0.f;
+      if (c < d) {
+        const float dyv = dy[(size_t)row * d + c];
+        xh[i] = xhat[(size_t)row * d + c];
+        g[i] = dyv * gamma[c];
+        dg[i] += dyv * xh[i];
+        db[i] += dyv;
+      }
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < LN_SLOTS; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) dsum[(size_t)row * d + c] = rs * (g[i] - s1 - xh[i] * s2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_SLOTS; ++i) {
+    sg[wave][lane + 64 * i] = dg[i];
+    sg[wave][64 * LN_SLOTS + lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      a += sg[w][c];
+      b += sg[w][64 * LN_SLOTS + c];
+    }
+    ws[(size_t)blockIdx.x * 2 * d + c] = a;
+    ws[(size_t)blockIdx.x * 2 * d + d + c] = b;
+  }
+}
+
+static inline int ln_blocks(int rows, int* rpb) {
+  int nb = (rows + 31) / 32;
+  if (nb > 128) nb = 128;
+  *rpb = (rows + nb - 1) / nb;
+  return (rows + *rpb - 1) / *rpb;
+}
+extern "C" size_t mmvae_layernorm_ws_floats(int rows, int d) {
+  int rpb;
+  return (size_t)ln_blocks(rows, &rpb) * 2 * d;
+}
+extern "C" int mmvae_layernorm_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta,
+                                            float* y, float* xhat, float* rstd, int rows, int d, int r_rows,
+                                            mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && gamma && beta && y && xhat && rstd && rows > 0 && d > 0);
+  if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y,
+                     xhat, rstd, rows, d, r_rows);
+  return mmvae_launch_status();
+}
+// dgamma and dbeta must be adjacent when both given separately is not required: two reductions are issued.
+extern "C" int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                                            float* dsum, float* dgamma, float* dbeta, float* ws, int rows, int d,
+                                            int accumulate, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && xhat && rstd && gamma && dsum && dgamma && dbeta && ws && rows > 0 && d > 0);
+  if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
+  int rpb;
+  const int nb = ln_blocks(rows, &rpb);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, ws, rows,
+                     d, rpb);
+  int rc = mmvae_launch_status();
+  if (rc) return rc;
+  if (dbeta == dgamma + d) return mmvae_reduce_rows(ws, dgamma, nb, 2L * d, 2L * d, accumulate, stream);
+  rc = mmvae_reduce_rows(ws, dgamma, nb, d, 2L * d, accumulate, stream);
+  if (rc) return rc;
+  return mmvae_reduce_rows(ws + d, dbeta, nb, d, 2L * d, accumulate, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// time reductions over x (L,N,d): y[n,c] = scale * sum_l x[l,n,c];  and the broadcast backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_sum_kernel(const float* __restrict__ x, float* __restrict__ y, int L,
+                                                       long nd, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nd) return;
+  float a = 0.f;
+  for (int l = 0; l < L; ++l) a += x[(size_t)l * nd + i];
+  y[i] = a * scale;
+}
+__global__ __launch_bounds__(256) void time_bcast_kernel(const float* __restrict__ dy, float* __restrict__ dx, int L,
+                                                         long nd, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nd) return;
+  const float g = dy[i] * scale;
+  for (int l = 0; l < L; ++l) dx[(size_t)l * nd + i] = g;
+}
+extern "C" int mmvae_mean_over_time_fwd(const float* x, float* y, int L, int N, int d, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && y && L > 0 && N > 0 && d > 0);
+  const long nd = (long)N * d;
+  hipLaunchKernelGGL(time_sum_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, L,
+                     nd, 1.0f / (float)L);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_mean_over_time_bwd(const float* dy, float* dx, int L, int N, int d, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && dx && L > 0 && N > 0 && d > 0);
+  const long nd = (long)N * d;
+  hipLaunchKernelGGL(time_bcast_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                     L, nd, 1.0f / (float)L);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_sum_over_time(const float* x, float* y, int L, int N, int d, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && y && L > 0 && N > 0 && d > 0);
+  const long nd = (long)N * d;
+  hipLaunchKernelGGL(time_sum_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, L,
+                     nd, 1.0f);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder output: (T,B,V) -> (B,T,V) * mask[b,t]   (models/decoders.py:722) and its transpose
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void permute_mask_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                           float* __restrict__ y, int T, int B, int V, int fwd) {
+  const long n = (long)T * B * V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    // i indexes the (B,T,V) side
+    const int v = (int)(i % V);
+    const long bt = i / V;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const long j = ((long)t * B + b) * V + v;  // (T,B,V) side
+    const float mk = m[bt] ? 1.f : 0.f;
+    if (fwd) y[i] = x[j] * mk; else y[j] = x[i] * mk;
+  }
+}
+extern "C" int mmvae_permute_mask_fwd(const float* x, const uint8_t* mask, float* y, int T, int B, int V,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && mask && y && T > 0 && B > 0 && V > 0);
+  long blocks = ((long)T * B * V + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(permute_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mask, y, T, B,
+                     V, 1);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, float* dx, int T, int B, int V,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && mask && dx && T > 0 && B > 0 && V > 0);
+  long blocks = ((long)T * B * V + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(permute_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, mask, dx, T, B,
+                     V, 0);
+  return mmvae_launch_status();
+}

@@ -1,0 +1,151 @@
+"""ctypes binding of the C-ABI hot-path library (include/mmvae_hip.h -> libmmvae_hip.so).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function below passes
+raw device pointers + sizes + the stream to the extern "C" entry points.  There is NO fallback: if the
+library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_f = ctypes.c_float
+c_u = ctypes.c_uint
+c_sz = ctypes.c_size_t
+
+MAX_EXPERTS = 8
+
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+EP_NONE, EP_RELU, EP_MUL_RELU_MASK, EP_MUL_SILU_GRAD, EP_GELU, EP_MUL_GELU_GRAD, EP_SIGMOID_CLAMP = range(7)
+
+_ERR = {1: "invalid argument", 2: "unsupported shape", 3: "kernel launch failed"}
+
+
+class PoeFwdArgs(ctypes.Structure):
+    _fields_ = [("mu", c_p * MAX_EXPERTS), ("lv", c_p * MAX_EXPERTS), ("eps", c_p * MAX_EXPERTS),
+                ("z", c_p * MAX_EXPERTS)]
+
+
+class PoeBwdArgs(ctypes.Structure):
+    _fields_ = [("mu", c_p * MAX_EXPERTS), ("lv", c_p * MAX_EXPERTS), ("eps", c_p * MAX_EXPERTS),
+                ("dz", c_p * MAX_EXPERTS), ("dmu", c_p * MAX_EXPERTS), ("dlv", c_p * MAX_EXPERTS)]
+
+
+# name -> (restype, argtypes); must list every symbol include/mmvae_hip.h declares (tests check this)
+SIGNATURES = {
+    "mmvae_version": (c_i, []),
+    "mmvae_arch": (ctypes.c_char_p, []),
+    "mmvae_conv2d_k4s2_fwd": (c_i, [c_p] * 5 + [c_i] * 6 + [c_p]),
+    "mmvae_conv2d_k4s2_dgrad": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
+    "mmvae_conv2d_k4s2_wgrad": (c_i, [c_p] * 5 + [c_i] * 6 + [c_p]),
+    "mmvae_convT2d_k4s2_fwd": (c_i, [c_p] * 5 + [c_i] * 6 + [c_p]),
+    "mmvae_convT2d_k4s2_dgrad": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
+    "mmvae_convT2d_k4s2_wgrad": (c_i, [c_p] * 5 + [c_i] * 6 + [c_p]),
+    "mmvae_conv_wgrad_ws_floats": (c_sz, [c_i] * 4),
+    "mmvae_gemm_f32": (c_i, [c_p] * 7 + [c_i] * 3 + [c_l] * 5 + [c_i] * 5 + [c_p]),
+    "mmvae_gemm_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_linear_fwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
+    "mmvae_linear_bwd_data": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
+    "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
+    "mmvae_linear_bwd_weight_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_head_softmax_fwd": (c_i, [c_p, c_i, c_i, c_p]),
+    "mmvae_head_softmax_bwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "mmvae_poe_reparam_kl_fwd": (c_i, [ctypes.POINTER(PoeFwdArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i, c_i,
+                                       c_p]),
+    "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
+                                       c_i, c_i, c_p]),
+    "mmvae_poe_ws_floats": (c_sz, [c_i, c_i]),
+    "mmvae_bce_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 2 + [c_p]),
+    "mmvae_bce_sigmoid_clamp_bwd": (c_i, [c_p] * 4 + [c_i] * 2 + [c_p]),
+    "mmvae_bce_rowsum_bwd": (c_i, [c_p] * 4 + [c_i] * 2 + [c_p]),
+    "mmvae_sigmoid_clamp_bwd": (c_i, [c_p] * 3 + [c_l] + [c_p]),
+    "mmvae_bce_elem_fwd": (c_i, [c_p] * 3 + [c_l] + [c_p]),
+    "mmvae_ce_over_time_fwd": (c_i, [c_p] * 4 + [c_i] * 3 + [c_p]),
+    "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_p]),
+    "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_p]),
+    "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
+    "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_p]),
+    "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_p]),
+    "mmvae_layernorm_residual_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_p]),
+    "mmvae_layernorm_residual_bwd": (c_i, [c_p] * 8 + [c_i] * 3 + [c_p]),
+    "mmvae_layernorm_ws_floats": (c_sz, [c_i, c_i]),
+    "mmvae_mean_over_time_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_mean_over_time_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_sum_over_time": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_permute_mask_fwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
+    "mmvae_permute_mask_bwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
+    "mmvae_adam_amsgrad_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_i, c_p, c_f, c_i, c_p]),
+    "mmvae_step_inc": (c_i, [c_p, c_p]),
+    "mmvae_reduce_rows": (c_i, [c_p, c_p, c_i, c_l, c_l, c_i, c_p]),
+    "mmvae_fill": (c_i, [c_p, c_l, c_f, c_p]),
+}
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  `import torch` has already loaded the HIP runtime
+    (libamdhip64.so.7) this library links against, so both share one runtime and one set of streams."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "
+                f"`make -C multimodal_vae_comparison_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "HIP ops need tensors on the GPU (no CPU fallback)"
+    return t.data_ptr()
+
+
+def f32c(t):
+    """contiguous fp32 view/copy of a CUDA tensor"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_ws = {}
+
+
+def workspace(n_floats, device):
+    """Caller-provided scratch for the *_ws_floats() contracts; grows monotonically per device.  Ops on one
+    stream run in order, so consecutive ops may share it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    t = _ws.get(key)
+    if t is None or t.numel() < n_floats:
+        t = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def reserve_workspace(n_floats, device):
+    """Pre-size the workspace (call before hipGraph capture so capture never reallocates it)."""
+    return workspace(n_floats, device)
