@@ -1,0 +1,86 @@
+"""One flat fp32 parameter buffer + one flat gradient buffer + fused Adam(amsgrad) (host plumbing).
+
+Why: the model has ~180 small tensors (0.99 M parameters).  Laid out contiguously they need ONE Adam kernel,
+ONE RCCL all-reduce (3.95 MB) and no per-tensor AccumulateGrad kernels: the weight-gradient kernels
+accumulate straight into views of `grad` (ops.py).  Layers that want several tensors adjacent (weight|bias,
+the mu|logvar head pair) declare `flat_groups()`; everything is 16-byte aligned.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, module: nn.Module):
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        by_id = {id(p): (n, p) for n, p in params}
+        order, seen = [], set()
+        for m in module.modules():
+            groups = m.flat_groups() if hasattr(m, "flat_groups") else []
+            for g in groups:
+                g = [p for p in g if p is not None and id(p) in by_id and id(p) not in seen]
+                if g:
+                    order.append(g)
+                    seen.update(id(p) for p in g)
+        for n, p in params:
+            if id(p) not in seen:
+                order.append([p])
+                seen.add(id(p))
+        offs, total = [], 0
+        for g in order:
+            total = (total + 3) // 4 * 4           # 16-byte alignment of every group
+            for p in g:
+                offs.append((p, total))
+                total += p.numel()
+        total = (total + 3) // 4 * 4
+        dev = params[0][1].device
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.n_params = sum(p.numel() for _, p in params)
+        self.index = {}
+        for p, o in offs:
+            self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + p.numel()].view(p.shape)
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            self.index[by_id[id(p)][0]] = (o, tuple(p.shape))
+        self.params = [p for p, _ in offs]
+
+    def rebind_grads(self):
+        """(re)attach the flat gradient views (after an optimizer.zero_grad(set_to_none=True))"""
+        for name_off, p in zip(self.index.values(), self.params):
+            o, shape = name_off
+            p.grad = self.grad[o:o + p.numel()].view(shape)
+
+    def zero_grad(self):
+        ops.fill(self.grad, 0.0)
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, amsgrad=True) (reference: models/trainer.py:79-81)
+    as one kernel over the flat buffer.  The step count lives on the device so that a captured hipGraph
+    replays with the correct bias correction."""
+
+    def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps, amsgrad=True))
+        self.flat = flat
+        self.m = torch.zeros_like(flat.data)
+        self.v = torch.zeros_like(flat.data)
+        self.vmax = torch.zeros_like(flat.data)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.data.device)
+        self.grad_scale = grad_scale
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        ops.step_inc(self.step_dev)
+        ops.adam_amsgrad_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]),
+                              g["betas"][0], g["betas"][1], g["eps"], 0, self.step_dev, self.grad_scale, True)
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        # step() already clears the buffer inside the Adam kernel; an explicit zero_grad() (Lightning calls it
+        # every step) keeps torch semantics: clear, and keep the flat views attached.
+        self.flat.rebind_grads()
+        self.flat.zero_grad()

@@ -1,0 +1,144 @@
+"""Decoder towers behind the reference's plugin names (`Dec_<Name>(latent_dim, data_dim, latent_private)`;
+reference: models/decoders.py).  Same signatures / attributes / state_dict keys (including the `.module.`
+segment of the reference's per-layer nn.DataParallel wrappers); arithmetic on the gfx950 kernels."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hipops as H
+from .. import ops
+from .NetworkTypes import NetworkRoles, NetworkTypes
+from .encoders import VaeComponent
+from .nn_modules import HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
+
+
+class VaeDecoder(VaeComponent):
+    def __init__(self, latent_dim, data_dim, latent_private, net_type: NetworkTypes):
+        # the reference passes net_type in the enc_mu_logvar slot (decoders.py:32); no numeric effect
+        super().__init__(latent_dim, data_dim, latent_private, net_type, NetworkRoles.DECODER)
+
+
+class HipConvT2d(nn.Module):
+    """nn.ConvTranspose2d(k=4, s=2, p=1) parameters (torch default init) on the MFMA kernels."""
+
+    def __init__(self, cin, cout, in_act=H.ACT_NONE, out_ep=H.EP_NONE):
+        super().__init__()
+        ref = nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1)
+        self.weight, self.bias = ref.weight, ref.bias
+        self.in_act, self.out_ep = in_act, out_ep
+
+    def flat_groups(self):
+        return [[self.weight, self.bias]]
+
+    def forward(self, x):
+        return ops.convT2d_k4s2(x, self.weight, self.bias, self.in_act, self.out_ep, self.weight.grad, self.bias.grad)
+
+
+class Dec_CNN(VaeDecoder):
+    """models/decoders.py:35-98: 3x [Linear + ReLU] D'->512->512->512, view (K*B,32,4,4), 3x [ConvT + ReLU],
+    ConvT 32->3, sigmoid, clamp[1e-6, 1-1e-6]; output labelled (..., 64,64,3) by view (no permute).
+    Every ReLU is applied by the consuming layer; sigmoid+clamp is the last kernel's epilogue."""
+
+    def __init__(self, latent_dim, data_dim, latent_private):
+        super().__init__(latent_dim, data_dim, latent_private, net_type=NetworkTypes.CNN)
+        hid, hidden_dim = 32, 512
+        self.reshape = (hid, 4, 4)
+        self.n_chan = 3
+        self.lin1 = ModuleWrap(HipLinear(self.out_dim, hidden_dim, H.ACT_NONE))
+        self.lin2 = ModuleWrap(HipLinear(hidden_dim, hidden_dim, H.ACT_RELU))
+        self.lin3 = ModuleWrap(HipLinear(hidden_dim, int(np.prod(self.reshape)), H.ACT_RELU))
+        self.convT_64 = ModuleWrap(HipConvT2d(hid, hid, H.ACT_RELU))
+        self.convT1 = ModuleWrap(HipConvT2d(hid, hid, H.ACT_RELU))
+        self.convT2 = ModuleWrap(HipConvT2d(hid, hid, H.ACT_RELU))
+        self.convT3 = ModuleWrap(HipConvT2d(hid, self.n_chan, H.ACT_RELU, H.EP_SIGMOID_CLAMP))
+
+    def forward(self, z):
+        z = z["latents"]
+        if z.dim() == 2:
+            z = z.unsqueeze(0)
+        K, bs = z.shape[0], z.shape[1]
+        u = self.lin3(self.lin2(self.lin1(z.reshape(K * bs, -1))))
+        u = u.view(bs * K, *self.reshape)
+        d = self.convT3(self.convT2(self.convT1(self.convT_64(u))))        # (K*B,3,64,64) clamped sigmoid
+        d = d.view(*z.size()[:-1], *self.data_dim)                          # decoders.py:96 (view, no permute)
+        return d.squeeze().reshape(-1, *self.data_dim), torch.tensor(0.75, device=z.device)
+
+
+class HipTransformerDecoderLayer(nn.Module):
+    """torch.nn.TransformerDecoderLayer (post-norm, gelu) parameter layout.  Memory length 1 (K = 1 latent
+    sample, decoders.py:718): the cross-attention softmax is identically 1."""
+
+    def __init__(self, d, nhead, ff):
+        super().__init__()
+        self.self_attn = HipSelfAttention(d, nhead)
+        self.multihead_attn = HipSelfAttention(d, nhead)
+        self.linear1 = HipLinear(d, ff)
+        self.linear2 = HipLinear(ff, d, H.ACT_GELU)
+        self.norm1 = HipLayerNorm(d)
+        self.norm2 = HipLayerNorm(d)
+        self.norm3 = HipLayerNorm(d)
+
+    def forward(self, x, mem, kpm_u8):
+        x = self.norm1(self.self_attn(x, kpm_u8), x)
+        x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
+        return self.norm3(self.linear2(self.linear1(x)), x)
+
+
+class HipTransformerDecoderStack(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+
+class Dec_TxtTransformer(VaeDecoder):
+    """models/decoders.py:668-723"""
+
+    def __init__(self, latent_dim, data_dim, latent_private, ff_size=128, num_layers=1, num_heads=2, dropout=0.1,
+                 activation="gelu"):
+        super().__init__(latent_dim, data_dim, latent_private, net_type=NetworkTypes.TXTTRANSFORMER)
+        assert activation == "gelu"
+        self.net_type = "Transformer"
+        self.njoints = data_dim[1]
+        self.nfeats = data_dim[2] if len(data_dim) > 2 else 1
+        self.data_dim = data_dim
+        self.latent_dim = latent_dim
+        self.ff_size, self.num_layers, self.num_heads, self.dropout = ff_size, num_layers, num_heads, dropout
+        self.input_feats = self.njoints * self.nfeats
+        self.seqTransDecoder = HipTransformerDecoderStack(
+            [HipTransformerDecoderLayer(self.out_dim, num_heads, ff_size) for _ in range(num_layers)])
+        self.finallayer = ModuleWrap(HipLinear(self.out_dim, self.input_feats))
+        self.sequence_pos_encoder = ModuleWrap(PositionalEncoding(self.out_dim, self.dropout))
+        self._tq_cache = {}
+
+    def _timequeries(self, T, bs, D, device):
+        """PositionalEncoding(zeros(T,bs,D)) = pe[:T] broadcast over the batch (decoders.py:716-717); constant for
+        a given (T, bs), so it is materialised once."""
+        key = (T, bs, D, str(device))
+        tq = self._tq_cache.get(key)
+        if tq is None:
+            pe = self.sequence_pos_encoder.module.pe[:T].to(device)          # (T,1,D)
+            tq = pe.expand(T, bs, D).contiguous()
+            self._tq_cache = {key: tq}
+        return tq
+
+    def forward(self, batch):
+        z = batch["latents"]
+        z = z.unsqueeze(0) if z.dim() == 2 else z
+        mask = batch["masks"]
+        K, bs, D = z.shape
+        if K != 1:
+            # the reference attends over the K samples as a length-K memory and then fails to reshape
+            # (SURVEY 0.4 / Appendix B17); only K = 1 is defined
+            raise NotImplementedError("Dec_TxtTransformer is defined for K = 1 latent sample only")
+        if mask is None:
+            mask = torch.ones(bs, self.data_dim[0], dtype=torch.bool, device=z.device)
+        mask = mask.to(z.device)
+        T = mask.shape[1]
+        kpm = (~mask).to(torch.uint8).contiguous()
+        x = self._timequeries(T, bs, D, z.device)
+        mem = z[0]
+        for layer in self.seqTransDecoder.layers:
+            x = layer(x, mem, kpm)
+        out = self.finallayer(x)                                              # (T, bs, V)
+        out = ops.permute_mask(out, mask.to(torch.uint8).contiguous())        # (bs, T, V), zero at padding
+        return out, torch.tensor(0.75, device=z.device)

@@ -1,0 +1,193 @@
+"""Encoder towers behind the reference's plugin names (`Enc_<Name>(latent_dim, data_dim, latent_private,
+enc_mu_logvar)`, looked up by string in models/vae.py; reference: models/encoders.py).
+
+Same constructor signatures, attributes (latent_dim, data_dim, out_dim) and state_dict key names as the
+reference; the arithmetic runs on the gfx950 kernels of the C-ABI library (no torch.nn.functional compute).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hipops as H
+from .. import ops
+from .NetworkTypes import NetworkRoles, NetworkTypes
+from .nn_modules import HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
+
+
+class VaeComponent(nn.Module):
+    """models/encoders.py:15-54"""
+
+    def __init__(self, latent_dim, data_dim, latent_private=None, enc_mu_logvar=True,
+                 net_type=NetworkTypes.UNSPECIFIED, net_role=NetworkRoles.UNSPECIFIED):
+        super().__init__()
+        self.net_role = net_role
+        self.latent_dim = latent_dim
+        self.enc_mu_logvar = enc_mu_logvar
+        self.latent_private = latent_private
+        self.out_dim = latent_dim + latent_private if latent_private is not None else latent_dim
+        self.data_dim = data_dim
+        self.net_type = net_type
+        self.mu_layer = None
+        self.logvar_layer = None
+
+    def init_final_layers(self, in_feats):
+        self.mu_layer = HipLinear(in_feats, self.out_dim)
+        if self.enc_mu_logvar:
+            self.logvar_layer = HipLinear(in_feats, self.out_dim)
+
+    # the two heads are laid out as one (2*out_dim, F) weight so that one GEMM produces [mu | u]
+    def _heads(self):
+        mu = self.mu_layer.module if isinstance(self.mu_layer, ModuleWrap) else self.mu_layer
+        lv = self.logvar_layer.module if isinstance(self.logvar_layer, ModuleWrap) else self.logvar_layer
+        return mu, lv
+
+    def flat_groups(self):
+        if self.mu_layer is None or self.logvar_layer is None:
+            return []
+        mu, lv = self._heads()
+        return [[mu.weight, lv.weight], [mu.bias, lv.bias]]
+
+    def process_output(self, data, in_act=H.ACT_NONE):
+        """mu = W_mu h + b;  "logvar" = softmax(W_lv h + b, -1) + 1e-6   (models/encoders.py:49-54).
+        Returns views of one packed (B, 2*out_dim) tensor; `mu._base` is that tensor (used by the fused
+        latent kernel)."""
+        mu_l, lv_l = self._heads()
+        D = self.out_dim
+        if not self.enc_mu_logvar:
+            return mu_l(data, in_act)
+        w_mu, w_lv, b_mu, b_lv = mu_l.weight, lv_l.weight, mu_l.bias, lv_l.bias
+        gw_mu, gw_lv, gb_mu, gb_lv = w_mu.grad, w_lv.grad, b_mu.grad, b_lv.grad
+        fused = (w_lv.data_ptr() == w_mu.data_ptr() + 4 * w_mu.numel()
+                 and b_lv.data_ptr() == b_mu.data_ptr() + 4 * b_mu.numel()
+                 and None not in (gw_mu, gw_lv, gb_mu, gb_lv)
+                 and gw_lv.data_ptr() == gw_mu.data_ptr() + 4 * w_mu.numel()
+                 and gb_lv.data_ptr() == gb_mu.data_ptr() + 4 * b_mu.numel()
+                 and data.requires_grad)
+        if fused:   # flat layout (flat.py): one (2D, F) GEMM, gradients accumulated in place
+            F = w_mu.shape[1]
+            w = torch.as_strided(w_mu.detach(), (2 * D, F), (F, 1))
+            b = torch.as_strided(b_mu.detach(), (2 * D,), (1,))
+            gw = torch.as_strided(gw_mu, (2 * D, F), (F, 1))
+            gb = torch.as_strided(gb_mu, (2 * D,), (1,))
+            h = ops.linear(data, w, b, in_act, gw, gb)
+        else:
+            h = torch.cat([mu_l(data, in_act), lv_l(data, in_act)], dim=-1)
+        h = ops.head_softmax(h)
+        return h[:, :D], h[:, D:]
+
+
+class VaeEncoder(VaeComponent):
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar, net_type: NetworkTypes):
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type, NetworkRoles.ENCODER)
+
+
+class HipConv2d(nn.Module):
+    """nn.Conv2d(k=4, s=2, p=1) parameters (torch default init) on the MFMA implicit-GEMM kernels."""
+
+    def __init__(self, cin, cout, in_act=H.ACT_NONE):
+        super().__init__()
+        ref = nn.Conv2d(cin, cout, 4, stride=2, padding=1)
+        self.weight, self.bias = ref.weight, ref.bias
+        self.in_act = in_act
+
+    def flat_groups(self):
+        return [[self.weight, self.bias]]
+
+    def forward(self, x):
+        return ops.conv2d_k4s2(x, self.weight, self.bias, self.in_act, self.weight.grad, self.bias.grad)
+
+
+class Enc_CNN2(VaeEncoder):
+    """models/encoders.py:163-223: 4x [Conv2d(k4,s2,p1) + SiLU] 3->32->32->32->32, flatten, Linear 512->512, heads.
+    The SiLU of layer l is applied by layer l+1 while it stages its input (ops.py conventions)."""
+
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar):
+        data_dim = (3, 64, 64)
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.CNN)
+        hid = 32
+        self.hidden_dim = 512
+        self.reshape = (hid, 4, 4)
+        self.conv1 = HipConv2d(3, hid, H.ACT_NONE)
+        self.conv2 = HipConv2d(hid, hid, H.ACT_SILU)
+        self.conv3 = HipConv2d(hid, hid, H.ACT_SILU)
+        self.conv4 = HipConv2d(hid, hid, H.ACT_SILU)
+        self.lin1 = HipLinear(int(np.prod(self.reshape)), self.hidden_dim, H.ACT_SILU)
+        self.init_final_layers(self.hidden_dim)
+
+    def forward(self, x):
+        if isinstance(x, dict):
+            x = x["data"]
+        bs = x.size(0)
+        u = self.conv4(self.conv3(self.conv2(self.conv1(x.float()))))
+        o5 = self.lin1(u.view(bs, -1))
+        return self.process_output(o5)
+
+
+class Enc_CNN(VaeEncoder):
+    """`encoder: CNN` in the reference is a torchvision ResNet-50 with downloaded ImageNet weights
+    (models/encoders.py:86-127); it is outside this build's hot-path scope and cannot be
+    constructed offline.  Use `encoder: CNN2` for the conv tower."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("Enc_CNN (ResNet-50 + ImageNet weights) is not part of the MI355X hot path; "
+                                  "use encoder: CNN2 (see DESIGN.md, out of scope)")
+
+
+class HipTransformerEncoderLayer(nn.Module):
+    """torch.nn.TransformerEncoderLayer (post-norm, gelu) parameter layout on the HIP kernels."""
+
+    def __init__(self, d, nhead, ff):
+        super().__init__()
+        self.self_attn = HipSelfAttention(d, nhead)
+        self.linear1 = HipLinear(d, ff)
+        self.linear2 = HipLinear(ff, d, H.ACT_GELU)
+        self.norm1 = HipLayerNorm(d)
+        self.norm2 = HipLayerNorm(d)
+
+    def forward(self, x, kpm_u8):
+        x = self.norm1(self.self_attn(x, kpm_u8), x)
+        return self.norm2(self.linear2(self.linear1(x)), x)
+
+
+class HipTransformerStack(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+
+class Enc_TxtTransformer(VaeEncoder):
+    """models/encoders.py:790-837 incl. the PositionalEncoding quirk."""
+
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar, ff_size=128, num_layers=1, num_heads=2,
+                 dropout=0.1, activation="gelu"):
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.TXTTRANSFORMER)
+        assert activation == "gelu" and num_layers >= 1
+        self.net_type = "TxtTransformer"
+        self.njoints, self.nfeats = data_dim[-1], data_dim[-2]
+        self.ff_size, self.num_layers, self.num_heads, self.dropout = ff_size, num_layers, num_heads, dropout
+        self.hidden_dim = self.out_dim
+        self.input_feats = self.njoints * self.nfeats
+        self.embedding_size = 2
+        self.embedding = nn.Embedding(self.input_feats, self.embedding_size)
+        self.sequence_pos_encoder = PositionalEncoding(self.embedding_size, self.dropout)
+        d = self.input_feats * self.embedding_size
+        self.seqTransEncoder = HipTransformerStack([HipTransformerEncoderLayer(d, num_heads, ff_size)
+                                                    for _ in range(num_layers)])
+        self.mu_layer = ModuleWrap(HipLinear(d, self.out_dim))
+        self.logvar_layer = ModuleWrap(HipLinear(d, self.out_dim))
+
+    def forward(self, batch):
+        x, mask = batch["data"], batch["masks"]
+        bs, nframes, _ = x.shape
+        if bs > self.sequence_pos_encoder.pe.shape[0]:
+            raise RuntimeError("batch larger than the positional table (reference: pe[:B], nn_modules.py:419)")
+        if mask is None:
+            mask = torch.ones(bs, nframes, dtype=torch.bool, device=x.device)
+        kpm = (~mask).to(torch.uint8).contiguous()
+        mode = 1 if (bs == nframes or bs == 1) else 0
+        w = self.embedding.weight
+        h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad)   # (T, B, 2V)
+        for layer in self.seqTransEncoder.layers:
+            h = layer(h, kpm)
+        z = ops.mean_over_time(h)
+        return self.process_output(z)

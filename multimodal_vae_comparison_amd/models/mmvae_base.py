@@ -1,0 +1,124 @@
+"""TorchMMVAE: base class of the multimodal mixers (reference: models/mmvae_base.py)."""
+import abc
+
+import numpy as np
+import torch
+import torch.distributions as dist
+import torch.nn as nn
+
+from .. import ops
+from .objectives import MultimodalObjective
+from .output_storage import VAEOutput
+
+
+def normal(loc, scale):
+    """torch.distributions.Normal without the argument validation pass (it forces a device->host sync)."""
+    return dist.Normal(loc, scale, validate_args=False)
+
+
+def packed_head(mu, lv):
+    """(B, 2D) = [mu | lv].  The towers of this package return mu / lv as the two halves of one tensor
+    (VaeComponent.process_output); recover it without a copy, else concatenate."""
+    base = mu._base
+    if base is not None and base is lv._base and base.dim() == 2 and base.shape[1] == 2 * mu.shape[1] \
+            and mu.data_ptr() == base.data_ptr() and lv.data_ptr() == base.data_ptr() + 4 * mu.shape[1] \
+            and base.is_contiguous():
+        return base
+    return torch.cat([mu, lv], dim=-1).contiguous()
+
+
+class TorchMMVAE(nn.Module):
+    """mmvae_base.py:12-240.  Plugin contract: subclass, implement modality_mixing(mods) and
+    objective(mods) -> {"loss": scalar, ["reconstruction_loss": ..., "kld": ...]}."""
+
+    def __init__(self, vaes, n_latents: int, obj: str, beta=1, K=1):
+        super().__init__()
+        self.vaes = nn.ModuleDict(vaes)
+        self.modelName = "TorchMMVAE"
+        self.qz_x = self.px_z = self.pz = dist.Normal
+        self.n_latents = n_latents
+        self.K = K
+        self.obj_fn = MultimodalObjective(obj, beta)
+        self._pz_params = nn.ParameterList([
+            nn.Parameter(torch.zeros(1, self.n_latents), requires_grad=False),  # mu
+            nn.Parameter(torch.zeros(1, self.n_latents), requires_grad=True)])  # logvar (trainable, mmvae_base.py:35-38)
+        self.set_likelihood_scales()
+        self.eps_override = None    # list of (K,B,D) noise tensors consumed in draw order (parity tests)
+
+    def set_likelihood_scales(self):
+        """mmvae_base.py:41-47"""
+        min_dim = min([np.prod(vae.enc.data_dim) for vae in self.vaes.values()])
+        for vae in self.vaes.values():
+            if vae.llik_scaling == "auto":
+                vae.llik_scaling = min_dim / np.prod(vae.enc.data_dim)
+            else:
+                vae.llik_scaling = float(vae.llik_scaling)
+
+    @property
+    def latent_factorization(self):
+        return any(v.private_latents is not None for v in self.vaes.values())
+
+    # ---- noise ----------------------------------------------------------------------------------
+    def _draw(self, B, D, device):
+        """one standard-normal draw of shape (B, D): replayed from `eps_override` or from the device generator"""
+        if self.eps_override is not None:
+            e = self.eps_override.pop(0)
+            return e.reshape(B, D).to(device=device, dtype=torch.float32).contiguous()
+        return torch.randn(B, D, device=device)
+
+    # ---- plumbing shared by the mixers ----------------------------------------------------------
+    def make_output_dict(self, encoder_dist=None, decoder_dist=None, latent_samples=None, joint_dist=None,
+                         enc_dist_private=None, dec_dist_private=None, joint_decoder_dist=None,
+                         cross_decoder_dist=None):
+        out = VAEOutput()
+        for v in ["encoder_dist", "decoder_dist", "latent_samples", "joint_dist", "enc_dist_private",
+                  "dec_dist_private", "joint_decoder_dist", "cross_decoder_dist"]:
+            out.set_with_dict(locals()[v], v)
+        return out
+
+    def encode(self, inputs):
+        """mmvae_base.py:139-159"""
+        qz_xs = {}
+        for modality, vae in self.vaes.items():
+            if modality in inputs and inputs[modality]["data"] is not None:
+                qz_x = vae.enc(inputs[modality])
+                if not self.latent_factorization:
+                    qz_xs[modality] = {"shared": qz_x, "private": None}
+                else:
+                    n = vae.n_latents
+                    qz_xs[modality] = {"shared": [qz_x[0][:, :n], qz_x[1][:, :n]],
+                                       "private": [qz_x[0][:, n:], qz_x[1][:, n:]]}
+            elif modality in inputs and inputs[modality]["data"] is None:
+                qz_xs[modality] = {"shared": None, "private": None}
+        return qz_xs
+
+    def decode(self, samples):
+        """mmvae_base.py:185-201"""
+        pz_xs = {}
+        for modality, vae in self.vaes.items():
+            if modality in samples and samples[modality]["latents"] is not None:
+                pz_xs[modality] = vae.dec(samples[modality])
+            elif modality in samples and samples[modality]["latents"] is None:
+                pz_xs[modality] = None
+        return pz_xs
+
+    @abc.abstractmethod
+    def modality_mixing(self, mods):
+        pass
+
+    @abc.abstractmethod
+    def objective(self, mods):
+        pass
+
+    def product_of_experts(self, mu, logvar, with_prior=False):
+        """mmvae_base.py:203-222 on the fused kernel: mu/logvar are lists of (B,D) tensors; returns
+        (mu, VARIANCE) of the product (the reference returns the variance as `pd_logvar`)."""
+        packed = [packed_head(m, l) for m, l in zip(mu, logvar)]
+        joint, _, _ = ops.poe_reparam_kl(self._pz_params[1], packed, [], with_prior, 0, self._pz_params[1].grad)
+        return joint[0], joint[1]
+
+    def get_missing_modalities(self, mods):
+        keys, keys_with_val = [], []
+        for modality, val in mods.items():
+            (keys if val["data"] is None else keys_with_val).append(modality)
+        return keys, keys_with_val

@@ -1,0 +1,202 @@
+"""The multimodal mixers behind the reference's registry names (reference: models/mmvae_models.py).
+
+`objective()` is the per-step hot path: towers -> ONE fused latent kernel (product of experts, reparameterised
+samples, analytic KL rows) -> decoders -> fused per-sample reconstruction sums -> ONE ELBO assembly kernel.
+No host synchronisation anywhere (the reference forces >= 6 per step)."""
+from itertools import chain, combinations
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .mmvae_base import TorchMMVAE, normal, packed_head
+from .objectives import recon_rowsum
+
+
+class MoPOE(TorchMMVAE):
+    """Generalised multimodal ELBO (mmvae_models.py:253-410).
+
+    Parity-critical behaviour of the reference kept as is (SURVEY Appendix B + tests/golden):
+      * the subset posteriors are stacked as (n_subsets, 1, B, D), so `mixture_component_selection`
+        (mmvae_models.py:396-410) splits the SINGLETON axis: the joint posterior is the LAST subset -- the product
+        of all modality experts and the N(0,1) prior expert -- for every sample;
+      * encoder "logvar" = softmax + 1e-6 is used as log-variance inside the product and as sigma in Normal();
+        the product returns the variance, used as sigma; one independent z per modality from the same joint;
+      * KL terms: q_m = N(mu_m, sigma = lv_m) and the joint, against N(0, softmax(theta) * D), weights 1/(M+1).
+    """
+
+    def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
+        super().__init__(vaes, n_latents, **obj_config)
+        self.model_config = model_config
+        self.modelName = "mopoe"
+        self.subsets = self.set_subsets()
+        self.weights = None
+
+    @property
+    def pz_params(self):
+        return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
+
+    def set_subsets(self):
+        """mmvae_models.py:279-294: non-empty subsets in itertools.combinations order, keyed 'mod_i_mod_j'"""
+        xs = list(self.vaes.keys())
+        subsets = {}
+        for mod_names in chain.from_iterable(combinations(xs, n) for n in range(len(xs) + 1)):
+            subsets["_".join(sorted(mod_names))] = [self.vaes[m] for m in sorted(mod_names)]
+        subsets.pop("", None)
+        return subsets
+
+    # ---- hot path --------------------------------------------------------------------------------
+    def objective(self, mods):
+        """mmvae_models.py:296-320 + weighted_group_kld (objectives.py:184-201)"""
+        names = list(self.vaes.keys())
+        M = len(names)
+        enc = [self.vaes[n].enc(mods[n]) for n in names]
+        packed = [packed_head(mu, lv) for mu, lv in enc]
+        B, D = packed[0].shape[0], self.n_latents
+        dev = packed[0].device
+        eps = [self._draw(B, D, dev) for _ in names]                       # one rsample per modality (:363-369)
+        theta = self._pz_params[1]
+        _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad)
+        recs = []
+        for i, n in enumerate(names):
+            vae = self.vaes[n]
+            out, _ = vae.dec({"latents": z[i].unsqueeze(0), "masks": mods[n]["masks"]})
+            recs.append(recon_rowsum(vae.ltype, out, mods[n]))             # (B,) = -lpx_z / llik_scaling
+        V = torch.cat([torch.stack(recs), kl], dim=0)                       # (M + M+1, B)
+        w_kl = 1.0 / (M + 1)
+        lam = [float(self.vaes[n].llik_scaling) for n in names]
+        W = [[l / B for l in lam] + [self.obj_fn.beta * w_kl / B] * (M + 1),
+             [0.0] * M + [w_kl / B] * (M + 1)]
+        out = ops.lincomb_rows(V, W)
+        return {"loss": out[0], "kld": out[1], "reconstruction_loss": recs}
+
+    # ---- API surface (inference / evaluation) ------------------------------------------------------
+    def modality_mixing(self, input_batch):
+        """mmvae_models.py:322-349"""
+        latents = {}
+        enc_mods = self.encode(input_batch)
+        latents["modalities"] = enc_mods
+        distr_subsets, last = {}, None
+        n_all = len(self.vaes)
+        for s_key, mods in self.subsets.items():
+            if all(m.modelName in input_batch and input_batch[m.modelName]["data"] is not None for m in mods):
+                mus = [enc_mods[m.modelName]["shared"][0] for m in mods]
+                lvs = [enc_mods[m.modelName]["shared"][1] for m in mods]
+                s_mu, s_var = self.product_of_experts(mus, lvs, with_prior=(len(mods) == n_all))   # :385-389
+                distr_subsets[s_key] = [s_mu.unsqueeze(0), s_var.unsqueeze(0)]
+                last = (s_mu, s_var)
+        self.weights = (1 / float(len(distr_subsets))) * torch.ones(len(distr_subsets), device=last[0].device)
+        latents["joint"] = [last[0], last[1]]        # singleton-axis selection => last available subset (:396-410)
+        latents["subsets"] = distr_subsets
+        return latents
+
+    def forward(self, inputs, K=1):
+        """mmvae_models.py:351-370"""
+        latents = self.modality_mixing(inputs)
+        qz_d, px_d, z_d, qz_joint = {}, {}, {}, {}
+        j_mu, j_var = latents["joint"]
+        for mod, vae in self.vaes.items():
+            sh = latents["modalities"][mod]["shared"]
+            qz_d[mod] = normal(*sh) if sh is not None else None
+            qz_joint[mod] = normal(j_mu, j_var)
+            eps = torch.stack([self._draw(j_mu.shape[0], j_mu.shape[1], j_mu.device) for _ in range(K)])
+            z = j_mu + j_var * eps
+            z_d[mod] = {"latents": z, "masks": inputs[mod]["masks"]}
+            px_d[mod] = normal(*vae.dec(z_d[mod]))
+        return self.make_output_dict(qz_d, px_d, z_d, qz_joint)
+
+
+class POE(TorchMMVAE):
+    """MVAE, product of experts (mmvae_models.py:134-250)."""
+
+    def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
+        super().__init__(vaes, n_latents, **obj_config)
+        self.model_config = model_config
+        self.modelName = "poe"
+        for vae in self.vaes.values():
+            assert vae.prior_str in ["normal", "gaussian"], "POE only works with gaussian priors! Adjust the config"
+        # utils.subsample_input_modalities (utils.py:86-112) iterates a Python set => its order within one subset
+        # size depends on PYTHONHASHSEED; the default here is itertools order, `subset_order` pins another one.
+        self.subset_order = None
+
+    @property
+    def pz_params(self):
+        return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
+
+    def _subsets(self):
+        names = list(self.vaes.keys())
+        if self.subset_order is not None:
+            return [tuple(names[i] for i in s) for s in self.subset_order]
+        return [c for n in range(1, len(names) + 1) for c in combinations(names, n)]
+
+    def objective(self, mods):
+        """mmvae_models.py:159-187: sum over input subsets of -(sum_b sum_m lpx - beta sum_b KL(joint || prior))"""
+        names = list(self.vaes.keys())
+        M = len(names)
+        theta = self._pz_params[1]
+        rows, W_loss, W_kld = [], [], []
+        rec_log = [None] * M
+        subsets = self._subsets()
+        for s_idx, S in enumerate(subsets):
+            packed = [packed_head(*self.vaes[n].enc(mods[n])) for n in names if n in S]
+            B, D = packed[0].shape[0], self.n_latents
+            eps = [self._draw(B, D, packed[0].device)]
+            E = len(packed)
+            _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, 1 << E, theta.grad)
+            for i, n in enumerate(names):
+                vae = self.vaes[n]
+                out, _ = vae.dec({"latents": z[0].unsqueeze(0), "masks": mods[n]["masks"] if n in S else None})
+                r = recon_rowsum(vae.ltype, out, mods[n])
+                rows.append(r)
+                W_loss.append(float(vae.llik_scaling))
+                W_kld.append(0.0)
+                if i == s_idx:
+                    rec_log[i] = r
+            rows.append(kl[E])
+            W_loss.append(float(self.obj_fn.beta))
+            W_kld.append(1.0 / len(subsets))
+        out = ops.lincomb_rows(torch.stack(rows), [W_loss, W_kld])
+        ind = [r.sum() for r in rec_log]
+        return {"loss": out[0], "reconstruction_loss": ind, "kld": out[1]}
+
+    def modality_mixing(self, x):
+        """mmvae_models.py:210-232: prior expert + present encoders -> product"""
+        mus, lvs, single = [], [], {}
+        for m, vae in self.vaes.items():
+            if x[m]["data"] is not None:
+                mu, lv = vae.enc(x[m])
+                single[m] = normal(mu, lv)
+                mus.append(mu)
+                lvs.append(lv)
+        mu, var = self.product_of_experts(mus, lvs, with_prior=True)
+        return mu, var, single
+
+    def forward(self, inputs, K=1):
+        """mmvae_models.py:189-208"""
+        mu, var, single = self.modality_mixing(inputs)
+        qz_x = normal(mu, var)
+        eps = torch.stack([self._draw(mu.shape[0], mu.shape[1], mu.device) for _ in range(K)])
+        z = mu + var * eps
+        qz_d, px_d, z_d = {}, {}, {}
+        for mod, vae in self.vaes.items():
+            px_d[mod] = normal(*vae.dec({"latents": z, "masks": inputs[mod]["masks"]}))
+        for key in inputs.keys():
+            qz_d[key] = qz_x
+            z_d[key] = {"latents": z, "masks": inputs[key]["masks"]}
+        return self.make_output_dict(single, px_d, z_d, joint_dist=qz_d)
+
+
+class MOE(TorchMMVAE):
+    """MMVAE, mixture of experts (mmvae_models.py:10-131) -- SURVEY 8(a) a18, next after the north-star path."""
+
+    def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
+        super().__init__(vaes, n_latents, **obj_config)
+        raise NotImplementedError("moe: not yet on the MI355X hot path (mopoe, poe are)")
+
+
+class DMVAE(TorchMMVAE):
+    """DMVAE shared/private latents (mmvae_models.py:413-509) -- SURVEY 8(a) a19, next after the north-star path."""
+
+    def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
+        super().__init__(vaes, n_latents, **obj_config)
+        raise NotImplementedError("dmvae: not yet on the MI355X hot path (mopoe, poe are)")

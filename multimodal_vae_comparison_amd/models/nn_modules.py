@@ -1,0 +1,110 @@
+"""Building blocks shared by the towers (host side).  Only what the hot path needs from the reference's
+models/nn_modules.py: PositionalEncoding (nn_modules.py:418-438)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import hipops as H
+from .. import ops
+
+
+class ModuleWrap(nn.Module):
+    """Keeps the reference's state_dict key layout: it wraps single layers in nn.DataParallel
+    (models/decoders.py:58-69, encoders.py:825-826), which adds a `.module.` segment to every key.  This shim
+    adds the same segment without any scatter/gather (one process drives one GPU here)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def positional_table(d_model, max_len=1000):
+    """The `pe` buffer of the reference's PositionalEncoding, (max_len, 1, d_model); nn_modules.py:422-429."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0).transpose(0, 1).contiguous()
+
+
+class PositionalEncoding(nn.Module):
+    """Holds the sin/cos table (host-computed once, as the reference does); the add itself is fused into the
+    consumers (ops.embed_pe for the text encoder, a cached (T,B,D) query tensor for the text decoder).
+    Dropout p is kept for train mode (applied by the consumer)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=1000):
+        super().__init__()
+        self.p = dropout
+        self.d_model = d_model
+        self.register_buffer("pe", positional_table(d_model, max_len))
+
+
+class HipLinear(nn.Module):
+    """nn.Linear parameters (torch default init) driven by the MFMA GEMM; `in_act` is applied to the input."""
+
+    def __init__(self, in_features, out_features, in_act=H.ACT_NONE):
+        super().__init__()
+        ref = nn.Linear(in_features, out_features)
+        self.weight, self.bias = ref.weight, ref.bias
+        self.in_features, self.out_features, self.in_act = in_features, out_features, in_act
+
+    def flat_groups(self):
+        return [[self.weight, self.bias]]
+
+    def forward(self, x, in_act=None):
+        return ops.linear(x, self.weight, self.bias, self.in_act if in_act is None else in_act, self.weight.grad,
+                          self.bias.grad)
+
+
+class HipLayerNorm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+    def flat_groups(self):
+        return [[self.weight, self.bias]]
+
+    def forward(self, x, residual=None):
+        gg, gb = self.weight.grad, self.bias.grad
+        if gg is not None and gb is not None and gb.data_ptr() != gg.data_ptr() + 4 * gg.numel():
+            gg = gb = None      # not laid out adjacently: let autograd accumulate
+        return ops.layernorm_residual(x, residual, self.weight, self.bias, gg, gb)
+
+
+class HipSelfAttention(nn.Module):
+    """nn.MultiheadAttention parameter layout (in_proj_weight/in_proj_bias/out_proj.{weight,bias}), xavier-uniform
+    in_proj like torch; forward = packed QKV GEMM -> masked softmax attention kernel -> out_proj GEMM."""
+
+    def __init__(self, d, nhead):
+        super().__init__()
+        ref = nn.MultiheadAttention(d, nhead)
+        self.in_proj_weight, self.in_proj_bias = ref.in_proj_weight, ref.in_proj_bias
+        self.out_proj = HipLinear(d, d)
+        with torch.no_grad():
+            self.out_proj.weight.copy_(ref.out_proj.weight)
+            self.out_proj.bias.copy_(ref.out_proj.bias)
+        self.d, self.nhead = d, nhead
+
+    def flat_groups(self):
+        return [[self.in_proj_weight, self.in_proj_bias]]
+
+    def forward(self, x, kpm_u8):
+        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, H.ACT_NONE, self.in_proj_weight.grad,
+                         self.in_proj_bias.grad)
+        a = ops.attention(qkv, kpm_u8, self.nhead)
+        return self.out_proj(a)
+
+    def value_path(self, mem):
+        """Cross-attention over a length-1 memory: softmax over one key == 1, so the output is
+        out_proj(v_proj(mem)) for every query (q/k projections receive exactly zero gradient)."""
+        d = self.d
+        gw, gb = self.in_proj_weight.grad, self.in_proj_bias.grad
+        v = ops.linear(mem, self.in_proj_weight[2 * d:], self.in_proj_bias[2 * d:], H.ACT_NONE,
+                       gw[2 * d:] if gw is not None else None, gb[2 * d:] if gb is not None else None)
+        return self.out_proj(v)

@@ -1,0 +1,102 @@
+"""MultimodalVAE: the LightningModule surface of the reference (models/trainer.py:15-128) without the Lightning
+dependency: `get_model`, `training_step(batch, idx) -> loss`, `configure_optimizers()`.  A Lightning Trainer can
+drive it unchanged (nn.Module + the same hook names); `fused_step()` is the MI355X fast path used by bench.py:
+forward + backward of the whole objective replayed from ONE hipGraph, optional RCCL all-reduce of the flat
+gradient buffer, ONE fused Adam kernel."""
+import torch
+import torch.nn as nn
+
+from .. import flat as flatmod
+from .. import hipops as H
+from . import mmvae_models  # noqa: F401
+from .mmvae_base import TorchMMVAE
+from .vae import VAE
+
+# feature_dims of the reference's dataset classes (models/datasets.py:207-209): the only part of the input
+# pipeline the towers depend on
+FEATURE_DIMS = {
+    "cdspritesplus": {"image": [64, 64, 3], "text": [45, 27, 1]},
+}
+
+
+class MultimodalVAE(nn.Module):
+    def __init__(self, cfg, feature_dims=None, device="cuda"):
+        super().__init__()
+        from .config_cls import Config
+        self.config = cfg if isinstance(cfg, Config) else Config(cfg)
+        self.feature_dims = feature_dims or FEATURE_DIMS[self.config.dataset_name.lower()]
+        self.optimizer = None
+        self.flat = None
+        self.model = None
+        self.get_model()
+        self.to(device)
+        self.flat = flatmod.FlatParams(self.model)
+        self._graph = None
+
+    def get_model(self):
+        """models/trainer.py:91-115"""
+        from .. import models
+        c = self.config
+        vaes = {}
+        for i, m in enumerate(c.mods):
+            vaes["mod_{}".format(i + 1)] = VAE(m["encoder"], m["decoder"], self.feature_dims[m["mod_type"]],
+                                               c.n_latents, m["recon_loss"], m["private_latents"], obj_fn=c.obj,
+                                               beta=c.beta, id_name="mod_{}".format(i + 1), prior_dist=m["prior"],
+                                               post_dist=m["prior"], likelihood_dist=m["prior"],
+                                               llik_scaling=m["llik_scaling"])
+        if len(c.mods) > 1:
+            obj_cfg = {"obj": c.obj, "beta": c.beta, "K": c.K}
+            self.model = getattr(models, c.mixing.lower())(nn.ModuleDict(vaes), c.n_latents, obj_cfg, c.model_cfg)
+            assert isinstance(self.model, TorchMMVAE)
+        else:
+            raise NotImplementedError("unimodal VAE objective is outside the multimodal hot path")
+        return self.model
+
+    def configure_optimizers(self):
+        """models/trainer.py:75-89: Adam(lr, amsgrad=True) over the trainable parameters"""
+        if self.config.optimizer.lower() != "adam":
+            raise NotImplementedError(self.config.optimizer)
+        self.optimizer = flatmod.FlatAdam(self.flat, lr=float(self.config.lr))
+        return self.optimizer
+
+    def training_step(self, train_batch, batch_idx=0):
+        """models/trainer.py:117-128 (logging left to the caller: the dict is kept in `last_losses`)"""
+        loss_d = self.model.objective(train_batch)
+        self.last_losses = loss_d
+        return loss_d["loss"]
+
+    # ---- MI355X fast path ------------------------------------------------------------------------
+    def capture(self, batch):
+        """Capture objective + backward for `batch`'s shapes into a hipGraph.  `batch` tensors become the static
+        input buffers: copy new data into them (`load_batch`) before each replay."""
+        assert self.optimizer is not None, "call configure_optimizers() first"
+        self._static_batch = batch
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                       # warm-up: sizes the shared workspace, loads code objects
+                self.model.objective(batch)["loss"].backward()
+            self.flat.zero_grad()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            out = self.model.objective(batch)
+            out["loss"].backward()
+        self._static_out = out
+        self.flat.zero_grad()
+        return out
+
+    def load_batch(self, batch):
+        for k, v in batch.items():
+            for kk in ("data", "masks"):
+                if v[kk] is not None:
+                    self._static_batch[k][kk].copy_(v[kk], non_blocking=True)
+
+    def fused_step(self, world_size=1):
+        """one optimisation step on the static batch: graph replay -> (all-reduce) -> fused Adam"""
+        self._graph.replay()
+        if world_size > 1:
+            torch.distributed.all_reduce(self.flat.grad)       # ONE RCCL collective over the 3.95 MB flat buffer
+        self.optimizer.step()
+        return self._static_out

@@ -1,0 +1,79 @@
+"""Per-modality VAE wrapper + tower factory by name (reference: models/vae.py)."""
+import torch
+import torch.distributions as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import decoders, encoders
+from .decoders import VaeDecoder
+from .encoders import VaeEncoder
+
+
+class DencoderFactory(object):
+    @classmethod
+    def get_nework_classes(cls, enc_name, dec_name, n_latents, private_latents, data_dim: tuple, enc_mu_logvar: bool):
+        """vae.py:15-30: `Enc_<name>` / `Dec_<name>` looked up by string"""
+        assert hasattr(encoders, "Enc_{}".format(enc_name)), "Did not find encoder {}".format(enc_name)
+        enc_obj = getattr(encoders, "Enc_{}".format(enc_name))(n_latents, data_dim, private_latents, enc_mu_logvar)
+        assert hasattr(decoders, "Dec_{}".format(dec_name)), "Did not find decoder {}".format(dec_name)
+        dec_obj = getattr(decoders, "Dec_{}".format(dec_name))(n_latents, data_dim, private_latents)
+        return enc_obj, dec_obj
+
+
+class BaseVae(nn.Module):
+    """vae.py:33-59"""
+
+    def __init__(self, enc, dec, prior_dist=dist.Normal, likelihood_dist=dist.Normal, post_dist=dist.Normal):
+        super().__init__()
+        assert isinstance(enc, VaeEncoder) and isinstance(dec, VaeDecoder)
+        self.enc, self.dec = enc, dec
+        assert enc.latent_dim == dec.latent_dim
+        self.n_latents = enc.latent_dim
+        self.pz, self.px_z, self.qz_x = prior_dist, likelihood_dist, post_dist
+
+    def encode(self, inp):
+        return self.enc(inp)
+
+    def decode(self, inp):
+        return self.dec(inp)
+
+
+class VAE(BaseVae):
+    """vae.py:121-204"""
+
+    def __init__(self, enc, dec, feature_dim, n_latents, ltype, private_latents=None, llik_scaling=1,
+                 prior_dist="normal", likelihood_dist="normal", post_dist="normal", obj_fn=None, beta=1,
+                 id_name="mod_1", enc_mu_logvar=True):
+        dist_map = {"normal": dist.Normal, "categorical": dist.Categorical, "laplace": dist.Laplace,
+                    "gumbel": dist.Gumbel, "gaussian": dist.Normal}
+        self.prior_str = prior_dist.lower()
+        enc_net, dec_net = DencoderFactory().get_nework_classes(enc, dec, n_latents, private_latents, feature_dim,
+                                                                enc_mu_logvar)
+        super().__init__(enc_net, dec_net, dist_map[prior_dist.lower()], dist_map[likelihood_dist.lower()],
+                         dist_map[post_dist.lower()])
+        self.llik_scaling = llik_scaling
+        self.data_dim = feature_dim
+        self.private_latents = private_latents
+        self.n_latents = n_latents
+        self.post_dist, self.likelihood_dist, self.prior_dist = self.qz_x, self.px_z, self.pz
+        self.total_latents = n_latents + private_latents if private_latents is not None else n_latents
+        self._pz_params = nn.ParameterList([
+            nn.Parameter(torch.zeros(1, self.total_latents), requires_grad=False),
+            nn.Parameter(torch.ones(1, self.total_latents), requires_grad=False)])
+        self._pz_params_private = None
+        if private_latents is not None:
+            self._pz_params_private = nn.ParameterList([
+                nn.Parameter(torch.zeros(1, private_latents), requires_grad=False),
+                nn.Parameter(torch.ones(1, private_latents), requires_grad=False)])
+        self.modelName = id_name
+        self.ltype = ltype
+        self.obj_name = obj_fn
+
+    @property
+    def pz_params(self):
+        return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
+
+    @property
+    def pz_params_private(self):
+        return self._pz_params_private[0], \
+            F.softmax(self._pz_params_private[1], dim=1) * self._pz_params_private[1].size(-1)

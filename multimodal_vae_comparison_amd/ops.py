@@ -1,0 +1,569 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels (host plumbing only).
+
+Conventions used by every layer op
+----------------------------------
+* layers emit PRE-activations; the consumer applies the activation while it stages its input
+  (`in_act`), and its data-gradient kernel multiplies by act'(input) in the epilogue.  No standalone
+  activation kernels exist and no layer depends on a neighbour's saved tensors.
+* weight/bias gradients: when the caller passes the parameter's preset `.grad` view (`gw`, `gb`; a slice of
+  the flat gradient buffer, see flat.py) the kernels ACCUMULATE into it and autograd gets None for that
+  input -- no AccumulateGrad kernels, no copies.  Without it, fresh tensors are returned to autograd.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import hipops as H
+
+_DACT = {H.ACT_NONE: H.EP_NONE, H.ACT_SILU: H.EP_MUL_SILU_GRAD, H.ACT_RELU: H.EP_MUL_RELU_MASK,
+         H.ACT_GELU: H.EP_MUL_GELU_GRAD}
+
+
+def _call(name, *args):
+    H.check(getattr(H.lib(), name)(*args), name)
+
+
+def _new_like_param(p, g):
+    """(destination tensor, accumulate flag, value to hand back to autograd)"""
+    if g is not None:
+        return g, 1, None
+    t = torch.empty_like(p)
+    return t, 0, t
+
+
+# ----------------------------------------------------------------------------------------------
+# convolutions
+# ----------------------------------------------------------------------------------------------
+class Conv2dK4S2(Function):
+    """y = conv2d(act(x), w, b, stride 2, pad 1)   [nn.Conv2d, models/encoders.py:186-191,214-217]"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, in_act, gw, gb):
+        x = H.f32c(x)
+        B, Cin, Hin, _ = x.shape
+        Cout = w.shape[0]
+        y = torch.empty(B, Cout, Hin // 2, Hin // 2, device=x.device, dtype=torch.float32)
+        _call("mmvae_conv2d_k4s2_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), B, Cin, Cout, Hin, in_act,
+              H.EP_NONE, H.stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (in_act, gw, gb, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        in_act, gw, gb, has_b = ctx.cfg
+        dy = H.f32c(dy)
+        B, Cin, Hin, _ = x.shape
+        Cout, Hout = w.shape[0], Hin // 2
+        dw, acc_w, ret_w = _new_like_param(w, gw)
+        db, ret_b = None, None
+        if has_b:
+            if gb is not None:
+                db = gb
+            else:
+                db = ret_b = torch.empty(Cout, device=x.device)
+        ws = H.workspace(H.lib().mmvae_conv_wgrad_ws_floats(B, Cout, Cin, Hout), x.device)
+        _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hout,
+              in_act, acc_w, H.stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ep = _DACT[in_act]
+            _call("mmvae_conv2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout,
+                  Hout, ep, H.stream())
+        return dx, ret_w, ret_b, None, None, None
+
+
+class ConvT2dK4S2(Function):
+    """y = ep(conv_transpose2d(act(x), w, b, stride 2, pad 1))   [nn.ConvTranspose2d, models/decoders.py:62-69,91-97]
+    out_ep: EP_NONE or EP_SIGMOID_CLAMP (decoders.py:96-97)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, in_act, out_ep, gw, gb):
+        x = H.f32c(x)
+        B, Cin, Hin, _ = x.shape
+        Cout = w.shape[1]
+        y = torch.empty(B, Cout, 2 * Hin, 2 * Hin, device=x.device, dtype=torch.float32)
+        _call("mmvae_convT2d_k4s2_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), B, Cin, Cout, Hin, in_act,
+              out_ep, H.stream())
+        ctx.save_for_backward(x, w, y if out_ep == H.EP_SIGMOID_CLAMP else None)
+        ctx.cfg = (in_act, out_ep, gw, gb, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        in_act, out_ep, gw, gb, has_b = ctx.cfg
+        dy = H.f32c(dy)
+        B, Cin, Hin, _ = x.shape
+        Cout = w.shape[1]
+        if out_ep == H.EP_SIGMOID_CLAMP:
+            dl = torch.empty_like(dy)
+            _call("mmvae_sigmoid_clamp_bwd", H.ptr(dy), H.ptr(y), H.ptr(dl), dy.numel(), H.stream())
+            dy = dl
+        dw, acc_w, ret_w = _new_like_param(w, gw)
+        db, ret_b = None, None
+        if has_b:
+            if gb is not None:
+                db = gb
+            else:
+                db = ret_b = torch.empty(Cout, device=x.device)
+        ws = H.workspace(H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin), x.device)
+        _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hin,
+              in_act, acc_w, H.stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ep = _DACT[in_act]
+            _call("mmvae_convT2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout,
+                  Hin, ep, H.stream())
+        return dx, ret_w, ret_b, None, None, None, None
+
+
+def conv2d_k4s2(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
+    return Conv2dK4S2.apply(x, w, b, in_act, gw, gb)
+
+
+def convT2d_k4s2(x, w, b, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None):
+    return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+
+
+# ----------------------------------------------------------------------------------------------
+# dense
+# ----------------------------------------------------------------------------------------------
+class Linear(Function):
+    """y = act(x) W^T + b over the last dim   [nn.Linear / MHA projections / FFN]"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, in_act, gw, gb):
+        x = H.f32c(x)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        _call("mmvae_linear_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), M, N, K, K, in_act, H.EP_NONE,
+              H.stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (in_act, gw, gb, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        in_act, gw, gb, has_b = ctx.cfg
+        dy = H.f32c(dy)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        dw, acc_w, ret_w = _new_like_param(w, gw)
+        db, ret_b = None, None
+        if has_b:
+            if gb is not None:
+                db = gb
+            else:
+                db = ret_b = torch.empty(N, device=x.device)
+        ws = H.workspace(H.lib().mmvae_linear_bwd_weight_ws_floats(M, N, K), x.device)
+        _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, in_act,
+              acc_w, H.stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ep = _DACT[in_act]
+            _call("mmvae_linear_bwd_data", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), M, N, K, ep, 0,
+                  H.stream())
+        return dx, ret_w, ret_b, None, None, None
+
+
+def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
+    return Linear.apply(x, w, b, in_act, gw, gb)
+
+
+class HeadSoftmax(Function):
+    """h (B,2D) = [mu | u]  ->  [mu | softmax(u)+1e-6]   (VaeComponent.process_output, models/encoders.py:49-54)"""
+
+    @staticmethod
+    def forward(ctx, h):
+        assert h.is_contiguous() and h.dtype == torch.float32
+        B, D2 = h.shape
+        _call("mmvae_head_softmax_fwd", H.ptr(h), B, D2 // 2, H.stream())   # in place on the fresh linear output
+        ctx.mark_dirty(h)
+        ctx.save_for_backward(h)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (out,) = ctx.saved_tensors
+        dh = H.f32c(dh).clone()
+        B, D2 = out.shape
+        _call("mmvae_head_softmax_bwd", H.ptr(out), H.ptr(dh), B, D2 // 2, H.stream())
+        return dh
+
+
+def head_softmax(h):
+    return HeadSoftmax.apply(h)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused latent op
+# ----------------------------------------------------------------------------------------------
+class PoeReparamKL(Function):
+    """Product of experts -> n_z reparameterised samples -> analytic KL rows.
+
+    packed[e]: (B,2D) = [mu_e | lv_e] head outputs.  Returns joint (2,B,D) [not differentiable],
+    kl (E+1,B), z (n_z,B,D)."""
+
+    @staticmethod
+    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, *tensors):
+        packed = [H.f32c(t) for t in tensors[:E]]
+        eps = [H.f32c(t) for t in tensors[E:E + n_z]]
+        B, D2 = packed[0].shape
+        D = D2 // 2
+        dev = packed[0].device
+        joint = torch.empty(2, B, D, device=dev)
+        kl = torch.zeros(E + 1, B, device=dev)
+        z = torch.empty(n_z, B, D, device=dev)
+        a = H.PoeFwdArgs()
+        for e, p in enumerate(packed):
+            a.mu[e] = p.data_ptr()
+            a.lv[e] = p.data_ptr() + 4 * D
+        for i, t in enumerate(eps):
+            a.eps[i] = t.data_ptr()
+            a.z[i] = z[i].data_ptr()
+        _call("mmvae_poe_reparam_kl_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(joint), H.ptr(kl), E, int(with_prior),
+              n_z, kl_mask, B, D, D2, H.stream())
+        ctx.save_for_backward(theta, *packed, *eps)
+        ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D)
+        ctx.mark_non_differentiable(joint)
+        return joint, kl, z
+
+    @staticmethod
+    def backward(ctx, _dj, dkl, dz):
+        gtheta, with_prior, n_z, kl_mask, E, B, D = ctx.cfg
+        theta = ctx.saved_tensors[0]
+        packed = ctx.saved_tensors[1:1 + E]
+        eps = ctx.saved_tensors[1 + E:]
+        dev = theta.device
+        dkl = H.f32c(dkl) if dkl is not None else torch.zeros(E + 1, B, device=dev)
+        dz = H.f32c(dz) if (dz is not None and n_z) else None
+        dpacked = [torch.empty_like(p) for p in packed]
+        a = H.PoeBwdArgs()
+        for e, p in enumerate(packed):
+            a.mu[e] = p.data_ptr()
+            a.lv[e] = p.data_ptr() + 4 * D
+            a.dmu[e] = dpacked[e].data_ptr()
+            a.dlv[e] = dpacked[e].data_ptr() + 4 * D
+        for i in range(n_z if dz is not None else 0):
+            a.eps[i] = eps[i].data_ptr()
+            a.dz[i] = dz[i].data_ptr()
+        if gtheta is not None:
+            dth, acc, ret = gtheta, 1, None
+        else:
+            dth = ret = torch.empty_like(theta)
+            acc = 0
+        ws = H.workspace(H.lib().mmvae_poe_ws_floats(B, D), dev)
+        _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws), E,
+              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * D, acc, H.stream())
+        return (ret, None, None, None, None, None, *dpacked, *([None] * n_z))
+
+
+def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None):
+    return PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), *packed, *eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+class BceRowsum(Function):
+    """row[b] = sum_f bce(x_hat[b,f], t[b,f])   (ReconLoss.bce + .sum(-1), models/objectives.py:392-406)"""
+
+    @staticmethod
+    def forward(ctx, x_hat, target):
+        x_hat, target = H.f32c(x_hat), H.f32c(target)
+        B = x_hat.shape[0]
+        F = x_hat.numel() // B
+        row = torch.empty(B, device=x_hat.device)
+        _call("mmvae_bce_rowsum_fwd", H.ptr(x_hat), H.ptr(target), H.ptr(row), B, F, H.stream())
+        ctx.save_for_backward(x_hat, target)
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        x_hat, target = ctx.saved_tensors
+        B = x_hat.shape[0]
+        F = x_hat.numel() // B
+        dx = torch.empty_like(x_hat)
+        _call("mmvae_bce_rowsum_bwd", H.ptr(x_hat), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(dx), B, F, H.stream())
+        return dx, None
+
+
+class BceElem(Function):
+    """elementwise bce (B,F) -- the literal ReconLoss.bce output"""
+
+    @staticmethod
+    def forward(ctx, x_hat, target):
+        x_hat, target = H.f32c(x_hat), H.f32c(target)
+        out = torch.empty_like(x_hat)
+        _call("mmvae_bce_elem_fwd", H.ptr(x_hat), H.ptr(target), H.ptr(out), x_hat.numel(), H.stream())
+        ctx.save_for_backward(x_hat, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x_hat, target = ctx.saved_tensors
+        # d/dx = (x - t) / max(x (1 - x), 1e-12); tiny elementwise epilogue on the caller's grad
+        return H.f32c(g) * (x_hat - target) / ((1 - x_hat) * x_hat).clamp_min(1e-12), None
+
+
+class CeOverTime(Function):
+    """category_ce with the softmax over TIME (models/objectives.py:486-500): logits/target (B,T,V) ->
+    loss (B,V) [per_v=True] or its row sums (B,)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, per_v):
+        logits, target = H.f32c(logits), H.f32c(target)
+        B, T, V = logits.shape
+        dev = logits.device
+        loss = torch.empty(B, V, device=dev) if per_v else None
+        row = None if per_v else torch.empty(B, device=dev)
+        _call("mmvae_ce_over_time_fwd", H.ptr(logits), H.ptr(target), H.ptr(loss), H.ptr(row), B, T, V, H.stream())
+        ctx.save_for_backward(logits, target)
+        ctx.per_v = per_v
+        return loss if per_v else row
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        B, T, V = logits.shape
+        g = H.f32c(g)
+        dl = torch.empty_like(logits)
+        _call("mmvae_ce_over_time_bwd", H.ptr(logits), H.ptr(target), H.ptr(g) if ctx.per_v else None,
+              None if ctx.per_v else H.ptr(g), H.ptr(dl), B, T, V, H.stream())
+        return dl, None, None
+
+
+class LincombRows(Function):
+    """out[k] = sum_n W[k][n] * sum_b V[n,b]  -- ELBO assembly with host-side constant weights"""
+
+    @staticmethod
+    def forward(ctx, V, W):
+        V = H.f32c(V)
+        n, B = V.shape
+        k = len(W)
+        flat = (H.c_f * (k * n))(*[float(x) for row in W for x in row])
+        out = torch.empty(k, device=V.device)
+        _call("mmvae_lincomb_rows_fwd", H.ptr(V), flat, H.ptr(out), n, B, k, H.stream())
+        ctx.cfg = (flat, n, B, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, n, B, k = ctx.cfg
+        g = H.f32c(g)
+        dV = torch.empty(n, B, device=g.device)
+        _call("mmvae_lincomb_rows_bwd", H.ptr(g), flat, H.ptr(dV), n, B, k, H.stream())
+        return dV, None
+
+
+def bce_rowsum(x_hat, target):
+    return BceRowsum.apply(x_hat, target)
+
+
+def bce_elem(x_hat, target):
+    return BceElem.apply(x_hat, target)
+
+
+def ce_over_time(logits, target, per_v=False):
+    return CeOverTime.apply(logits, target, per_v)
+
+
+def lincomb_rows(V, W):
+    return LincombRows.apply(V, W)
+
+
+# ----------------------------------------------------------------------------------------------
+# text tower
+# ----------------------------------------------------------------------------------------------
+class EmbedPE(Function):
+    """Embedding(one-hot.long()) + PositionalEncoding quirk -> (T, B, 2V)  (models/encoders.py:833-835)"""
+
+    @staticmethod
+    def forward(ctx, onehot, emb, pe, mode, gemb):
+        onehot = H.f32c(onehot)
+        B, T, V = onehot.shape
+        x = torch.empty(T, B, 2 * V, device=onehot.device)
+        _call("mmvae_embed_pe_fwd", H.ptr(onehot), H.ptr(emb), H.ptr(pe), H.ptr(x), B, T, V, mode, H.stream())
+        ctx.save_for_backward(onehot, emb)
+        ctx.cfg = (mode, gemb)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        onehot, emb = ctx.saved_tensors
+        mode, gemb = ctx.cfg
+        B, T, V = onehot.shape
+        dx = H.f32c(dx)
+        de, acc, ret = _new_like_param(emb, gemb)
+        ws = H.workspace(H.lib().mmvae_embed_ws_floats(B, T, V), dx.device)
+        _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, H.stream())
+        return None, ret, None, None, None
+
+
+class Attention(Function):
+    """softmax(q k^T / sqrt(hd) + key-padding mask) v for packed qkv (L, N, 3E), L <= 64"""
+
+    @staticmethod
+    def forward(ctx, qkv, kpm, nhead):
+        qkv = H.f32c(qkv)
+        L, N, E3 = qkv.shape
+        E = E3 // 3
+        hd = E // nhead
+        out = torch.empty(L, N, E, device=qkv.device)
+        probs = torch.empty(N, nhead, L, L, device=qkv.device)
+        p = qkv.data_ptr()
+        _call("mmvae_attn_fwd", p, p + 4 * E, p + 8 * E, H.ptr(kpm), H.ptr(out), H.ptr(probs), L, L, N, nhead, hd, E3,
+              E3, E3, H.stream())
+        ctx.save_for_backward(qkv, probs)
+        ctx.nhead = nhead
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, probs = ctx.saved_tensors
+        L, N, E3 = qkv.shape
+        E = E3 // 3
+        nhead = ctx.nhead
+        dout = H.f32c(dout)
+        dqkv = torch.empty_like(qkv)
+        p, d = qkv.data_ptr(), dqkv.data_ptr()
+        _call("mmvae_attn_bwd", p, p + 4 * E, p + 8 * E, H.ptr(probs), H.ptr(dout), d, d + 4 * E, d + 8 * E, L, L, N,
+              nhead, E // nhead, E3, E3, E3, H.stream())
+        return dqkv, None, None
+
+
+class LayerNormResidual(Function):
+    """y = LayerNorm(x + r); r None, same shape, or (N,d) broadcast over the leading (time) axis"""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, gg, gb):
+        x = H.f32c(x)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        r_rows = 0
+        if r is not None:
+            r = H.f32c(r)
+            if r.numel() != x.numel():
+                r_rows = r.numel() // d
+        y = torch.empty_like(x)
+        xhat = torch.empty_like(x)
+        rstd = torch.empty(rows, device=x.device)
+        _call("mmvae_layernorm_residual_fwd", H.ptr(x), H.ptr(r), H.ptr(gamma), H.ptr(beta), H.ptr(y), H.ptr(xhat),
+              H.ptr(rstd), rows, d, r_rows, H.stream())
+        ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.cfg = (gg, gb, r is not None, r_rows, tuple(x.shape), tuple(r.shape) if r is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd, gamma = ctx.saved_tensors
+        gg, gb, has_r, r_rows, xshape, rshape = ctx.cfg
+        dy = H.f32c(dy)
+        d = xshape[-1]
+        rows = xhat.numel() // d
+        dsum = torch.empty_like(xhat)
+        if gg is not None:
+            dg, dbt, acc, ret_g, ret_b = gg, gb, 1, None, None
+        else:
+            both = torch.empty(2 * d, device=dy.device)
+            dg, dbt, acc = both[:d], both[d:], 0
+            ret_g, ret_b = dg, dbt
+        ws = H.workspace(H.lib().mmvae_layernorm_ws_floats(rows, d), dy.device)
+        _call("mmvae_layernorm_residual_bwd", H.ptr(dy), H.ptr(xhat), H.ptr(rstd), H.ptr(gamma), H.ptr(dsum),
+              dg.data_ptr(), dbt.data_ptr(), H.ptr(ws), rows, d, acc, H.stream())
+        dr = None
+        if has_r and ctx.needs_input_grad[1]:
+            if r_rows:
+                dr = torch.empty(rshape, device=dy.device)
+                _call("mmvae_sum_over_time", H.ptr(dsum), H.ptr(dr), rows // r_rows, r_rows, d, H.stream())
+            else:
+                dr = dsum
+        return (dsum if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None
+
+
+class MeanOverTime(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = H.f32c(x)
+        L, N, d = x.shape
+        y = torch.empty(N, d, device=x.device)
+        _call("mmvae_mean_over_time_fwd", H.ptr(x), H.ptr(y), L, N, d, H.stream())
+        ctx.shape = (L, N, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L, N, d = ctx.shape
+        dy = H.f32c(dy)
+        dx = torch.empty(L, N, d, device=dy.device)
+        _call("mmvae_mean_over_time_bwd", H.ptr(dy), H.ptr(dx), L, N, d, H.stream())
+        return dx
+
+
+class PermuteMask(Function):
+    """(T,B,V) -> (B,T,V) * mask[b,t]   (models/decoders.py:722)"""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8):
+        x = H.f32c(x)
+        T, B, V = x.shape
+        y = torch.empty(B, T, V, device=x.device)
+        _call("mmvae_permute_mask_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(y), T, B, V, H.stream())
+        ctx.save_for_backward(mask_u8)
+        ctx.shape = (T, B, V)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask_u8,) = ctx.saved_tensors
+        T, B, V = ctx.shape
+        dy = H.f32c(dy)
+        dx = torch.empty(T, B, V, device=dy.device)
+        _call("mmvae_permute_mask_bwd", H.ptr(dy), H.ptr(mask_u8), H.ptr(dx), T, B, V, H.stream())
+        return dx, None
+
+
+def embed_pe(onehot, emb, pe, mode, gemb=None):
+    return EmbedPE.apply(onehot, emb, pe, mode, gemb)
+
+
+def attention(qkv, kpm_u8, nhead):
+    return Attention.apply(qkv, kpm_u8, nhead)
+
+
+def layernorm_residual(x, r, gamma, beta, gg=None, gb=None):
+    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb)
+
+
+def mean_over_time(x):
+    return MeanOverTime.apply(x)
+
+
+def permute_mask(x, mask_u8):
+    return PermuteMask.apply(x, mask_u8)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser / utilities (no autograd)
+# ----------------------------------------------------------------------------------------------
+def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=None, grad_scale=1.0, zero_grad=True):
+    _call("mmvae_adam_amsgrad_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), lr, beta1, beta2,
+          eps, int(step), H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())
+
+
+def step_inc(step_dev):
+    _call("mmvae_step_inc", H.ptr(step_dev), H.stream())
+
+
+def fill(t, value):
+    _call("mmvae_fill", H.ptr(t), t.numel(), float(value), H.stream())

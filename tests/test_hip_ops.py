@@ -1,0 +1,338 @@
+"""GPU parity of every C-ABI kernel family against a plain PyTorch fp32 reference of the same op
+(computed on the CPU in float64 where cheap).  Tolerance: 1e-4 relative to the tensor's max magnitude
+(north-star: 1e-4 relative fp32), tighter where the op is elementwise."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def check(a, b, tol, what):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = rel_err(a, b)
+    assert math.isfinite(e) and e <= tol, f"{what}: rel err {e:.3e} > {tol}"
+
+
+def _act(x, act):
+    return {0: lambda t: t, 1: F.silu, 2: torch.relu, 3: F.gelu}[act](x)
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    from multimodal_vae_comparison_amd import ops
+    return ops
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,Hin,act", [(3, 3, 64, 0), (5, 32, 32, 1), (6, 32, 16, 1), (5, 32, 8, 1), (128, 32, 8, 2),
+                                           (2, 32, 32, 0), (130, 32, 16, 1), (64, 3, 64, 0)])
+def test_conv2d_fwd_bwd(ops, B, Cin, Hin, act):
+    g = torch.Generator().manual_seed(B * 1000 + Hin)
+    x = torch.randn(B, Cin, Hin, Hin, generator=g)
+    w = torch.randn(32, Cin, 4, 4, generator=g) * (1.0 / math.sqrt(Cin * 16))
+    b = torch.randn(32, generator=g) * 0.1
+    dy = torch.randn(B, 32, Hin // 2, Hin // 2, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(_act(xr, act), wr, br, stride=2, padding=1)
+    yr.backward(dy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d_k4s2(xg, wg, bg, act)
+    y.backward(dy.to(DEV))
+    check(y, yr, 2e-5, "y")
+    check(wg.grad, wr.grad, 5e-5, "dw")
+    check(bg.grad, br.grad, 5e-5, "db")
+    check(xg.grad, xr.grad, 5e-5, "dx")
+    # accumulate-into-preset-gradient path
+    gw, gb = torch.ones_like(wg), torch.ones_like(bg)
+    x2 = x.to(DEV).requires_grad_(True)
+    ops.conv2d_k4s2(x2, wg.detach(), bg.detach(), act, gw, gb).backward(dy.to(DEV))
+    check(gw - 1, wr.grad, 5e-5, "dw (accumulated)")
+    check(gb - 1, br.grad, 5e-5, "db (accumulated)")
+
+
+@pytest.mark.parametrize("B,Cout,Hin,act,ep", [(3, 32, 4, 2, 0), (5, 32, 8, 2, 0), (6, 32, 16, 2, 0), (128, 32, 4, 0, 0),
+                                               (4, 3, 32, 2, 6), (130, 32, 8, 2, 0), (33, 3, 32, 2, 6), (7, 3, 16, 0, 0)])
+def test_convT2d_fwd_bwd(ops, B, Cout, Hin, act, ep):
+    g = torch.Generator().manual_seed(B * 1000 + Hin + Cout)
+    x = torch.randn(B, 32, Hin, Hin, generator=g)
+    w = torch.randn(32, Cout, 4, 4, generator=g) * (1.0 / math.sqrt(32 * 4))
+    b = torch.randn(Cout, generator=g) * 0.1
+    dy = torch.randn(B, Cout, 2 * Hin, 2 * Hin, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv_transpose2d(_act(xr, act), wr, br, stride=2, padding=1)
+    if ep == 6:
+        yr = torch.sigmoid(yr).clamp(1e-6, 1 - 1e-6)
+    yr.backward(dy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.convT2d_k4s2(xg, wg, bg, act, ep)
+    y.backward(dy.to(DEV))
+    check(y, yr, 2e-5, "y")
+    check(wg.grad, wr.grad, 5e-5, "dw")
+    check(bg.grad, br.grad, 5e-5, "db")
+    check(xg.grad, xr.grad, 5e-5, "dx")
+
+
+@pytest.mark.parametrize("M,K,N,act", [(128, 512, 512, 1), (6, 8, 512, 0), (7, 512, 64, 2), (4096, 54, 162, 0),
+                                       (160, 128, 54, 3), (33000, 54, 128, 0), (5, 54, 16, 0), (300, 32, 27, 0)])
+def test_linear_fwd_bwd(ops, M, K, N, act):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(_act(xr, act), wr, br)
+    yr.backward(dy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xg, wg, bg, act)
+    y.backward(dy.to(DEV))
+    check(y, yr, 2e-5, "y")
+    check(wg.grad, wr.grad, 5e-5, "dw")
+    check(bg.grad, br.grad, 5e-5, "db")
+    check(xg.grad, xr.grad, 5e-5, "dx")
+
+
+def test_head_softmax(ops):
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(37, 2 * 42, generator=g)
+    dh = torch.randn(37, 84, generator=g)
+    hr = h.double().requires_grad_(True)
+    outr = torch.cat([hr[:, :42], F.softmax(hr[:, 42:], -1) + 1e-6], -1)
+    outr.backward(dh.double())
+    hg = h.to(DEV).requires_grad_(True)
+    out = ops.head_softmax(hg * 1.0)
+    out.backward(dh.to(DEV))
+    check(out, outr, 1e-6, "out")
+    check(hg.grad, hr.grad, 1e-5, "dh")
+
+
+def _poe_ref(theta, packed, eps, with_prior, kl_mask):
+    D = theta.shape[1]
+    sp = F.softmax(theta, dim=1) * D
+    mus = [p[:, :D] for p in packed]
+    lvs = [p[:, D:] for p in packed]
+    T = [1.0 / (torch.exp(l) + 1e-8) for l in lvs]
+    P = sum(T) + (1.0 / (1.0 + 1e-8) if with_prior else 0.0)
+    muJ = sum(m * t for m, t in zip(mus, T)) / P
+    varJ = 1.0 / P
+
+    def kl(mu, s):
+        vr = (s / sp) ** 2
+        return (0.5 * (vr + (mu / sp) ** 2 - 1 - vr.log())).sum(-1)
+
+    E = len(packed)
+    rows = [kl(m, l) if kl_mask >> e & 1 else torch.zeros(m.shape[0], dtype=m.dtype) for e, (m, l) in enumerate(zip(mus, lvs))]
+    rows.append(kl(muJ, varJ) if kl_mask >> E & 1 else torch.zeros(muJ.shape[0], dtype=muJ.dtype))
+    z = torch.stack([muJ + varJ * e for e in eps]) if eps else torch.zeros(0, *muJ.shape)
+    return torch.stack([muJ, varJ]), torch.stack(rows), z
+
+
+@pytest.mark.parametrize("E,n_z,with_prior,kl_mask,B,D", [(2, 2, True, 0b111, 128, 32), (1, 1, True, 0b10, 7, 8),
+                                                          (3, 3, True, 0b1111, 130, 42), (2, 0, False, 0, 5, 16),
+                                                          (2, 1, True, 0b100, 300, 70)])
+def test_poe_reparam_kl(ops, E, n_z, with_prior, kl_mask, B, D):
+    g = torch.Generator().manual_seed(E * 100 + B)
+    packed = [torch.cat([torch.randn(B, D, generator=g), F.softmax(torch.randn(B, D, generator=g), -1) + 1e-6], -1)
+              for _ in range(E)]
+    eps = [torch.randn(B, D, generator=g) for _ in range(n_z)]
+    theta = torch.randn(1, D, generator=g) * 0.3
+    gkl = torch.randn(E + 1, B, generator=g)
+    gz = torch.randn(n_z, B, D, generator=g)
+    pr = [p.double().requires_grad_(True) for p in packed]
+    tr = theta.double().requires_grad_(True)
+    jr, klr, zr = _poe_ref(tr, pr, [e.double() for e in eps], with_prior, kl_mask)
+    tot = (klr * gkl.double()).sum() + ((zr * gz.double()).sum() if n_z else 0.0)
+    pg = [p.to(DEV).requires_grad_(True) for p in packed]
+    tg = theta.to(DEV).requires_grad_(True)
+    j, kl, z = ops.poe_reparam_kl(tg, pg, [e.to(DEV) for e in eps], with_prior, kl_mask)
+    check(j, jr, 1e-5, "joint")
+    check(kl, klr, 2e-5, "kl")
+    if n_z:
+        check(z, zr, 1e-5, "z")
+    if kl_mask or n_z:
+        tot.backward()
+        totg = (kl * gkl.to(DEV)).sum() + ((z * gz.to(DEV)).sum() if n_z else 0.0)
+        totg.backward()
+        for e in range(E):
+            check(pg[e].grad, pr[e].grad, 5e-5, f"dpacked[{e}]")
+        if kl_mask:
+            check(tg.grad, tr.grad, 5e-5, "dtheta")
+
+
+def test_bce_and_ce(ops):
+    g = torch.Generator().manual_seed(3)
+    B, Fd = 9, 3 * 64 * 64
+    xh = torch.sigmoid(torch.randn(B, Fd, generator=g) * 4).clamp(1e-6, 1 - 1e-6)
+    t = torch.rand(B, Fd, generator=g)
+    gr = torch.randn(B, generator=g)
+    xr = xh.double().requires_grad_(True)
+    rr = F.binary_cross_entropy(xr, t.double(), reduction="none").sum(-1)
+    rr.backward(gr.double())
+    xg = xh.to(DEV).requires_grad_(True)
+    r = ops.bce_rowsum(xg, t.to(DEV))
+    r.backward(gr.to(DEV))
+    check(r, rr, 1e-5, "bce rowsum")
+    check(xg.grad, xr.grad, 1e-5, "bce dx")
+    e = ops.bce_elem(xh.to(DEV), t.to(DEV))
+    check(e, F.binary_cross_entropy(xh.double(), t.double(), reduction="none"), 1e-5, "bce elem")
+    # category_ce over time
+    B, T, V = 11, 9, 27
+    lg = torch.randn(B, T, V, generator=g) * 2
+    tg = F.one_hot(torch.randint(0, V, (B, T), generator=g), V).float()
+    tg[:, 6:] = 0
+    lg[:, 6:] = 0
+    for per_v in (True, False):
+        lr_ = lg.double().requires_grad_(True)
+        ref = -(tg.double() * F.log_softmax(lr_, dim=1)).sum(1)
+        ref = ref if per_v else ref.sum(-1)
+        gg = torch.randn(*ref.shape, generator=g)
+        ref.backward(gg.double())
+        lgg = lg.to(DEV).requires_grad_(True)
+        out = ops.ce_over_time(lgg, tg.to(DEV), per_v)
+        out.backward(gg.to(DEV))
+        check(out, ref, 1e-5, f"ce per_v={per_v}")
+        check(lgg.grad, lr_.grad, 2e-5, f"ce dlogits per_v={per_v}")
+
+
+def test_lincomb_rows(ops):
+    g = torch.Generator().manual_seed(4)
+    V = torch.randn(5, 130, generator=g)
+    W = [[0.5, 1.0, -2.0, 0.25, 3.0], [0.0, 0.0, 1.0, 1.0, 1.0]]
+    Vr = V.double().requires_grad_(True)
+    ref = torch.tensor(W, dtype=torch.float64) @ Vr.sum(1)
+    ref.backward(torch.tensor([1.5, -0.5], dtype=torch.float64))
+    Vg = V.to(DEV).requires_grad_(True)
+    out = ops.lincomb_rows(Vg, W)
+    out.backward(torch.tensor([1.5, -0.5], device=DEV))
+    check(out, ref, 1e-5, "lincomb")
+    check(Vg.grad, Vr.grad, 1e-6, "lincomb dV")
+
+
+@pytest.mark.parametrize("B,T", [(6, 5), (5, 5), (1, 7), (128, 32)])
+def test_embed_pe(ops, B, T):
+    from multimodal_vae_comparison_amd.models.nn_modules import positional_table
+    V = 27
+    g = torch.Generator().manual_seed(B + T)
+    oh = F.one_hot(torch.randint(0, V, (B, T), generator=g), V).float()
+    oh[:, T - 1:] = 0
+    emb = torch.randn(V, 2, generator=g)
+    pe = positional_table(2, 1000)
+    dx = torch.randn(T, B, 2 * V, generator=g)
+    er = emb.double().requires_grad_(True)
+    x = er[oh.long()]
+    p = pe[:B].double()                       # (B,1,2)
+    if B == T or B == 1:
+        x = x + p
+    else:
+        x = x.permute(1, 0, 2, 3) + p
+    xr = x.contiguous().view(T, B, -1)
+    xr.backward(dx.double())
+    eg = emb.to(DEV).requires_grad_(True)
+    mode = 1 if (B == T or B == 1) else 0
+    out = ops.embed_pe(oh.to(DEV), eg, pe.view(-1, 2).to(DEV), mode)
+    out.backward(dx.to(DEV))
+    check(out, xr, 1e-6, "embed")
+    check(eg.grad, er.grad, 2e-5, "demb")
+
+
+@pytest.mark.parametrize("L,N,E,H_", [(5, 6, 54, 2), (32, 128, 54, 2), (9, 7, 32, 2), (64, 3, 16, 2)])
+def test_attention(ops, L, N, E, H_):
+    g = torch.Generator().manual_seed(L * N)
+    qkv = torch.randn(L, N, 3 * E, generator=g)
+    lens = torch.randint(1, L + 1, (N,), generator=g)
+    kpm = torch.arange(L)[None, :] >= lens[:, None]          # True = ignore
+    do = torch.randn(L, N, E, generator=g)
+    qr = qkv.double().requires_grad_(True)
+    hd = E // H_
+    q, k, v = qr[..., :E], qr[..., E:2 * E], qr[..., 2 * E:]
+    q = q.reshape(L, N * H_, hd).transpose(0, 1) / math.sqrt(hd)
+    k = k.reshape(L, N * H_, hd).transpose(0, 1)
+    v = v.reshape(L, N * H_, hd).transpose(0, 1)
+    att = torch.bmm(q, k.transpose(1, 2)).reshape(N, H_, L, L).masked_fill(kpm[:, None, None, :], float("-inf"))
+    att = F.softmax(att, -1).reshape(N * H_, L, L)
+    ref = torch.bmm(att, v).transpose(0, 1).reshape(L, N, E)
+    ref.backward(do.double())
+    qg = qkv.to(DEV).requires_grad_(True)
+    out = ops.attention(qg, kpm.to(torch.uint8).to(DEV), H_)
+    out.backward(do.to(DEV))
+    check(out, ref, 2e-5, "attn out")
+    check(qg.grad, qr.grad, 5e-5, "attn dqkv")
+
+
+@pytest.mark.parametrize("L,N,d,bcast", [(5, 6, 54, False), (32, 128, 32, True), (1, 300, 8, False), (9, 7, 70, True)])
+def test_layernorm_residual(ops, L, N, d, bcast):
+    g = torch.Generator().manual_seed(L + N + d)
+    x = torch.randn(L, N, d, generator=g)
+    r = torch.randn(N, d, generator=g) if bcast else torch.randn(L, N, d, generator=g)
+    ga = 1 + 0.1 * torch.randn(d, generator=g)
+    be = 0.1 * torch.randn(d, generator=g)
+    dy = torch.randn(L, N, d, generator=g)
+    xr, rr, gr, br = (t.double().requires_grad_(True) for t in (x, r, ga, be))
+    ref = F.layer_norm(xr + rr, (d,), gr, br, 1e-5)
+    ref.backward(dy.double())
+    xg, rg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, r, ga, be))
+    out = ops.layernorm_residual(xg, rg, gg, bg)
+    out.backward(dy.to(DEV))
+    check(out, ref, 1e-5, "ln out")
+    check(xg.grad, xr.grad, 2e-5, "ln dx")
+    check(rg.grad, rr.grad, 2e-5, "ln dr")
+    check(gg.grad, gr.grad, 2e-5, "ln dgamma")
+    check(bg.grad, br.grad, 2e-5, "ln dbeta")
+
+
+def test_time_reduce_and_permute_mask(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(7, 5, 54, generator=g)
+    dy = torch.randn(5, 54, generator=g)
+    xr = x.double().requires_grad_(True)
+    xr.mean(0).backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    out = ops.mean_over_time(xg)
+    out.backward(dy.to(DEV))
+    check(out, x.double().mean(0), 1e-6, "mean")
+    check(xg.grad, xr.grad, 1e-6, "mean dx")
+    T, B, V = 6, 4, 27
+    y = torch.randn(T, B, V, generator=g)
+    m = torch.rand(B, T, generator=g) > 0.3
+    dz = torch.randn(B, T, V, generator=g)
+    yr = y.double().requires_grad_(True)
+    ref = yr.permute(1, 0, 2) * m.unsqueeze(-1).double()
+    ref.backward(dz.double())
+    yg = y.to(DEV).requires_grad_(True)
+    o = ops.permute_mask(yg, m.to(torch.uint8).to(DEV))
+    o.backward(dz.to(DEV))
+    check(o, ref, 1e-6, "permute_mask")
+    check(yg.grad, yr.grad, 1e-6, "permute_mask dx")
+
+
+def test_adam_amsgrad_flat_matches_torch(ops):
+    g = torch.Generator().manual_seed(11)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, amsgrad=True)
+    p = p0.to(DEV)
+    # the flat kernel needs 16-byte aligned bases; torch allocations are
+    m, v, vm = (torch.zeros(n, device=DEV) for _ in range(3))
+    step_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for it in range(1, 6):
+        gr = torch.randn(n, generator=g) * (0.1 if it != 3 else 10.0)
+        pr.grad = gr.clone()
+        opt.step()
+        gd = gr.to(DEV)
+        ops.step_inc(step_dev)
+        ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, 0, step_dev, 1.0, True)
+        assert float(gd.abs().max()) == 0.0
+        check(p, pr.detach(), 2e-6, f"adam step {it}")
