@@ -213,21 +213,39 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
   }
 }
 
-// dtheta_d (+)= D * s_d * (dsp_d - sum_k s_k dsp_k), dsp = sum over the per-wave partial rows
-__global__ __launch_bounds__(64) void poe_theta_kernel(const float* __restrict__ theta, const float* __restrict__ ws,
-                                                       float* __restrict__ dtheta, int nrows, int D, int accumulate) {
-  const int lane = threadIdx.x;
+// dtheta_d (+)= D * s_d * (dsp_d - sum_k s_k dsp_k), dsp = sum over the per-wave partial rows.
+// 4 waves split the rows, 8 independent loads in flight per lane, LDS combine (D <= 256).
+__global__ __launch_bounds__(256) void poe_theta_kernel(const float* __restrict__ theta, const float* __restrict__ ws,
+                                                        float* __restrict__ dtheta, int nrows, int D, int accumulate) {
+  __shared__ float part[4][64 * POE_SLOTS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    const int d = lane + 64 * s;
+    float acc = 0.f;
+    if (d < D) {
+      int r = wave;
+      for (; r + 28 < nrows; r += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(r + 4 * u) * D + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; r < nrows; r += 4) acc += ws[(size_t)r * D + d];
+    }
+    part[wave][d] = acc;
+  }
+  __syncthreads();
+  if (wave != 0) return;
   float sp[POE_SLOTS], sm[POE_SLOTS], dsp[POE_SLOTS];
   prior_sigma(theta, D, lane, sp, sm);
   float dot = 0.f;
 #pragma unroll
   for (int s = 0; s < POE_SLOTS; ++s) {
     const int d = lane + 64 * s;
-    float acc = 0.f;
-    if (d < D)
-      for (int r = 0; r < nrows; ++r) acc += ws[(size_t)r * D + d];
-    dsp[s] = acc;
-    dot += acc * sm[s];
+    dsp[s] = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    dot += dsp[s] * sm[s];
   }
   dot = wave_sum(dot);
 #pragma unroll
@@ -267,7 +285,7 @@ extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float
   hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
                      n_z, kl_mask, B, D, ld_in);
   if (dtheta)
-    hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
+    hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
                        accumulate);
   return mmvae_launch_status();
 }

@@ -92,10 +92,11 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   __shared__ float smask[ATT_MAX];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const int HP = ATT_HD + 1;
-  for (int e = lane; e < S * hd; e += 64) {
-    const int s = e / hd, d = e - s * hd;
-    sk[s * HP + d] = k[((size_t)s * N + n) * ldk + h * hd + d];
-    sv[s * HP + d] = v[((size_t)s * N + n) * ldv + h * hd + d];
+  // columns [hd, ATT_HD) are zero-filled: the dot products below run over the full ATT_HD width
+  for (int e = lane; e < S * ATT_HD; e += 64) {
+    const int s = e / ATT_HD, d = e - s * ATT_HD;
+    sk[s * HP + d] = d < hd ? k[((size_t)s * N + n) * ldk + h * hd + d] : 0.f;
+    sv[s * HP + d] = d < hd ? v[((size_t)s * N + n) * ldv + h * hd + d] : 0.f;
   }
   if (lane < S) smask[lane] = (kpm && kpm[(size_t)n * S + lane]) ? 1.f : 0.f;
   __syncthreads();

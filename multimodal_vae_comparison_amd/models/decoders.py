@@ -51,6 +51,7 @@ class Dec_CNN(VaeDecoder):
         self.convT1 = ModuleWrap(HipConvT2d(hid, hid, H.ACT_RELU))
         self.convT2 = ModuleWrap(HipConvT2d(hid, hid, H.ACT_RELU))
         self.convT3 = ModuleWrap(HipConvT2d(hid, self.n_chan, H.ACT_RELU, H.EP_SIGMOID_CLAMP))
+        self.register_buffer("_scale", torch.tensor(0.75), persistent=False)   # the decoders' fixed likelihood scale
 
     def forward(self, z):
         z = z["latents"]
@@ -61,7 +62,7 @@ class Dec_CNN(VaeDecoder):
         u = u.view(bs * K, *self.reshape)
         d = self.convT3(self.convT2(self.convT1(self.convT_64(u))))        # (K*B,3,64,64) clamped sigmoid
         d = d.view(*z.size()[:-1], *self.data_dim)                          # decoders.py:96 (view, no permute)
-        return d.squeeze().reshape(-1, *self.data_dim), torch.tensor(0.75, device=z.device)
+        return d.squeeze().reshape(-1, *self.data_dim), self._scale
 
 
 class HipTransformerDecoderLayer(nn.Module):
@@ -109,6 +110,7 @@ class Dec_TxtTransformer(VaeDecoder):
         self.finallayer = ModuleWrap(HipLinear(self.out_dim, self.input_feats))
         self.sequence_pos_encoder = ModuleWrap(PositionalEncoding(self.out_dim, self.dropout))
         self._tq_cache = {}
+        self.register_buffer("_scale", torch.tensor(0.75), persistent=False)
 
     def _timequeries(self, T, bs, D, device):
         """PositionalEncoding(zeros(T,bs,D)) = pe[:T] broadcast over the batch (decoders.py:716-717); constant for
@@ -141,4 +143,4 @@ class Dec_TxtTransformer(VaeDecoder):
             x = layer(x, mem, kpm)
         out = self.finallayer(x)                                              # (T, bs, V)
         out = ops.permute_mask(out, mask.to(torch.uint8).contiguous())        # (bs, T, V), zero at padding
-        return out, torch.tensor(0.75, device=z.device)
+        return out, self._scale
