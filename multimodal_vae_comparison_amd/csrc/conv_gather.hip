@@ -46,19 +46,58 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvGatherArgs a) {
   const int first_row = blockIdx.x * NR;
   const MacroTile mt = macro_tile(first_row, NR, Hout);
   const int NRin = 2 * mt.nrow + 2, RS = Win + 2, CS = NRin * RS, IS = CC * CS;
-  const int PSZ = CS;  // one (img, channel) plane, contiguous in LDS
 
-  // per-thread staging slots (same for every chunk / plane)
-  int goff[3];
-  bool gval[3];
+  // Per-thread staging slots.  The chunk's LDS region [0, nimg*IS) is contiguous ([img][c][row][col]); thread t
+  // owns elements t, t+256, ...  Their global offsets (relative to the chunk's first channel of image b0) and
+  // validity never change across chunks, so the index math (two runtime divisions per slot) is done once and
+  // every chunk's loads are issued back to back with nothing but an address add in between.
+  constexpr int MAXSLOT = IN_MAX / 256;
+  const int region = mt.nimg * IS;
+  int soff[MAXSLOT];
+  unsigned svalid = 0;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int e = tid + 256 * j;
-    const int lr = e / RS, col = e - lr * RS;
+  for (int sidx = 0; sidx < MAXSLOT; ++sidx) {
+    const int e = tid + 256 * sidx;
+    const int pl = e / CS, rem = e - pl * CS;
+    const int img = pl / CC, cl = pl - img * CC;
+    const int lr = rem / RS, col = rem - lr * RS;
     const int ih = 2 * mt.h0 - 1 + lr, iw = col - 1;
-    gval[j] = (e < PSZ) && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
-    goff[j] = ih * Win + iw;
+    const bool ok = e < region && (mt.b0 + img) < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
+    svalid |= (ok ? 1u : 0u) << sidx;
+    soff[sidx] = ok ? ((img * CIN + cl) * Hin + ih) * Win + iw : 0;
   }
+  const float* xbase = a.x + (size_t)mt.b0 * CIN * Hin * Win;
+  constexpr int WSLOT = CC * 16 * CONV_CO / 256;
+  float rv[MAXSLOT], rw[WSLOT];
+  auto load_chunk = [&](int ch) {
+    const float* xch = xbase + (size_t)ch * CC * Hin * Win;
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSLOT; ++sidx)
+      if (tid + 256 * sidx < region) rv[sidx] = xch[soff[sidx]];
+#pragma unroll
+    for (int i = 0; i < WSLOT; ++i) {
+      const int e = i * 256 + tid;
+      const int kl = e % (CC * 16), o = e / (CC * 16);
+      rw[i] = a.w[((size_t)o * CIN + ch * CC) * 16 + kl];
+    }
+  };
+  auto store_chunk = [&]() {
+    if (a.in_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int sidx = 0; sidx < MAXSLOT; ++sidx) rv[sidx] = apply_in_act(rv[sidx], a.in_act);
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSLOT; ++sidx) {
+      const int e = tid + 256 * sidx;
+      if (e < region) s_in[e] = (svalid >> sidx & 1u) ? rv[sidx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WSLOT; ++i) {
+      const int e = i * 256 + tid;
+      const int kl = e % (CC * 16), o = e / (CC * 16);
+      s_w[kl * WP + o] = rw[i];
+    }
+  };
 
   // per-lane A-operand base
   const int tile_p0 = (blockIdx.x * TM + tm) * 32;
@@ -82,34 +121,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvGatherArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  load_chunk(0);
   for (int ch = 0; ch < NCHUNK; ++ch) {
     if (ch > 0) __syncthreads();
-    // ---- stage input planes ----
-    for (int img = 0; img < mt.nimg; ++img) {
-      const int b = mt.b0 + img;
-      const bool bval = b < a.B;
-      for (int cl = 0; cl < CC; ++cl) {
-        const float* plane = a.x + ((size_t)(b * CIN + ch * CC + cl)) * Hin * Win;
-        float* dst = s_in + img * IS + cl * CS;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int e = tid + 256 * j;
-          if (e < PSZ) {
-            float v = 0.f;
-            if (gval[j] && bval) v = apply_in_act(plane[goff[j]], a.in_act);
-            dst[e] = v;
-          }
-        }
-      }
-    }
-    // ---- stage weights: w[(o*CIN + c)*16 + t] -> s_w[(cl*16+t)*WP + o] ----
-#pragma unroll
-    for (int i = 0; i < CC * 16 * CONV_CO / 256; ++i) {
-      const int e = i * 256 + tid;
-      const int kl = e % (CC * 16), o = e / (CC * 16);
-      s_w[kl * WP + o] = a.w[((size_t)o * CIN + ch * CC) * 16 + kl];
-    }
+    store_chunk();
     __syncthreads();
+    if (ch + 1 < NCHUNK) load_chunk(ch + 1);  // next chunk's loads fly under this chunk's MFMAs
     // ---- MFMAs ----
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {

@@ -47,18 +47,59 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(ConvScatterArgs a) {
   const int first_row = blockIdx.x * NR;
   const MacroTile mt = macro_tile(first_row, NR, Hin);
   const int NRin = mt.nrow + 2, RS = Win + 2, CS = NRin * RS, IS = CC * CS;
-  const int PSZ = CS;
 
-  int goff[2];
-  bool gval[2];
+  // staging slots precomputed once (see conv_gather.hip): region [0, nimg*IS) is contiguous in LDS
+  constexpr int MAXSLOT = IN_MAX / 256;
+  const int region = mt.nimg * IS;
+  int soff[MAXSLOT];
+  unsigned svalid = 0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + 256 * j;
-    const int lr = e / RS, col = e - lr * RS;
+  for (int sidx = 0; sidx < MAXSLOT; ++sidx) {
+    const int e = tid + 256 * sidx;
+    const int pl = e / CS, rem = e - pl * CS;
+    const int img = pl / CC, cl = pl - img * CC;
+    const int lr = rem / RS, col = rem - lr * RS;
     const int ih = mt.h0 - 1 + lr, iw = col - 1;
-    gval[j] = (e < PSZ) && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
-    goff[j] = ih * Win + iw;
+    const bool ok = e < region && (mt.b0 + img) < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
+    svalid |= (ok ? 1u : 0u) << sidx;
+    soff[sidx] = ok ? ((img * CIN + cl) * Hin + ih) * Win + iw : 0;
   }
+  const float* xbase = a.x + (size_t)mt.b0 * CIN * Hin * Win;
+  constexpr int WSLOT = CC * 16 * CONV_CO / 256;
+  float rv[MAXSLOT], rw[WSLOT];
+  auto load_chunk = [&](int ch) {
+    const float* xch = xbase + (size_t)ch * CC * Hin * Win;
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSLOT; ++sidx)
+      if (tid + 256 * sidx < region) rv[sidx] = xch[soff[sidx]];
+#pragma unroll
+    for (int i = 0; i < WSLOT; ++i) {
+      const int e = i * 256 + tid;
+      const int o = e & 31, t = (e >> 5) & 15, cl = e >> 9;
+      rw[i] = a.w[((size_t)(ch * CC + cl) * CONV_CO + o) * 16 + t];
+    }
+  };
+  auto store_chunk = [&]() {
+    if (a.in_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int sidx = 0; sidx < MAXSLOT; ++sidx) rv[sidx] = apply_in_act(rv[sidx], a.in_act);
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSLOT; ++sidx) {
+      const int e = tid + 256 * sidx;
+      if (e < region) s_in[e] = (svalid >> sidx & 1u) ? rv[sidx] : 0.f;
+    }
+    // weights: w[(c*32 + o)*16 + kh*4 + kw] -> s_w[(((cls*CC + cl)*2 + th)*2 + tw)*32 + o]
+#pragma unroll
+    for (int i = 0; i < WSLOT; ++i) {
+      const int e = i * 256 + tid;
+      const int o = e & 31, t = (e >> 5) & 15, cl = e >> 9;
+      const int kh = t >> 2, kw = t & 3;
+      const int ph = 1 - (kh & 1), th = kh >> 1, pw = 1 - (kw & 1), tw = kw >> 1;
+      const int cls = ph * 2 + pw;
+      s_w[(((cls * CC + cl) * 2 + th) * 2 + tw) * CONV_CO + o] = rw[i];
+    }
+  };
 
   const int tile_p0 = (blockIdx.x * TM + tm) * 32;
   int abase;
@@ -84,32 +125,12 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(ConvScatterArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
+  load_chunk(0);
   for (int ch = 0; ch < NCHUNK; ++ch) {
     if (ch > 0) __syncthreads();
-    for (int img = 0; img < mt.nimg; ++img) {
-      const int b = mt.b0 + img;
-      const bool bval = b < a.B;
-      for (int cl = 0; cl < CC; ++cl) {
-        const float* plane = a.x + ((size_t)(b * CIN + ch * CC + cl)) * Hin * Win;
-        float* dst = s_in + img * IS + cl * CS;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = tid + 256 * j;
-          if (e < PSZ) dst[e] = (gval[j] && bval) ? apply_in_act(plane[goff[j]], a.in_act) : 0.f;
-        }
-      }
-    }
-    // weights: w[(c*32 + o)*16 + kh*4 + kw] -> s_w[(((cls*CC + cl)*2 + th)*2 + tw)*32 + o]
-#pragma unroll
-    for (int i = 0; i < CC * 16 * CONV_CO / 256; ++i) {
-      const int e = i * 256 + tid;
-      const int o = e & 31, t = (e >> 5) & 15, cl = e >> 9;
-      const int kh = t >> 2, kw = t & 3;
-      const int ph = 1 - (kh & 1), th = kh >> 1, pw = 1 - (kw & 1), tw = kw >> 1;
-      const int cls = ph * 2 + pw;
-      s_w[(((cls * CC + cl) * 2 + th) * 2 + tw) * CONV_CO + o] = a.w[((size_t)(ch * CC + cl) * CONV_CO + o) * 16 + t];
-    }
+    store_chunk();
     __syncthreads();
+    if (ch + 1 < NCHUNK) load_chunk(ch + 1);
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
 #pragma unroll
@@ -223,31 +244,49 @@ __global__ __launch_bounds__(256) void conv_scatter3_kernel(ConvScatter3Args a) 
   int CS = NRin * RS;
   CS += (16 - (CS & 31) + 32) & 31;  // CS == 16 (mod 32): the 4 k-lanes of a 32-lane LDS group hit disjoint banks
 
-  // stage all input channels (zero halo)
-  for (int e = tid; e < CIN * NRin * RS; e += 256) {
-    const int c = e / (NRin * RS), rem = e - c * (NRin * RS);
-    const int lr = rem / RS, col = rem - lr * RS;
-    const int ih = h0 - 1 + lr, iw = col - 1;
-    float v = 0.f;
-    if (b0 < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win)
-      v = apply_in_act(a.x[(((size_t)b0 * CIN + c) * Hin + ih) * Win + iw], a.in_act);
-    s_in[c * CS + rem] = v;
+  // stage all input channels (zero halo): fixed-trip unrolled loops so that the loads are issued back to back
+  {
+    const int total = CIN * NRin * RS;
+    constexpr int NS = (IN_MAX + 255) / 256;
+    float rv[NS];
+    int lo[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const int e = tid + 256 * sidx;
+      const int c = e / (NRin * RS), rem = e - c * (NRin * RS);
+      const int lr = rem / RS, col = rem - lr * RS;
+      const int ih = h0 - 1 + lr, iw = col - 1;
+      const bool ok = e < total && b0 < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
+      lo[sidx] = e < total ? c * CS + rem : -1;
+      const float v = a.x[ok ? (((size_t)b0 * CIN + c) * Hin + ih) * Win + iw : 0];
+      rv[sidx] = ok ? v : 0.f;
+    }
+    if (a.in_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) rv[sidx] = apply_in_act(rv[sidx], a.in_act);
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx)
+      if (lo[sidx] >= 0) s_in[lo[sidx]] = rv[sidx];
   }
   // build the dense B matrix
-  for (int e = tid; e < 9 * CIN * 16; e += 256) {
+#pragma unroll
+  for (int it = 0; it < 9 * CIN * 16 / 256; ++it) {
+    const int e = tid + 256 * it;
     const int n = e & 15, k = e >> 4;
     const int c = k & 31, o9 = k >> 5;
     const int dr = o9 / 3 - 1, ds = o9 % 3 - 1;
-    float v = 0.f;
+    int kh = -1, kw = -1, co = 0;
     if (n < CO * 4) {
-      const int co = n >> 2, ph = (n >> 1) & 1, pw = n & 1;
+      co = n >> 2;
+      const int ph = (n >> 1) & 1, pw = n & 1;
       // ph = 0: dr = 0 -> kh 1, dr = -1 -> kh 3 ; ph = 1: dr = +1 -> kh 0, dr = 0 -> kh 2
-      int kh = -1, kw = -1;
       if (ph == 0) kh = dr == 0 ? 1 : (dr == -1 ? 3 : -1); else kh = dr == 1 ? 0 : (dr == 0 ? 2 : -1);
       if (pw == 0) kw = ds == 0 ? 1 : (ds == -1 ? 3 : -1); else kw = ds == 1 ? 0 : (ds == 0 ? 2 : -1);
-      if (kh >= 0 && kw >= 0) v = a.w[((size_t)c * CO + co) * 16 + kh * 4 + kw];
     }
-    s_b[e] = v;
+    const bool ok = kh >= 0 && kw >= 0;
+    const float v = a.w[ok ? ((size_t)c * CO + co) * 16 + kh * 4 + kw : 0];
+    s_b[e] = ok ? v : 0.f;
   }
   __syncthreads();
 

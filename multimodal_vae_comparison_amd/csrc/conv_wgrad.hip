@@ -49,57 +49,103 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
 
   const int ql = nt * 2 + (li >> 4), kh = (li >> 2) & 3, kw = li & 3;
 
-  for (int mtile = blockIdx.x; mtile < a.n_macro; mtile += gridDim.x) {
-    const int first_row = mtile * NR;
-    const MacroTile mt = macro_tile(first_row, NR, Hs);
-    const int NRin = 2 * mt.nrow + 2;
-    int CS = NRin * RS;
-    CS += (16 - (CS & 31) + 32) & 31;  // == 16 (mod 32)
-    const int IS = QC * CS;
-    const int MP = mt.nimg * mt.nrow * Ws;  // positions in this macro tile
-    const int PSm = MP + 1;
+  // Every macro tile has the same shape, so the staging index math is done once per thread: slot -> (global
+  // offset relative to the tile origin, LDS index, halo flags).  Per tile only the origin and three uniform
+  // flags change, and the next tile's loads are issued before the current tile's MFMAs.
+  const MacroTile mt0 = macro_tile(0, NR, Hs);
+  const int nimg = mt0.nimg, nrow = mt0.nrow;
+  const int NRin = 2 * nrow + 2;
+  int CS = NRin * RS;
+  CS += (16 - (CS & 31) + 32) & 31;  // == 16 (mod 32)
+  const int IS = QC * CS;
+  const int per_img = nrow * Ws;
+  const int MP = nimg * per_img;  // positions per macro tile
+  const int PSm = MP + 1;
+  const int lgMP = ilog2i(MP);  // MP is a power of two (32, 64 or 128)
+  const int plane_n = NRin * RSraw;
+  const int lregion = nimg * QC * plane_n;
+  constexpr int SS = S_MAX / 32 * 32 / 256 + 1;  // 17 >= 32*128/256
+  constexpr int LS = 20;                         // >= 8 ch * 18 rows * 34 cols / 256
+  int s_off[SS], l_off[LS], l_idx[LS];
+  unsigned s_ok = 0, s_img1 = 0, l_ok = 0, l_top = 0, l_bot = 0, l_img1 = 0;
+#pragma unroll
+  for (int i = 0; i < SS; ++i) {
+    const int e = tid + 256 * i;
+    const int p = e >> lgMP, pos = e - (p << lgMP);
+    const int img = pos / per_img, within = pos - img * per_img;
+    const bool ok = e < P * MP;
+    s_ok |= (ok ? 1u : 0u) << i;
+    s_img1 |= ((ok && img >= 1) ? 1u : 0u) << i;
+    s_off[i] = ok ? ((img * P + p) * Hs) * Ws + within : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < LS; ++i) {
+    const int e = tid + 256 * i;
+    const int pl = e / plane_n, rem = e - pl * plane_n;
+    const int img = pl / QC, qq = pl - img * QC;
+    const int lr = rem / RSraw, col = rem - lr * RSraw;
+    const int q = chunk * QC + qq, iw = col - 1;
+    const bool in = e < lregion;
+    const bool ok = in && q < Q && iw >= 0 && iw < Wl;
+    l_ok |= (ok ? 1u : 0u) << i;
+    l_top |= ((in && lr == 0) ? 1u : 0u) << i;
+    l_bot |= ((in && lr == NRin - 1) ? 1u : 0u) << i;
+    l_img1 |= ((in && img >= 1) ? 1u : 0u) << i;
+    l_off[i] = ok ? ((img * Q + q) * Hl + lr) * Wl + iw : 0;
+    l_idx[i] = in ? img * IS + qq * CS + lr * RS + col : -1;
+  }
+  float sv[SS], lv[LS];
+  unsigned s_val = 0, l_val = 0;
+  auto load_tile = [&](int mtile) {
+    const MacroTile mt = macro_tile(mtile * NR, NR, Hs);
+    const bool img1bad = nimg > 1 && (mt.b0 + 1) >= a.B;   // nimg <= 2 here
+    s_val = s_ok & ~(img1bad ? s_img1 : 0u);
+    l_val = l_ok & ~(mt.h0 == 0 ? l_top : 0u) & ~(mt.h0 + nrow == Hs ? l_bot : 0u) & ~(img1bad ? l_img1 : 0u);
+    const float* sb = a.small + ((size_t)mt.b0 * P * Hs + mt.h0) * Ws;
+    const float* lb = a.large + ((long)mt.b0 * Q * Hl + 2 * mt.h0 - 1) * Wl;
+#pragma unroll
+    for (int i = 0; i < SS; ++i) sv[i] = sb[(s_val >> i & 1u) ? s_off[i] : 0];
+#pragma unroll
+    for (int i = 0; i < LS; ++i) {
+      const long o = (l_val >> i & 1u) ? (long)l_off[i] : (long)(Wl + 1);   // (Wl+1) keeps the dummy address in range
+      lv[i] = lb[o];
+    }
+  };
+  auto store_tile = [&]() {
+    if (a.small_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < SS; ++i) sv[i] = apply_in_act(sv[i], a.small_act);
+    }
+    if (a.large_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < LS; ++i) lv[i] = apply_in_act(lv[i], a.large_act);
+    }
+#pragma unroll
+    for (int i = 0; i < SS; ++i) {
+      const int e = tid + 256 * i;
+      if (s_ok >> i & 1u) {
+        const int p = e >> lgMP;
+        s_small[e + p] = (s_val >> i & 1u) ? sv[i] : 0.f;   // p*PSm + pos = e + p
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LS; ++i)
+      if (l_idx[i] >= 0) s_large[l_idx[i]] = (l_val >> i & 1u) ? lv[i] : 0.f;
+  };
 
+  const int rows_total = nimg * nrow;
+  const int r_beg = half * (rows_total / PSPLIT), r_end = r_beg + rows_total / PSPLIT;
+  const int bbase = ql * CS + kh * RS + kw + 2 * lh;
+  const int abase = li * PSm + lh;
+
+  if ((int)blockIdx.x < a.n_macro) load_tile(blockIdx.x);
+  for (int mtile = blockIdx.x; mtile < a.n_macro; mtile += gridDim.x) {
     __syncthreads();  // previous tile's MFMAs are done with LDS
-    // ---- stage small: s_small[p*PSm + pos] ----
-    {
-      const int per_img = mt.nrow * Ws;
-      for (int e = tid; e < P * MP; e += 256) {
-        const int p = e / MP, pos = e - p * MP;
-        const int img = pos / per_img, within = pos - img * per_img;
-        const int b = mt.b0 + img;
-        float v = 0.f;
-        if (b < a.B) v = apply_in_act(a.small[((size_t)(b * P + p) * Hs + mt.h0) * Ws + within], a.small_act);
-        s_small[p * PSm + pos] = v;
-      }
-    }
-    // ---- stage large planes with zero halo ----
-    {
-      const int plane_n = NRin * RSraw;
-      for (int img = 0; img < mt.nimg; ++img) {
-        const int b = mt.b0 + img;
-        for (int qq = 0; qq < QC; ++qq) {
-          const int q = chunk * QC + qq;
-          const float* plane = a.large + ((size_t)(b * Q + q)) * Hl * Wl;
-          float* dst = s_large + img * IS + qq * CS;
-          for (int e = tid; e < plane_n; e += 256) {
-            const int lr = e / RSraw, col = e - lr * RSraw;
-            const int ih = 2 * mt.h0 - 1 + lr, iw = col - 1;
-            float v = 0.f;
-            if (q < Q && b < a.B && ih >= 0 && ih < Hl && iw >= 0 && iw < Wl)
-              v = apply_in_act(plane[ih * Wl + iw], a.large_act);
-            dst[lr * RS + col] = v;
-          }
-        }
-      }
-    }
+    store_tile();
     __syncthreads();
-    // ---- MFMAs over this wave's share of the positions ----
-    const int rows_total = mt.nimg * mt.nrow;
-    const int r_beg = half * (rows_total / PSPLIT), r_end = r_beg + rows_total / PSPLIT;
-    const int bbase = ql * CS + kh * RS + kw + 2 * lh;
-    const int abase = li * PSm + lh;
+    if (mtile + (int)gridDim.x < a.n_macro) load_tile(mtile + gridDim.x);
     for (int rr = r_beg; rr < r_end; ++rr) {
-      const int img = rr / mt.nrow, oh_l = rr - img * mt.nrow;
+      const int img = rr / nrow, oh_l = rr - img * nrow;
       const float* brow = s_large + img * IS + (2 * oh_l) * RS + bbase;
       const float* arow = s_small + abase + rr * Ws;
 #pragma unroll 4
