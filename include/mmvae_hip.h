@@ -214,9 +214,11 @@ size_t mmvae_embed_ws_floats(int B, int T, int V);
 
 /* Scaled-dot-product attention with key padding mask for L,S <= 64 (nn.MultiheadAttention core).
  *   q (L*N, ldq) rows r = l*N+n, head h at columns [h*hd,(h+1)*hd); k, v (S*N, ld) likewise.
- *   kpm (N,S) bytes, 1 = ignore key (may be NULL).  out (L*N, E=H*hd).  probs (N,H,L,S) saved for bwd. */
+ *   kpm (N,S) bytes, 1 = ignore key (may be NULL); with mask_is_valid != 0 the bytes are the batch's validity
+ *   mask instead (1 = real token).  out (L*N, E=H*hd).  probs (N,H,L,S) saved for bwd. */
 int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out, float* probs,
-                   int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv, mmvae_stream_t stream);
+                   int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv, int mask_is_valid,
+                   mmvae_stream_t stream);
 int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                    float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
                    long ldv, mmvae_stream_t stream);
@@ -260,6 +262,30 @@ int mmvae_step_inc(int* step_dev, mmvae_stream_t stream);
 int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long len, long stride, int accumulate,
                       mmvae_stream_t stream);
 int mmvae_fill(float* p, long n, float value, mmvae_stream_t stream);
+
+/* Deferred gradient reduction.  With accumulate == MMVAE_ACC_DEFER the *_wgrad / *_bwd_weight / layernorm /
+ * embed backward entry points only leave their split partials in `ws` (which must then be private to that call
+ * until the reduction runs); the *_layout queries describe them, and ONE mmvae_reduce_segments launch at the end
+ * of backward adds every registered segment into its destination:  dst[i] += sum_r src[r*stride + i]. */
+#define MMVAE_ACC_DEFER 2
+#define MMVAE_MAX_SEGMENTS 64
+typedef struct {
+  const float* src[MMVAE_MAX_SEGMENTS];
+  float* dst[MMVAE_MAX_SEGMENTS];
+  int rows[MMVAE_MAX_SEGMENTS];
+  int len[MMVAE_MAX_SEGMENTS];
+  int stride[MMVAE_MAX_SEGMENTS];
+  int blk0[MMVAE_MAX_SEGMENTS]; /* filled by the library */
+  int n;
+} mmvae_reduce_segments_t;
+int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream);
+/* partial layouts: rows x rowlen floats in ws; weight part at column 0, bias part at column bias_col */
+int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen, int* bias_col);
+/* linear weight gradient: `splits` partial (N*K) slabs followed by `splits` partial (N) bias rows; splits == 1
+ * means the kernel accumulated directly (nothing to reduce) */
+int mmvae_linear_bwd_weight_splits(int M, int N, int K);
+int mmvae_layernorm_bwd_rows(int rows, int d); /* partial rows of length 2*d: [dgamma | dbeta] */
+int mmvae_embed_bwd_rows(int B, int T, int V);  /* partial rows of length 4 */
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ int conv_scatter_dispatch(const float* x, const float* w, const float* bias, con
 int conv_wgrad_dispatch(const float* small, const float* large, float* dw, float* db, float* ws, int B, int P, int Q,
                         int Hs, int small_act, int large_act, int bias_from, int accumulate, hipStream_t st);
 size_t conv_wgrad_ws_floats(int B, int Q, int Hs);
+void conv_wgrad_layout(int B, int Q, int Hs, int* rows, int* rowlen, int* bias_col);
 
 extern "C" int mmvae_conv2d_k4s2_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y,
                                      int B, int Cin, int Cout, int Hin, int in_act, int ep_mode,
@@ -52,4 +53,11 @@ extern "C" int mmvae_convT2d_k4s2_wgrad(const float* x, const float* dy, float* 
 extern "C" size_t mmvae_conv_wgrad_ws_floats(int B, int Csmall, int Clarge, int Hsmall) {
   (void)Csmall;
   return conv_wgrad_ws_floats(B, Clarge, Hsmall);
+}
+extern "C" int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen,
+                                       int* bias_col) {
+  (void)Csmall;
+  MMVAE_CHECK_ARG(rows && rowlen && bias_col);
+  conv_wgrad_layout(B, Clarge, Hsmall, rows, rowlen, bias_col);
+  return MMVAE_OK;
 }

@@ -11,6 +11,11 @@ __host__ __device__ __forceinline__ int ilog2i(int v) {
   return l;
 }
 
+// Exact floor(e / d) for 0 <= e < 2^20 and small d through one float multiply (a runtime integer division costs
+// ~40 VALU instructions; the staging-slot decode below does a few of them per slot).  (e + 0.5) / d is at least
+// 0.5 / d away from an integer, far above the float rounding error at these magnitudes.
+__device__ __forceinline__ int fdiv_small(int e, float inv_d) { return (int)(((float)e + 0.5f) * inv_d); }
+
 // Geometry of one workgroup's macro tile: `nr` consecutive global rows (row = b*H + h) of an H x H map.
 // Either a slice of rows inside one image (nr <= H) or `nimg` whole images (nr = nimg * H).
 struct MacroTile {

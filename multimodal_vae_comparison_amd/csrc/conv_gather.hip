@@ -55,16 +55,20 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvGatherArgs a) {
   const int region = mt.nimg * IS;
   int soff[MAXSLOT];
   unsigned svalid = 0;
+  const float inv_CS = 1.0f / (float)CS, inv_RS = 1.0f / (float)RS;
 #pragma unroll
   for (int sidx = 0; sidx < MAXSLOT; ++sidx) {
-    const int e = tid + 256 * sidx;
-    const int pl = e / CS, rem = e - pl * CS;
-    const int img = pl / CC, cl = pl - img * CC;
-    const int lr = rem / RS, col = rem - lr * RS;
-    const int ih = 2 * mt.h0 - 1 + lr, iw = col - 1;
-    const bool ok = e < region && (mt.b0 + img) < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
-    svalid |= (ok ? 1u : 0u) << sidx;
-    soff[sidx] = ok ? ((img * CIN + cl) * Hin + ih) * Win + iw : 0;
+    soff[sidx] = 0;
+    if (sidx * 256 < region) {   // uniform: slots beyond the region cost nothing
+      const int e = tid + 256 * sidx;
+      const int pl = fdiv_small(e, inv_CS), rem = e - pl * CS;
+      const int img = pl / CC, cl = pl - img * CC;
+      const int lr = fdiv_small(rem, inv_RS), col = rem - lr * RS;
+      const int ih = 2 * mt.h0 - 1 + lr, iw = col - 1;
+      const bool ok = e < region && (mt.b0 + img) < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
+      svalid |= (ok ? 1u : 0u) << sidx;
+      soff[sidx] = ok ? ((img * CIN + cl) * Hin + ih) * Win + iw : 0;
+    }
   }
   const float* xbase = a.x + (size_t)mt.b0 * CIN * Hin * Win;
   constexpr int WSLOT = CC * 16 * CONV_CO / 256;

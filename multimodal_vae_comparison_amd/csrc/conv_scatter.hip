@@ -53,16 +53,20 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(ConvScatterArgs a) {
   const int region = mt.nimg * IS;
   int soff[MAXSLOT];
   unsigned svalid = 0;
+  const float inv_CS = 1.0f / (float)CS, inv_RS = 1.0f / (float)RS;
 #pragma unroll
   for (int sidx = 0; sidx < MAXSLOT; ++sidx) {
-    const int e = tid + 256 * sidx;
-    const int pl = e / CS, rem = e - pl * CS;
-    const int img = pl / CC, cl = pl - img * CC;
-    const int lr = rem / RS, col = rem - lr * RS;
-    const int ih = mt.h0 - 1 + lr, iw = col - 1;
-    const bool ok = e < region && (mt.b0 + img) < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
-    svalid |= (ok ? 1u : 0u) << sidx;
-    soff[sidx] = ok ? ((img * CIN + cl) * Hin + ih) * Win + iw : 0;
+    soff[sidx] = 0;
+    if (sidx * 256 < region) {
+      const int e = tid + 256 * sidx;
+      const int pl = fdiv_small(e, inv_CS), rem = e - pl * CS;
+      const int img = pl / CC, cl = pl - img * CC;
+      const int lr = fdiv_small(rem, inv_RS), col = rem - lr * RS;
+      const int ih = mt.h0 - 1 + lr, iw = col - 1;
+      const bool ok = e < region && (mt.b0 + img) < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
+      svalid |= (ok ? 1u : 0u) << sidx;
+      soff[sidx] = ok ? ((img * CIN + cl) * Hin + ih) * Win + iw : 0;
+    }
   }
   const float* xbase = a.x + (size_t)mt.b0 * CIN * Hin * Win;
   constexpr int WSLOT = CC * 16 * CONV_CO / 256;
@@ -247,14 +251,15 @@ __global__ __launch_bounds__(256) void conv_scatter3_kernel(ConvScatter3Args a) 
   // stage all input channels (zero halo): fixed-trip unrolled loops so that the loads are issued back to back
   {
     const int total = CIN * NRin * RS;
+    const float inv_PL = 1.0f / (float)(NRin * RS), inv_RS3 = 1.0f / (float)RS;
     constexpr int NS = (IN_MAX + 255) / 256;
     float rv[NS];
     int lo[NS];
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       const int e = tid + 256 * sidx;
-      const int c = e / (NRin * RS), rem = e - c * (NRin * RS);
-      const int lr = rem / RS, col = rem - lr * RS;
+      const int c = fdiv_small(e, inv_PL), rem = e - c * (NRin * RS);
+      const int lr = fdiv_small(rem, inv_RS3), col = rem - lr * RS;
       const int ih = h0 - 1 + lr, iw = col - 1;
       const bool ok = e < total && b0 < a.B && ih >= 0 && ih < Hin && iw >= 0 && iw < Win;
       lo[sidx] = e < total ? c * CS + rem : -1;

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
   const int lgMP = ilog2i(MP);  // MP is a power of two (32, 64 or 128)
   const int plane_n = NRin * RSraw;
   const int lregion = nimg * QC * plane_n;
+  const float inv_plane = 1.0f / (float)plane_n, inv_RSraw = 1.0f / (float)RSraw;
   constexpr int SS = S_MAX / 32 * 32 / 256 + 1;  // 17 >= 32*128/256
   constexpr int LS = 20;                         // >= 8 ch * 18 rows * 34 cols / 256
   int s_off[SS], l_off[LS], l_idx[LS];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
   for (int i = 0; i < SS; ++i) {
     const int e = tid + 256 * i;
     const int p = e >> lgMP, pos = e - (p << lgMP);
-    const int img = pos / per_img, within = pos - img * per_img;
+    const int img = pos >= per_img ? 1 : 0, within = pos - img * per_img;   // nimg <= 2
     const bool ok = e < P * MP;
     s_ok |= (ok ? 1u : 0u) << i;
     s_img1 |= ((ok && img >= 1) ? 1u : 0u) << i;
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
 #pragma unroll
   for (int i = 0; i < LS; ++i) {
     const int e = tid + 256 * i;
-    const int pl = e / plane_n, rem = e - pl * plane_n;
+    const int pl = fdiv_small(e, inv_plane), rem = e - pl * plane_n;
     const int img = pl / QC, qq = pl - img * QC;
-    const int lr = rem / RSraw, col = rem - lr * RSraw;
+    const int lr = fdiv_small(rem, inv_RSraw), col = rem - lr * RSraw;
     const int q = chunk * QC + qq, iw = col - 1;
     const bool in = e < lregion;
     const bool ok = in && q < Q && iw >= 0 && iw < Wl;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     __syncthreads();
     if (mtile + (int)gridDim.x < a.n_macro) load_tile(mtile + gridDim.x);
     for (int rr = r_beg; rr < r_end; ++rr) {
-      const int img = rr / nrow, oh_l = rr - img * nrow;
+      const int img = rr >= nrow ? 1 : 0, oh_l = rr - img * nrow;
       const float* brow = s_large + img * IS + (2 * oh_l) * RS + bbase;
       const float* arow = s_small + abase + rr * Ws;
 #pragma unroll 4
@@ -195,6 +196,11 @@ static int wgrad_n_macro(int B, int Hs) {
   return (int)(((long)B * Hs + NR - 1) / NR);
 }
 
+void conv_wgrad_layout(int B, int Q, int Hs, int* rows, int* rowlen, int* bias_col) {
+  *rows = wgrad_rows(wgrad_n_macro(B, Hs), Q);
+  *bias_col = 32 * Q * 16;
+  *rowlen = *bias_col + 32;
+}
 size_t conv_wgrad_ws_floats(int B, int Q, int Hs) {
   return (size_t)wgrad_rows(wgrad_n_macro(B, Hs), Q) * ((size_t)32 * Q * 16 + 32);
 }
@@ -215,6 +221,7 @@ int conv_wgrad_dispatch(const float* small, const float* large, float* dw, float
     hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(nsplit, 1), dim3(256), 0, st, a);
   int rc = mmvae_launch_status();
   if (rc) return rc;
+  if (accumulate == MMVAE_ACC_DEFER) return rc;   // partials stay in ws; the caller registers the segments
   const int rows = wgrad_rows(n_macro, Q);
   const long dwlen = (long)32 * Q * 16, rowlen = dwlen + 32;
   rc = mmvae_reduce_rows(ws, dw, rows, dwlen, rowlen, accumulate, st);

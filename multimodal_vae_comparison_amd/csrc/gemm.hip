@@ -192,7 +192,8 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   GemmArgs g;
   g.A = A; g.B = Bm; g.bias = bias; g.aux = const_cast<float*>(aux); g.C = C; g.a_rowsum = a_rowsum; g.ws = ws;
   g.M = M; g.N = N; g.K = K; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
-  g.a_act = a_act; g.b_act = b_act; g.ep = ep_mode; g.accumulate = accumulate;
+  g.a_act = a_act; g.b_act = b_act; g.ep = ep_mode;
+  g.accumulate = accumulate ? 1 : 0;   // DEFER without a split == plain accumulation
   const int ntn = (N + 31) / 32;
   // enough 128x32 tiles to give every CU one => big-tile kernel; otherwise the intra-workgroup K-split tile
   const bool big = (long)((M + 127) / 128) * ntn >= 256;
@@ -209,7 +210,7 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
     hipLaunchKernelGGL(gemm_kernel<4>, dim3(ntn, (M + 31) / 32, nz), dim3(256), 0, st, g);
   int rc = mmvae_launch_status();
   if (rc) return rc;
-  if (nz > 1) {
+  if (nz > 1 && accumulate != MMVAE_ACC_DEFER) {
     rc = mmvae_reduce_rows(ws, C, nz, (long)M * N, (long)M * N, accumulate, stream);
     if (rc) return rc;
     if (a_rowsum) rc = mmvae_reduce_rows(ws + (size_t)nz * M * N, a_rowsum, nz, M, M, accumulate, stream);
@@ -239,6 +240,15 @@ static int wgrad_splitk(int M, int N, int K) {
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   return s;
+}
+extern "C" int mmvae_linear_bwd_weight_splits(int M, int N, int K) {
+  // mirrors the kper rounding of mmvae_gemm_f32 for the (N x K) = dy^T x problem with reduction length M
+  int sk = wgrad_splitk(M, N, K);
+  const long tiles128 = (long)((N + 127) / 128) * ((K + 31) / 32);
+  const int bk = tiles128 >= 256 ? 32 : 128;
+  int kper = (M + sk - 1) / sk;
+  kper = (kper + bk - 1) / bk * bk;
+  return (M + kper - 1) / kper;
 }
 extern "C" size_t mmvae_linear_bwd_weight_ws_floats(int M, int N, int K) {
   return mmvae_gemm_ws_floats(N, K, wgrad_splitk(M, N, K));

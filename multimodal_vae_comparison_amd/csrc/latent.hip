@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
 #pragma unroll
       for (int j = 0; j <= MMVAE_MAX_EXPERTS; ++j) {
         if (j > E) continue;
-        float v = wave_sum(klacc[j]);
+        float v = wave_sum(klacc[j]);   // rows outside kl_mask accumulate nothing: written as 0
         if (lane == 0) kl[(size_t)j * B + b] = v;
       }
     }

@@ -112,6 +112,49 @@ extern "C" int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long 
   return mmvae_launch_status();
 }
 
+// Many partial-sum reductions in ONE launch: dst_s[i] += sum_r src_s[r*stride_s + i] for up to 64 segments.
+// Used at the end of backward: every weight-gradient kernel of the step leaves its split partials in a private
+// region of the step arena and registers a segment; a single launch folds all of them into the flat gradient
+// buffer (40 tiny reduce launches per step otherwise).  Same 64-column x 4-row-slice blocks as reduce_rows.
+__global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t) {
+  __shared__ float part[4][64];
+  int sg = 0;
+  while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan, n <= 64
+  const float* __restrict__ src = t.src[sg];
+  float* __restrict__ dst = t.dst[sg];
+  const int n_rows = t.rows[sg];
+  const long len = t.len[sg], stride = t.stride[sg];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x - t.blk0[sg]) * 64 + cx;
+  float a = 0.f;
+  if (i < len) {
+    int r = ry;
+    for (; r + 28 < n_rows; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + 4 * u) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; r < n_rows; r += 4) a += src[(size_t)r * stride + i];
+  }
+  part[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && i < len) dst[i] += part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+}
+extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(table && table->n > 0 && table->n <= MMVAE_MAX_SEGMENTS);
+  mmvae_reduce_segments_t t = *table;
+  int blocks = 0;
+  for (int s = 0; s < t.n; ++s) {
+    if (!t.src[s] || !t.dst[s] || t.rows[s] <= 0 || t.len[s] <= 0) return MMVAE_ERR_ARG;
+    t.blk0[s] = blocks;
+    blocks += (t.len[s] + 63) / 64;
+  }
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+  return mmvae_launch_status();
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float value) {
   const long gs = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) p[i] = value;

@@ -54,6 +54,7 @@ static inline int embed_blocks(int B, int T, int V) {
   long b = (n + 255) / 256;
   return (int)(b > 256 ? 256 : (b < 1 ? 1 : b));
 }
+extern "C" int mmvae_embed_bwd_rows(int B, int T, int V) { return embed_blocks(B, T, V); }
 extern "C" size_t mmvae_embed_ws_floats(int B, int T, int V) { return (size_t)embed_blocks(B, T, V) * 4; }
 
 extern "C" int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T,
@@ -65,11 +66,12 @@ extern "C" int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const f
 }
 extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V,
                                   int mode, int accumulate, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(onehot && dx && demb && ws && B > 0 && T > 0 && V > 1);
+  MMVAE_CHECK_ARG(onehot && dx && ws && B > 0 && T > 0 && V > 1);
+  MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || demb);
   const int nb = embed_blocks(B, T, V);
   hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, onehot, dx, ws, B, T, V, mode);
   int rc = mmvae_launch_status();
-  if (rc) return rc;
+  if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   if (!accumulate && V > 2) {
     rc = mmvae_fill(demb + 4, (long)(V - 2) * 2, 0.f, stream);  // rows >= 2 are never looked up
     if (rc) return rc;
@@ -78,68 +80,97 @@ extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* d
 }
 
 // ---------------------------------------------------------------------------------------------
-// Attention core of nn.MultiheadAttention, one wavefront per (sample n, head h); lane = query index.
+// Attention core of nn.MultiheadAttention for L, S <= 64, head_dim <= 32.  One wavefront per (sample n, head h).
+// Rows of K / V / Q / dO live in LDS with pitch 36 floats and are consumed as broadcast ds_read_b128 (all lanes
+// read the same row => conflict free); the L x S score / probability tiles live in LDS with pitch 65 (lane =
+// row or lane = column are both conflict free).  Every dot product is computed exactly once.
 // ---------------------------------------------------------------------------------------------
 #define ATT_MAX 64
-#define ATT_HD 32  // head_dim <= 32 (27 encoder, D/2 decoder)
+#define ATT_HD 32  // head_dim <= 32 (27 encoder, D/2 decoder); padded columns are zero
+#define ATT_HP 36  // row pitch (16-byte aligned rows)
+#define ATT_SP 65
+
+__device__ __forceinline__ void att_stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int N,
+                                               int n, long ld, int col0, int hd, int lane) {
+  for (int e = lane; e < rows * ATT_HD; e += 64) {
+    const int r = e >> 5, d = e & 31;
+    dst[r * ATT_HP + d] = d < hd ? src[((size_t)r * N + n) * ld + col0 + d] : 0.f;
+  }
+}
+__device__ __forceinline__ float att_dot(const float* __restrict__ row, const float (&x)[ATT_HD]) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int d = 0; d < ATT_HD; d += 4) {
+    const float4 k4 = *reinterpret_cast<const float4*>(row + d);
+    a0 += x[d] * k4.x;
+    a1 += x[d + 1] * k4.y;
+    a2 += x[d + 2] * k4.z;
+    a3 += x[d + 3] * k4.w;
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ void att_axpy(float (&acc)[ATT_HD], float p, const float* __restrict__ row) {
+#pragma unroll
+  for (int d = 0; d < ATT_HD; d += 4) {
+    const float4 v4 = *reinterpret_cast<const float4*>(row + d);
+    acc[d] += p * v4.x;
+    acc[d + 1] += p * v4.y;
+    acc[d + 2] += p * v4.z;
+    acc[d + 3] += p * v4.w;
+  }
+}
 
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const uint8_t* __restrict__ kpm,
                                                       float* __restrict__ out, float* __restrict__ probs, int L, int S,
-                                                      int N, int H, int hd, long ldq, long ldk, long ldv) {
-  __shared__ float sk[ATT_MAX * (ATT_HD + 1)];
-  __shared__ float sv[ATT_MAX * (ATT_HD + 1)];
+                                                      int N, int H, int hd, long ldq, long ldk, long ldv,
+                                                      int mask_is_valid) {
+  __shared__ __attribute__((aligned(16))) float sk[ATT_MAX * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sv[ATT_MAX * ATT_HP];
+  __shared__ float sp[ATT_MAX * ATT_SP];
   __shared__ float smask[ATT_MAX];
+  __shared__ float sinv[ATT_MAX];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  const int HP = ATT_HD + 1;
-  // columns [hd, ATT_HD) are zero-filled: the dot products below run over the full ATT_HD width
-  for (int e = lane; e < S * ATT_HD; e += 64) {
-    const int s = e / ATT_HD, d = e - s * ATT_HD;
-    sk[s * HP + d] = d < hd ? k[((size_t)s * N + n) * ldk + h * hd + d] : 0.f;
-    sv[s * HP + d] = d < hd ? v[((size_t)s * N + n) * ldv + h * hd + d] : 0.f;
-  }
-  if (lane < S) smask[lane] = (kpm && kpm[(size_t)n * S + lane]) ? 1.f : 0.f;
+  att_stage_rows(sk, k, S, N, n, ldk, h * hd, hd, lane);
+  att_stage_rows(sv, v, S, N, n, ldv, h * hd, hd, lane);
+  // kpm bytes: 1 = ignore this key (key_padding_mask) or, with mask_is_valid, the batch's own validity mask
+  // (1 = real token) read in place -- no conversion kernel
+  if (lane < S) smask[lane] = (kpm && ((kpm[(size_t)n * S + lane] != 0) != (mask_is_valid != 0))) ? 1.f : 0.f;
   __syncthreads();
-  if (lane >= L) return;
   const float scale = 1.0f / sqrtf((float)hd);
-  float qr[ATT_HD];
+  if (lane < L) {
+    float qr[ATT_HD];
 #pragma unroll
-  for (int d = 0; d < ATT_HD; ++d) qr[d] = d < hd ? q[((size_t)lane * N + n) * ldq + h * hd + d] * scale : 0.f;
-  float mx = -INFINITY;
-  for (int s = 0; s < S; ++s) {
-    float sc = 0.f;
+    for (int d = 0; d < ATT_HD; ++d) qr[d] = d < hd ? q[((size_t)lane * N + n) * ldq + h * hd + d] * scale : 0.f;
+    float mx = -INFINITY;
+    for (int s = 0; s < S; ++s) {
+      float sc = att_dot(sk + s * ATT_HP, qr);
+      if (smask[s] != 0.f) sc = -INFINITY;
+      sp[lane * ATT_SP + s] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    float o[ATT_HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) sc += qr[d] * sk[s * HP + d];
-    if (smask[s] != 0.f) sc = -INFINITY;
-    mx = fmaxf(mx, sc);
+    for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float p = expf(sp[lane * ATT_SP + s] - mx);
+      sp[lane * ATT_SP + s] = p;
+      sum += p;
+      att_axpy(o, p, sv + s * ATT_HP);
+    }
+    const float inv = 1.0f / sum;
+    sinv[lane] = inv;
+    float* orow = out + ((size_t)lane * N + n) * ((size_t)H * hd) + h * hd;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d)
+      if (d < hd) orow[d] = o[d] * inv;
   }
-  float sum = 0.f;
-  for (int s = 0; s < S; ++s) {
-    float sc = 0.f;
-#pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) sc += qr[d] * sk[s * HP + d];
-    if (smask[s] != 0.f) sc = -INFINITY;
-    sum += expf(sc - mx);
-  }
-  const float inv = 1.0f / sum;
-  float o[ATT_HD];
-#pragma unroll
-  for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
-  float* prow = probs + (((size_t)n * H + h) * L + lane) * S;
-  for (int s = 0; s < S; ++s) {
-    float sc = 0.f;
-#pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) sc += qr[d] * sk[s * HP + d];
-    if (smask[s] != 0.f) sc = -INFINITY;
-    const float p = expf(sc - mx) * inv;
-    prow[s] = p;
-#pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) o[d] += p * sv[s * HP + d];
-  }
-  float* orow = out + ((size_t)lane * N + n) * ((size_t)H * hd) + h * hd;
-#pragma unroll
-  for (int d = 0; d < ATT_HD; ++d)
-    if (d < hd) orow[d] = o[d];
+  __syncthreads();
+  // normalised probabilities, written row by row with lane = key index (coalesced)
+  float* P = probs + ((size_t)n * H + h) * L * S;
+  if (lane < S)
+    for (int l = 0; l < L; ++l) P[(size_t)l * S + lane] = sp[l * ATT_SP + lane] * sinv[l];
 }
 
 // dV[s] = sum_l P[l,s] dO[l];  dP[l,s] = dO[l].V[s];  dS = P (dP - sum_s P dP);
@@ -149,70 +180,75 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ dout, float* __restrict__ dq,
                                                       float* __restrict__ dk, float* __restrict__ dv, int L, int S,
                                                       int N, int H, int hd, long ldq, long ldk, long ldv) {
-  constexpr int HP = ATT_HD + 1, SP = ATT_MAX + 1;
-  __shared__ float sq[ATT_MAX * HP];
-  __shared__ float sk[ATT_MAX * HP];
-  __shared__ float sv[ATT_MAX * HP];
-  __shared__ float sdo[ATT_MAX * HP];
-  __shared__ float sp[ATT_MAX * SP];
-  __shared__ float sds[ATT_MAX * SP];
+  __shared__ __attribute__((aligned(16))) float sq[ATT_MAX * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sk[ATT_MAX * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sv[ATT_MAX * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sdo[ATT_MAX * ATT_HP];
+  __shared__ float sp[ATT_MAX * ATT_SP];
+  __shared__ float sds[ATT_MAX * ATT_SP];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  const size_t E = (size_t)H * hd;
-  for (int e = lane; e < S * hd; e += 64) {
-    const int s = e / hd, d = e - s * hd;
-    sk[s * HP + d] = k[((size_t)s * N + n) * ldk + h * hd + d];
-    sv[s * HP + d] = v[((size_t)s * N + n) * ldv + h * hd + d];
-  }
-  for (int e = lane; e < L * hd; e += 64) {
-    const int l = e / hd, d = e - l * hd;
-    sq[l * HP + d] = q[((size_t)l * N + n) * ldq + h * hd + d];
-    sdo[l * HP + d] = dout[((size_t)l * N + n) * E + h * hd + d];
-  }
+  const long E = (long)H * hd;
+  att_stage_rows(sk, k, S, N, n, ldk, h * hd, hd, lane);
+  att_stage_rows(sv, v, S, N, n, ldv, h * hd, hd, lane);
+  att_stage_rows(sq, q, L, N, n, ldq, h * hd, hd, lane);
+  att_stage_rows(sdo, dout, L, N, n, E, h * hd, hd, lane);
   const float* P = probs + ((size_t)n * H + h) * L * S;
-  for (int e = lane; e < L * S; e += 64) {
-    const int l = e / S, s = e - l * S;
-    sp[l * SP + s] = P[e];
-  }
+  if (lane < S)
+    for (int l = 0; l < L; ++l) sp[l * ATT_SP + lane] = P[(size_t)l * S + lane];
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)hd);
   if (lane < L) {
     const int l = lane;
+    float dor[ATT_HD];
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) dor[d] = sdo[l * ATT_HP + d];
     float delta = 0.f;
     for (int s = 0; s < S; ++s) {
-      float dp = 0.f;
-      for (int d = 0; d < hd; ++d) dp += sdo[l * HP + d] * sv[s * HP + d];
-      sds[l * SP + s] = dp;
-      delta += sp[l * SP + s] * dp;
+      const float dp = att_dot(sv + s * ATT_HP, dor);
+      sds[l * ATT_SP + s] = dp;
+      delta += sp[l * ATT_SP + s] * dp;
     }
-    for (int s = 0; s < S; ++s) sds[l * SP + s] = sp[l * SP + s] * (sds[l * SP + s] - delta);
-    for (int d = 0; d < hd; ++d) {
-      float a = 0.f;
-      for (int s = 0; s < S; ++s) a += sds[l * SP + s] * sk[s * HP + d];
-      dq[((size_t)l * N + n) * ldq + h * hd + d] = a * scale;
+    float dqr[ATT_HD];
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) dqr[d] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float ds = sp[l * ATT_SP + s] * (sds[l * ATT_SP + s] - delta);
+      sds[l * ATT_SP + s] = ds;
+      att_axpy(dqr, ds, sk + s * ATT_HP);
     }
+    float* dqrow = dq + ((size_t)l * N + n) * ldq + h * hd;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d)
+      if (d < hd) dqrow[d] = dqr[d] * scale;
   }
   __syncthreads();
   if (lane < S) {
     const int s = lane;
-    for (int d = 0; d < hd; ++d) {
-      float av = 0.f, ak = 0.f;
-      for (int l = 0; l < L; ++l) {
-        av += sp[l * SP + s] * sdo[l * HP + d];
-        ak += sds[l * SP + s] * sq[l * HP + d];
-      }
-      dv[((size_t)s * N + n) * ldv + h * hd + d] = av;
-      dk[((size_t)s * N + n) * ldk + h * hd + d] = ak * scale;
+    float dvr[ATT_HD], dkr[ATT_HD];
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) dvr[d] = dkr[d] = 0.f;
+    for (int l = 0; l < L; ++l) {
+      att_axpy(dvr, sp[l * ATT_SP + s], sdo + l * ATT_HP);
+      att_axpy(dkr, sds[l * ATT_SP + s], sq + l * ATT_HP);
     }
+    float* dvrow = dv + ((size_t)s * N + n) * ldv + h * hd;
+    float* dkrow = dk + ((size_t)s * N + n) * ldk + h * hd;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d)
+      if (d < hd) {
+        dvrow[d] = dvr[d];
+        dkrow[d] = dkr[d] * scale;
+      }
   }
 }
 
 extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out,
                               float* probs, int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv,
-                              mmvae_stream_t stream) {
+                              int mask_is_valid, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L, S, N,
-                     H, hd, ldq, ldk, ldv);
+                     H, hd, ldq, ldk, ldv, mask_is_valid);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
@@ -331,6 +367,11 @@ static inline int ln_blocks(int rows, int* rpb) {
   *rpb = (rows + nb - 1) / nb;
   return (rows + *rpb - 1) / *rpb;
 }
+extern "C" int mmvae_layernorm_bwd_rows(int rows, int d) {
+  (void)d;
+  int rpb;
+  return ln_blocks(rows, &rpb);
+}
 extern "C" size_t mmvae_layernorm_ws_floats(int rows, int d) {
   int rpb;
   return (size_t)ln_blocks(rows, &rpb) * 2 * d;
@@ -348,14 +389,15 @@ extern "C" int mmvae_layernorm_residual_fwd(const float* x, const float* r, cons
 extern "C" int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
                                             float* dsum, float* dgamma, float* dbeta, float* ws, int rows, int d,
                                             int accumulate, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(dy && xhat && rstd && gamma && dsum && dgamma && dbeta && ws && rows > 0 && d > 0);
+  MMVAE_CHECK_ARG(dy && xhat && rstd && gamma && dsum && ws && rows > 0 && d > 0);
+  MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || (dgamma && dbeta));
   if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   int rpb;
   const int nb = ln_blocks(rows, &rpb);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, ws, rows,
                      d, rpb);
   int rc = mmvae_launch_status();
-  if (rc) return rc;
+  if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   if (dbeta == dgamma + d) return mmvae_reduce_rows(ws, dgamma, nb, 2L * d, 2L * d, accumulate, stream);
   rc = mmvae_reduce_rows(ws, dgamma, nb, d, 2L * d, accumulate, stream);
   if (rc) return rc;

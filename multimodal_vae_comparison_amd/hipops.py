@@ -74,7 +74,7 @@ SIGNATURES = {
     "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_p]),
     "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
-    "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_p]),
+    "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_i, c_p]),
     "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_p]),
     "mmvae_layernorm_residual_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_p]),
     "mmvae_layernorm_residual_bwd": (c_i, [c_p] * 8 + [c_i] * 3 + [c_p]),
@@ -88,7 +88,20 @@ SIGNATURES = {
     "mmvae_step_inc": (c_i, [c_p, c_p]),
     "mmvae_reduce_rows": (c_i, [c_p, c_p, c_i, c_l, c_l, c_i, c_p]),
     "mmvae_fill": (c_i, [c_p, c_l, c_f, c_p]),
+    "mmvae_reduce_segments": (c_i, [c_p, c_p]),
+    "mmvae_conv_wgrad_layout": (c_i, [c_i] * 4 + [c_p] * 3),
+    "mmvae_linear_bwd_weight_splits": (c_i, [c_i] * 3),
+    "mmvae_layernorm_bwd_rows": (c_i, [c_i, c_i]),
+    "mmvae_embed_bwd_rows": (c_i, [c_i] * 3),
 }
+ACC_DEFER = 2
+MAX_SEGMENTS = 64
+
+
+class ReduceSegments(ctypes.Structure):
+    _fields_ = [("src", c_p * MAX_SEGMENTS), ("dst", c_p * MAX_SEGMENTS), ("rows", c_i * MAX_SEGMENTS),
+                ("len", c_i * MAX_SEGMENTS), ("stride", c_i * MAX_SEGMENTS), ("blk0", c_i * MAX_SEGMENTS),
+                ("n", c_i)]
 
 
 def lib():

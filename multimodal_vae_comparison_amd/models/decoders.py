@@ -79,8 +79,8 @@ class HipTransformerDecoderLayer(nn.Module):
         self.norm2 = HipLayerNorm(d)
         self.norm3 = HipLayerNorm(d)
 
-    def forward(self, x, mem, kpm_u8):
-        x = self.norm1(self.self_attn(x, kpm_u8), x)
+    def forward(self, x, mem, mask_u8):
+        x = self.norm1(self.self_attn(x, mask_u8), x)
         x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
         return self.norm3(self.linear2(self.linear1(x)), x)
 
@@ -136,11 +136,11 @@ class Dec_TxtTransformer(VaeDecoder):
             mask = torch.ones(bs, self.data_dim[0], dtype=torch.bool, device=z.device)
         mask = mask.to(z.device)
         T = mask.shape[1]
-        kpm = (~mask).to(torch.uint8).contiguous()
+        mask_u8 = ops.as_u8(mask)
         x = self._timequeries(T, bs, D, z.device)
         mem = z[0]
         for layer in self.seqTransDecoder.layers:
-            x = layer(x, mem, kpm)
+            x = layer(x, mem, mask_u8)
         out = self.finallayer(x)                                              # (T, bs, V)
-        out = ops.permute_mask(out, mask.to(torch.uint8).contiguous())        # (bs, T, V), zero at padding
+        out = ops.permute_mask(out, mask_u8)                                  # (bs, T, V), zero at padding
         return out, self._scale

@@ -144,8 +144,8 @@ class HipTransformerEncoderLayer(nn.Module):
         self.norm1 = HipLayerNorm(d)
         self.norm2 = HipLayerNorm(d)
 
-    def forward(self, x, kpm_u8):
-        x = self.norm1(self.self_attn(x, kpm_u8), x)
+    def forward(self, x, mask_u8):
+        x = self.norm1(self.self_attn(x, mask_u8), x)
         return self.norm2(self.linear2(self.linear1(x)), x)
 
 
@@ -183,11 +183,11 @@ class Enc_TxtTransformer(VaeEncoder):
             raise RuntimeError("batch larger than the positional table (reference: pe[:B], nn_modules.py:419)")
         if mask is None:
             mask = torch.ones(bs, nframes, dtype=torch.bool, device=x.device)
-        kpm = (~mask).to(torch.uint8).contiguous()
+        mask_u8 = ops.as_u8(mask)            # validity bytes, read in place by the attention kernel
         mode = 1 if (bs == nframes or bs == 1) else 0
         w = self.embedding.weight
         h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad)   # (T, B, 2V)
         for layer in self.seqTransEncoder.layers:
-            h = layer(h, kpm)
+            h = layer(h, mask_u8)
         z = ops.mean_over_time(h)
         return self.process_output(z)

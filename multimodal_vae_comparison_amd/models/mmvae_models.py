@@ -62,12 +62,11 @@ class MoPOE(TorchMMVAE):
             vae = self.vaes[n]
             out, _ = vae.dec({"latents": z[i].unsqueeze(0), "masks": mods[n]["masks"]})
             recs.append(recon_rowsum(vae.ltype, out, mods[n]))             # (B,) = -lpx_z / llik_scaling
-        V = torch.cat([torch.stack(recs), kl], dim=0)                       # (M + M+1, B)
         w_kl = 1.0 / (M + 1)
         lam = [float(self.vaes[n].llik_scaling) for n in names]
         W = [[l / B for l in lam] + [self.obj_fn.beta * w_kl / B] * (M + 1),
              [0.0] * M + [w_kl / B] * (M + 1)]
-        out = ops.lincomb_rows(V, W)
+        out = ops.lincomb_rows(recs + [kl], W)                              # rows: M recon sums, M+1 KL rows
         return {"loss": out[0], "kld": out[1], "reconstruction_loss": recs}
 
     # ---- API surface (inference / evaluation) ------------------------------------------------------
@@ -155,7 +154,7 @@ class POE(TorchMMVAE):
             rows.append(kl[E])
             W_loss.append(float(self.obj_fn.beta))
             W_kld.append(1.0 / len(subsets))
-        out = ops.lincomb_rows(torch.stack(rows), [W_loss, W_kld])
+        out = ops.lincomb_rows(rows, [W_loss, W_kld])
         ind = [r.sum() for r in rec_log]
         return {"loss": out[0], "reconstruction_loss": ind, "kld": out[1]}
 

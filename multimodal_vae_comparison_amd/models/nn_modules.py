@@ -94,10 +94,11 @@ class HipSelfAttention(nn.Module):
     def flat_groups(self):
         return [[self.in_proj_weight, self.in_proj_bias]]
 
-    def forward(self, x, kpm_u8):
+    def forward(self, x, mask_u8):
+        """mask_u8: (N, L) validity bytes (1 = real token); padded keys are ignored"""
         qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, H.ACT_NONE, self.in_proj_weight.grad,
                          self.in_proj_bias.grad)
-        a = ops.attention(qkv, kpm_u8, self.nhead)
+        a = ops.attention(qkv, mask_u8, self.nhead, mask_is_valid=True)
         return self.out_proj(a)
 
     def value_path(self, mem):

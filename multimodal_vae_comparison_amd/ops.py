@@ -24,6 +24,70 @@ def _call(name, *args):
     H.check(getattr(H.lib(), name)(*args), name)
 
 
+class GradReducer:
+    """Deferred reduction of split weight-gradient partials (one launch per backward instead of ~40).
+
+    While a backward pass runs, every op whose gradient kernel produces split partials takes a PRIVATE slice of
+    the step arena for them and registers a segment (partials -> destination in the flat gradient buffer).  An
+    autograd-engine callback queued by the first registration fires when the backward pass is complete and folds
+    all segments with mmvae_reduce_segments.  Works unchanged under hipGraph capture (fixed arena offsets)."""
+
+    enabled = True
+    _arena = {}
+    _state = {}
+
+    @classmethod
+    def _st(cls, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        st = cls._state.get(key)
+        if st is None:
+            st = {"off": 0, "segs": [], "armed": False, "device": device}
+            cls._state[key] = st
+        return key, st
+
+    @classmethod
+    def alloc(cls, n_floats, device):
+        key, st = cls._st(device)
+        n = (int(n_floats) + 63) // 64 * 64
+        ar = cls._arena.get(key)
+        if ar is None or st["off"] + n > ar.numel():
+            if st["segs"]:
+                cls.flush(device)              # cannot grow under pending segments: fold what we have first
+            if ar is None or n > ar.numel():
+                ar = torch.empty(max(n, 16 << 20), dtype=torch.float32, device=device)   # 64 MB
+                cls._arena[key] = ar
+            st["off"] = 0
+        out = ar[st["off"]:st["off"] + n]
+        st["off"] += n
+        return out
+
+    @classmethod
+    def add(cls, src_ptr, dst, rows, length, stride):
+        _, st = cls._st(dst.device)
+        st["segs"].append((src_ptr, dst.data_ptr(), int(rows), int(length), int(stride)))
+        if not st["armed"]:
+            st["armed"] = True
+            dev = dst.device
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: cls.flush(dev))
+
+    @classmethod
+    def flush(cls, device):
+        _, st = cls._st(device)
+        segs, st["segs"], st["armed"], st["off"] = st["segs"], [], False, 0
+        for i in range(0, len(segs), H.MAX_SEGMENTS):
+            chunk = segs[i:i + H.MAX_SEGMENTS]
+            t = H.ReduceSegments()
+            for j, (sp, dp, r, ln, sd) in enumerate(chunk):
+                t.src[j], t.dst[j], t.rows[j], t.len[j], t.stride[j] = sp, dp, r, ln, sd
+            t.n = len(chunk)
+            _call("mmvae_reduce_segments", ctypes.byref(t), H.stream())
+
+
+def _defer(*grads):
+    """deferred reduction applies when the op accumulates into preset (flat) gradient views"""
+    return GradReducer.enabled and all(g is not None for g in grads)
+
+
 def _new_like_param(p, g):
     """(destination tensor, accumulate flag, value to hand back to autograd)"""
     if g is not None:
@@ -64,9 +128,16 @@ class Conv2dK4S2(Function):
                 db = gb
             else:
                 db = ret_b = torch.empty(Cout, device=x.device)
-        ws = H.workspace(H.lib().mmvae_conv_wgrad_ws_floats(B, Cout, Cin, Hout), x.device)
-        _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hout,
-              in_act, acc_w, H.stream())
+        nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cout, Cin, Hout)
+        if _defer(gw, gb if has_b else gw):
+            ws = GradReducer.alloc(nws, x.device)
+            _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
+                  Hout, in_act, H.ACC_DEFER, H.stream())
+            _conv_segments(ws, dw, db, B, Cout, Cin, Hout, Cout)
+        else:
+            ws = H.workspace(nws, x.device)
+            _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
+                  Hout, in_act, acc_w, H.stream())
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -110,9 +181,16 @@ class ConvT2dK4S2(Function):
                 db = gb
             else:
                 db = ret_b = torch.empty(Cout, device=x.device)
-        ws = H.workspace(H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin), x.device)
-        _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hin,
-              in_act, acc_w, H.stream())
+        nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin)
+        if _defer(gw, gb if has_b else gw):
+            ws = GradReducer.alloc(nws, x.device)
+            _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
+                  Hin, in_act, H.ACC_DEFER, H.stream())
+            _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
+        else:
+            ws = H.workspace(nws, x.device)
+            _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
+                  Hin, in_act, acc_w, H.stream())
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -120,6 +198,15 @@ class ConvT2dK4S2(Function):
             _call("mmvae_convT2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout,
                   Hin, ep, H.stream())
         return dx, ret_w, ret_b, None, None, None, None
+
+
+def _conv_segments(ws, dw, db, B, c_small, c_large, h_small, n_bias):
+    rows, rowlen, bias_col = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _call("mmvae_conv_wgrad_layout", B, c_small, c_large, h_small, ctypes.byref(rows), ctypes.byref(rowlen),
+          ctypes.byref(bias_col))
+    GradReducer.add(ws.data_ptr(), dw, rows.value, dw.numel(), rowlen.value)
+    if db is not None:
+        GradReducer.add(ws.data_ptr() + 4 * bias_col.value, db, rows.value, n_bias, rowlen.value)
 
 
 def conv2d_k4s2(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
@@ -164,9 +251,20 @@ class Linear(Function):
                 db = gb
             else:
                 db = ret_b = torch.empty(N, device=x.device)
-        ws = H.workspace(H.lib().mmvae_linear_bwd_weight_ws_floats(M, N, K), x.device)
-        _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, in_act,
-              acc_w, H.stream())
+        nws = H.lib().mmvae_linear_bwd_weight_ws_floats(M, N, K)
+        if _defer(gw, gb if has_b else gw):
+            nz = H.lib().mmvae_linear_bwd_weight_splits(M, N, K)
+            ws = GradReducer.alloc(nws, x.device) if nz > 1 else None
+            _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, in_act,
+                  H.ACC_DEFER, H.stream())
+            if nz > 1:
+                GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
+                if db is not None:
+                    GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
+        else:
+            ws = H.workspace(nws, x.device)
+            _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, in_act,
+                  acc_w, H.stream())
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -195,7 +293,8 @@ class HeadSoftmax(Function):
     @staticmethod
     def backward(ctx, dh):
         (out,) = ctx.saved_tensors
-        dh = H.f32c(dh).clone()
+        # h feeds nothing but this op, so the incoming gradient buffer is exclusively ours: transform it in place
+        dh = H.f32c(dh)
         B, D2 = out.shape
         _call("mmvae_head_softmax_bwd", H.ptr(out), H.ptr(dh), B, D2 // 2, H.stream())
         return dh
@@ -212,7 +311,7 @@ class PoeReparamKL(Function):
     """Product of experts -> n_z reparameterised samples -> analytic KL rows.
 
     packed[e]: (B,2D) = [mu_e | lv_e] head outputs.  Returns joint (2,B,D) [not differentiable],
-    kl (E+1,B), z (n_z,B,D)."""
+    kl (E+1,B), then n_z tensors z_i (B,D)."""
 
     @staticmethod
     def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, *tensors):
@@ -222,31 +321,31 @@ class PoeReparamKL(Function):
         D = D2 // 2
         dev = packed[0].device
         joint = torch.empty(2, B, D, device=dev)
-        kl = torch.zeros(E + 1, B, device=dev)
-        z = torch.empty(n_z, B, D, device=dev)
+        kl = torch.empty(E + 1, B, device=dev)
+        zs = [torch.empty(B, D, device=dev) for _ in range(n_z)]     # separate tensors: no select/stack backward
         a = H.PoeFwdArgs()
         for e, p in enumerate(packed):
             a.mu[e] = p.data_ptr()
             a.lv[e] = p.data_ptr() + 4 * D
         for i, t in enumerate(eps):
             a.eps[i] = t.data_ptr()
-            a.z[i] = z[i].data_ptr()
+            a.z[i] = zs[i].data_ptr()
         _call("mmvae_poe_reparam_kl_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(joint), H.ptr(kl), E, int(with_prior),
               n_z, kl_mask, B, D, D2, H.stream())
         ctx.save_for_backward(theta, *packed, *eps)
         ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D)
         ctx.mark_non_differentiable(joint)
-        return joint, kl, z
+        return (joint, kl, *zs)
 
     @staticmethod
-    def backward(ctx, _dj, dkl, dz):
+    def backward(ctx, _dj, dkl, *dzs):
         gtheta, with_prior, n_z, kl_mask, E, B, D = ctx.cfg
         theta = ctx.saved_tensors[0]
         packed = ctx.saved_tensors[1:1 + E]
         eps = ctx.saved_tensors[1 + E:]
         dev = theta.device
         dkl = H.f32c(dkl) if dkl is not None else torch.zeros(E + 1, B, device=dev)
-        dz = H.f32c(dz) if (dz is not None and n_z) else None
+        dz = [H.f32c(g) if g is not None else torch.zeros(B, D, device=dev) for g in dzs] if n_z else None
         dpacked = [torch.empty_like(p) for p in packed]
         a = H.PoeBwdArgs()
         for e, p in enumerate(packed):
@@ -269,7 +368,9 @@ class PoeReparamKL(Function):
 
 
 def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None):
-    return PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), *packed, *eps)
+    """-> joint (2,B,D), kl (E+1,B), [z_0 .. z_{n_z-1}] each (B,D)"""
+    out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), *packed, *eps)
+    return out[0], out[1], list(out[2:])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -344,26 +445,34 @@ class CeOverTime(Function):
 
 
 class LincombRows(Function):
-    """out[k] = sum_n W[k][n] * sum_b V[n,b]  -- ELBO assembly with host-side constant weights"""
+    """out[k] = sum_n W[k][n] * sum_b rows_n[b]  -- ELBO assembly with host-side constant weights.
+    `blocks`: tensors of shape (B,) or (r,B); their rows are concatenated logically (no cat/stack kernel)."""
 
     @staticmethod
-    def forward(ctx, V, W):
-        V = H.f32c(V)
-        n, B = V.shape
-        k = len(W)
+    def forward(ctx, W, *blocks):
+        blocks = [H.f32c(t) for t in blocks]
+        B = blocks[0].shape[-1]
+        rows = [t.numel() // B for t in blocks]
+        n, k = sum(rows), len(W)
+        V = torch.empty(n, B, device=blocks[0].device)
+        torch.cat([t.reshape(-1, B) for t in blocks], dim=0, out=V)
         flat = (H.c_f * (k * n))(*[float(x) for row in W for x in row])
         out = torch.empty(k, device=V.device)
         _call("mmvae_lincomb_rows_fwd", H.ptr(V), flat, H.ptr(out), n, B, k, H.stream())
-        ctx.cfg = (flat, n, B, k)
+        ctx.cfg = (flat, n, B, k, rows, [tuple(t.shape) for t in blocks])
         return out
 
     @staticmethod
     def backward(ctx, g):
-        flat, n, B, k = ctx.cfg
+        flat, n, B, k, rows, shapes = ctx.cfg
         g = H.f32c(g)
         dV = torch.empty(n, B, device=g.device)
         _call("mmvae_lincomb_rows_bwd", H.ptr(g), flat, H.ptr(dV), n, B, k, H.stream())
-        return dV, None
+        outs, r0 = [], 0
+        for r, shp in zip(rows, shapes):
+            outs.append(dV[r0:r0 + r].view(shp))
+            r0 += r
+        return (None, *outs)
 
 
 def bce_rowsum(x_hat, target):
@@ -378,8 +487,10 @@ def ce_over_time(logits, target, per_v=False):
     return CeOverTime.apply(logits, target, per_v)
 
 
-def lincomb_rows(V, W):
-    return LincombRows.apply(V, W)
+def lincomb_rows(blocks, W):
+    if torch.is_tensor(blocks):
+        blocks = [blocks]
+    return LincombRows.apply(W, *blocks)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -405,8 +516,15 @@ class EmbedPE(Function):
         B, T, V = onehot.shape
         dx = H.f32c(dx)
         de, acc, ret = _new_like_param(emb, gemb)
-        ws = H.workspace(H.lib().mmvae_embed_ws_floats(B, T, V), dx.device)
-        _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, H.stream())
+        nws = H.lib().mmvae_embed_ws_floats(B, T, V)
+        if _defer(gemb):
+            ws = GradReducer.alloc(nws, dx.device)
+            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), None, H.ptr(ws), B, T, V, mode, H.ACC_DEFER,
+                  H.stream())
+            GradReducer.add(ws.data_ptr(), de, H.lib().mmvae_embed_bwd_rows(B, T, V), 4, 4)
+        else:
+            ws = H.workspace(nws, dx.device)
+            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, H.stream())
         return None, ret, None, None, None
 
 
@@ -414,7 +532,7 @@ class Attention(Function):
     """softmax(q k^T / sqrt(hd) + key-padding mask) v for packed qkv (L, N, 3E), L <= 64"""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, nhead):
+    def forward(ctx, qkv, kpm, nhead, mask_is_valid):
         qkv = H.f32c(qkv)
         L, N, E3 = qkv.shape
         E = E3 // 3
@@ -423,7 +541,7 @@ class Attention(Function):
         probs = torch.empty(N, nhead, L, L, device=qkv.device)
         p = qkv.data_ptr()
         _call("mmvae_attn_fwd", p, p + 4 * E, p + 8 * E, H.ptr(kpm), H.ptr(out), H.ptr(probs), L, L, N, nhead, hd, E3,
-              E3, E3, H.stream())
+              E3, E3, int(mask_is_valid), H.stream())
         ctx.save_for_backward(qkv, probs)
         ctx.nhead = nhead
         return out
@@ -439,7 +557,7 @@ class Attention(Function):
         p, d = qkv.data_ptr(), dqkv.data_ptr()
         _call("mmvae_attn_bwd", p, p + 4 * E, p + 8 * E, H.ptr(probs), H.ptr(dout), d, d + 4 * E, d + 8 * E, L, L, N,
               nhead, E // nhead, E3, E3, E3, H.stream())
-        return dqkv, None, None
+        return dqkv, None, None, None
 
 
 class LayerNormResidual(Function):
@@ -478,9 +596,18 @@ class LayerNormResidual(Function):
             both = torch.empty(2 * d, device=dy.device)
             dg, dbt, acc = both[:d], both[d:], 0
             ret_g, ret_b = dg, dbt
-        ws = H.workspace(H.lib().mmvae_layernorm_ws_floats(rows, d), dy.device)
-        _call("mmvae_layernorm_residual_bwd", H.ptr(dy), H.ptr(xhat), H.ptr(rstd), H.ptr(gamma), H.ptr(dsum),
-              dg.data_ptr(), dbt.data_ptr(), H.ptr(ws), rows, d, acc, H.stream())
+        nws = H.lib().mmvae_layernorm_ws_floats(rows, d)
+        if _defer(gg, gb):
+            ws = GradReducer.alloc(nws, dy.device)
+            _call("mmvae_layernorm_residual_bwd", H.ptr(dy), H.ptr(xhat), H.ptr(rstd), H.ptr(gamma), H.ptr(dsum),
+                  None, None, H.ptr(ws), rows, d, H.ACC_DEFER, H.stream())
+            nb = H.lib().mmvae_layernorm_bwd_rows(rows, d)
+            GradReducer.add(ws.data_ptr(), dg, nb, d, 2 * d)
+            GradReducer.add(ws.data_ptr() + 4 * d, dbt, nb, d, 2 * d)
+        else:
+            ws = H.workspace(nws, dy.device)
+            _call("mmvae_layernorm_residual_bwd", H.ptr(dy), H.ptr(xhat), H.ptr(rstd), H.ptr(gamma), H.ptr(dsum),
+                  dg.data_ptr(), dbt.data_ptr(), H.ptr(ws), rows, d, acc, H.stream())
         dr = None
         if has_r and ctx.needs_input_grad[1]:
             if r_rows:
@@ -537,8 +664,16 @@ def embed_pe(onehot, emb, pe, mode, gemb=None):
     return EmbedPE.apply(onehot, emb, pe, mode, gemb)
 
 
-def attention(qkv, kpm_u8, nhead):
-    return Attention.apply(qkv, kpm_u8, nhead)
+def attention(qkv, mask_u8, nhead, mask_is_valid=False):
+    """mask_u8 (N,L) bytes: key-padding mask (1 = ignore) or, with mask_is_valid, the validity mask (1 = token)"""
+    return Attention.apply(qkv, mask_u8, nhead, mask_is_valid)
+
+
+def as_u8(mask):
+    """zero-copy byte view of a bool mask (torch.bool is one 0/1 byte per element)"""
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
 
 
 def layernorm_residual(x, r, gamma, beta, gg=None, gb=None):

@@ -160,10 +160,10 @@ def test_poe_reparam_kl(ops, E, n_z, with_prior, kl_mask, B, D):
     check(j, jr, 1e-5, "joint")
     check(kl, klr, 2e-5, "kl")
     if n_z:
-        check(z, zr, 1e-5, "z")
+        check(torch.stack(z), zr, 1e-5, "z")
     if kl_mask or n_z:
         tot.backward()
-        totg = (kl * gkl.to(DEV)).sum() + ((z * gz.to(DEV)).sum() if n_z else 0.0)
+        totg = (kl * gkl.to(DEV)).sum() + ((torch.stack(z) * gz.to(DEV)).sum() if n_z else 0.0)
         totg.backward()
         for e in range(E):
             check(pg[e].grad, pr[e].grad, 5e-5, f"dpacked[{e}]")
@@ -214,7 +214,8 @@ def test_lincomb_rows(ops):
     ref = torch.tensor(W, dtype=torch.float64) @ Vr.sum(1)
     ref.backward(torch.tensor([1.5, -0.5], dtype=torch.float64))
     Vg = V.to(DEV).requires_grad_(True)
-    out = ops.lincomb_rows(Vg, W)
+    Va, Vb = Vg[:2], Vg[2:]
+    out = ops.lincomb_rows([Va[0], Va[1], Vb], W)
     out.backward(torch.tensor([1.5, -0.5], device=DEV))
     check(out, ref, 1e-5, "lincomb")
     check(Vg.grad, Vr.grad, 1e-6, "lincomb dV")
@@ -266,6 +267,8 @@ def test_attention(ops, L, N, E, H_):
     ref.backward(do.double())
     qg = qkv.to(DEV).requires_grad_(True)
     out = ops.attention(qg, kpm.to(torch.uint8).to(DEV), H_)
+    out2 = ops.attention(qg.detach(), (~kpm).to(DEV).view(torch.uint8), H_, mask_is_valid=True)
+    check(out2, ref, 2e-5, "attn out (validity-mask form)")
     out.backward(do.to(DEV))
     check(out, ref, 2e-5, "attn out")
     check(qg.grad, qr.grad, 5e-5, "attn dqkv")
