@@ -276,6 +276,7 @@ typedef struct {
   int len[MMVAE_MAX_SEGMENTS];
   int stride[MMVAE_MAX_SEGMENTS];
   int blk0[MMVAE_MAX_SEGMENTS]; /* filled by the library */
+  int next[MMVAE_MAX_SEGMENTS]; /* filled by the library: chain of segments sharing one destination */
   int n;
 } mmvae_reduce_segments_t;
 int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream);

@@ -119,24 +119,30 @@ extern "C" int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long 
 __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t) {
   __shared__ float part[4][64];
   int sg = 0;
-  while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan, n <= 64
-  const float* __restrict__ src = t.src[sg];
+  while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan over head segments, n <= 64
   float* __restrict__ dst = t.dst[sg];
-  const int n_rows = t.rows[sg];
-  const long len = t.len[sg], stride = t.stride[sg];
+  const long len = t.len[sg];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const long i = ((long)blockIdx.x - t.blk0[sg]) * 64 + cx;
   float a = 0.f;
-  if (i < len) {
-    int r = ry;
-    for (; r + 28 < n_rows; r += 32) {
-      float v[8];
+  // a parameter used several times in one backward (PoE re-runs its towers per subset) has several partial
+  // regions with the SAME destination: they are chained (`next`) and summed by the same block -- two blocks
+  // doing dst += concurrently would race.
+  for (int cur = sg; cur >= 0; cur = t.next[cur]) {
+    const float* __restrict__ src = t.src[cur];
+    const int n_rows = t.rows[cur];
+    const long stride = t.stride[cur];
+    if (i < len) {
+      int r = ry;
+      for (; r + 28 < n_rows; r += 32) {
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + 4 * u) * stride + i];
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + 4 * u) * stride + i];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; r < n_rows; r += 4) a += src[(size_t)r * stride + i];
     }
-    for (; r < n_rows; r += 4) a += src[(size_t)r * stride + i];
   }
   part[ry][cx] = a;
   __syncthreads();
@@ -145,12 +151,41 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segme
 extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(table && table->n > 0 && table->n <= MMVAE_MAX_SEGMENTS);
   mmvae_reduce_segments_t t = *table;
-  int blocks = 0;
+  // chain segments that share a destination; chain heads are compacted to the front and only they get workgroups
+  mmvae_reduce_segments_t o;
+  int n_heads = 0;
+  int head_of[MMVAE_MAX_SEGMENTS], tail_of[MMVAE_MAX_SEGMENTS];
   for (int s = 0; s < t.n; ++s) {
     if (!t.src[s] || !t.dst[s] || t.rows[s] <= 0 || t.len[s] <= 0) return MMVAE_ERR_ARG;
-    t.blk0[s] = blocks;
-    blocks += (t.len[s] + 63) / 64;
+    int h = -1;
+    for (int k = 0; k < n_heads; ++k)
+      if (t.dst[head_of[k]] == t.dst[s] && t.len[head_of[k]] == t.len[s]) { h = k; break; }
+    if (h < 0) { head_of[n_heads] = s; tail_of[n_heads] = s; ++n_heads; }
+    else tail_of[h] = s;
   }
+  // build output table: heads first (slots 0..n_heads-1), chained members after
+  int pos = n_heads;
+  for (int k = 0; k < n_heads; ++k) {
+    const int hs = head_of[k];
+    o.src[k] = t.src[hs]; o.dst[k] = t.dst[hs]; o.rows[k] = t.rows[hs]; o.len[k] = t.len[hs];
+    o.stride[k] = t.stride[hs]; o.next[k] = -1;
+    int last = k;
+    for (int s = hs + 1; s < t.n; ++s) {
+      if (t.dst[s] == t.dst[hs] && t.len[s] == t.len[hs]) {
+        o.src[pos] = t.src[s]; o.dst[pos] = t.dst[s]; o.rows[pos] = t.rows[s]; o.len[pos] = t.len[s];
+        o.stride[pos] = t.stride[s]; o.next[pos] = -1; o.blk0[pos] = 0x7fffffff;
+        o.next[last] = pos;
+        last = pos++;
+      }
+    }
+  }
+  o.n = n_heads;   // the device scan only walks head slots
+  int blocks = 0;
+  for (int k = 0; k < n_heads; ++k) {
+    o.blk0[k] = blocks;
+    blocks += (o.len[k] + 63) / 64;
+  }
+  t = o;
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
   return mmvae_launch_status();
 }

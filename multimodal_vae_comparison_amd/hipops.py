@@ -101,7 +101,7 @@ MAX_SEGMENTS = 64
 class ReduceSegments(ctypes.Structure):
     _fields_ = [("src", c_p * MAX_SEGMENTS), ("dst", c_p * MAX_SEGMENTS), ("rows", c_i * MAX_SEGMENTS),
                 ("len", c_i * MAX_SEGMENTS), ("stride", c_i * MAX_SEGMENTS), ("blk0", c_i * MAX_SEGMENTS),
-                ("n", c_i)]
+                ("next", c_i * MAX_SEGMENTS), ("n", c_i)]
 
 
 def lib():
