@@ -131,17 +131,30 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvGatherArgs a) {
     store_chunk();
     __syncthreads();
     if (ch + 1 < NCHUNK) load_chunk(ch + 1);  // next chunk's loads fly under this chunk's MFMAs
-    // ---- MFMAs ----
+    // ---- MFMAs: operands of channel cc+1 are read from LDS while the 8 MFMAs of channel cc issue ----
+    {
+      float av[2][8], bv[2][8];
+      auto load_ops = [&](int cc, int buf) {
 #pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
+        for (int kh = 0; kh < 4; ++kh) {
 #pragma unroll
-      for (int kh = 0; kh < 4; ++kh) {
-#pragma unroll
-        for (int kw0 = 0; kw0 < 4; kw0 += 2) {
-          const float av = s_in[abase + cc * CS + kh * RS + kw0];
-          const float bv = s_w[wbase + (cc * 16 + kh * 4 + kw0) * WP];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+          for (int j = 0; j < 2; ++j) {
+            av[buf][kh * 2 + j] = s_in[abase + cc * CS + kh * RS + 2 * j];
+            bv[buf][kh * 2 + j] = s_w[wbase + (cc * 16 + kh * 4 + 2 * j) * WP];
+          }
         }
+      };
+      load_ops(0, 0);
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        if (cc + 1 < CPW) load_ops(cc + 1, (cc + 1) & 1);
+        // keep the reads above the MFMAs: hipcc's scheduler otherwise sinks every ds_read next to its consumer
+        // (one LDS round trip exposed per MFMA pair)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cc & 1][t], bv[cc & 1][t], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

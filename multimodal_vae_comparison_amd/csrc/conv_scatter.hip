@@ -135,17 +135,32 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(ConvScatterArgs a) {
     store_chunk();
     __syncthreads();
     if (ch + 1 < NCHUNK) load_chunk(ch + 1);
+    // operands of channel cc+1 are read from LDS while the 8 MFMAs (4 classes x 2 row taps) of channel cc issue
+    {
+      float av[2][8], bv[2][8];
+      auto load_ops = [&](int cc, int buf) {
 #pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
+        for (int cls = 0; cls < 4; ++cls) {
 #pragma unroll
-      for (int cls = 0; cls < 4; ++cls) {
-        const int ph = cls >> 1, pw = cls & 1;
-#pragma unroll
-        for (int th = 0; th < 2; ++th) {
-          const float av = s_in[abase + cc * CS + (ph - th) * RS + pw];
-          const float bv = s_w[wbase + (((cls * CC + cc) * 2 + th) * 2) * CONV_CO];
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[cls], 0, 0, 0);
+          for (int th = 0; th < 2; ++th) {
+            const int ph = cls >> 1, pw = cls & 1;
+            av[buf][cls * 2 + th] = s_in[abase + cc * CS + (ph - th) * RS + pw];
+            bv[buf][cls * 2 + th] = s_w[wbase + (((cls * CC + cc) * 2 + th) * 2) * CONV_CO];
+          }
         }
+      };
+      load_ops(0, 0);
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        if (cc + 1 < CPW) load_ops(cc + 1, (cc + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (see conv_gather.hip)
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+          for (int th = 0; th < 2; ++th)
+            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cc & 1][cls * 2 + th], bv[cc & 1][cls * 2 + th],
+                                                            acc[cls], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

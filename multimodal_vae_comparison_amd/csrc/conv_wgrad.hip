@@ -145,17 +145,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
     store_tile();
     __syncthreads();
     if (mtile + (int)gridDim.x < a.n_macro) load_tile(mtile + gridDim.x);
-    for (int rr = r_beg; rr < r_end; ++rr) {
-      const int img = rr >= nrow ? 1 : 0, oh_l = rr - img * nrow;
-      const float* brow = s_large + img * IS + (2 * oh_l) * RS + bbase;
-      const float* arow = s_small + abase + rr * Ws;
-#pragma unroll 4
-      for (int ow0 = 0; ow0 < Ws; ow0 += 2) {
-        const float av = arow[ow0];
-        const float bv = brow[2 * ow0];
-        asum += av;
-        bsum += bv;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    // Positions are walked in groups of 16 (= 8 MFMAs, k = 2 positions each).  s_small is position-linear, so the
+    // A operands of a group are 8 consecutive pairs; the B operand address is decoded per MFMA from the
+    // (uniform) position.  Group g+1's operands are read from LDS while group g's MFMAs issue.
+    {
+      const int pbeg = r_beg * Ws, ngrp = (r_end - r_beg) * Ws / 16;
+      float av[2][8], bv[2][8];
+      auto load_grp = [&](int gi, int buf) {
+        const int p0 = pbeg + 16 * gi;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int p = p0 + 2 * t;
+          const int rr = p >> lgWs, ow0 = p & (Ws - 1);
+          const int img = rr >= nrow ? 1 : 0, oh_l = rr - img * nrow;
+          av[buf][t] = s_small[abase + p];
+          bv[buf][t] = s_large[img * IS + (2 * oh_l) * RS + 2 * ow0 + bbase];
+        }
+      };
+      auto mfma_grp = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          asum += av[buf][t];
+          bsum += bv[buf][t];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf][t], acc, 0, 0, 0);
+        }
+      };
+      if (ngrp > 0) load_grp(0, 0);
+      for (int gi = 0; gi < ngrp; gi += 2) {
+        if (gi + 1 < ngrp) load_grp(gi + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_grp(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gi + 1 < ngrp) {
+          if (gi + 2 < ngrp) load_grp(gi + 2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_grp(1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }

@@ -5,7 +5,7 @@
 //
 // Workgroup = 4 wavefronts.  Two tilings share one body:
 //   KSPLIT = 1 : 128 x 32 output tile, wave w owns rows [32w, 32w+32), K staged 32 deep;
-//   KSPLIT = 4 : 32 x 32 output tile, the four waves split every 128-deep K stage four ways and the
+//   KSPLIT = 4 / 8 : 32 x 32 output tile, the 4 (8) waves split every 128 (256)-deep K stage and the
 //                partial accumulators are summed through LDS (used when M*N is too small to fill the
 //                chip: batch-128 linears, weight gradients).
 // A and B tiles are staged global -> registers -> LDS as [k][m] / [k][n] (row pitch odd => both the
@@ -31,14 +31,15 @@ struct GemmArgs {
 };
 
 template <int KSPLIT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = KSPLIT == 8 ? 512 : 256;  // threads
   constexpr int BM = KSPLIT == 1 ? 128 : 32;
   constexpr int BN = 32;
-  constexpr int BK = KSPLIT == 1 ? 32 : 128;
+  constexpr int BK = KSPLIT == 1 ? 32 : 32 * KSPLIT;  // every wave owns a 32-deep K slice of a stage
   constexpr int AP = BM + 1;  // LDS row pitch of As (odd)
   constexpr int BP = BN + 1;
-  constexpr int A_PER_T = BM * BK / 256;  // 16
-  constexpr int B_PER_T = BK * BN / 256;  // 4 or 16
+  constexpr int A_PER_T = BM * BK / NT;  // 16
+  constexpr int B_PER_T = BK * BN / NT;  // 4 or 16
   __shared__ float As[BK * AP];
   __shared__ float Bs[BK * BP];
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     va = vb = 0;
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
-      const int e = i * 256 + tid;
+      const int e = i * NT + tid;
       int ml, kl;
       if (a_kmajor) { kl = e % BK; ml = e / BK; } else { ml = e % BM; kl = e / BM; }
       const int m = m0 + ml, k = k0 + kl;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
-      const int e = i * 256 + tid;
+      const int e = i * NT + tid;
       int nl, kl;
       if (b_kmajor) { kl = e % BK; nl = e / BK; } else { nl = e % BN; kl = e / BN; }
       const int n = n0 + nl, k = k0 + kl;
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
-      const int e = i * 256 + tid;
+      const int e = i * NT + tid;
       int ml, kl;
       if (a_kmajor) { kl = e % BK; ml = e / BK; } else { ml = e % BM; kl = e / BM; }
       As[kl * AP + ml] = (va >> i & 1u) ? ra[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
-      const int e = i * 256 + tid;
+      const int e = i * NT + tid;
       int nl, kl;
       if (b_kmajor) { kl = e % BK; nl = e / BK; } else { nl = e % BN; kl = e / BN; }
       Bs[kl * BP + nl] = (vb >> i & 1u) ? rb[i] : 0.f;
@@ -156,22 +157,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + asum : asum;
     }
   } else {
-    float* red = As;  // 4 waves x 16 regs x 64 lanes = 4096 floats <= BK*AP
-    float* rsr = Bs;  // 4 x 32 row sums
+    float* red = As;  // KSPLIT waves x 16 regs x 64 lanes floats <= BK*AP
+    float* rsr = Bs;  // KSPLIT x 32 row sums
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     if (lh == 0) rsr[wave * 32 + li] = asum;
     __syncthreads();
+    constexpr int RPW = 16 / KSPLIT > 0 ? 16 / KSPLIT : 1;  // accumulator registers summed and emitted per wave
+    if (wave < 16 / RPW) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = wave * 4 + q;
-      const float v = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] +
-                      red[(3 * 16 + r) * 64 + lane];
-      emit(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, v);
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave * RPW + q;
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < KSPLIT; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
+        emit(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, v);
+      }
     }
     if (g.a_rowsum && blockIdx.x == 0 && wave == 0 && lh == 0) {
       const int row = m0 + li;
-      const float v = rsr[li] + rsr[32 + li] + rsr[64 + li] + rsr[96 + li];
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < KSPLIT; ++w2) v += rsr[w2 * 32 + li];
       if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + v : v;
     }
   }
@@ -195,17 +202,25 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   g.a_act = a_act; g.b_act = b_act; g.ep = ep_mode;
   g.accumulate = accumulate ? 1 : 0;   // DEFER without a split == plain accumulation
   const int ntn = (N + 31) / 32;
-  // enough 128x32 tiles to give every CU one => big-tile kernel; otherwise the intra-workgroup K-split tile
-  const bool big = (long)((M + 127) / 128) * ntn >= 256;
-  const int bk = big ? 32 : 128;
+  // Tiling choice (all that matters at batch 128 is the length of the serial load -> MFMA chain per workgroup):
+  //   K <= 128 and many rows : 128x32 tiles, one stage, no cross-wave reduction            (KSPLIT 1)
+  //   K >= 384, few tiles    : 32x32 tile, 8 waves x 256-deep stages (half the serial stages)  (KSPLIT 8)
+  //   otherwise              : 32x32 tile, 4 waves x 128-deep stages                       (KSPLIT 4)
+  const long tiles128 = (long)((M + 127) / 128) * ntn, tiles32 = (long)((M + 31) / 32) * ntn;
+  int variant = 4;
+  if (tiles128 >= 256 || (K <= 128 && M >= 1024)) variant = 1;
+  else if (K >= 384 && tiles32 <= 512 && splitk == 1) variant = 8;
+  const int bk = variant == 1 ? 32 : 32 * variant;
   int kper = (K + splitk - 1) / splitk;
   kper = (kper + bk - 1) / bk * bk;
   const int nz = (K + kper - 1) / kper;
   g.kper = kper;
   if (nz > 1 && !ws) return MMVAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (big)
+  if (variant == 1)
     hipLaunchKernelGGL(gemm_kernel<1>, dim3(ntn, (M + 127) / 128, nz), dim3(256), 0, st, g);
+  else if (variant == 8)
+    hipLaunchKernelGGL(gemm_kernel<8>, dim3(ntn, (M + 31) / 32, nz), dim3(512), 0, st, g);
   else
     hipLaunchKernelGGL(gemm_kernel<4>, dim3(ntn, (M + 31) / 32, nz), dim3(256), 0, st, g);
   int rc = mmvae_launch_status();
@@ -244,8 +259,12 @@ static int wgrad_splitk(int M, int N, int K) {
 extern "C" int mmvae_linear_bwd_weight_splits(int M, int N, int K) {
   // mirrors the kper rounding of mmvae_gemm_f32 for the (N x K) = dy^T x problem with reduction length M
   int sk = wgrad_splitk(M, N, K);
-  const long tiles128 = (long)((N + 127) / 128) * ((K + 31) / 32);
-  const int bk = tiles128 >= 256 ? 32 : 128;
+  // gemm problem: rows N, cols K, reduction M
+  const long tiles128 = (long)((N + 127) / 128) * ((K + 31) / 32), tiles32 = (long)((N + 31) / 32) * ((K + 31) / 32);
+  int variant = 4;
+  if (tiles128 >= 256 || (M <= 128 && N >= 1024)) variant = 1;
+  else if (M >= 384 && tiles32 <= 512 && sk == 1) variant = 8;
+  const int bk = variant == 1 ? 32 : 32 * variant;
   int kper = (M + sk - 1) / sk;
   kper = (kper + bk - 1) / bk * bk;
   return (M + kper - 1) / kper;

@@ -90,11 +90,48 @@ extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* d
 #define ATT_HP 36  // row pitch (16-byte aligned rows)
 #define ATT_SP 65
 
+// rows x 32 floats -> LDS, 8 independent loads in flight per lane (a load -> store loop waits one memory
+// latency per iteration)
 __device__ __forceinline__ void att_stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int N,
                                                int n, long ld, int col0, int hd, int lane) {
-  for (int e = lane; e < rows * ATT_HD; e += 64) {
-    const int r = e >> 5, d = e & 31;
-    dst[r * ATT_HP + d] = d < hd ? src[((size_t)r * N + n) * ld + col0 + d] : 0.f;
+  const int total = rows * ATT_HD;
+  for (int e0 = 0; e0 < total; e0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 64 + lane;
+      const int r = e >> 5, d = e & 31;
+      const bool ok = e < total && d < hd;
+      v[u] = src[ok ? ((size_t)r * N + n) * ld + col0 + d : (size_t)n * ld + col0];
+      v[u] = ok ? v[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 64 + lane;
+      if (e < total) dst[(e >> 5) * ATT_HP + (e & 31)] = v[u];
+    }
+  }
+}
+// L x S probability tile -> LDS (pitch ATT_SP), same batching
+__device__ __forceinline__ void att_stage_tile(float* __restrict__ dst, const float* __restrict__ src, int L, int S,
+                                               int lane) {
+  const int total = L * S;
+  const float invS = 1.0f / (float)S;
+  for (int e0 = 0; e0 < total; e0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 64 + lane;
+      v[u] = src[e < total ? e : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 64 + lane;
+      if (e < total) {
+        const int l = (int)(((float)e + 0.5f) * invS);
+        dst[l * ATT_SP + (e - l * S)] = v[u];
+      }
+    }
   }
 }
 __device__ __forceinline__ float att_dot(const float* __restrict__ row, const float (&x)[ATT_HD]) {
@@ -192,9 +229,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   att_stage_rows(sv, v, S, N, n, ldv, h * hd, hd, lane);
   att_stage_rows(sq, q, L, N, n, ldq, h * hd, hd, lane);
   att_stage_rows(sdo, dout, L, N, n, E, h * hd, hd, lane);
-  const float* P = probs + ((size_t)n * H + h) * L * S;
-  if (lane < S)
-    for (int l = 0; l < L; ++l) sp[l * ATT_SP + lane] = P[(size_t)l * S + lane];
+  att_stage_tile(sp, probs + ((size_t)n * H + h) * L * S, L, S, lane);
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)hd);
   if (lane < L) {

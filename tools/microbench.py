@@ -1,0 +1,74 @@
+"""Per-kernel timings on the GPU box (HIP events, back-to-back launches on the current stream)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from multimodal_vae_comparison_amd import hipops as H
+from multimodal_vae_comparison_amd import ops
+
+dev = "cuda"
+
+
+def timeit(fn, reps=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+out = {}
+batches = [int(b) for b in os.environ.get("MB_BATCHES", "128,512,2048,4096").split(",")]
+with torch.no_grad():
+    L = H.lib()
+    for B in batches:
+        for name, Cin, Hin in (("conv1", 3, 64), ("conv2", 32, 32), ("conv3", 32, 16), ("conv4", 32, 8)):
+            x = torch.randn(B, Cin, Hin, Hin, device=dev)
+            w = torch.randn(32, Cin, 4, 4, device=dev) * .05
+            b = torch.zeros(32, device=dev)
+            us = timeit(lambda: ops.conv2d_k4s2(x, w, b, H.ACT_SILU if Cin == 32 else 0))
+            fl = 2.0 * B * (Hin // 2) ** 2 * 32 * Cin * 16
+            out[f"gather {name} B={B}"] = (us, fl / us / 1e6)
+        for name, Cout, Hin in (("convT_64", 32, 4), ("convT1", 32, 8), ("convT2", 32, 16), ("convT3", 3, 32)):
+            x = torch.randn(B, 32, Hin, Hin, device=dev)
+            w = torch.randn(32, Cout, 4, 4, device=dev) * .05
+            b = torch.zeros(Cout, device=dev)
+            us = timeit(lambda: ops.convT2d_k4s2(x, w, b, H.ACT_RELU, H.EP_SIGMOID_CLAMP if Cout == 3 else 0))
+            fl = 2.0 * B * Hin ** 2 * 32 * Cout * 16
+            out[f"scatter {name} B={B}"] = (us, fl / us / 1e6)
+        for name, Q, Hs in (("conv2.wgrad", 32, 16), ("conv3.wgrad", 32, 8), ("conv4.wgrad", 32, 4), ("conv1.wgrad", 3, 32)):
+            dy = torch.randn(B, 32, Hs, Hs, device=dev)
+            x = torch.randn(B, Q, 2 * Hs, 2 * Hs, device=dev)
+            dw = torch.zeros(32, Q, 4, 4, device=dev)
+            db = torch.zeros(32, device=dev)
+            ws = torch.empty(L.mmvae_conv_wgrad_ws_floats(B, 32, Q, Hs), device=dev)
+            us = timeit(lambda: L.mmvae_conv2d_k4s2_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                           ws.data_ptr(), B, Q, 32, Hs, 1, 1, H.stream()))
+            fl = 2.0 * B * Hs * Hs * 32 * Q * 16
+            out[f"{name} (+reduce) B={B}"] = (us, fl / us / 1e6)
+    for M, K, N in ((128, 512, 512), (4096, 54, 162), (4096, 128, 54), (4096, 54, 128), (128, 32, 512), (131072, 54, 162)):
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev)
+        b = torch.zeros(N, device=dev)
+        us = timeit(lambda: ops.linear(x, w, b))
+        out[f"linear fwd M={M} K={K} N={N}"] = (us, 2.0 * M * K * N / us / 1e6)
+    t = torch.zeros(64, device=dev)
+    out["eager launch of a trivial kernel"] = (timeit(lambda: ops.fill(t, 1.0), reps=200), 0)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.fill(t, 1.0)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(100):
+                ops.fill(t, 1.0)
+    out["graph of 100 trivial kernels: us per kernel"] = (timeit(lambda: g.replay(), reps=50) / 100, 0)
+for k, v in out.items():
+    print(f"{k:48s} {v[0]:10.2f} us" + (f"   {v[1]:8.2f} TFLOP/s" if v[1] else ""))
