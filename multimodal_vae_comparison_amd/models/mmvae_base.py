@@ -66,6 +66,34 @@ class TorchMMVAE(nn.Module):
             return e.reshape(B, D).to(device=device, dtype=torch.float32).contiguous()
         return torch.randn(B, D, device=device)
 
+    # ---- tower-level concurrency -------------------------------------------------------------------
+    def _tower_streams(self, device):
+        """stream per modality: modality 0 stays on the current stream, the others get side streams (ops.StreamPlan)
+        so that independent towers overlap -- each of them alone cannot fill the chip at batch 128"""
+        names = list(self.vaes.keys())
+        if not (ops.StreamPlan.enabled and device.type == "cuda") or len(names) < 2:
+            return [None] * len(names)
+        out = [None]
+        for i in range(1, len(names)):
+            s = ops.StreamPlan.get(f"tower{i}", device)
+            ops.GradReducer.note_stream(device, s)
+            out.append(s)
+        return out
+
+    @staticmethod
+    def _fork(streams, device):
+        cur = torch.cuda.current_stream(device)
+        for s in streams:
+            if s is not None:
+                s.wait_stream(cur)
+
+    @staticmethod
+    def _join(streams, device):
+        cur = torch.cuda.current_stream(device)
+        for s in streams:
+            if s is not None:
+                cur.wait_stream(s)
+
     # ---- plumbing shared by the mixers ----------------------------------------------------------
     def make_output_dict(self, encoder_dist=None, decoder_dist=None, latent_samples=None, joint_dist=None,
                          enc_dist_private=None, dec_dist_private=None, joint_decoder_dist=None,

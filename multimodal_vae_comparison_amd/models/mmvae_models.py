@@ -50,18 +50,27 @@ class MoPOE(TorchMMVAE):
         """mmvae_models.py:296-320 + weighted_group_kld (objectives.py:184-201)"""
         names = list(self.vaes.keys())
         M = len(names)
-        enc = [self.vaes[n].enc(mods[n]) for n in names]
+        dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
+        streams = self._tower_streams(dev)
+        self._fork(streams, dev)
+        enc = []
+        for n, st in zip(names, streams):
+            with torch.cuda.stream(st):
+                enc.append(self.vaes[n].enc(mods[n]))
+        self._join(streams, dev)
         packed = [packed_head(mu, lv) for mu, lv in enc]
         B, D = packed[0].shape[0], self.n_latents
-        dev = packed[0].device
         eps = [self._draw(B, D, dev) for _ in names]                       # one rsample per modality (:363-369)
         theta = self._pz_params[1]
         _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad)
+        self._fork(streams, dev)
         recs = []
-        for i, n in enumerate(names):
+        for i, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
-            out, _ = vae.dec({"latents": z[i].unsqueeze(0), "masks": mods[n]["masks"]})
-            recs.append(recon_rowsum(vae.ltype, out, mods[n]))             # (B,) = -lpx_z / llik_scaling
+            with torch.cuda.stream(st):
+                out, _ = vae.dec({"latents": z[i].unsqueeze(0), "masks": mods[n]["masks"]})
+                recs.append(recon_rowsum(vae.ltype, out, mods[n]))         # (B,) = -lpx_z / llik_scaling
+        self._join(streams, dev)
         w_kl = 1.0 / (M + 1)
         lam = [float(self.vaes[n].llik_scaling) for n in names]
         W = [[l / B for l in lam] + [self.obj_fn.beta * w_kl / B] * (M + 1),
@@ -136,21 +145,32 @@ class POE(TorchMMVAE):
         rows, W_loss, W_kld = [], [], []
         rec_log = [None] * M
         subsets = self._subsets()
+        dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
+        streams = self._tower_streams(dev)
         for s_idx, S in enumerate(subsets):
-            packed = [packed_head(*self.vaes[n].enc(mods[n])) for n in names if n in S]
+            self._fork(streams, dev)
+            packed = []
+            for n, st in zip(names, streams):
+                if n in S:
+                    with torch.cuda.stream(st):
+                        packed.append(packed_head(*self.vaes[n].enc(mods[n])))
+            self._join(streams, dev)
             B, D = packed[0].shape[0], self.n_latents
             eps = [self._draw(B, D, packed[0].device)]
             E = len(packed)
             _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, 1 << E, theta.grad)
-            for i, n in enumerate(names):
+            self._fork(streams, dev)
+            for i, (n, st) in enumerate(zip(names, streams)):
                 vae = self.vaes[n]
-                out, _ = vae.dec({"latents": z[0].unsqueeze(0), "masks": mods[n]["masks"] if n in S else None})
-                r = recon_rowsum(vae.ltype, out, mods[n])
+                with torch.cuda.stream(st):
+                    out, _ = vae.dec({"latents": z[0].unsqueeze(0), "masks": mods[n]["masks"] if n in S else None})
+                    r = recon_rowsum(vae.ltype, out, mods[n])
                 rows.append(r)
                 W_loss.append(float(vae.llik_scaling))
                 W_kld.append(0.0)
                 if i == s_idx:
                     rec_log[i] = r
+            self._join(streams, dev)
             rows.append(kl[E])
             W_loss.append(float(self.obj_fn.beta))
             W_kld.append(1.0 / len(subsets))

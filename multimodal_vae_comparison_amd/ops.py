@@ -10,6 +10,7 @@ Conventions used by every layer op
   input -- no AccumulateGrad kernels, no copies.  Without it, fresh tensors are returned to autograd.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -35,13 +36,14 @@ class GradReducer:
     enabled = True
     _arena = {}
     _state = {}
+    _side = {}        # device key -> {"wgrad": Stream, "tower": Stream}: see StreamPlan below
 
     @classmethod
     def _st(cls, device):
         key = device.index if device.index is not None else torch.cuda.current_device()
         st = cls._state.get(key)
         if st is None:
-            st = {"off": 0, "segs": [], "armed": False, "device": device}
+            st = {"off": 0, "segs": [], "armed": False, "device": device, "keep": [], "used": set()}
             cls._state[key] = st
         return key, st
 
@@ -71,8 +73,23 @@ class GradReducer:
             torch.autograd.Variable._execution_engine.queue_callback(lambda: cls.flush(dev))
 
     @classmethod
+    def keep(cls, device, *tensors):
+        """hold tensors that a side-stream kernel still reads until the end-of-backward join"""
+        cls._st(device)[1]["keep"].extend(t for t in tensors if t is not None)
+
+    @classmethod
+    def note_stream(cls, device, stream):
+        cls._st(device)[1]["used"].add(stream)
+
+    @classmethod
     def flush(cls, device):
         _, st = cls._st(device)
+        cur = torch.cuda.current_stream(device)
+        for side in st["used"]:               # join every side stream that carried gradient work
+            if side != cur:
+                cur.wait_stream(side)
+        st["used"] = set()
+        st["keep"] = []
         segs, st["segs"], st["armed"], st["off"] = st["segs"], [], False, 0
         for i in range(0, len(segs), H.MAX_SEGMENTS):
             chunk = segs[i:i + H.MAX_SEGMENTS]
@@ -81,6 +98,48 @@ class GradReducer:
                 t.src[j], t.dst[j], t.rows[j], t.len[j], t.stride[j] = sp, dp, r, ln, sd
             t.n = len(chunk)
             _call("mmvae_reduce_segments", ctypes.byref(t), H.stream())
+
+
+class StreamPlan:
+    """Overlap on separate HIP streams (captured into one hipGraph as parallel branches).
+
+    At batch 128 every kernel of the step is far too small to fill 256 CUs, so the step time is the length of the
+    dependency chain.  Two independent chains are taken off the critical path:
+      * `wgrad`: every weight-gradient kernel (conv wgrad, dW GEMMs) -- nothing but the end-of-backward reduction
+        consumes its output;
+      * `tower`: the text tower (encoder / decoder, forward and backward) runs beside the image tower.
+    Side streams are forked with events from the stream that produced their inputs and joined before the
+    deferred reduction (GradReducer.flush) / at the fusion and loss points in the mixers."""
+
+    enabled = os.environ.get("MMVAE_STREAMS", "1") != "0"
+    _streams = {}
+
+    @classmethod
+    def get(cls, kind, device):
+        key = (kind, device.index if device.index is not None else torch.cuda.current_device())
+        s = cls._streams.get(key)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            cls._streams[key] = s
+        return s
+
+    @classmethod
+    def fork(cls, kind, device):
+        """side stream that has waited for everything enqueued so far on the current stream"""
+        side = cls.get(kind, device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        return side
+
+
+def _wgrad_side(device, *keep):
+    """stream for a weight-gradient launch: the wgrad side stream (forked from the current one) when gradients are
+    deferred, else None (= stay on the current stream)"""
+    if not (StreamPlan.enabled and GradReducer.enabled):
+        return None
+    side = StreamPlan.fork("wgrad", device)
+    GradReducer.note_stream(device, side)
+    GradReducer.keep(device, *keep)
+    return side
 
 
 def _defer(*grads):
@@ -131,8 +190,10 @@ class Conv2dK4S2(Function):
         nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cout, Cin, Hout)
         if _defer(gw, gb if has_b else gw):
             ws = GradReducer.alloc(nws, x.device)
-            _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                  Hout, in_act, H.ACC_DEFER, H.stream())
+            side = _wgrad_side(x.device, dy, x)
+            with torch.cuda.stream(side):
+                _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
+                      Hout, in_act, H.ACC_DEFER, H.stream())
             _conv_segments(ws, dw, db, B, Cout, Cin, Hout, Cout)
         else:
             ws = H.workspace(nws, x.device)
@@ -184,8 +245,10 @@ class ConvT2dK4S2(Function):
         nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin)
         if _defer(gw, gb if has_b else gw):
             ws = GradReducer.alloc(nws, x.device)
-            _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                  Hin, in_act, H.ACC_DEFER, H.stream())
+            side = _wgrad_side(x.device, dy, x)
+            with torch.cuda.stream(side):
+                _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
+                      Hin, in_act, H.ACC_DEFER, H.stream())
             _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
         else:
             ws = H.workspace(nws, x.device)
@@ -255,8 +318,13 @@ class Linear(Function):
         if _defer(gw, gb if has_b else gw):
             nz = H.lib().mmvae_linear_bwd_weight_splits(M, N, K)
             ws = GradReducer.alloc(nws, x.device) if nz > 1 else None
-            _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, in_act,
-                  H.ACC_DEFER, H.stream())
+            # nz == 1 accumulates straight into the flat gradient: still safe on the side stream, because a
+            # parameter's gradient slice is only touched by its own wgrad launches (same stream, in order) and by
+            # the reduction after the join
+            side = _wgrad_side(x.device, dy, x)
+            with torch.cuda.stream(side):
+                _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K,
+                      in_act, H.ACC_DEFER, H.stream())
             if nz > 1:
                 GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
                 if db is not None:
