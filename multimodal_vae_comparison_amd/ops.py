@@ -111,7 +111,10 @@ class StreamPlan:
     Side streams are forked with events from the stream that produced their inputs and joined before the
     deferred reduction (GradReducer.flush) / at the fusion and loss points in the mixers."""
 
-    enabled = os.environ.get("MMVAE_STREAMS", "1") != "0"
+    # Measured on MI355X / ROCm 7.2 (profiles/r01 notes in DESIGN.md): hipGraph replay does not overlap the parallel
+    # branches (1.51 ms/step with the plan vs 1.40 ms without), so the plan is opt-in until the graph executor
+    # schedules branches concurrently.
+    enabled = os.environ.get("MMVAE_STREAMS", "0") != "0"
     _streams = {}
 
     @classmethod
