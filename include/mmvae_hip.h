@@ -48,6 +48,35 @@ enum {
   MMVAE_EP_SIGMOID_CLAMP = 6  /* y = clamp(sigmoid(acc + bias), 1e-6, 1 - 1e-6)                     */
 };
 
+/* Inverted dropout (train mode of the text towers: nn.Dropout(0.1) in PositionalEncoding and in every
+ * Transformer sub-layer, models/encoders.py:790, decoders.py:669).  Counter-based: element i of site `site` is kept
+ * iff hash(seed, counter, site, i) >= p, so the backward kernels regenerate the mask instead of storing it.
+ * state[0] = seed, state[1] = running counter, state[2 + slot] = the counter value of forward call `slot` of this
+ * step (mmvae_dropout_advance bumps the counter and fills the slot; forward and backward of that call read it).
+ * A NULL pointer / p == 0 disables dropout.  Philox streams of the reference cannot be matched bit for bit; parity
+ * under dropout is tested with the masks extracted by mmvae_dropout_mask and fed to the oracle. */
+typedef struct {
+  const uint32_t* state;
+  uint32_t slot;
+  uint32_t site;
+  float p;
+} mmvae_dropout_t;
+#define MMVAE_DROPOUT_SLOTS 16
+int mmvae_dropout_advance(uint32_t* state, uint32_t slot, mmvae_stream_t stream);
+/* out[i] = 0 or 1/(1-p): the multiplicative mask of element i (test / inspection helper) */
+int mmvae_dropout_mask(const mmvae_dropout_t* drop, float* out, long n, mmvae_stream_t stream);
+/* y = dropout(act(x)) elementwise; dx = dy * mask * act'(x).  act: MMVAE_ACT_NONE or MMVAE_ACT_GELU */
+int mmvae_dropout_act_fwd(const float* x, float* y, long n, int act, const mmvae_dropout_t* drop,
+                          mmvae_stream_t stream);
+int mmvae_dropout_act_bwd(const float* dy, const float* x, float* dx, long n, int act, const mmvae_dropout_t* drop,
+                          mmvae_stream_t stream);
+/* cross-attention over a length-1 memory with attention-weight dropout (nn.MultiheadAttention dropout on the
+ * (N*H, L, 1) weights): out[l,n,c] = v[n,c] * mask[(n*H + head(c))*L + l];  bwd: dv[n,c] = sum_l dout * mask */
+int mmvae_head_bcast_dropout_fwd(const float* v, float* out, int L, int N, int H, int hd, const mmvae_dropout_t* drop,
+                                 mmvae_stream_t stream);
+int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L, int N, int H, int hd,
+                                 const mmvae_dropout_t* drop, mmvae_stream_t stream);
+
 int mmvae_version(void);
 const char* mmvae_arch(void); /* "gfx950" */
 
@@ -207,9 +236,9 @@ int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, in
  *   mode 0 (B != T, B != 1): x[t,b,v,e] = emb[oh[b,t,v],e] + pe[b,e]
  *   mode 1 (B == T or B == 1): memory (B,T,2V) with pe[t] (pe[0] if B == 1), relabelled as (T,B,2V). */
 int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T, int V,
-                       int mode, mmvae_stream_t stream);
+                       int mode, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V, int mode,
-                       int accumulate, mmvae_stream_t stream);
+                       int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 size_t mmvae_embed_ws_floats(int B, int T, int V);
 
 /* Scaled-dot-product attention with key padding mask for L,S <= 64 (nn.MultiheadAttention core).
@@ -218,19 +247,22 @@ size_t mmvae_embed_ws_floats(int B, int T, int V);
  *   mask instead (1 = real token).  out (L*N, E=H*hd).  probs (N,H,L,S) saved for bwd. */
 int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out, float* probs,
                    int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv, int mask_is_valid,
-                   mmvae_stream_t stream);
+                   const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                    float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
-                   long ldv, mmvae_stream_t stream);
+                   long ldv, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 
 /* y = LayerNorm(x + r) * gamma + beta (eps 1e-5); r may be NULL, same-shape (r_rows = 0) or broadcast over time
  * (r_rows = N: row index = row % N).  xhat (rows,d) and rstd (rows) are saved for the backward.
- * bwd: dsum = grad wrt (x + r); dgamma/dbeta (+)= through ws (mmvae_layernorm_ws_floats). */
+ * With dropout: y = LN(dropout(x) + r).
+ * bwd: dsum = grad wrt the sum (= grad of r); with dropout dx_drop = dsum * mask is the grad of x;
+ * dgamma/dbeta (+)= through ws (mmvae_layernorm_ws_floats). */
 int mmvae_layernorm_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,
-                                 float* xhat, float* rstd, int rows, int d, int r_rows, mmvae_stream_t stream);
+                                 float* xhat, float* rstd, int rows, int d, int r_rows, const mmvae_dropout_t* drop,
+                                 mmvae_stream_t stream);
 int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                                 float* dsum, float* dgamma, float* dbeta, float* ws, int rows, int d,
-                                 int accumulate, mmvae_stream_t stream);
+                                 float* dsum, float* dx_drop, float* dgamma, float* dbeta, float* ws, int rows, int d,
+                                 int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 size_t mmvae_layernorm_ws_floats(int rows, int d);
 
 /* mean over the leading (time) axis: x (L,N,d) -> y (N,d)  (encoders.py:836); bwd: dx = dy / L broadcast */

@@ -56,6 +56,39 @@ __host__ __device__ __forceinline__ bool ep_reads_aux(int ep) {
   return ep == MMVAE_EP_MUL_RELU_MASK || ep == MMVAE_EP_MUL_SILU_GRAD || ep == MMVAE_EP_MUL_GELU_GRAD;
 }
 
+// ---- counter-based dropout -----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t drop_fmix(uint32_t h) {  // murmur3 finaliser
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+struct DropKey {
+  uint32_t key;
+  float p, inv_keep;
+  bool on;
+};
+__device__ __forceinline__ DropKey drop_key(const mmvae_dropout_t& d) {
+  DropKey k;
+  k.on = d.state != nullptr && d.p > 0.f;
+  k.p = d.p;
+  k.inv_keep = k.on ? 1.0f / (1.0f - d.p) : 1.0f;
+  k.key = k.on ? drop_fmix(d.state[0] ^ (d.state[2 + d.slot] * 0x9E3779B1u) ^ (d.site * 0x85EBCA77u + 0x165667B1u)) : 0u;
+  return k;
+}
+// multiplicative mask of element idx: 0 or 1/(1-p)
+__device__ __forceinline__ float drop_mul(const DropKey& k, uint32_t idx) {
+  if (!k.on) return 1.0f;
+  const uint32_t h = drop_fmix(k.key + idx * 0x9E3779B1u);
+  return ((float)(h >> 8) * (1.0f / 16777216.0f) >= k.p) ? k.inv_keep : 0.0f;
+}
+static inline mmvae_dropout_t drop_arg(const mmvae_dropout_t* d) {
+  mmvae_dropout_t z = {nullptr, 0u, 0u, 0.f};
+  return d ? *d : z;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

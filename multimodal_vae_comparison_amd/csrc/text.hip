@@ -12,8 +12,9 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const float* __restrict__ oh, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, float* __restrict__ out, int B,
-                                                           int T, int V, int mode) {
+                                                           int T, int V, int mode, mmvae_dropout_t drop) {
   const int n = B * T * V;
+  const DropKey dk = drop_key(drop);
   const float e00 = emb[0], e01 = emb[1], e10 = emb[2], e11 = emb[3];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int v = i % V, bt = i / V, t = bt % T, b = bt / T;
@@ -21,22 +22,26 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const float* __restri
     const int pos = mode == 0 ? b : (B == 1 ? 0 : t);
     const size_t o = mode == 0 ? (((size_t)t * B + b) * V + v) * 2 : (size_t)i * 2;
     float2 r;
-    r.x = (one ? e10 : e00) + pe[pos * 2];
-    r.y = (one ? e11 : e01) + pe[pos * 2 + 1];
+    r.x = ((one ? e10 : e00) + pe[pos * 2]) * drop_mul(dk, (uint32_t)o);
+    r.y = ((one ? e11 : e01) + pe[pos * 2 + 1]) * drop_mul(dk, (uint32_t)o + 1u);
     *reinterpret_cast<float2*>(out + o) = r;
   }
 }
 
 // per-block partial of demb rows 0/1: ws[block][4] = {sum dx0 | oh=0, sum dx1 | oh=0, sum dx0 | oh=1, sum dx1 | oh=1}
 __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restrict__ oh, const float* __restrict__ dx,
-                                                           float* __restrict__ ws, int B, int T, int V, int mode) {
+                                                           float* __restrict__ ws, int B, int T, int V, int mode,
+                                                           mmvae_dropout_t drop) {
   __shared__ float red[4];
   const int n = B * T * V;
+  const DropKey dk = drop_key(drop);
   float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int v = i % V, bt = i / V, t = bt % T, b = bt / T;
     const size_t o = mode == 0 ? (((size_t)t * B + b) * V + v) * 2 : (size_t)i * 2;
-    const float2 g = *reinterpret_cast<const float2*>(dx + o);
+    float2 g = *reinterpret_cast<const float2*>(dx + o);
+    g.x *= drop_mul(dk, (uint32_t)o);
+    g.y *= drop_mul(dk, (uint32_t)o + 1u);
     if (oh[i] != 0.f) { a10 += g.x; a11 += g.y; } else { a00 += g.x; a01 += g.y; }
   }
   a00 = block_sum_256(a00, red);
@@ -58,18 +63,19 @@ extern "C" int mmvae_embed_bwd_rows(int B, int T, int V) { return embed_blocks(B
 extern "C" size_t mmvae_embed_ws_floats(int B, int T, int V) { return (size_t)embed_blocks(B, T, V) * 4; }
 
 extern "C" int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T,
-                                  int V, int mode, mmvae_stream_t stream) {
+                                  int V, int mode, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(onehot && emb && pe && x && B > 0 && T > 0 && V > 1);
   hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(embed_blocks(B, T, V)), dim3(256), 0, (hipStream_t)stream, onehot, emb,
-                     pe, x, B, T, V, mode);
+                     pe, x, B, T, V, mode, drop_arg(drop));
   return mmvae_launch_status();
 }
 extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V,
-                                  int mode, int accumulate, mmvae_stream_t stream) {
+                                  int mode, int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(onehot && dx && ws && B > 0 && T > 0 && V > 1);
   MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || demb);
   const int nb = embed_blocks(B, T, V);
-  hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, onehot, dx, ws, B, T, V, mode);
+  hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, onehot, dx, ws, B, T, V, mode,
+                     drop_arg(drop));
   int rc = mmvae_launch_status();
   if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   if (!accumulate && V > 2) {
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ v, const uint8_t* __restrict__ kpm,
                                                       float* __restrict__ out, float* __restrict__ probs, int L, int S,
                                                       int N, int H, int hd, long ldq, long ldk, long ldv,
-                                                      int mask_is_valid) {
+                                                      int mask_is_valid, mmvae_dropout_t drop) {
   __shared__ __attribute__((aligned(16))) float sk[ATT_MAX * ATT_HP];
   __shared__ __attribute__((aligned(16))) float sv[ATT_MAX * ATT_HP];
   __shared__ float sp[ATT_MAX * ATT_SP];
@@ -190,11 +196,13 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
     float sum = 0.f;
+    const DropKey dk = drop_key(drop);   // dropout on the attention weights (after the softmax, before P V)
+    const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + lane) * S);
     for (int s = 0; s < S; ++s) {
       const float p = expf(sp[lane * ATT_SP + s] - mx);
       sp[lane * ATT_SP + s] = p;
       sum += p;
-      att_axpy(o, p, sv + s * ATT_HP);
+      att_axpy(o, p * drop_mul(dk, drow + s), sv + s * ATT_HP);
     }
     const float inv = 1.0f / sum;
     sinv[lane] = inv;
@@ -216,7 +224,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ v, const float* __restrict__ probs,
                                                       const float* __restrict__ dout, float* __restrict__ dq,
                                                       float* __restrict__ dk, float* __restrict__ dv, int L, int S,
-                                                      int N, int H, int hd, long ldq, long ldk, long ldv) {
+                                                      int N, int H, int hd, long ldq, long ldk, long ldv,
+                                                      mmvae_dropout_t drop) {
   __shared__ __attribute__((aligned(16))) float sq[ATT_MAX * ATT_HP];
   __shared__ __attribute__((aligned(16))) float sk[ATT_MAX * ATT_HP];
   __shared__ __attribute__((aligned(16))) float sv[ATT_MAX * ATT_HP];
@@ -238,8 +247,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < ATT_HD; ++d) dor[d] = sdo[l * ATT_HP + d];
     float delta = 0.f;
+    const DropKey dkey = drop_key(drop);
+    const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + l) * S);
     for (int s = 0; s < S; ++s) {
-      const float dp = att_dot(sv + s * ATT_HP, dor);
+      const float dp = att_dot(sv + s * ATT_HP, dor) * drop_mul(dkey, drow + s);   // through the weight dropout
       sds[l * ATT_SP + s] = dp;
       delta += sp[l * ATT_SP + s] * dp;
     }
@@ -262,8 +273,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     float dvr[ATT_HD], dkr[ATT_HD];
 #pragma unroll
     for (int d = 0; d < ATT_HD; ++d) dvr[d] = dkr[d] = 0.f;
+    const DropKey dkey = drop_key(drop);
     for (int l = 0; l < L; ++l) {
-      att_axpy(dvr, sp[l * ATT_SP + s], sdo + l * ATT_HP);
+      const uint32_t di = (uint32_t)((((size_t)n * H + h) * L + l) * S + s);
+      att_axpy(dvr, sp[l * ATT_SP + s] * drop_mul(dkey, di), sdo + l * ATT_HP);   // dV sees the dropped weights
       att_axpy(dkr, sds[l * ATT_SP + s], sq + l * ATT_HP);
     }
     float* dvrow = dv + ((size_t)s * N + n) * ldv + h * hd;
@@ -279,20 +292,20 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
 
 extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out,
                               float* probs, int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv,
-                              int mask_is_valid, mmvae_stream_t stream) {
+                              int mask_is_valid, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L, S, N,
-                     H, hd, ldq, ldk, ldv, mask_is_valid);
+                     H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
   return mmvae_launch_status();
 }
 extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                               float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
-                              long ldv, mmvae_stream_t stream) {
+                              long ldv, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk, dv,
-                     L, S, N, H, hd, ldq, ldk, ldv);
+                     L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
   return mmvae_launch_status();
 }
 
@@ -304,19 +317,21 @@ extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, co
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ xhat,
-                                                     float* __restrict__ rstd, int rows, int d, int r_rows) {
+                                                     float* __restrict__ rstd, int rows, int d, int r_rows,
+                                                     mmvae_dropout_t drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (size_t)row * d;
   const float* rr = r ? r + (size_t)(r_rows > 0 ? row % r_rows : row) * d : nullptr;
+  const DropKey dkey = drop_key(drop);   // dropout on x (the sub-layer output), not on the residual
   float vals[LN_SLOTS];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_SLOTS; ++i) {
     const int c = lane + 64 * i;
     float v = 0.f;
-    if (c < d) v = xr[c] + (rr ? rr[c] : 0.f);
+    if (c < d) v = xr[c] * drop_mul(dkey, (uint32_t)((size_t)row * d + c)) + (rr ? rr[c] : 0.f);
     vals[i] = v;
     s += v;
   }
@@ -344,10 +359,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dsum = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partials of dgamma, dbeta
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     float* __restrict__ dsum, float* __restrict__ ws, int rows, int d,
-                                                     int rows_per_block) {
+                                                     float* __restrict__ dsum, float* __restrict__ dxd,
+                                                     float* __restrict__ ws, int rows, int d, int rows_per_block,
+                                                     mmvae_dropout_t drop) {
   __shared__ float sg[4][2 * 64 * LN_SLOTS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const DropKey dkey = drop_key(drop);
   float dg[LN_SLOTS], db[LN_SLOTS];
 #pragma unroll
   for (int i = 0; i < LN_SLOTS; ++i) dg[i] = db[i] = 0.f;
@@ -376,7 +393,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < LN_SLOTS; ++i) {
       const int c = lane + 64 * i;
-      if (c < d) dsum[(size_t)row * d + c] = rs * (g[i] - s1 - xh[i] * s2);
+      if (c < d) {
+        const float ds = rs * (g[i] - s1 - xh[i] * s2);
+        dsum[(size_t)row * d + c] = ds;
+        if (dxd) dxd[(size_t)row * d + c] = ds * drop_mul(dkey, (uint32_t)((size_t)row * d + c));
+      }
     }
   }
 #pragma unroll
@@ -413,24 +434,25 @@ extern "C" size_t mmvae_layernorm_ws_floats(int rows, int d) {
 }
 extern "C" int mmvae_layernorm_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta,
                                             float* y, float* xhat, float* rstd, int rows, int d, int r_rows,
-                                            mmvae_stream_t stream) {
+                                            const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && gamma && beta && y && xhat && rstd && rows > 0 && d > 0);
   if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y,
-                     xhat, rstd, rows, d, r_rows);
+                     xhat, rstd, rows, d, r_rows, drop_arg(drop));
   return mmvae_launch_status();
 }
 // dgamma and dbeta must be adjacent when both given separately is not required: two reductions are issued.
 extern "C" int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                                            float* dsum, float* dgamma, float* dbeta, float* ws, int rows, int d,
-                                            int accumulate, mmvae_stream_t stream) {
+                                            float* dsum, float* dx_drop, float* dgamma, float* dbeta, float* ws,
+                                            int rows, int d, int accumulate, const mmvae_dropout_t* drop,
+                                            mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(dy && xhat && rstd && gamma && dsum && ws && rows > 0 && d > 0);
   MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || (dgamma && dbeta));
   if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   int rpb;
   const int nb = ln_blocks(rows, &rpb);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, ws, rows,
-                     d, rpb);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, dx_drop,
+                     ws, rows, d, rpb, drop_arg(drop));
   int rc = mmvae_launch_status();
   if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   if (dbeta == dgamma + d) return mmvae_reduce_rows(ws, dgamma, nb, 2L * d, 2L * d, accumulate, stream);
@@ -511,5 +533,100 @@ extern "C" int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, floa
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(permute_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, mask, dx, T, B,
                      V, 0);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout utilities (train mode)
+// ---------------------------------------------------------------------------------------------
+__global__ void dropout_advance_kernel(uint32_t* st, uint32_t slot) {
+  const uint32_t c = st[1] + 1u;
+  st[1] = c;
+  st[2 + slot] = c;
+}
+extern "C" int mmvae_dropout_advance(uint32_t* state, uint32_t slot, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(state && slot < MMVAE_DROPOUT_SLOTS);
+  hipLaunchKernelGGL(dropout_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, slot);
+  return mmvae_launch_status();
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, mmvae_dropout_t drop) {
+  const DropKey dk = drop_key(drop);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = drop_mul(dk, (uint32_t)i);
+}
+extern "C" int mmvae_dropout_mask(const mmvae_dropout_t* drop, float* out, long n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(drop && out && n > 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, *drop);
+  return mmvae_launch_status();
+}
+__global__ __launch_bounds__(256) void dropout_act_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                          float* __restrict__ out, long n, int act, int bwd,
+                                                          mmvae_dropout_t drop) {
+  // fwd: out = act(x) * m ; bwd: out = a(=dy) * m * act'(x)
+  const DropKey dk = drop_key(drop);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float m = drop_mul(dk, (uint32_t)i);
+    const float xv = x[i];
+    float v;
+    if (!bwd) v = apply_in_act(xv, act) * m;
+    else v = a[i] * m * (act == MMVAE_ACT_GELU ? dev_gelu_grad(xv) : 1.0f);
+    out[i] = v;
+  }
+}
+extern "C" int mmvae_dropout_act_fwd(const float* x, float* y, long n, int act, const mmvae_dropout_t* drop,
+                                     mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && y && n > 0 && (act == MMVAE_ACT_NONE || act == MMVAE_ACT_GELU));
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, nullptr, x, y, n,
+                     act, 0, drop_arg(drop));
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_dropout_act_bwd(const float* dy, const float* x, float* dx, long n, int act,
+                                     const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && dx && n > 0 && (act == MMVAE_ACT_NONE || act == MMVAE_ACT_GELU));
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n, act,
+                     1, drop_arg(drop));
+  return mmvae_launch_status();
+}
+// out[l,n,c] = v[n,c] * mask[(n*H + c/hd)*L + l]   (attention-weight dropout over a length-1 memory)
+__global__ __launch_bounds__(256) void head_bcast_dropout_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                 int L, int N, int H, int hd, int bwd,
+                                                                 mmvae_dropout_t drop) {
+  const DropKey dk = drop_key(drop);
+  const int E = H * hd;
+  const long ne = (long)N * E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ne; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / E), c = (int)(i - (long)n * E), h = c / hd;
+    const uint32_t base = (uint32_t)(((size_t)n * H + h) * L);
+    if (!bwd) {
+      const float v = src[i];
+      for (int l = 0; l < L; ++l) dst[(size_t)l * ne + i] = v * drop_mul(dk, base + l);
+    } else {
+      float a = 0.f;
+      for (int l = 0; l < L; ++l) a += src[(size_t)l * ne + i] * drop_mul(dk, base + l);
+      dst[i] = a;
+    }
+  }
+}
+extern "C" int mmvae_head_bcast_dropout_fwd(const float* v, float* out, int L, int N, int H, int hd,
+                                            const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(v && out && L > 0 && N > 0 && H > 0 && hd > 0);
+  long blocks = ((long)N * H * hd + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(head_bcast_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, v, out, L,
+                     N, H, hd, 0, drop_arg(drop));
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L, int N, int H, int hd,
+                                            const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dout && dv && L > 0 && N > 0 && H > 0 && hd > 0);
+  long blocks = ((long)N * H * hd + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(head_bcast_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, dv, L,
+                     N, H, hd, 1, drop_arg(drop));
   return mmvae_launch_status();
 }

@@ -38,6 +38,13 @@ class PoeBwdArgs(ctypes.Structure):
                 ("dz", c_p * MAX_EXPERTS), ("dmu", c_p * MAX_EXPERTS), ("dlv", c_p * MAX_EXPERTS)]
 
 
+class Dropout(ctypes.Structure):
+    _fields_ = [("state", c_p), ("slot", c_u), ("site", c_u), ("p", c_f)]
+
+
+c_dp = ctypes.POINTER(Dropout)
+DROPOUT_SLOTS = 16
+
 # name -> (restype, argtypes); must list every symbol include/mmvae_hip.h declares (tests check this)
 SIGNATURES = {
     "mmvae_version": (c_i, []),
@@ -71,13 +78,13 @@ SIGNATURES = {
     "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_p]),
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
-    "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_p]),
-    "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
+    "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_dp, c_p]),
+    "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_dp, c_p]),
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
-    "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_i, c_p]),
-    "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_p]),
-    "mmvae_layernorm_residual_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_p]),
-    "mmvae_layernorm_residual_bwd": (c_i, [c_p] * 8 + [c_i] * 3 + [c_p]),
+    "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_i, c_dp, c_p]),
+    "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_dp, c_p]),
+    "mmvae_layernorm_residual_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_dp, c_p]),
+    "mmvae_layernorm_residual_bwd": (c_i, [c_p] * 9 + [c_i] * 3 + [c_dp, c_p]),
     "mmvae_layernorm_ws_floats": (c_sz, [c_i, c_i]),
     "mmvae_mean_over_time_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "mmvae_mean_over_time_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
@@ -89,6 +96,12 @@ SIGNATURES = {
     "mmvae_reduce_rows": (c_i, [c_p, c_p, c_i, c_l, c_l, c_i, c_p]),
     "mmvae_fill": (c_i, [c_p, c_l, c_f, c_p]),
     "mmvae_reduce_segments": (c_i, [c_p, c_p]),
+    "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),
+    "mmvae_dropout_mask": (c_i, [c_dp, c_p, c_l, c_p]),
+    "mmvae_dropout_act_fwd": (c_i, [c_p, c_p, c_l, c_i, c_dp, c_p]),
+    "mmvae_dropout_act_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_dp, c_p]),
+    "mmvae_head_bcast_dropout_fwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_dp, c_p]),
+    "mmvae_head_bcast_dropout_bwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_dp, c_p]),
     "mmvae_conv_wgrad_layout": (c_i, [c_i] * 4 + [c_p] * 3),
     "mmvae_linear_bwd_weight_splits": (c_i, [c_i] * 3),
     "mmvae_layernorm_bwd_rows": (c_i, [c_i, c_i]),

@@ -9,7 +9,7 @@ from .. import hipops as H
 from .. import ops
 from .NetworkTypes import NetworkRoles, NetworkTypes
 from .encoders import VaeComponent
-from .nn_modules import HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
+from .nn_modules import DropoutState, HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
 
 
 class VaeDecoder(VaeComponent):
@@ -79,10 +79,17 @@ class HipTransformerDecoderLayer(nn.Module):
         self.norm2 = HipLayerNorm(d)
         self.norm3 = HipLayerNorm(d)
 
-    def forward(self, x, mem, mask_u8):
-        x = self.norm1(self.self_attn(x, mask_u8), x)
-        x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
-        return self.norm3(self.linear2(self.linear1(x)), x)
+    def forward(self, x, mem, mask_u8, ds=None):
+        if ds is None:
+            x = self.norm1(self.self_attn(x, mask_u8), x)
+            x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
+            return self.norm3(self.linear2(self.linear1(x)), x)
+        L = x.shape[0]
+        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"]), x, ds["drop1"])
+        ca = self.multihead_attn.value_path(mem, L, ds["xattn"])          # (L,N,d): weight dropout varies with l
+        x = self.norm2(ca, x, ds["drop2"])
+        h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])
+        return self.norm3(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop3"])
 
 
 class HipTransformerDecoderStack(nn.Module):
@@ -111,6 +118,7 @@ class Dec_TxtTransformer(VaeDecoder):
         self.sequence_pos_encoder = ModuleWrap(PositionalEncoding(self.out_dim, self.dropout))
         self._tq_cache = {}
         self.register_buffer("_scale", torch.tensor(0.75), persistent=False)
+        self.drop_state = DropoutState()
 
     def _timequeries(self, T, bs, D, device):
         """PositionalEncoding(zeros(T,bs,D)) = pe[:T] broadcast over the batch (decoders.py:716-717); constant for
@@ -139,8 +147,19 @@ class Dec_TxtTransformer(VaeDecoder):
         mask_u8 = ops.as_u8(mask)
         x = self._timequeries(T, bs, D, z.device)
         mem = z[0]
-        for layer in self.seqTransDecoder.layers:
-            x = layer(x, mem, mask_u8)
+        p = self.dropout
+        nl = len(self.seqTransDecoder.layers)
+        if self.training and p > 0:       # nn.Dropout sites of the reference: PE + 6 per layer
+            slot, call = self.drop_state.begin()
+            sp = lambda site, name: self.drop_state.spec(slot, call, site, p, name)
+            x = ops.dropout_act(x, H.ACT_NONE, sp(0, "pe"))
+            ds = [{"attn": sp(1 + 6 * i, f"l{i}.attn"), "drop1": sp(2 + 6 * i, f"l{i}.drop1"),
+                   "xattn": sp(3 + 6 * i, f"l{i}.xattn"), "drop2": sp(4 + 6 * i, f"l{i}.drop2"),
+                   "ffn": sp(5 + 6 * i, f"l{i}.ffn"), "drop3": sp(6 + 6 * i, f"l{i}.drop3")} for i in range(nl)]
+        else:
+            ds = [None] * nl
+        for layer, d in zip(self.seqTransDecoder.layers, ds):
+            x = layer(x, mem, mask_u8, d)
         out = self.finallayer(x)                                              # (T, bs, V)
         out = ops.permute_mask(out, mask_u8)                                  # (bs, T, V), zero at padding
         return out, self._scale

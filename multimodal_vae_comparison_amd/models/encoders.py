@@ -11,7 +11,7 @@ import torch.nn as nn
 from .. import hipops as H
 from .. import ops
 from .NetworkTypes import NetworkRoles, NetworkTypes
-from .nn_modules import HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
+from .nn_modules import DropoutState, HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
 
 
 class VaeComponent(nn.Module):
@@ -144,9 +144,14 @@ class HipTransformerEncoderLayer(nn.Module):
         self.norm1 = HipLayerNorm(d)
         self.norm2 = HipLayerNorm(d)
 
-    def forward(self, x, mask_u8):
-        x = self.norm1(self.self_attn(x, mask_u8), x)
-        return self.norm2(self.linear2(self.linear1(x)), x)
+    def forward(self, x, mask_u8, ds=None):
+        """`ds`: dict of DropSpec for train mode (attn, drop1, ffn, drop2) or None"""
+        if ds is None:
+            x = self.norm1(self.self_attn(x, mask_u8), x)
+            return self.norm2(self.linear2(self.linear1(x)), x)
+        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"]), x, ds["drop1"])
+        h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])           # dropout(gelu(.)) materialised
+        return self.norm2(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop2"])
 
 
 class HipTransformerStack(nn.Module):
@@ -175,6 +180,7 @@ class Enc_TxtTransformer(VaeEncoder):
                                                     for _ in range(num_layers)])
         self.mu_layer = ModuleWrap(HipLinear(d, self.out_dim))
         self.logvar_layer = ModuleWrap(HipLinear(d, self.out_dim))
+        self.drop_state = DropoutState()
 
     def forward(self, batch):
         x, mask = batch["data"], batch["masks"]
@@ -186,8 +192,18 @@ class Enc_TxtTransformer(VaeEncoder):
         mask_u8 = ops.as_u8(mask)            # validity bytes, read in place by the attention kernel
         mode = 1 if (bs == nframes or bs == 1) else 0
         w = self.embedding.weight
-        h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad)   # (T, B, 2V)
-        for layer in self.seqTransEncoder.layers:
-            h = layer(h, mask_u8)
+        p = self.dropout
+        if self.training and p > 0:       # nn.Dropout sites of the reference: PE + 4 per layer
+            slot, call = self.drop_state.begin()
+            sp = lambda site, name: self.drop_state.spec(slot, call, site, p, name)
+            d_pe = sp(0, "pe")
+            ds = [{"attn": sp(1 + 4 * i, f"l{i}.attn"), "drop1": sp(2 + 4 * i, f"l{i}.drop1"),
+                   "ffn": sp(3 + 4 * i, f"l{i}.ffn"), "drop2": sp(4 + 4 * i, f"l{i}.drop2")}
+                  for i in range(len(self.seqTransEncoder.layers))]
+        else:
+            d_pe, ds = None, [None] * len(self.seqTransEncoder.layers)
+        h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad, d_pe)   # (T, B, 2V)
+        for layer, d in zip(self.seqTransEncoder.layers, ds):
+            h = layer(h, mask_u8, d)
         z = ops.mean_over_time(h)
         return self.process_output(z)

@@ -43,6 +43,11 @@ class TorchMMVAE(nn.Module):
             nn.Parameter(torch.zeros(1, self.n_latents), requires_grad=False),  # mu
             nn.Parameter(torch.zeros(1, self.n_latents), requires_grad=True)])  # logvar (trainable, mmvae_base.py:35-38)
         self.set_likelihood_scales()
+        for name, vae in self.vaes.items():      # names of the dropout sites (tests map them onto the oracle's)
+            for part in ("enc", "dec"):
+                st = getattr(getattr(vae, part), "drop_state", None)
+                if st is not None:
+                    st.prefix = f"vaes.{name}.{part}"
         self.eps_override = None    # list of (K,B,D) noise tensors consumed in draw order (parity tests)
 
     def set_likelihood_scales(self):
@@ -57,6 +62,14 @@ class TorchMMVAE(nn.Module):
     @property
     def latent_factorization(self):
         return any(v.private_latents is not None for v in self.vaes.values())
+
+    def _begin_step(self):
+        """start of an objective() call: per-step dropout call counters back to 0"""
+        for vae in self.vaes.values():
+            for part in (vae.enc, vae.dec):
+                st = getattr(part, "drop_state", None)
+                if st is not None:
+                    st.reset_calls()
 
     # ---- noise ----------------------------------------------------------------------------------
     def _draw(self, B, D, device):

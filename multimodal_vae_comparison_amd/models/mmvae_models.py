@@ -48,6 +48,7 @@ class MoPOE(TorchMMVAE):
     # ---- hot path --------------------------------------------------------------------------------
     def objective(self, mods):
         """mmvae_models.py:296-320 + weighted_group_kld (objectives.py:184-201)"""
+        self._begin_step()
         names = list(self.vaes.keys())
         M = len(names)
         dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
@@ -139,6 +140,7 @@ class POE(TorchMMVAE):
 
     def objective(self, mods):
         """mmvae_models.py:159-187: sum over input subsets of -(sum_b sum_m lpx - beta sum_b KL(joint || prior))"""
+        self._begin_step()
         names = list(self.vaes.keys())
         M = len(names)
         theta = self._pz_params[1]

@@ -44,6 +44,35 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", positional_table(d_model, max_len))
 
 
+class DropoutState(nn.Module):
+    """Per-tower counter-based dropout state (include/mmvae_hip.h: mmvae_dropout_t): int32 buffer
+    [seed, counter, slot_0 .. slot_15].  `begin()` (once per tower forward in train mode) bumps the counter on
+    the device and parks its value in the slot of this call, so that the backward kernels of the same call -- which
+    may run after later calls of the same tower (PoE) -- regenerate identical masks."""
+    _next_seed = [0x1234567]
+
+    def __init__(self):
+        super().__init__()
+        st = torch.zeros(2 + H.DROPOUT_SLOTS, dtype=torch.int32)
+        DropoutState._next_seed[0] = (DropoutState._next_seed[0] * 1103515245 + 12345) & 0x7FFFFFFF
+        st[0] = (torch.initial_seed() ^ DropoutState._next_seed[0]) & 0x7FFFFFFF
+        self.register_buffer("state", st, persistent=False)
+        self.call = 0
+        self.prefix = ""
+
+    def reset_calls(self):
+        self.call = 0
+
+    def begin(self):
+        slot = self.call % H.DROPOUT_SLOTS
+        self.call += 1
+        ops.dropout_advance(self.state, slot)
+        return slot, self.call - 1
+
+    def spec(self, slot, call, site, p, name):
+        return ops.DropSpec(self.state, slot, site, p, f"{self.prefix}.{name}#{call}")
+
+
 class HipLinear(nn.Module):
     """nn.Linear parameters (torch default init) driven by the MFMA GEMM; `in_act` is applied to the input."""
 
@@ -70,11 +99,12 @@ class HipLayerNorm(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, drop=None):
+        """LayerNorm(dropout(x) + residual)"""
         gg, gb = self.weight.grad, self.bias.grad
         if gg is not None and gb is not None and gb.data_ptr() != gg.data_ptr() + 4 * gg.numel():
             gg = gb = None      # not laid out adjacently: let autograd accumulate
-        return ops.layernorm_residual(x, residual, self.weight, self.bias, gg, gb)
+        return ops.layernorm_residual(x, residual, self.weight, self.bias, gg, gb, drop)
 
 
 class HipSelfAttention(nn.Module):
@@ -94,18 +124,22 @@ class HipSelfAttention(nn.Module):
     def flat_groups(self):
         return [[self.in_proj_weight, self.in_proj_bias]]
 
-    def forward(self, x, mask_u8):
-        """mask_u8: (N, L) validity bytes (1 = real token); padded keys are ignored"""
+    def forward(self, x, mask_u8, drop=None):
+        """mask_u8: (N, L) validity bytes (1 = real token); padded keys are ignored; `drop`: attention-weight dropout"""
         qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, H.ACT_NONE, self.in_proj_weight.grad,
                          self.in_proj_bias.grad)
-        a = ops.attention(qkv, mask_u8, self.nhead, mask_is_valid=True)
+        a = ops.attention(qkv, mask_u8, self.nhead, mask_is_valid=True, drop=drop)
         return self.out_proj(a)
 
-    def value_path(self, mem):
+    def value_path(self, mem, L=None, drop=None):
         """Cross-attention over a length-1 memory: softmax over one key == 1, so the output is
-        out_proj(v_proj(mem)) for every query (q/k projections receive exactly zero gradient)."""
+        out_proj(v_proj(mem)) for every query (q/k projections receive exactly zero gradient).  In train mode the
+        attention-weight dropout acts on that single weight per (query, head): the value row is replicated over the
+        L queries with a per-(sample, head, query) mask before out_proj."""
         d = self.d
         gw, gb = self.in_proj_weight.grad, self.in_proj_bias.grad
         v = ops.linear(mem, self.in_proj_weight[2 * d:], self.in_proj_bias[2 * d:], H.ACT_NONE,
                        gw[2 * d:] if gw is not None else None, gb[2 * d:] if gb is not None else None)
+        if drop is not None:
+            v = ops.head_bcast_dropout(v, L, self.nhead, drop)        # (L, N, d)
         return self.out_proj(v)

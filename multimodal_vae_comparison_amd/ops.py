@@ -150,6 +150,39 @@ def _defer(*grads):
     return GradReducer.enabled and all(g is not None for g in grads)
 
 
+class DropSpec:
+    """One dropout application: (state tensor, slot, site, p) -> the C struct, plus an optional recorder used by the
+    tests to extract the very masks a forward pass used."""
+    recorder = None     # list collecting (name, state, slot, site, p, n) when set
+
+    def __init__(self, state, slot, site, p, name=""):
+        self.state, self.slot, self.site, self.p, self.name = state, int(slot), int(site), float(p), name
+
+    def c(self):
+        return ctypes.byref(H.Dropout(self.state.data_ptr(), self.slot, self.site, self.p))
+
+    def note(self, n):
+        if DropSpec.recorder is not None:
+            DropSpec.recorder.append((self.name, self.state, self.slot, self.site, self.p, int(n)))
+
+
+def _dp(drop, n=0):
+    if drop is None:
+        return None
+    drop.note(n)
+    return drop.c()
+
+
+def dropout_advance(state, slot):
+    _call("mmvae_dropout_advance", H.ptr(state), int(slot), H.stream())
+
+
+def dropout_mask(drop, n):
+    out = torch.empty(n, device=drop.state.device)
+    _call("mmvae_dropout_mask", drop.c(), H.ptr(out), n, H.stream())
+    return out
+
+
 def _new_like_param(p, g):
     """(destination tensor, accumulate flag, value to hand back to autograd)"""
     if g is not None:
@@ -571,39 +604,42 @@ class EmbedPE(Function):
     """Embedding(one-hot.long()) + PositionalEncoding quirk -> (T, B, 2V)  (models/encoders.py:833-835)"""
 
     @staticmethod
-    def forward(ctx, onehot, emb, pe, mode, gemb):
+    def forward(ctx, onehot, emb, pe, mode, gemb, drop):
         onehot = H.f32c(onehot)
         B, T, V = onehot.shape
         x = torch.empty(T, B, 2 * V, device=onehot.device)
-        _call("mmvae_embed_pe_fwd", H.ptr(onehot), H.ptr(emb), H.ptr(pe), H.ptr(x), B, T, V, mode, H.stream())
+        _call("mmvae_embed_pe_fwd", H.ptr(onehot), H.ptr(emb), H.ptr(pe), H.ptr(x), B, T, V, mode, _dp(drop, x.numel()),
+              H.stream())
         ctx.save_for_backward(onehot, emb)
-        ctx.cfg = (mode, gemb)
+        ctx.cfg = (mode, gemb, drop)
         return x
 
     @staticmethod
     def backward(ctx, dx):
         onehot, emb = ctx.saved_tensors
-        mode, gemb = ctx.cfg
+        mode, gemb, drop = ctx.cfg
+        dpc = drop.c() if drop is not None else None
         B, T, V = onehot.shape
         dx = H.f32c(dx)
         de, acc, ret = _new_like_param(emb, gemb)
         nws = H.lib().mmvae_embed_ws_floats(B, T, V)
         if _defer(gemb):
             ws = GradReducer.alloc(nws, dx.device)
-            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), None, H.ptr(ws), B, T, V, mode, H.ACC_DEFER,
+            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), None, H.ptr(ws), B, T, V, mode, H.ACC_DEFER, dpc,
                   H.stream())
             GradReducer.add(ws.data_ptr(), de, H.lib().mmvae_embed_bwd_rows(B, T, V), 4, 4)
         else:
             ws = H.workspace(nws, dx.device)
-            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, H.stream())
-        return None, ret, None, None, None
+            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, dpc,
+                  H.stream())
+        return None, ret, None, None, None, None
 
 
 class Attention(Function):
     """softmax(q k^T / sqrt(hd) + key-padding mask) v for packed qkv (L, N, 3E), L <= 64"""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, nhead, mask_is_valid):
+    def forward(ctx, qkv, kpm, nhead, mask_is_valid, drop):
         qkv = H.f32c(qkv)
         L, N, E3 = qkv.shape
         E = E3 // 3
@@ -612,9 +648,10 @@ class Attention(Function):
         probs = torch.empty(N, nhead, L, L, device=qkv.device)
         p = qkv.data_ptr()
         _call("mmvae_attn_fwd", p, p + 4 * E, p + 8 * E, H.ptr(kpm), H.ptr(out), H.ptr(probs), L, L, N, nhead, hd, E3,
-              E3, E3, int(mask_is_valid), H.stream())
+              E3, E3, int(mask_is_valid), _dp(drop, probs.numel()), H.stream())
         ctx.save_for_backward(qkv, probs)
         ctx.nhead = nhead
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -627,15 +664,15 @@ class Attention(Function):
         dqkv = torch.empty_like(qkv)
         p, d = qkv.data_ptr(), dqkv.data_ptr()
         _call("mmvae_attn_bwd", p, p + 4 * E, p + 8 * E, H.ptr(probs), H.ptr(dout), d, d + 4 * E, d + 8 * E, L, L, N,
-              nhead, E // nhead, E3, E3, E3, H.stream())
-        return dqkv, None, None, None
+              nhead, E // nhead, E3, E3, E3, ctx.drop.c() if ctx.drop is not None else None, H.stream())
+        return dqkv, None, None, None, None
 
 
 class LayerNormResidual(Function):
     """y = LayerNorm(x + r); r None, same shape, or (N,d) broadcast over the leading (time) axis"""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, gg, gb):
+    def forward(ctx, x, r, gamma, beta, gg, gb, drop):
         x = H.f32c(x)
         d = x.shape[-1]
         rows = x.numel() // d
@@ -648,19 +685,21 @@ class LayerNormResidual(Function):
         xhat = torch.empty_like(x)
         rstd = torch.empty(rows, device=x.device)
         _call("mmvae_layernorm_residual_fwd", H.ptr(x), H.ptr(r), H.ptr(gamma), H.ptr(beta), H.ptr(y), H.ptr(xhat),
-              H.ptr(rstd), rows, d, r_rows, H.stream())
+              H.ptr(rstd), rows, d, r_rows, _dp(drop, x.numel()), H.stream())
         ctx.save_for_backward(xhat, rstd, gamma)
-        ctx.cfg = (gg, gb, r is not None, r_rows, tuple(x.shape), tuple(r.shape) if r is not None else None)
+        ctx.cfg = (gg, gb, r is not None, r_rows, tuple(x.shape), tuple(r.shape) if r is not None else None, drop)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xhat, rstd, gamma = ctx.saved_tensors
-        gg, gb, has_r, r_rows, xshape, rshape = ctx.cfg
+        gg, gb, has_r, r_rows, xshape, rshape, drop = ctx.cfg
         dy = H.f32c(dy)
         d = xshape[-1]
         rows = xhat.numel() // d
         dsum = torch.empty_like(xhat)
+        dxd = torch.empty_like(xhat) if drop is not None else None      # grad of x = dsum * mask under dropout
+        dpc = drop.c() if drop is not None else None
         if gg is not None:
             dg, dbt, acc, ret_g, ret_b = gg, gb, 1, None, None
         else:
@@ -671,14 +710,14 @@ class LayerNormResidual(Function):
         if _defer(gg, gb):
             ws = GradReducer.alloc(nws, dy.device)
             _call("mmvae_layernorm_residual_bwd", H.ptr(dy), H.ptr(xhat), H.ptr(rstd), H.ptr(gamma), H.ptr(dsum),
-                  None, None, H.ptr(ws), rows, d, H.ACC_DEFER, H.stream())
+                  H.ptr(dxd), None, None, H.ptr(ws), rows, d, H.ACC_DEFER, dpc, H.stream())
             nb = H.lib().mmvae_layernorm_bwd_rows(rows, d)
             GradReducer.add(ws.data_ptr(), dg, nb, d, 2 * d)
             GradReducer.add(ws.data_ptr() + 4 * d, dbt, nb, d, 2 * d)
         else:
             ws = H.workspace(nws, dy.device)
             _call("mmvae_layernorm_residual_bwd", H.ptr(dy), H.ptr(xhat), H.ptr(rstd), H.ptr(gamma), H.ptr(dsum),
-                  dg.data_ptr(), dbt.data_ptr(), H.ptr(ws), rows, d, acc, H.stream())
+                  H.ptr(dxd), dg.data_ptr(), dbt.data_ptr(), H.ptr(ws), rows, d, acc, dpc, H.stream())
         dr = None
         if has_r and ctx.needs_input_grad[1]:
             if r_rows:
@@ -686,7 +725,8 @@ class LayerNormResidual(Function):
                 _call("mmvae_sum_over_time", H.ptr(dsum), H.ptr(dr), rows // r_rows, r_rows, d, H.stream())
             else:
                 dr = dsum
-        return (dsum if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None
+        dx = dxd if drop is not None else dsum
+        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None
 
 
 class MeanOverTime(Function):
@@ -731,13 +771,13 @@ class PermuteMask(Function):
         return dx, None
 
 
-def embed_pe(onehot, emb, pe, mode, gemb=None):
-    return EmbedPE.apply(onehot, emb, pe, mode, gemb)
+def embed_pe(onehot, emb, pe, mode, gemb=None, drop=None):
+    return EmbedPE.apply(onehot, emb, pe, mode, gemb, drop)
 
 
-def attention(qkv, mask_u8, nhead, mask_is_valid=False):
+def attention(qkv, mask_u8, nhead, mask_is_valid=False, drop=None):
     """mask_u8 (N,L) bytes: key-padding mask (1 = ignore) or, with mask_is_valid, the validity mask (1 = token)"""
-    return Attention.apply(qkv, mask_u8, nhead, mask_is_valid)
+    return Attention.apply(qkv, mask_u8, nhead, mask_is_valid, drop)
 
 
 def as_u8(mask):
@@ -747,8 +787,63 @@ def as_u8(mask):
     return mask.to(torch.uint8).contiguous()
 
 
-def layernorm_residual(x, r, gamma, beta, gg=None, gb=None):
-    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb)
+def layernorm_residual(x, r, gamma, beta, gg=None, gb=None, drop=None):
+    """LayerNorm(dropout(x) + r)"""
+    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop)
+
+
+class DropoutAct(Function):
+    """y = dropout(act(x)), act in {none, gelu}"""
+
+    @staticmethod
+    def forward(ctx, x, act, drop):
+        x = H.f32c(x)
+        y = torch.empty_like(x)
+        _call("mmvae_dropout_act_fwd", H.ptr(x), H.ptr(y), x.numel(), act, _dp(drop, x.numel()), H.stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        act, drop = ctx.cfg
+        dy = H.f32c(dy)
+        dx = torch.empty_like(x)
+        _call("mmvae_dropout_act_bwd", H.ptr(dy), H.ptr(x), H.ptr(dx), x.numel(), act, drop.c() if drop else None,
+              H.stream())
+        return dx, None, None
+
+
+class HeadBcastDropout(Function):
+    """(N,E) -> (L,N,E) with per-(n, head, l) attention-weight dropout (length-1 memory cross-attention)"""
+
+    @staticmethod
+    def forward(ctx, v, L, nhead, drop):
+        v = H.f32c(v)
+        N, E = v.shape
+        out = torch.empty(L, N, E, device=v.device)
+        _call("mmvae_head_bcast_dropout_fwd", H.ptr(v), H.ptr(out), L, N, nhead, E // nhead, _dp(drop, N * nhead * L),
+              H.stream())
+        ctx.cfg = (L, N, E, nhead, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, N, E, nhead, drop = ctx.cfg
+        dout = H.f32c(dout)
+        dv = torch.empty(N, E, device=dout.device)
+        _call("mmvae_head_bcast_dropout_bwd", H.ptr(dout), H.ptr(dv), L, N, nhead, E // nhead,
+              drop.c() if drop else None, H.stream())
+        return dv, None, None, None
+
+
+def dropout_act(x, act, drop):
+    return DropoutAct.apply(x, act, drop)
+
+
+def head_bcast_dropout(v, L, nhead, drop):
+    return HeadBcastDropout.apply(v, L, nhead, drop)
 
 
 def mean_over_time(x):

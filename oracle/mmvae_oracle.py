@@ -24,9 +24,12 @@ Conventions
 * `eps`: list of standard-normal tensors consumed in the order the reference draws them
   (one `Normal.rsample` each); the reference's own generator is never used here.
 * dropout: the reference trains with p=0.1 dropout (PositionalEncoding + every transformer sub-layer).
-  `train=False` (default) is the parity mode (dropout off == reference .eval()).  `train=True`
-  applies torch CPU dropout at the same sites and exists only so that the timed CPU baseline does the
-  same work as a reference training step.
+  `train` selects how the sites behave: False / None = off (parity mode == reference .eval()); True / "rng" =
+  torch CPU dropout at the same sites (only so that the timed CPU baseline does the work of a reference training
+  step); a dict {site name: multiplicative mask} = explicit masks (train-mode parity against the HIP path, whose
+  counter-based masks are extracted with mmvae_dropout_mask).  Site names: "<prefix>.<enc|dec>.<site>#<call>"
+  with sites pe, l0.attn, l0.drop1, l0.ffn, l0.drop2 (encoder) and pe, l0.attn, l0.drop1, l0.xattn, l0.drop2,
+  l0.ffn, l0.drop3 (decoder); <call> counts the forward calls of that tower within one objective.
 """
 import itertools
 import math
@@ -175,11 +178,25 @@ def positional_table(d_model, n, dtype=torch.float32):
     return pe
 
 
-def _dropout(x, train):
-    return F.dropout(x, DROPOUT_P, True) if train else x
+def _dropout(x, train, name=None):
+    if not train:
+        return x
+    if isinstance(train, dict):
+        return x * train[name].reshape(x.shape).to(x.dtype)
+    return F.dropout(x, DROPOUT_P, True)
 
 
-def mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, kpm=None, train=False):
+def _tower_call(train, tower):
+    """site-name prefix '<tower>.' + call counter for explicit-mask mode"""
+    if not isinstance(train, dict):
+        return lambda site: None
+    calls = train.setdefault("_calls", {})
+    k = calls.get(tower, 0)
+    calls[tower] = k + 1
+    return lambda site: f"{tower}.{site}#{k}"
+
+
+def mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, kpm=None, train=False, name=None):
     """torch.nn.MultiheadAttention forward (seq-first).  q_in (L,N,E), kv_in (S,N,E), kpm (N,S) True=ignore."""
     L, N, E = q_in.shape
     S = kv_in.shape[0]
@@ -193,32 +210,39 @@ def mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, kpm=None, train=False):
     att = torch.bmm(q, k.transpose(1, 2))                      # (N*h, L, S)
     if kpm is not None:
         att = att.reshape(N, nhead, L, S).masked_fill(kpm[:, None, None, :], float("-inf")).reshape(N * nhead, L, S)
-    att = _dropout(F.softmax(att, dim=-1), train)
+    att = _dropout(F.softmax(att, dim=-1), train, name)
     o = torch.bmm(att, v).transpose(0, 1).reshape(L, N, E)
     return F.linear(o, w_out, b_out)
 
 
-def transformer_encoder_layer(x, p, L, nhead, kpm, train=False):
+def transformer_encoder_layer(x, p, L, nhead, kpm, train=False, nm=lambda s: None, li=0):
     """torch.nn.TransformerEncoderLayer, norm_first=False, activation gelu (exact)."""
     sa = mha(x, x, p[f"{L}.self_attn.in_proj_weight"], p[f"{L}.self_attn.in_proj_bias"],
-             p[f"{L}.self_attn.out_proj.weight"], p[f"{L}.self_attn.out_proj.bias"], nhead, kpm, train)
-    x = F.layer_norm(x + _dropout(sa, train), x.shape[-1:], p[f"{L}.norm1.weight"], p[f"{L}.norm1.bias"], LN_EPS)
-    ff = F.linear(_dropout(F.gelu(F.linear(x, p[f"{L}.linear1.weight"], p[f"{L}.linear1.bias"])), train),
+             p[f"{L}.self_attn.out_proj.weight"], p[f"{L}.self_attn.out_proj.bias"], nhead, kpm, train, nm(f"l{li}.attn"))
+    x = F.layer_norm(x + _dropout(sa, train, nm(f"l{li}.drop1")), x.shape[-1:], p[f"{L}.norm1.weight"],
+                     p[f"{L}.norm1.bias"], LN_EPS)
+    ff = F.linear(_dropout(F.gelu(F.linear(x, p[f"{L}.linear1.weight"], p[f"{L}.linear1.bias"])), train, nm(f"l{li}.ffn")),
                   p[f"{L}.linear2.weight"], p[f"{L}.linear2.bias"])
-    return F.layer_norm(x + _dropout(ff, train), x.shape[-1:], p[f"{L}.norm2.weight"], p[f"{L}.norm2.bias"], LN_EPS)
+    return F.layer_norm(x + _dropout(ff, train, nm(f"l{li}.drop2")), x.shape[-1:], p[f"{L}.norm2.weight"],
+                        p[f"{L}.norm2.bias"], LN_EPS)
 
 
-def transformer_decoder_layer(x, mem, p, L, nhead, tgt_kpm, train=False):
+def transformer_decoder_layer(x, mem, p, L, nhead, tgt_kpm, train=False, nm=lambda s: None, li=0):
     """torch.nn.TransformerDecoderLayer, norm_first=False, activation gelu."""
     sa = mha(x, x, p[f"{L}.self_attn.in_proj_weight"], p[f"{L}.self_attn.in_proj_bias"],
-             p[f"{L}.self_attn.out_proj.weight"], p[f"{L}.self_attn.out_proj.bias"], nhead, tgt_kpm, train)
-    x = F.layer_norm(x + _dropout(sa, train), x.shape[-1:], p[f"{L}.norm1.weight"], p[f"{L}.norm1.bias"], LN_EPS)
+             p[f"{L}.self_attn.out_proj.weight"], p[f"{L}.self_attn.out_proj.bias"], nhead, tgt_kpm, train,
+             nm(f"l{li}.attn"))
+    x = F.layer_norm(x + _dropout(sa, train, nm(f"l{li}.drop1")), x.shape[-1:], p[f"{L}.norm1.weight"],
+                     p[f"{L}.norm1.bias"], LN_EPS)
     ca = mha(x, mem, p[f"{L}.multihead_attn.in_proj_weight"], p[f"{L}.multihead_attn.in_proj_bias"],
-             p[f"{L}.multihead_attn.out_proj.weight"], p[f"{L}.multihead_attn.out_proj.bias"], nhead, None, train)
-    x = F.layer_norm(x + _dropout(ca, train), x.shape[-1:], p[f"{L}.norm2.weight"], p[f"{L}.norm2.bias"], LN_EPS)
-    ff = F.linear(_dropout(F.gelu(F.linear(x, p[f"{L}.linear1.weight"], p[f"{L}.linear1.bias"])), train),
+             p[f"{L}.multihead_attn.out_proj.weight"], p[f"{L}.multihead_attn.out_proj.bias"], nhead, None, train,
+             nm(f"l{li}.xattn"))
+    x = F.layer_norm(x + _dropout(ca, train, nm(f"l{li}.drop2")), x.shape[-1:], p[f"{L}.norm2.weight"],
+                     p[f"{L}.norm2.bias"], LN_EPS)
+    ff = F.linear(_dropout(F.gelu(F.linear(x, p[f"{L}.linear1.weight"], p[f"{L}.linear1.bias"])), train, nm(f"l{li}.ffn")),
                   p[f"{L}.linear2.weight"], p[f"{L}.linear2.bias"])
-    return F.layer_norm(x + _dropout(ff, train), x.shape[-1:], p[f"{L}.norm3.weight"], p[f"{L}.norm3.bias"], LN_EPS)
+    return F.layer_norm(x + _dropout(ff, train, nm(f"l{li}.drop3")), x.shape[-1:], p[f"{L}.norm3.weight"],
+                        p[f"{L}.norm3.bias"], LN_EPS)
 
 
 def enc_txt_transformer(p, pre, data, mask, train=False):
@@ -239,9 +263,10 @@ def enc_txt_transformer(p, pre, data, mask, train=False):
     else:
         # except-branch: permute to (T,B,V,2) then add pe[:B] (B,1,2) -> indexed by *batch* index
         x = x.permute(1, 0, 2, 3) + pe
-    x = _dropout(x, train).contiguous()
+    nm = _tower_call(train, f"{pre}.enc")
+    x = _dropout(x.contiguous(), train, nm("pe")).contiguous()
     x = x.view(T, B, -1)                                        # encoders.py:835: nframes, bs
-    x = transformer_encoder_layer(x, p, f"{pre}.enc.seqTransEncoder.layers.0", 2, ~mask, train)
+    x = transformer_encoder_layer(x, p, f"{pre}.enc.seqTransEncoder.layers.0", 2, ~mask, train, nm)
     z = x.mean(dim=0)                                           # includes padded steps
     return process_output(z, p[f"{pre}.enc.mu_layer.module.weight"], p[f"{pre}.enc.mu_layer.module.bias"],
                           p[f"{pre}.enc.logvar_layer.module.weight"], p[f"{pre}.enc.logvar_layer.module.bias"])
@@ -256,8 +281,9 @@ def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
         mask = torch.ones(B, data_dim[0], dtype=torch.bool)
     T = mask.shape[1]
     tq = torch.zeros(T, B, D) + positional_table(D, T).reshape(T, 1, D)
-    tq = _dropout(tq, train)
-    out = transformer_decoder_layer(tq, z, p, f"{pre}.dec.seqTransDecoder.layers.0", 2, ~mask, train)
+    nm = _tower_call(train, f"{pre}.dec")
+    tq = _dropout(tq, train, nm("pe"))
+    out = transformer_decoder_layer(tq, z, p, f"{pre}.dec.seqTransDecoder.layers.0", 2, ~mask, train, nm)
     out = F.linear(out, p[f"{pre}.dec.finallayer.module.weight"], p[f"{pre}.dec.finallayer.module.bias"])
     return out.permute(1, 0, 2) * mask.unsqueeze(-1).float()    # (B,T,V), zero at padding
 

@@ -18,4 +18,5 @@ done
 run tests/test_parity_e2e.py -k golden
 run tests/test_parity_e2e.py -k full_size -s
 run tests/test_parity_e2e.py -k graph_replay
+run tests/test_parity_e2e.py -k dropout
 grep -E "^===|passed|failed|error|exit=" $LOG | tail -60
