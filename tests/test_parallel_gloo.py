@@ -1,0 +1,100 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The flat-buffer protocol (parameter packing order, one all-reduce, mean
+folded into the optimiser scale) must make 2 ranks with local batches equal 1 rank that averages the two batches'
+gradients -- the oracle does the arithmetic, the package's FlatParams / parallel helpers do the plumbing."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+MODS = [{"enc": "CNN2", "dec": "CNN", "data_dim": [64, 64, 3], "ltype": "bce"},
+        {"enc": "TxtTransformer", "dec": "TxtTransformer", "data_dim": [45, 27, 1], "ltype": "category_ce"}]
+B, T, D = 3, 4, 8
+
+
+class _Holder(torch.nn.Module):
+    """parameters with the reference's key names, packed by FlatParams (CPU tensors here)"""
+
+    def __init__(self, params):
+        super().__init__()
+        self.keys = list(params)
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(v.clone()) for v in params.values()])
+
+    def as_dict(self):
+        return dict(zip(self.keys, self.ps))
+
+
+def _local_grads(rank, flat_holder):
+    from oracle import mmvae_oracle as orc
+    from multimodal_vae_comparison_amd.synthetic import cdsprites_batch
+    batch = cdsprites_batch(B, T, seed=100 + rank)
+    g = torch.Generator().manual_seed(7 + rank)
+    eps = [torch.randn(1, B, D, generator=g) for _ in range(2)]
+    out = orc.mopoe_objective(flat_holder.as_dict(), MODS, batch, eps, D)
+    out["loss"].backward()          # accumulates into the preset flat .grad views
+    return float(out["loss"])
+
+
+def _make(seed=0):
+    from oracle import golden_weights as gw
+    from oracle import mmvae_oracle as orc
+    from multimodal_vae_comparison_amd.flat import FlatParams
+    holder = _Holder(gw.make_params(orc.model_param_shapes(MODS, D), seed))
+    return holder, FlatParams(holder)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from multimodal_vae_comparison_amd import parallel
+    r, _, w = parallel.init_from_env("gloo")
+    holder, flat = _make(seed=rank)                 # deliberately different initial replicas
+    parallel.broadcast_flat_parameters(flat.data)   # -> rank 0's parameters everywhere
+    _local_grads(r, holder)
+    scale = parallel.allreduce_flat_gradients(flat.grad, w)
+    q.put((rank, flat.data.clone(), (flat.grad * scale).clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, data, grad = q.get(timeout=300)
+        res[rank] = (data, grad)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: same parameters (seed 0), average of the two local-batch gradients
+    holder, flat = _make(seed=0)
+    _local_grads(0, holder)
+    g0 = flat.grad.clone()
+    flat.grad.zero_()
+    _local_grads(1, holder)
+    mean = 0.5 * (g0 + flat.grad)
+    for rank in (0, 1):
+        data, grad = res[rank]
+        assert torch.equal(data, flat.data), "broadcast must leave identical replicas"
+        err = float((grad - mean).abs().max() / mean.abs().max())
+        assert err < 1e-6, err
+    assert torch.equal(res[0][1], res[1][1]), "all ranks hold the same reduced gradient"
+
+
+def test_flat_params_layout_is_aligned_and_grouped():
+    holder, flat = _make()
+    assert flat.data.numel() % 4 == 0 and flat.n_params == sum(p.numel() for p in holder.ps)
+    for p in holder.ps:
+        assert p.data_ptr() >= flat.data.data_ptr() and p.grad.data_ptr() >= flat.grad.data_ptr()
+        assert (p.data_ptr() - flat.data.data_ptr()) == (p.grad.data_ptr() - flat.grad.data_ptr())
