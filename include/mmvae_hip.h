@@ -164,7 +164,9 @@ int mmvae_head_softmax_bwd(const float* h, float* dh, int B, int D, mmvae_stream
  *   mu[e], lv[e] : (B,D) each with row stride ld_in (2D when they are the halves of a packed head output;
  *                  dmu/dlv use the same stride); lv is the encoder's softmax output, used as log-variance
  *                  inside PoE.  eps, z, dz are contiguous (B,D).
- *   with_prior   : add the N(0,1) expert (mu 0, logvar 0).
+ *   with_prior   : 0 = product of the experts only; 1 = add the N(0,1) expert (mu 0, logvar 0);
+ *                  2 = no product (E must be 1): the "joint" is expert 0 itself with sigma = its lv -- the
+ *                  per-modality posteriors of MoE (models/mmvae_models.py:96-100).
  *   n_z draws    : z[i] = mu_J + var_J * eps[i]   (eps[i], z[i] : (B,D))
  *   kl (n_kl,B)  : row j < E: sum_d KL(N(mu_j, sigma=lv_j) || p) if kl_mask bit j set;
  *                  row E    : sum_d KL(N(mu_J, sigma=var_J) || p) if kl_mask bit E set; p = N(0, softmax(theta)*D)
@@ -193,6 +195,13 @@ int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, co
                              float* ws, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
                              int accumulate, mmvae_stream_t stream);
 size_t mmvae_poe_ws_floats(int B, int D);
+
+/* MoE importance weights, models/mmvae_models.py:56-62:  lw[b] = sum_d [log N(z; mu_r, s_r) - log N(z; mu_o, s_o)]
+ * with z and the source posterior detached; packed_* = (B,2D) [mu | sigma].  bwd: dpacked_r (B,2D) = g[b] * d lw. */
+int mmvae_normal_logratio_fwd(const float* packed_r, const float* packed_o, const float* z, float* lw, int B, int D,
+                              mmvae_stream_t stream);
+int mmvae_normal_logratio_bwd(const float* packed_r, const float* z, const float* g, float* dpacked_r, int B, int D,
+                              mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Reconstruction losses (per-sample sums), ReconLoss.* in models/objectives.py
@@ -226,6 +235,17 @@ int mmvae_lincomb_rows_fwd(const float* V, const float* W_host, float* out, int 
                            mmvae_stream_t stream);
 int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, int n_rows, int B, int n_out,
                            mmvae_stream_t stream);
+
+/* MoE ELBO (models/mmvae_models.py:61-77): wc = exp(lw) * r;  loss = (sum_n W_n rowsum_n + n_nz beta sum kld) / M
+ * where n_nz counts the rows whose weighted sum is not exactly 0 (the reference's `lp.sum() != 0` filter and the
+ * broadcast in BaseObjective.elbo).  out[0] = loss, out[1] = n_nz (kept for the backward). */
+int mmvae_expmul_fwd(const float* lw, const float* r, float* out, int n, mmvae_stream_t stream);
+int mmvae_expmul_bwd(const float* lw, const float* r, const float* g, float* dlw, float* dr, int n,
+                     mmvae_stream_t stream);
+int mmvae_moe_elbo_fwd(const float* rows, const float* W_host, const float* kld, float* out, int n_rows, int M, int B,
+                       float beta, mmvae_stream_t stream);
+int mmvae_moe_elbo_bwd(const float* g, const float* out, const float* W_host, float* drows, float* dkld, int n_rows,
+                       int M, int B, float beta, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Text towers (Enc_TxtTransformer / Dec_TxtTransformer, models/encoders.py:790-837, decoders.py:668-723)

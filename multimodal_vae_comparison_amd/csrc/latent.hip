@@ -110,8 +110,12 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
         S += mu * T;
         if (kl_mask & (1u << e)) klacc[e] += kl_elem(mu, lv, sp[s]);
       }
-      if (with_prior) P += 1.0f / (1.0f + 1e-8f);
-      const float muJ = S / P, varJ = 1.0f / P;
+      if (with_prior == 1) P += 1.0f / (1.0f + 1e-8f);
+      float muJ = S / P, varJ = 1.0f / P;
+      if (with_prior == 2) {   // no product: the "joint" is expert 0 itself, sigma = its lv (MoE posteriors)
+        muJ = a.mu[0][oi];
+        varJ = a.lv[0][oi];
+      }
       joint[o] = muJ;
       joint[(size_t)B * D + o] = varJ;
       if (kl_mask & (1u << E)) klacc[E] += kl_elem(muJ, varJ, sp[s]);
@@ -172,8 +176,12 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
         P += T[e];
         S += mu[e] * T[e];
       }
-      if (with_prior) P += 1.0f / (1.0f + 1e-8f);
-      const float muJ = S / P, varJ = 1.0f / P;
+      if (with_prior == 1) P += 1.0f / (1.0f + 1e-8f);
+      float muJ = S / P, varJ = 1.0f / P;
+      if (with_prior == 2) {
+        muJ = mu[0];
+        varJ = lv[0];
+      }
       float Gmu = 0.f, Gvar = 0.f;
 #pragma unroll
       for (int i = 0; i < MMVAE_MAX_EXPERTS; ++i) {
@@ -194,6 +202,10 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
         float dmu = Gmu * T[e] * varJ;
         float dT = Gmu * (mu[e] - muJ) * varJ - Gvar * varJ * varJ;
         float dlv = dT * (-expf(lv[e]) * T[e] * T[e]);
+        if (with_prior == 2) {   // direct: z = mu + lv * eps
+          dmu = Gmu;
+          dlv = Gvar;
+        }
         if (gk[e] != 0.f) {
           dmu += gk[e] * mu[e] * isp2;
           dlv += gk[e] * (lv[e] * isp2 - 1.0f / lv[e]);
@@ -270,6 +282,7 @@ extern "C" int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float
                                         mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && joint && B > 0 && D > 0 && E > 0 && ld_in >= D);
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
+  if (with_prior == 2 && E != 1) return MMVAE_ERR_ARG;
   if (kl_mask && !kl) return MMVAE_ERR_ARG;
   hipLaunchKernelGGL(poe_fwd_kernel, dim3(poe_blocks(B)), dim3(256), 0, (hipStream_t)stream, *a, theta, joint, kl, E,
                      with_prior, n_z, kl_mask, B, D, ld_in);
@@ -287,5 +300,56 @@ extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float
   if (dtheta)
     hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
                        accumulate);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MoE importance weights (models/mmvae_models.py:56-62):
+//   lw[b] = sum_d [ log N(z; mu_r, s_r) - log N(z; mu_o, s_o) ],  z and (mu_o, s_o) detached.
+// packed_* = (B, 2D) [mu | sigma] head outputs.  One wave per sample.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normal_logratio_fwd_kernel(const float* __restrict__ pr,
+                                                                  const float* __restrict__ po,
+                                                                  const float* __restrict__ z, float* __restrict__ lw,
+                                                                  int B, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float a = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float zz = z[(size_t)b * D + d];
+    const float mr = pr[(size_t)b * 2 * D + d], sr = pr[(size_t)b * 2 * D + D + d];
+    const float mo = po[(size_t)b * 2 * D + d], so = po[(size_t)b * 2 * D + D + d];
+    const float tr = (zz - mr) / sr, to = (zz - mo) / so;
+    a += (-0.5f * tr * tr - logf(sr)) - (-0.5f * to * to - logf(so));
+  }
+  a = wave_sum(a);
+  if (lane == 0) lw[b] = a;
+}
+// d lw / d mu_r = (z - mu_r) / s_r^2 ; d lw / d s_r = (z - mu_r)^2 / s_r^3 - 1 / s_r
+__global__ __launch_bounds__(256) void normal_logratio_bwd_kernel(const float* __restrict__ pr,
+                                                                  const float* __restrict__ z,
+                                                                  const float* __restrict__ g, float* __restrict__ dpr,
+                                                                  int B, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  const float zz = z[i], mr = pr[(size_t)b * 2 * D + d], sr = pr[(size_t)b * 2 * D + D + d];
+  const float t = (zz - mr) / sr, gb = g[b];
+  dpr[(size_t)b * 2 * D + d] = gb * t / sr;
+  dpr[(size_t)b * 2 * D + D + d] = gb * (t * t - 1.0f) / sr;
+}
+extern "C" int mmvae_normal_logratio_fwd(const float* packed_r, const float* packed_o, const float* z, float* lw,
+                                         int B, int D, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(packed_r && packed_o && z && lw && B > 0 && D > 0);
+  hipLaunchKernelGGL(normal_logratio_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, packed_r,
+                     packed_o, z, lw, B, D);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_normal_logratio_bwd(const float* packed_r, const float* z, const float* g, float* dpacked_r,
+                                         int B, int D, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(packed_r && z && g && dpacked_r && B > 0 && D > 0);
+  hipLaunchKernelGGL(normal_logratio_bwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     packed_r, z, g, dpacked_r, B, D);
   return mmvae_launch_status();
 }

@@ -246,3 +246,87 @@ extern "C" int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, fl
                      dV, n_rows, B, n_out);
   return mmvae_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// MoE ELBO assembly (models/mmvae_models.py:61-77 + BaseObjective.elbo objectives.py:54-67)
+//   wc[b] = exp(lw[b]) * r[b]                                  (importance-weighted cross term)
+//   loss  = ( sum_n w_n rowsum_n + n_nz * beta * sum kld ) / M,   n_nz = #rows with w_n rowsum_n != 0:
+//   the reference drops rows whose sum is exactly 0 (`lp.sum() != 0`, a host sync there) and its broadcast
+//   subtracts beta*kld.sum() once per surviving row -- reproduced on the device, no sync.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expmul_kernel(const float* __restrict__ lw, const float* __restrict__ r,
+                                                     const float* __restrict__ g, float* __restrict__ o0,
+                                                     float* __restrict__ o1, int n, int bwd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float e = expf(lw[i]);
+  if (!bwd) o0[i] = e * r[i];
+  else {
+    o0[i] = g[i] * e * r[i];  // d/dlw
+    o1[i] = g[i] * e;         // d/dr
+  }
+}
+extern "C" int mmvae_expmul_fwd(const float* lw, const float* r, float* out, int n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(lw && r && out && n > 0);
+  hipLaunchKernelGGL(expmul_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, lw, r, nullptr, out,
+                     nullptr, n, 0);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_expmul_bwd(const float* lw, const float* r, const float* g, float* dlw, float* dr, int n,
+                                mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(lw && r && g && dlw && dr && n > 0);
+  hipLaunchKernelGGL(expmul_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, lw, r, g, dlw, dr, n, 1);
+  return mmvae_launch_status();
+}
+__global__ __launch_bounds__(256) void moe_elbo_fwd_kernel(const float* __restrict__ rows, lincomb_w W,
+                                                           const float* __restrict__ kld, float* __restrict__ out,
+                                                           int n_rows, int M, int B, float beta) {
+  __shared__ float red[4];
+  __shared__ float acc[2];
+  if (threadIdx.x == 0) acc[0] = acc[1] = 0.f;
+  float total = 0.f, nnz = 0.f;
+  for (int n = 0; n < n_rows; ++n) {
+    float a = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) a += rows[(size_t)n * B + b];
+    a = block_sum_256(a, red) * W.w[n];
+    total += a;
+    nnz += (a != 0.f) ? 1.f : 0.f;
+  }
+  float k = 0.f;
+  for (int i = threadIdx.x; i < M * B; i += 256) k += kld[i];
+  k = block_sum_256(k, red);
+  if (threadIdx.x == 0) {
+    out[0] = (total + nnz * beta * k) / (float)M;
+    out[1] = nnz;
+  }
+}
+__global__ __launch_bounds__(256) void moe_elbo_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                           lincomb_w W, float* __restrict__ drows,
+                                                           float* __restrict__ dkld, int n_rows, int M, int B,
+                                                           float beta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float gg = g[0] / (float)M;
+  if (i < n_rows * B) drows[i] = gg * W.w[i / B];
+  if (i < M * B) dkld[i] = gg * out[1] * beta;
+}
+extern "C" int mmvae_moe_elbo_fwd(const float* rows, const float* W_host, const float* kld, float* out, int n_rows,
+                                  int M, int B, float beta, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(rows && W_host && kld && out && n_rows > 0 && M > 0 && B > 0);
+  lincomb_w w;
+  int rc = pack_w(W_host, n_rows, 1, &w);
+  if (rc) return rc;
+  hipLaunchKernelGGL(moe_elbo_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, w, kld, out, n_rows, M, B,
+                     beta);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_moe_elbo_bwd(const float* g, const float* out, const float* W_host, float* drows, float* dkld,
+                                  int n_rows, int M, int B, float beta, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(g && out && W_host && drows && dkld && n_rows > 0 && M > 0 && B > 0);
+  lincomb_w w;
+  int rc = pack_w(W_host, n_rows, 1, &w);
+  if (rc) return rc;
+  const int n = (n_rows > M ? n_rows : M) * B;
+  hipLaunchKernelGGL(moe_elbo_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, out, w, drows,
+                     dkld, n_rows, M, B, beta);
+  return mmvae_launch_status();
+}

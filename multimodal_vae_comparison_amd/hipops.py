@@ -96,6 +96,12 @@ SIGNATURES = {
     "mmvae_reduce_rows": (c_i, [c_p, c_p, c_i, c_l, c_l, c_i, c_p]),
     "mmvae_fill": (c_i, [c_p, c_l, c_f, c_p]),
     "mmvae_reduce_segments": (c_i, [c_p, c_p]),
+    "mmvae_normal_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
+    "mmvae_normal_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
+    "mmvae_expmul_fwd": (c_i, [c_p] * 3 + [c_i, c_p]),
+    "mmvae_expmul_bwd": (c_i, [c_p] * 5 + [c_i, c_p]),
+    "mmvae_moe_elbo_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "mmvae_moe_elbo_bwd": (c_i, [c_p, c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),
     "mmvae_dropout_mask": (c_i, [c_dp, c_p, c_l, c_p]),
     "mmvae_dropout_act_fwd": (c_i, [c_p, c_p, c_l, c_i, c_dp, c_p]),

@@ -208,11 +208,78 @@ class POE(TorchMMVAE):
 
 
 class MOE(TorchMMVAE):
-    """MMVAE, mixture of experts (mmvae_models.py:10-131) -- SURVEY 8(a) a18, next after the north-star path."""
+    """MMVAE, mixture of experts (mmvae_models.py:10-131), objective "elbo" with K = 1 (`iwae`
+    crashes in the reference and `dreg` / K > 1 fail with the text decoder).
+
+    q_m = Normal(mu_m, sigma = lv_m), one z per modality; every modality is decoded from its own z and from the z
+    of the LAST other modality (the reference's dict overwrite, :112-116); KL against the per-VAE fixed N(0,1)
+    prior; cross terms weighted by exp(log q_r(z_o) - log q_o(z_o).detach()) with z_o detached; rows whose weighted
+    sum is exactly 0 are dropped and beta*kld.sum() is subtracted once per surviving row (:73, objectives.py:67);
+    loss / M."""
 
     def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
         super().__init__(vaes, n_latents, **obj_config)
-        raise NotImplementedError("moe: not yet on the MI355X hot path (mopoe, poe are)")
+        self.model_config = model_config
+        self.modelName = "moe"
+        if self.obj_fn.obj_name != "elbo" or self.K != 1:
+            raise NotImplementedError("moe: only obj 'elbo' with K = 1 is defined on this path "
+                                      "(reference: iwae crashes, dreg/K>1 fail with the text decoder)")
+        self.register_buffer("_theta0", torch.zeros(1, n_latents), persistent=False)   # softmax(0)*D = 1: N(0,1)
+
+    @property
+    def pz_params(self):
+        return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
+
+    def objective(self, data):
+        """mmvae_models.py:32-78"""
+        self._begin_step()
+        names = list(self.vaes.keys())
+        M = len(names)
+        dev = next(v["data"] for v in data.values() if v["data"] is not None).device
+        packed = [packed_head(*self.vaes[n].enc(data[n])) for n in names]
+        B, D = packed[0].shape[0], self.n_latents
+        zs, kls = [], []
+        for i in range(M):
+            _, kl, z = ops.poe_reparam_kl(self._theta0, [packed[i]], [self._draw(B, D, dev)], 2, 0b10)
+            zs.append(z[0])
+            kls.append(kl[1])
+        rows, W = [], []
+        for r, n in enumerate(names):
+            vae = self.vaes[n]
+            own, _ = vae.dec({"latents": zs[r].unsqueeze(0), "masks": data[n]["masks"]})
+            o = [s for s in range(M) if s != r][-1]
+            cross, _ = vae.dec({"latents": zs[o].unsqueeze(0), "masks": data[n]["masks"]})
+            lw = ops.normal_logratio(packed[r], packed[o].detach(), zs[o].detach())
+            rows += [recon_rowsum(vae.ltype, own, data[n]), ops.expmul(lw, recon_rowsum(vae.ltype, cross, data[n]))]
+            W += [float(vae.llik_scaling)] * 2
+        kld = torch.stack(kls)                                              # (M, B), also the logged "kld"
+        loss = ops.moe_elbo(rows, W, kld, self.obj_fn.beta, M)
+        with torch.no_grad():                                               # logged only: lpx rows, reference sign
+            lpx = [-w * r for w, r in zip(W, rows)]
+        return {"loss": loss, "reconstruction_loss": lpx, "kld": kld}
+
+    def modality_mixing(self, mods):
+        return self.encode(mods)
+
+    def forward(self, x, K=1):
+        """mmvae_models.py:80-117 (all modalities present)"""
+        missing, filled = self.get_missing_modalities(x)
+        assert len(filled) > 0, "at least one modality must be present for forward call"
+        if missing:
+            raise NotImplementedError("moe.forward with missing modalities is not on the MI355X path yet")
+        qz, zs, px, cross = {}, {}, {}, {}
+        for m, vae in self.vaes.items():
+            mu, lv = vae.enc(x[m])
+            qz[m] = normal(mu, lv)
+            eps = torch.stack([self._draw(mu.shape[0], mu.shape[1], mu.device) for _ in range(K)])
+            zs[m] = {"latents": mu + lv * eps, "masks": x[m]["masks"]}
+        for m, vae in self.vaes.items():
+            px[m] = normal(*vae.dec(zs[m]))
+        for src, z in zs.items():
+            for tgt, vae in self.vaes.items():
+                if tgt != src:
+                    cross[tgt] = {src: normal(*vae.dec({"latents": z["latents"], "masks": x[tgt]["masks"]}))}
+        return self.make_output_dict(qz, px, zs, cross_decoder_dist=cross)
 
 
 class DMVAE(TorchMMVAE):

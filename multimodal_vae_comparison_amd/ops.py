@@ -579,6 +579,88 @@ class LincombRows(Function):
         return (None, *outs)
 
 
+class NormalLogRatio(Function):
+    """lw[b] = sum_d [log N(z; mu_r, s_r) - log N(z; mu_o, s_o)]; gradient only into packed_r (MoE, :56-62)"""
+
+    @staticmethod
+    def forward(ctx, packed_r, packed_o, z):
+        packed_r, packed_o, z = H.f32c(packed_r), H.f32c(packed_o), H.f32c(z)
+        B, D2 = packed_r.shape
+        lw = torch.empty(B, device=z.device)
+        _call("mmvae_normal_logratio_fwd", H.ptr(packed_r), H.ptr(packed_o), H.ptr(z), H.ptr(lw), B, D2 // 2,
+              H.stream())
+        ctx.save_for_backward(packed_r, z)
+        return lw
+
+    @staticmethod
+    def backward(ctx, g):
+        packed_r, z = ctx.saved_tensors
+        B, D2 = packed_r.shape
+        d = torch.empty_like(packed_r)
+        _call("mmvae_normal_logratio_bwd", H.ptr(packed_r), H.ptr(z), H.ptr(H.f32c(g)), H.ptr(d), B, D2 // 2,
+              H.stream())
+        return d, None, None
+
+
+class ExpMul(Function):
+    """exp(lw) * r"""
+
+    @staticmethod
+    def forward(ctx, lw, r):
+        lw, r = H.f32c(lw), H.f32c(r)
+        out = torch.empty_like(r)
+        _call("mmvae_expmul_fwd", H.ptr(lw), H.ptr(r), H.ptr(out), r.numel(), H.stream())
+        ctx.save_for_backward(lw, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lw, r = ctx.saved_tensors
+        dlw, dr = torch.empty_like(lw), torch.empty_like(r)
+        _call("mmvae_expmul_bwd", H.ptr(lw), H.ptr(r), H.ptr(H.f32c(g)), H.ptr(dlw), H.ptr(dr), r.numel(), H.stream())
+        return dlw, dr
+
+
+class MoeElbo(Function):
+    """loss = (sum_n W_n sum_b rows_n[b] + n_nz * beta * sum kld) / M  (see mmvae_moe_elbo_fwd)"""
+
+    @staticmethod
+    def forward(ctx, kld, W, beta, M, *rows):
+        rows = [H.f32c(t) for t in rows]
+        B, n = rows[0].shape[0], len(rows)
+        V = torch.empty(n, B, device=rows[0].device)
+        torch.stack(rows, out=V)
+        kld = H.f32c(kld)
+        flat = (H.c_f * n)(*[float(x) for x in W])
+        out = torch.empty(2, device=V.device)
+        _call("mmvae_moe_elbo_fwd", H.ptr(V), flat, H.ptr(kld), H.ptr(out), n, M, B, float(beta), H.stream())
+        ctx.save_for_backward(out)
+        ctx.cfg = (flat, n, M, B, float(beta), tuple(kld.shape))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        flat, n, M, B, beta, kshape = ctx.cfg
+        drows = torch.empty(n, B, device=out.device)
+        dkld = torch.empty(kshape, device=out.device)
+        _call("mmvae_moe_elbo_bwd", H.ptr(H.f32c(g).reshape(1)), H.ptr(out), flat, H.ptr(drows), H.ptr(dkld), n, M, B,
+              beta, H.stream())
+        return (dkld, None, None, None, *[drows[i] for i in range(n)])
+
+
+def normal_logratio(packed_r, packed_o, z):
+    return NormalLogRatio.apply(packed_r, packed_o, z)
+
+
+def expmul(lw, r):
+    return ExpMul.apply(lw, r)
+
+
+def moe_elbo(rows, W, kld, beta, M):
+    return MoeElbo.apply(kld, W, beta, M, *rows)
+
+
 def bce_rowsum(x_hat, target):
     return BceRowsum.apply(x_hat, target)
 

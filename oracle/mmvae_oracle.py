@@ -474,7 +474,47 @@ def poe_objective(p, mods, batch, eps, n_latents, beta=1.0, order=None, train=Fa
             "kld": torch.stack(klds).mean(0).sum(), "_inter": inter}
 
 
-OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective}
+def normal_log_prob(z, mu, sigma):
+    """torch.distributions.Normal.log_prob"""
+    return -((z - mu) ** 2) / (2 * sigma ** 2) - sigma.log() - math.log(math.sqrt(2 * math.pi))
+
+
+def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+    """MOE.forward + objective (obj "elbo", K = 1), models/mmvae_models.py:32-117.
+
+    q_m = Normal(mu_m, lv_m as sigma), z_m = rsample; own decode; cross decode of every target from the LAST other
+    source in iteration order (dict overwrite, :112-116); KL against the per-VAE fixed prior N(0, 1)
+    (`vae._pz_params`, models/vae.py:159-162; :45); importance weight exp(log q_r(z_o) - log q_o(z_o).detach()) on
+    the cross terms with z_o detached (:56-62); rows [own_1, w_1 cross_1, own_2, ...]; loss = elbo / M (:73-77).
+    """
+    M = len(mods)
+    enc = [encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in range(M)]
+    B = enc[0][0].shape[0]
+    zs = [enc[i][0] + enc[i][1] * eps[i].reshape(-1, B, n_latents) for i in range(M)]     # (1,B,D)
+    lam = [float(m.get("llik_scaling", 1.0)) for m in mods]
+    rows, klds = [], []
+    own = [decode(p, mods, i, zs[i], batch[f"mod_{i + 1}"]["masks"], train) for i in range(M)]
+    cross_src = [[s for s in range(M) if s != t][-1] for t in range(M)]
+    cross = [decode(p, mods, t, zs[cross_src[t]], batch[f"mod_{t + 1}"]["masks"], train) for t in range(M)]
+    for r in range(M):
+        mu, sig = enc[r]
+        klds.append(kl_normal(mu, sig, 0.0, torch.ones(1, n_latents)).sum(-1))
+        lpx_own = (-recon_loss(mods[r]["ltype"], own[r], batch[f"mod_{r + 1}"]) * lam[r]).sum(-1)
+        lpx_cross = (-recon_loss(mods[r]["ltype"], cross[r], batch[f"mod_{r + 1}"]) * lam[r]).sum(-1)
+        o = cross_src[r]
+        z_o = zs[o].detach()
+        lwt = (normal_log_prob(z_o, mu, sig) - normal_log_prob(z_o, enc[o][0], enc[o][1]).detach()).sum(-1).reshape(-1)
+        rows.append(lpx_own)
+        rows.append(lwt.exp() * lpx_cross)
+    # `lp.sum() != 0` filter (:73): rows whose importance weight underflowed to exactly 0 are DROPPED, which also
+    # changes how many times beta * kld.sum() is subtracted by the broadcast in BaseObjective.elbo
+    lpx = torch.stack([lp for lp in rows if lp.sum() != 0])
+    kld = torch.stack(klds)
+    loss = -(lpx.sum(-1) - beta * kld.sum()).sum() / M
+    return {"loss": loss, "kld": kld, "reconstruction_loss": lpx, "_rows": torch.stack(rows), "_z": zs, "_enc": enc}
+
+
+OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective, "moe": moe_objective}
 
 
 # ----------------------------------------------------------------------------------------------

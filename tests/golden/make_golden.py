@@ -44,6 +44,8 @@ CASES = [
     ("mopoe_b7_t9_d32_trainp0", "mopoe", 7, 9, 32, [9, 4, 7, 1, 3, 9, 5], "train_p0", 1.0),
     ("poe_b4_t5_d8", "poe", 4, 5, 8, [5, 2, 3, 4], "eval", 1.0),
     ("poe_b4_t4_d16_BeqT", "poe", 4, 4, 16, [4, 1, 3, 2], "eval", 0.5),
+    ("moe_b5_t6_d8", "moe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.0),
+    ("moe_b6_t6_d16_BeqT", "moe", 6, 6, 16, [6, 5, 1, 3, 2, 4], "eval", 2.0),
 ]
 
 
@@ -111,6 +113,10 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     out["kld"] = res["kld"].detach().numpy()
     for i, r in enumerate(res["reconstruction_loss"]):
         out[f"rec_{i}"] = r.detach().numpy()
+    if mixing == "moe":      # MoE leaves the trainable model prior untouched: the reference has no gradient for it
+        for k, q in model.named_parameters():
+            if q.requires_grad and q.grad is None:
+                q.grad = torch.zeros_like(q)
 
     # intermediates straight from the reference's own methods (deterministic in this mode)
     with torch.no_grad():
@@ -146,11 +152,13 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: loss={float(res['loss']):.6f} kld={float(res['kld']):.6f} order={order} "
+    print(f"{name}: loss={float(res['loss']):.6f} kld={float(res['kld'].sum()):.6f} order={order} "
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0 (PoE subset order, utils.py:98)"
+    only = sys.argv[1:]
     for c in CASES:
-        run_case(*c)
+        if not only or any(o in c[0] for o in only):
+            run_case(*c)

@@ -37,7 +37,7 @@ def test_objective_matches_reference(name):
     meta, g = load_golden(name)
     p, out = _run(meta, g)
     _close(out["loss"].item(), g["loss"], 2e-5, "loss")
-    _close(out["kld"].item(), g["kld"], 2e-5, "kld")
+    _close(out["kld"].detach().numpy(), g["kld"], 2e-5, "kld")
     for i, r in enumerate(out["reconstruction_loss"]):
         _close(r.detach().numpy(), g[f"rec_{i}"], 2e-5, f"rec_{i}")
     if meta["mixing"] == "mopoe":
@@ -61,7 +61,9 @@ def test_gradients_and_adam_match_reference(name):
     p, out = _run(meta, g)
     out["loss"].backward()
     for k, t in p.items():
-        assert t.grad is not None, k
+        if t.grad is None:      # MoE never touches the trainable model prior (the fixture stores zeros for it)
+            assert meta["mixing"] == "moe" and k == "_pz_params.1", k
+            t.grad = torch.zeros_like(t)
         _close(gw.summarize(t.grad), g[f"g/{k}"], 1e-4, f"grad {k}", floor=0.02)
     state = {k: (torch.zeros_like(t), torch.zeros_like(t), torch.zeros_like(t)) for k, t in p.items()}
     orc.adam_amsgrad_step(p, {k: t.grad for k, t in p.items()}, state, meta["lr"], 1)
