@@ -143,6 +143,11 @@ int mmvae_linear_bwd_data(const float* dy, const float* w, const float* aux, flo
 int mmvae_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, float* ws, int M, int N, int K,
                             long ldx, int x_act, int accumulate, mmvae_stream_t stream);
 size_t mmvae_linear_bwd_weight_ws_floats(int M, int N, int K);
+/* both of the above in one grouped launch: dx = ep(dy W), dW (+)= dy^T act(x), db (+)= colsum(dy) */
+int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const float* aux, float* dx, float* dw,
+                     float* db, float* ws, int M, int N, int K, long ldx, int x_act, int ep_mode, int accumulate,
+                     mmvae_stream_t stream);
+size_t mmvae_linear_bwd_ws_floats(int M, int N, int K);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder heads: VaeComponent.process_output, models/encoders.py:49-54

@@ -31,7 +31,8 @@ struct GemmArgs {
 };
 
 template <int KSPLIT>
-__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, const int nz,
+                                          float* __restrict__ As, float* __restrict__ Bs) {
   constexpr int NT = KSPLIT == 8 ? 512 : 256;  // threads
   constexpr int BM = KSPLIT == 1 ? 128 : 32;
   constexpr int BN = 32;
@@ -40,13 +41,10 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs 
   constexpr int BP = BN + 1;
   constexpr int A_PER_T = BM * BK / NT;  // 16
   constexpr int B_PER_T = BK * BN / NT;  // 4 or 16
-  __shared__ float As[BK * AP];
-  __shared__ float Bs[BK * BP];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.kper;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * g.kper;
   const int kend = min(g.K, kbeg + g.kper);
   const bool a_kmajor = (g.sak == 1);
   const bool b_kmajor = (g.sbk == 1 && g.sbn != 1);
@@ -128,10 +126,10 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs 
     __syncthreads();
   }
 
-  const bool partial = gridDim.z > 1;
-  float* Cout = partial ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+  const bool partial = nz > 1;
+  float* Cout = partial ? g.ws + (size_t)bz * g.M * g.N : g.C;
   const long ldc = partial ? g.N : g.ldc;
-  float* rs_out = partial ? g.ws + (size_t)gridDim.z * g.M * g.N + (size_t)blockIdx.z * g.M : g.a_rowsum;
+  float* rs_out = partial ? g.ws + (size_t)nz * g.M * g.N + (size_t)bz * g.M : g.a_rowsum;
   const int ep = partial ? MMVAE_EP_NONE : g.ep;
   const bool acc_out = !partial && g.accumulate;
 
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs 
   if (KSPLIT == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) emit(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, acc[r]);
-    if (g.a_rowsum && blockIdx.x == 0 && lh == 0) {
+    if (g.a_rowsum && bx == 0 && lh == 0) {
       const int row = m0 + wave * 32 + li;
       if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + asum : asum;
     }
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs 
         emit(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, v);
       }
     }
-    if (g.a_rowsum && blockIdx.x == 0 && wave == 0 && lh == 0) {
+    if (g.a_rowsum && bx == 0 && wave == 0 && lh == 0) {
       const int row = m0 + li;
       float v = 0.f;
 #pragma unroll
@@ -182,6 +180,35 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs 
       if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + v : v;
     }
   }
+}
+
+template <int KSPLIT>
+__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs g) {
+  constexpr int BM = KSPLIT == 1 ? 128 : 32;
+  constexpr int BK = KSPLIT == 1 ? 32 : 32 * KSPLIT;
+  __shared__ float As[BK * (BM + 1)];
+  __shared__ float Bs[BK * 33];
+  gemm_body<KSPLIT>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, As, Bs);
+}
+
+// Several independent GEMMs in ONE launch (same tiling): workgroup id -> (problem, tile).  Used for the data- and
+// weight-gradient GEMMs of a Linear layer, which only share their inputs: each alone fills a fraction of the chip.
+#define GEMM_GROUP_MAX 4
+struct GemmGroup {
+  GemmArgs g[GEMM_GROUP_MAX];
+  int blk0[GEMM_GROUP_MAX + 1];
+  int nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX], nz[GEMM_GROUP_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(GemmGroup grp) {
+  __shared__ float As[128 * 33];
+  __shared__ float Bs[128 * 33];
+  int p = 0;
+  while (p + 1 < grp.n && (int)blockIdx.x >= grp.blk0[p + 1]) ++p;
+  const int local = blockIdx.x - grp.blk0[p];
+  const int bx = local % grp.nx[p], t = local / grp.nx[p];
+  const int by = t % grp.ny[p], bz = t / grp.ny[p];
+  gemm_body<4>(grp.g[p], bx, by, bz, grp.nz[p], As, Bs);
 }
 
 extern "C" size_t mmvae_gemm_ws_floats(int M, int N, int splitk) {
@@ -208,7 +235,7 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   //   otherwise              : 32x32 tile, 4 waves x 128-deep stages                       (KSPLIT 4)
   const long tiles128 = (long)((M + 127) / 128) * ntn, tiles32 = (long)((M + 31) / 32) * ntn;
   int variant = 4;
-  if (tiles128 >= 256 || (K <= 128 && M >= 1024)) variant = 1;
+  if (tiles128 >= 256) variant = 1;   // measured: below that the single-stage 32x32 tiles are faster
   else if (K >= 384 && tiles32 <= 512 && splitk == 1) variant = 8;
   const int bk = variant == 1 ? 32 : 32 * variant;
   int kper = (K + splitk - 1) / splitk;
@@ -262,7 +289,7 @@ extern "C" int mmvae_linear_bwd_weight_splits(int M, int N, int K) {
   // gemm problem: rows N, cols K, reduction M
   const long tiles128 = (long)((N + 127) / 128) * ((K + 31) / 32), tiles32 = (long)((N + 31) / 32) * ((K + 31) / 32);
   int variant = 4;
-  if (tiles128 >= 256 || (M <= 128 && N >= 1024)) variant = 1;
+  if (tiles128 >= 256) variant = 1;
   else if (M >= 384 && tiles32 <= 512 && sk == 1) variant = 8;
   const int bk = variant == 1 ? 32 : 32 * variant;
   int kper = (M + sk - 1) / sk;
@@ -279,4 +306,56 @@ extern "C" int mmvae_linear_bwd_weight(const float* dy, const float* x, float* d
   const int sk = wgrad_splitk(M, N, K);
   return mmvae_gemm_f32(dy, x, nullptr, nullptr, dw, db, ws, N, K, M, 1, N, ldx, 1, K, MMVAE_ACT_NONE, x_act,
                         MMVAE_EP_NONE, accumulate, sk, stream);
+}
+
+// Fused nn.Linear backward: dx = ep(dy W) and dW (+)= dy^T act(x), db (+)= colsum(dy) in ONE grouped launch.
+// Falls back to two launches when either problem wants a different tiling.
+extern "C" size_t mmvae_linear_bwd_ws_floats(int M, int N, int K) { return mmvae_linear_bwd_weight_ws_floats(M, N, K); }
+extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const float* aux, float* dx,
+                                float* dw, float* db, float* ws, int M, int N, int K, long ldx, int x_act, int ep_mode,
+                                int accumulate, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && w && dx && dw && M > 0 && N > 0 && K > 0);
+  if (ep_reads_aux(ep_mode) && !aux) return MMVAE_ERR_ARG;
+  // problem 0 (data):   C[M,K] = dy[M,N] W[N,K]            reduction N
+  // problem 1 (weight): C[N,K] = dy^T[N,M] act(x)[M,K]     reduction M, split over workgroups
+  const long t128_d = (long)((M + 127) / 128) * ((K + 31) / 32), t32_d = (long)((M + 31) / 32) * ((K + 31) / 32);
+  const bool d_ok = t128_d < 256 && !(N >= 384 && t32_d <= 512);
+  const int nz = mmvae_linear_bwd_weight_splits(M, N, K);
+  const long t128_w = (long)((N + 127) / 128) * ((K + 31) / 32), t32_w = (long)((N + 31) / 32) * ((K + 31) / 32);
+  const int sk = wgrad_splitk(M, N, K);
+  const bool w_ok = t128_w < 256 && !(M >= 384 && t32_w <= 512 && sk == 1);
+  if (!d_ok || !w_ok) {
+    int rc = mmvae_linear_bwd_weight(dy, x, dw, db, ws, M, N, K, ldx, x_act, accumulate, stream);
+    if (rc) return rc;
+    return mmvae_linear_bwd_data(dy, w, aux, dx, M, N, K, ep_mode, 0, stream);
+  }
+  if (nz > 1 && !ws) return MMVAE_ERR_ARG;
+  GemmGroup grp;
+  GemmArgs& gd = grp.g[0];
+  gd.A = dy; gd.B = w; gd.bias = nullptr; gd.aux = const_cast<float*>(aux); gd.C = dx; gd.a_rowsum = nullptr; gd.ws = nullptr;
+  gd.M = M; gd.N = K; gd.K = N; gd.sam = N; gd.sak = 1; gd.sbk = K; gd.sbn = 1; gd.ldc = K;
+  gd.a_act = MMVAE_ACT_NONE; gd.b_act = MMVAE_ACT_NONE; gd.ep = ep_mode; gd.accumulate = 0;
+  gd.kper = (N + 127) / 128 * 128;
+  GemmArgs& gw = grp.g[1];
+  gw.A = dy; gw.B = x; gw.bias = nullptr; gw.aux = nullptr; gw.C = dw; gw.a_rowsum = db; gw.ws = ws;
+  gw.M = N; gw.N = K; gw.K = M; gw.sam = 1; gw.sak = N; gw.sbk = ldx; gw.sbn = 1; gw.ldc = K;
+  gw.a_act = MMVAE_ACT_NONE; gw.b_act = x_act; gw.ep = MMVAE_EP_NONE; gw.accumulate = accumulate ? 1 : 0;
+  int kper = (M + sk - 1) / sk;
+  kper = (kper + 127) / 128 * 128;
+  gw.kper = kper;
+  grp.n = 2;
+  grp.nx[0] = (K + 31) / 32; grp.ny[0] = (M + 31) / 32; grp.nz[0] = 1;
+  grp.nx[1] = (K + 31) / 32; grp.ny[1] = (N + 31) / 32; grp.nz[1] = nz;
+  grp.blk0[0] = 0;
+  grp.blk0[1] = grp.nx[0] * grp.ny[0];
+  grp.blk0[2] = grp.blk0[1] + grp.nx[1] * grp.ny[1] * nz;
+  hipLaunchKernelGGL(gemm_grouped_kernel, dim3(grp.blk0[2]), dim3(256), 0, (hipStream_t)stream, grp);
+  int rc = mmvae_launch_status();
+  if (rc) return rc;
+  if (nz > 1 && accumulate != MMVAE_ACC_DEFER) {
+    rc = mmvae_reduce_rows(ws, dw, nz, (long)N * K, (long)N * K, accumulate, stream);
+    if (rc) return rc;
+    if (db) rc = mmvae_reduce_rows(ws + (size_t)nz * N * K, db, nz, N, N, accumulate, stream);
+  }
+  return rc;
 }

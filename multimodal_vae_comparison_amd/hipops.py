@@ -62,6 +62,8 @@ SIGNATURES = {
     "mmvae_linear_bwd_data": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
     "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_linear_bwd_weight_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_linear_bwd": (c_i, [c_p] * 8 + [c_i] * 3 + [c_l] + [c_i] * 3 + [c_p]),
+    "mmvae_linear_bwd_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_head_softmax_fwd": (c_i, [c_p, c_i, c_i, c_p]),
     "mmvae_head_softmax_bwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "mmvae_poe_reparam_kl_fwd": (c_i, [ctypes.POINTER(PoeFwdArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i, c_i,

@@ -351,30 +351,29 @@ class Linear(Function):
             else:
                 db = ret_b = torch.empty(N, device=x.device)
         nws = H.lib().mmvae_linear_bwd_weight_ws_floats(M, N, K)
-        if _defer(gw, gb if has_b else gw):
-            nz = H.lib().mmvae_linear_bwd_weight_splits(M, N, K)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        ep = _DACT[in_act]
+        aux = H.ptr(x) if ep else None
+        defer = _defer(gw, gb if has_b else gw)
+        nz = H.lib().mmvae_linear_bwd_weight_splits(M, N, K)
+        if defer:
             ws = GradReducer.alloc(nws, x.device) if nz > 1 else None
-            # nz == 1 accumulates straight into the flat gradient: still safe on the side stream, because a
-            # parameter's gradient slice is only touched by its own wgrad launches (same stream, in order) and by
-            # the reduction after the join
-            side = _wgrad_side(x.device, dy, x)
+            acc = H.ACC_DEFER
+        else:
+            ws, acc = H.workspace(nws, x.device), acc_w
+        side = None if need_dx else (_wgrad_side(x.device, dy, x) if defer else None)
+        if need_dx:   # data and weight gradients in ONE grouped launch
+            _call("mmvae_linear_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), aux, H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
+                  M, N, K, K, in_act, ep, acc, H.stream())
+        else:
             with torch.cuda.stream(side):
                 _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K,
-                      in_act, H.ACC_DEFER, H.stream())
-            if nz > 1:
-                GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
-                if db is not None:
-                    GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
-        else:
-            ws = H.workspace(nws, x.device)
-            _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, in_act,
-                  acc_w, H.stream())
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            ep = _DACT[in_act]
-            _call("mmvae_linear_bwd_data", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), M, N, K, ep, 0,
-                  H.stream())
+                      in_act, acc, H.stream())
+        if defer and nz > 1:
+            GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
+            if db is not None:
+                GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
         return dx, ret_w, ret_b, None, None, None
 
 
