@@ -43,7 +43,7 @@ class GradReducer:
         key = device.index if device.index is not None else torch.cuda.current_device()
         st = cls._state.get(key)
         if st is None:
-            st = {"off": 0, "segs": [], "armed": False, "device": device, "keep": [], "used": set()}
+            st = {"off": 0, "segs": [], "armed": False, "device": device, "keep": [], "used": set(), "pending": []}
             cls._state[key] = st
         return key, st
 
@@ -82,7 +82,28 @@ class GradReducer:
         cls._st(device)[1]["used"].add(stream)
 
     @classmethod
+    def queue(cls, device, launch, *keep):
+        """postpone a weight-gradient launch (nothing but the final reduction reads its output) to the next batch
+        point: one fork for many launches instead of one per launch"""
+        st = cls._st(device)[1]
+        st["pending"].append(launch)
+        st["keep"].extend(t for t in keep if t is not None)
+
+    @classmethod
+    def launch_pending(cls, device):
+        st = cls._st(device)[1]
+        if not st["pending"]:
+            return
+        side = StreamPlan.fork("wgrad", device)
+        st["used"].add(side)
+        with torch.cuda.stream(side):
+            for launch in st["pending"]:
+                launch()
+        st["pending"] = []
+
+    @classmethod
     def flush(cls, device):
+        cls.launch_pending(device)
         _, st = cls._st(device)
         cur = torch.cuda.current_stream(device)
         for side in st["used"]:               # join every side stream that carried gradient work
@@ -111,10 +132,18 @@ class StreamPlan:
     Side streams are forked with events from the stream that produced their inputs and joined before the
     deferred reduction (GradReducer.flush) / at the fusion and loss points in the mixers."""
 
-    # Measured on MI355X / ROCm 7.2 (profiles/r01 notes in DESIGN.md): hipGraph replay does not overlap the parallel
-    # branches (1.51 ms/step with the plan vs 1.40 ms without), so the plan is opt-in until the graph executor
-    # schedules branches concurrently.
-    enabled = os.environ.get("MMVAE_STREAMS", "0") != "0"
+    # Measured on MI355X / ROCm 7.2, B=128 (DESIGN.md section 5): parallel graph branches DO overlap, but every
+    # fork/join costs several microseconds, so only coarse forks pay:
+    #   MMVAE_STREAMS=0         1.30 ms/step   single stream
+    #   MMVAE_STREAMS=toweronly 0.99 ms/step   text tower beside image tower (2 forks + 2 joins per step)
+    #   MMVAE_STREAMS=tower     (default) + conv weight gradients queued and launched in two batches on a side stream
+    #   MMVAE_STREAMS=conv      1.20 ms/step   + one fork per conv weight-gradient launch
+    #   MMVAE_STREAMS=1         1.30 ms/step   + one fork per weight-gradient launch
+    _mode = os.environ.get("MMVAE_STREAMS", "tower")
+    enabled = _mode != "0"
+    batch_wgrad = _mode == "tower"                            # queue conv wgrads, launch them in batches
+    wgrad_enabled = _mode in ("conv", "1")                    # fork per wgrad launch
+    wgrad_linear = _mode == "1"
     _streams = {}
 
     @classmethod
@@ -137,7 +166,7 @@ class StreamPlan:
 def _wgrad_side(device, *keep):
     """stream for a weight-gradient launch: the wgrad side stream (forked from the current one) when gradients are
     deferred, else None (= stay on the current stream)"""
-    if not (StreamPlan.enabled and GradReducer.enabled):
+    if not (StreamPlan.enabled and StreamPlan.wgrad_enabled and GradReducer.enabled):
         return None
     side = StreamPlan.fork("wgrad", device)
     GradReducer.note_stream(device, side)
@@ -226,10 +255,15 @@ class Conv2dK4S2(Function):
         nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cout, Cin, Hout)
         if _defer(gw, gb if has_b else gw):
             ws = GradReducer.alloc(nws, x.device)
-            side = _wgrad_side(x.device, dy, x)
-            with torch.cuda.stream(side):
+
+            def launch(dy=dy, x=x, dw=dw, db=db, ws=ws):
                 _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
                       Hout, in_act, H.ACC_DEFER, H.stream())
+            if StreamPlan.enabled and StreamPlan.batch_wgrad:
+                GradReducer.queue(x.device, launch, dy, x)
+            else:
+                with torch.cuda.stream(_wgrad_side(x.device, dy, x)):
+                    launch()
             _conv_segments(ws, dw, db, B, Cout, Cin, Hout, Cout)
         else:
             ws = H.workspace(nws, x.device)
@@ -281,10 +315,15 @@ class ConvT2dK4S2(Function):
         nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin)
         if _defer(gw, gb if has_b else gw):
             ws = GradReducer.alloc(nws, x.device)
-            side = _wgrad_side(x.device, dy, x)
-            with torch.cuda.stream(side):
+
+            def launch(dy=dy, x=x, dw=dw, db=db, ws=ws):
                 _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
                       Hin, in_act, H.ACC_DEFER, H.stream())
+            if StreamPlan.enabled and StreamPlan.batch_wgrad:
+                GradReducer.queue(x.device, launch, dy, x)
+            else:
+                with torch.cuda.stream(_wgrad_side(x.device, dy, x)):
+                    launch()
             _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
         else:
             ws = H.workspace(nws, x.device)
@@ -362,7 +401,7 @@ class Linear(Function):
             acc = H.ACC_DEFER
         else:
             ws, acc = H.workspace(nws, x.device), acc_w
-        side = None if need_dx else (_wgrad_side(x.device, dy, x) if defer else None)
+        side = None if need_dx else (_wgrad_side(x.device, dy, x) if (defer and StreamPlan.wgrad_linear) else None)
         if need_dx:   # data and weight gradients in ONE grouped launch
             _call("mmvae_linear_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), aux, H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
                   M, N, K, K, in_act, ep, acc, H.stream())
@@ -443,6 +482,9 @@ class PoeReparamKL(Function):
     @staticmethod
     def backward(ctx, _dj, dkl, *dzs):
         gtheta, with_prior, n_z, kl_mask, E, B, D = ctx.cfg
+        # batch point: every decoder's backward is done, so the queued decoder weight-gradient kernels can run on
+        # the side stream underneath the encoder backward chains
+        GradReducer.launch_pending(ctx.saved_tensors[0].device)
         theta = ctx.saved_tensors[0]
         packed = ctx.saved_tensors[1:1 + E]
         eps = ctx.saved_tensors[1 + E:]
