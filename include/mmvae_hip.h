@@ -118,6 +118,15 @@ int mmvae_convT2d_k4s2_wgrad(const float* x, const float* dy, float* dw, float* 
 
 size_t mmvae_conv_wgrad_ws_floats(int B, int Csmall, int Clarge, int Hsmall);
 
+/* Whole-layer backward in ONE launch (input-gradient and weight-gradient workgroups side by side):
+ *   conv2d : dx = dgrad(dy, w) * act'(x);  dw (+)= wgrad(dy, act(x));  db (+)= sum dy      x (B,Cin,2Hout,2Hout)
+ *   convT2d: dx = dgrad(dy, w) * act'(x);  dw (+)= wgrad(act(x), dy);  db (+)= sum dy      dy (B,Cout,2Hin,2Hin)
+ * ws as for the *_wgrad entry points; shapes that are not fused fall back to two launches. */
+int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                          int B, int Cin, int Cout, int Hout, int x_act, int accumulate, mmvae_stream_t stream);
+int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                           int B, int Cin, int Cout, int Hin, int x_act, int accumulate, mmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small dense layers: torch.nn.Linear and the projections inside nn.MultiheadAttention /
  * nn.Transformer*Layer  (models/encoders.py:194,43-54,825-826; models/decoders.py:58-60,86-88,705)

@@ -1,0 +1,165 @@
+// Convolution family (4x4 / stride 2 / pad 1) for gfx950: one translation unit so that the three kernel forms can
+// also be combined into fused backward launches.
+//   conv_gather.inc  : "gather" implicit GEMM   (Conv2d forward, ConvTranspose2d input-gradient)
+//   conv_scatter.inc : "scatter" implicit GEMM  (ConvTranspose2d forward, Conv2d input-gradient)
+//   conv_wgrad.inc   : weight / bias gradients
+// The C-ABI entry points of include/mmvae_hip.h are at the bottom.
+#include "conv_common.hpp"
+
+#include "conv_gather.inc"
+#include "conv_scatter.inc"
+#include "conv_wgrad.inc"
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward of one layer: the input-gradient kernel and the weight-gradient kernel only share their inputs
+// and each alone fills a fraction of the chip at batch 128 (256-512 resp. 256 workgroups of one wave per SIMD), so
+// both run in ONE launch: workgroups [0, n_w) execute the weight-gradient body, the rest the input-gradient body.
+// ------------------------------------------------------------------------------------------------
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int TM>
+__global__ __launch_bounds__(256) void conv2d_bwd_fused_kernel(ConvScatterArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax(ScatterCfg::SMEM, WgradCfg::SMEM)];
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<32>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  else conv_scatter_body<TM>(ad, blockIdx.x - n_w, smem);
+}
+template <int TM>
+__global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax(GatherCfg<32>::SMEM, WgradCfg::SMEM)];
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<32>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  else conv_gather_body<32, TM>(ad, blockIdx.x - n_w, smem);
+}
+__global__ __launch_bounds__(256) void convT3_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax(GatherCfg<3>::SMEM, WgradCfg::SMEM)];
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<3>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  else conv_gather_body<3, 4>(ad, blockIdx.x - n_w, smem);
+}
+
+static inline int dact_ep(int act) {
+  return act == MMVAE_ACT_SILU ? MMVAE_EP_MUL_SILU_GRAD : act == MMVAE_ACT_RELU ? MMVAE_EP_MUL_RELU_MASK
+                                                        : act == MMVAE_ACT_GELU ? MMVAE_EP_MUL_GELU_GRAD : MMVAE_EP_NONE;
+}
+static int conv_bwd_reduce(float* ws, float* dw, float* db, int B, int Q, int Hs, int nbias, int accumulate,
+                           mmvae_stream_t stream) {
+  if (accumulate == MMVAE_ACC_DEFER) return MMVAE_OK;
+  int rows, rowlen, bias_col;
+  conv_wgrad_layout(B, Q, Hs, &rows, &rowlen, &bias_col);
+  int rc = mmvae_reduce_rows(ws, dw, rows, bias_col, rowlen, accumulate, stream);
+  if (rc) return rc;
+  if (db) rc = mmvae_reduce_rows(ws + bias_col, db, rows, nbias, rowlen, accumulate, stream);
+  return rc;
+}
+
+// Conv2d backward: dx = (dy (*) w) * act'(x), dw (+)= dy (x) act(x), db (+)= sum dy.  x (B,Cin,2Hout,2Hout).
+extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                     float* ws, int B, int Cin, int Cout, int Hout, int x_act, int accumulate,
+                                     mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && w && dx && dw && ws && B > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin != 32 || Cout != 32 || Hout < 4 || Hout > 16 || (Hout & (Hout - 1))) {   // not a fused shape: two launches
+    int rc = conv_wgrad_dispatch(dy, x, dw, db, ws, B, Cout, Cin, Hout, MMVAE_ACT_NONE, x_act, db ? 1 : 0, accumulate, st);
+    if (rc) return rc;
+    return conv_scatter_dispatch(dy, w, nullptr, x, dx, B, Cout, Cin, Hout, MMVAE_ACT_NONE, dact_ep(x_act), st);
+  }
+  const int ep = dact_ep(x_act);
+  ConvScatterArgs ad{dy, w, nullptr, x, dx, B, Hout, ilog2i(Hout), MMVAE_ACT_NONE, ep};
+  const int rows_per_tile = Hout >= 32 ? 1 : 32 / Hout;
+  const long tiles = ((long)B * Hout * Hout + 31) / 32;
+  int TM = 4;
+  if (tiles < 512 * 4) TM = 2;
+  if (tiles < 512 * 2) TM = 1;
+  const int n_d = (int)(((long)B * Hout + TM * rows_per_tile - 1) / (TM * rows_per_tile));
+  const int n_macro = wgrad_n_macro(B, Hout), nsplit = wgrad_splits(n_macro, 32);
+  ConvWgradArgs aw{dy, x, ws, B, Hout, ilog2i(Hout), MMVAE_ACT_NONE, x_act, db ? 1 : 0, n_macro};
+  const int n_w = nsplit * 4;
+  if (TM == 4) hipLaunchKernelGGL(conv2d_bwd_fused_kernel<4>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  else if (TM == 2) hipLaunchKernelGGL(conv2d_bwd_fused_kernel<2>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  else hipLaunchKernelGGL(conv2d_bwd_fused_kernel<1>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  int rc = mmvae_launch_status();
+  if (rc) return rc;
+  return conv_bwd_reduce(ws, dw, db, B, Cin, Hout, 32, accumulate, stream);
+}
+
+// ConvTranspose2d backward: dx = (dy (*) w) * act'(x), dw (+)= act(x) (x) dy, db (+)= sum dy.  dy (B,Cout,2Hin,2Hin).
+extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                      float* ws, int B, int Cin, int Cout, int Hin, int x_act, int accumulate,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && w && dx && dw && ws && B > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int ep = dact_ep(x_act);
+  const bool fused = Cin == 32 && (Cout == 32 || Cout == 3) && Hin >= 4 && Hin <= 32 && !(Hin & (Hin - 1)) &&
+                     !(Cout == 3 && Hin != 32) && !(Cout == 32 && Hin > 16);
+  if (!fused) {
+    int rc = conv_wgrad_dispatch(x, dy, dw, db, ws, B, Cin, Cout, Hin, x_act, MMVAE_ACT_NONE, db ? 2 : 0, accumulate, st);
+    if (rc) return rc;
+    return conv_gather_dispatch(dy, w, nullptr, x, dx, B, Cout, Cin, 2 * Hin, MMVAE_ACT_NONE, ep, st);
+  }
+  // input gradient = gather conv over dy (2Hin x 2Hin, Cout channels) -> (Hin x Hin, 32 channels)
+  ConvGatherArgs ad{dy, w, nullptr, x, dx, B, 2 * Hin, Hin, ilog2i(Hin), MMVAE_ACT_NONE, ep};
+  const int rows_per_tile = Hin >= 32 ? 1 : 32 / Hin;
+  const long tiles = ((long)B * Hin * Hin + 31) / 32;
+  const int TM = gather_tm(Cout, tiles);
+  const int n_d = (int)(((long)B * Hin + TM * rows_per_tile - 1) / (TM * rows_per_tile));
+  const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
+  ConvWgradArgs aw{x, dy, ws, B, Hin, ilog2i(Hin), x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro};
+  const int n_w = nsplit * (Cout == 32 ? 4 : 1);
+  if (Cout == 3) hipLaunchKernelGGL(convT3_bwd_fused_kernel, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  else if (TM == 4) hipLaunchKernelGGL(convT_bwd_fused_kernel<4>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  else if (TM == 2) hipLaunchKernelGGL(convT_bwd_fused_kernel<2>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  else hipLaunchKernelGGL(convT_bwd_fused_kernel<1>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  int rc = mmvae_launch_status();
+  if (rc) return rc;
+  return conv_bwd_reduce(ws, dw, db, B, Cout, Hin, Cout, accumulate, stream);
+}
+
+extern "C" int mmvae_conv2d_k4s2_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y,
+                                     int B, int Cin, int Cout, int Hin, int in_act, int ep_mode,
+                                     mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && w && y && B > 0);
+  return conv_gather_dispatch(x, w, bias, aux, y, B, Cin, Cout, Hin, in_act, ep_mode, (hipStream_t)stream);
+}
+extern "C" int mmvae_conv2d_k4s2_dgrad(const float* dy, const float* w, const float* aux, float* dx, int B, int Cin,
+                                       int Cout, int Hout, int ep_mode, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && w && dx && B > 0);
+  // reduce over the conv's output channels, produce its input channels; w is [Cout][Cin] = [red][out]
+  return conv_scatter_dispatch(dy, w, nullptr, aux, dx, B, Cout, Cin, Hout, MMVAE_ACT_NONE, ep_mode,
+                               (hipStream_t)stream);
+}
+extern "C" int mmvae_conv2d_k4s2_wgrad(const float* dy, const float* x, float* dw, float* db, float* ws, int B,
+                                       int Cin, int Cout, int Hout, int x_act, int accumulate,
+                                       mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && dw && B > 0);
+  return conv_wgrad_dispatch(dy, x, dw, db, ws, B, Cout, Cin, Hout, MMVAE_ACT_NONE, x_act, 1, accumulate,
+                             (hipStream_t)stream);
+}
+extern "C" int mmvae_convT2d_k4s2_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y,
+                                      int B, int Cin, int Cout, int Hin, int in_act, int ep_mode,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && w && y && B > 0);
+  return conv_scatter_dispatch(x, w, bias, aux, y, B, Cin, Cout, Hin, in_act, ep_mode, (hipStream_t)stream);
+}
+extern "C" int mmvae_convT2d_k4s2_dgrad(const float* dy, const float* w, const float* aux, float* dx, int B, int Cin,
+                                        int Cout, int Hin, int ep_mode, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && w && dx && B > 0);
+  // dx[c] = sum_o dy[o] (gathered) * w[c][o]: w is [Cin][Cout] = [out][red]
+  return conv_gather_dispatch(dy, w, nullptr, aux, dx, B, Cout, Cin, 2 * Hin, MMVAE_ACT_NONE, ep_mode,
+                              (hipStream_t)stream);
+}
+extern "C" int mmvae_convT2d_k4s2_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B,
+                                        int Cin, int Cout, int Hin, int x_act, int accumulate,
+                                        mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && dy && dw && B > 0);
+  return conv_wgrad_dispatch(x, dy, dw, db, ws, B, Cin, Cout, Hin, x_act, MMVAE_ACT_NONE, 2, accumulate,
+                             (hipStream_t)stream);
+}
+extern "C" size_t mmvae_conv_wgrad_ws_floats(int B, int Csmall, int Clarge, int Hsmall) {
+  (void)Csmall;
+  return conv_wgrad_ws_floats(B, Clarge, Hsmall);
+}
+extern "C" int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen,
+                                       int* bias_col) {
+  (void)Csmall;
+  MMVAE_CHECK_ARG(rows && rowlen && bias_col);
+  conv_wgrad_layout(B, Clarge, Hsmall, rows, rowlen, bias_col);
+  return MMVAE_OK;
+}

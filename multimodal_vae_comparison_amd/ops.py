@@ -135,13 +135,13 @@ class StreamPlan:
     # Measured on MI355X / ROCm 7.2, B=128: parallel graph branches DO overlap, but every
     # fork/join costs several microseconds, so only coarse forks pay:
     #   MMVAE_STREAMS=0         1.30 ms/step   single stream
-    #   MMVAE_STREAMS=toweronly 0.99 ms/step   text tower beside image tower (2 forks + 2 joins per step)
-    #   MMVAE_STREAMS=tower     (default) + conv weight gradients queued and launched in two batches on a side stream
+    #   MMVAE_STREAMS=tower     0.99 ms/step   (default) text tower beside image tower: 2 forks + 2 joins per step
+    #   MMVAE_STREAMS=batch     1.06 ms/step   + conv weight gradients queued, launched in two side-stream batches
     #   MMVAE_STREAMS=conv      1.20 ms/step   + one fork per conv weight-gradient launch
     #   MMVAE_STREAMS=1         1.30 ms/step   + one fork per weight-gradient launch
     _mode = os.environ.get("MMVAE_STREAMS", "tower")
     enabled = _mode != "0"
-    batch_wgrad = _mode == "tower"                            # queue conv wgrads, launch them in batches
+    batch_wgrad = _mode == "batch"                            # queue conv wgrads, launch them in batches
     wgrad_enabled = _mode in ("conv", "1")                    # fork per wgrad launch
     wgrad_linear = _mode == "1"
     _streams = {}
@@ -253,28 +253,25 @@ class Conv2dK4S2(Function):
             else:
                 db = ret_b = torch.empty(Cout, device=x.device)
         nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cout, Cin, Hout)
-        if _defer(gw, gb if has_b else gw):
-            ws = GradReducer.alloc(nws, x.device)
-
+        defer = _defer(gw, gb if has_b else gw)
+        ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
+        acc = H.ACC_DEFER if defer else acc_w
+        dx = None
+        if ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
+            dx = torch.empty_like(x)
+            _call("mmvae_conv2d_k4s2_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
+                  B, Cin, Cout, Hout, in_act, acc, H.stream())
+        else:
             def launch(dy=dy, x=x, dw=dw, db=db, ws=ws):
                 _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                      Hout, in_act, H.ACC_DEFER, H.stream())
-            if StreamPlan.enabled and StreamPlan.batch_wgrad:
+                      Hout, in_act, acc, H.stream())
+            if defer and StreamPlan.enabled and StreamPlan.batch_wgrad:
                 GradReducer.queue(x.device, launch, dy, x)
             else:
-                with torch.cuda.stream(_wgrad_side(x.device, dy, x)):
+                with torch.cuda.stream(_wgrad_side(x.device, dy, x) if defer else None):
                     launch()
+        if defer:
             _conv_segments(ws, dw, db, B, Cout, Cin, Hout, Cout)
-        else:
-            ws = H.workspace(nws, x.device)
-            _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                  Hout, in_act, acc_w, H.stream())
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            ep = _DACT[in_act]
-            _call("mmvae_conv2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout,
-                  Hout, ep, H.stream())
         return dx, ret_w, ret_b, None, None, None
 
 
@@ -313,28 +310,19 @@ class ConvT2dK4S2(Function):
             else:
                 db = ret_b = torch.empty(Cout, device=x.device)
         nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin)
-        if _defer(gw, gb if has_b else gw):
-            ws = GradReducer.alloc(nws, x.device)
-
-            def launch(dy=dy, x=x, dw=dw, db=db, ws=ws):
-                _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                      Hin, in_act, H.ACC_DEFER, H.stream())
-            if StreamPlan.enabled and StreamPlan.batch_wgrad:
-                GradReducer.queue(x.device, launch, dy, x)
-            else:
-                with torch.cuda.stream(_wgrad_side(x.device, dy, x)):
-                    launch()
-            _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
-        else:
-            ws = H.workspace(nws, x.device)
-            _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                  Hin, in_act, acc_w, H.stream())
+        defer = _defer(gw, gb if has_b else gw)
+        ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
+        acc = H.ACC_DEFER if defer else acc_w
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
             dx = torch.empty_like(x)
-            ep = _DACT[in_act]
-            _call("mmvae_convT2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout,
-                  Hin, ep, H.stream())
+            _call("mmvae_convT2d_k4s2_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
+                  B, Cin, Cout, Hin, in_act, acc, H.stream())
+        else:
+            _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hin,
+                  in_act, acc, H.stream())
+        if defer:
+            _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
         return dx, ret_w, ret_b, None, None, None, None
 
 
