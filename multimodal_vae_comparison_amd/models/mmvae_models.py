@@ -283,8 +283,76 @@ class MOE(TorchMMVAE):
 
 
 class DMVAE(TorchMMVAE):
-    """DMVAE shared/private latents (mmvae_models.py:413-509) -- SURVEY 8(a) a19, next after the north-star path."""
+    """DMVAE, shared + private latents (mmvae_models.py:413-509), K = 1, all modalities present.
+
+    Every encoder emits D + P columns; [:D] is the shared posterior, [D:] the private one (split after the softmax
+    over all D + P columns, mmvae_base.py:152-156).  joint = product of the shared experts, no prior expert.  Noise is
+    drawn in the reference's order: z_joint, then per modality z_shared, z_private and a fresh shared draw of every
+    other modality for the cross reconstruction.  Three ELBOs per modality (:458-459), all summed over the batch."""
 
     def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
         super().__init__(vaes, n_latents, **obj_config)
-        raise NotImplementedError("dmvae: not yet on the MI355X hot path (mopoe, poe are)")
+        self.model_config = model_config
+        self.modelName = "dmvae"
+        assert self.latent_factorization, "DMVAE requires private_latents in the config"
+        if self.K != 1:
+            raise NotImplementedError("dmvae: K = 1 only on this path")
+        pmax = max(v.private_latents for v in self.vaes.values())
+        self.register_buffer("_theta0", torch.zeros(1, pmax), persistent=False)    # N(0,1) prior of the private part
+
+    @property
+    def pz_params(self):
+        return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
+
+    def objective(self, mods):
+        self._begin_step()
+        names = list(self.vaes.keys())
+        M, D = len(names), self.n_latents
+        beta = float(self.obj_fn.beta)
+        theta = self._pz_params[1]
+        packed = [packed_head(*self.vaes[n].enc(mods[n])) for n in names]
+        B, dev = packed[0].shape[0], packed[0].device
+        P = [self.vaes[n].private_latents for n in names]
+        # noise in the reference's draw order (mmvae_models.py:486-502)
+        e_joint = self._draw(B, D, dev)
+        e_sh, e_pr, e_cross = {}, {}, {}
+        for i in range(M):
+            e_sh[i] = self._draw(B, D, dev)
+            e_pr[i] = self._draw(B, P[i], dev)
+            for m in range(M):
+                if m != i:
+                    e_cross[(i, m)] = self._draw(B, D, dev)        # target i, fresh draw of q_shared(m)
+        _, klj, zj = ops.poe_reparam_kl(theta, packed, [e_joint], 0, 1 << M, theta.grad, cols=(0, D))
+        z_sh, z_cr, kl_sh, z_pr, kl_pr = {}, {}, {}, {}, {}
+        for m in range(M):
+            targets = [i for i in range(M) if i != m]
+            _, kl, z = ops.poe_reparam_kl(theta, [packed[m]], [e_sh[m]] + [e_cross[(i, m)] for i in targets], 2, 0b10,
+                                          theta.grad, cols=(0, D))
+            z_sh[m], kl_sh[m] = z[0], kl[1]
+            for i, zc in zip(targets, z[1:]):
+                z_cr[(i, m)] = zc
+            _, klp, zp = ops.poe_reparam_kl(self._theta0[:, :P[m]].contiguous(), [packed[m]], [e_pr[m]], 2, 0b10, None,
+                                            cols=(D, P[m]))
+            z_pr[m], kl_pr[m] = zp[0], klp[1]
+        rows, W_loss, W_kld, ind = [], [], [], []
+        for i, n in enumerate(names):
+            vae = self.vaes[n]
+            lam = float(vae.llik_scaling)
+
+            def rec(z, i=i, n=n, vae=vae):
+                out, _ = vae.dec({"latents": torch.cat([z, z_pr[i]], -1).unsqueeze(0), "masks": mods[n]["masks"]})
+                return recon_rowsum(vae.ltype, out, mods[n])
+            own = rec(z_sh[i])
+            ind.append(own)
+            cross = [rec(z_cr[(i, m)]) for m in range(M) if m != i]
+            rows += [own, kl_sh[i], rec(zj[0]), klj[M]] + cross + [kl_pr[i]]
+            W_loss += [lam, beta, lam, beta] + [lam] * len(cross) + [beta * len(cross)]
+            W_kld += [0.0, 1.0 / M, 0.0, 0.0] + [0.0] * len(cross) + [0.0]
+        out = ops.lincomb_rows(rows, [W_loss, W_kld])
+        return {"loss": out[0], "reconstruction_loss": [r.sum() for r in ind], "kld": out[1]}
+
+    def modality_mixing(self, mods):
+        return self.encode(mods)
+
+    def forward(self, x, K=1):
+        raise NotImplementedError("dmvae.forward (inference container) is not on the MI355X path yet; objective() is")

@@ -440,36 +440,38 @@ def head_softmax(h):
 class PoeReparamKL(Function):
     """Product of experts -> n_z reparameterised samples -> analytic KL rows.
 
-    packed[e]: (B,2D) = [mu_e | lv_e] head outputs.  Returns joint (2,B,D) [not differentiable],
-    kl (E+1,B), then n_z tensors z_i (B,D)."""
+    packed[e]: (B, 2*Dtot) = [mu_e | lv_e] head outputs; the experts are columns [col0, col0+D) of both halves
+    (col0 = 0, D = Dtot unless `cols` selects a sub-range: DMVAE's shared / private split).  Returns joint (2,B,D)
+    [not differentiable], kl (E+1,B), then n_z tensors z_i (B,D)."""
 
     @staticmethod
-    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, *tensors):
+    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, cols, *tensors):
         packed = [H.f32c(t) for t in tensors[:E]]
         eps = [H.f32c(t) for t in tensors[E:E + n_z]]
         B, D2 = packed[0].shape
-        D = D2 // 2
+        Dtot = D2 // 2
+        col0, D = cols if cols is not None else (0, Dtot)
         dev = packed[0].device
         joint = torch.empty(2, B, D, device=dev)
         kl = torch.empty(E + 1, B, device=dev)
         zs = [torch.empty(B, D, device=dev) for _ in range(n_z)]     # separate tensors: no select/stack backward
         a = H.PoeFwdArgs()
         for e, p in enumerate(packed):
-            a.mu[e] = p.data_ptr()
-            a.lv[e] = p.data_ptr() + 4 * D
+            a.mu[e] = p.data_ptr() + 4 * col0
+            a.lv[e] = p.data_ptr() + 4 * (Dtot + col0)
         for i, t in enumerate(eps):
             a.eps[i] = t.data_ptr()
             a.z[i] = zs[i].data_ptr()
         _call("mmvae_poe_reparam_kl_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(joint), H.ptr(kl), E, int(with_prior),
               n_z, kl_mask, B, D, D2, H.stream())
         ctx.save_for_backward(theta, *packed, *eps)
-        ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D)
+        ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0)
         ctx.mark_non_differentiable(joint)
         return (joint, kl, *zs)
 
     @staticmethod
     def backward(ctx, _dj, dkl, *dzs):
-        gtheta, with_prior, n_z, kl_mask, E, B, D = ctx.cfg
+        gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0 = ctx.cfg
         # batch point: every decoder's backward is done, so the queued decoder weight-gradient kernels can run on
         # the side stream underneath the encoder backward chains
         GradReducer.launch_pending(ctx.saved_tensors[0].device)
@@ -479,13 +481,14 @@ class PoeReparamKL(Function):
         dev = theta.device
         dkl = H.f32c(dkl) if dkl is not None else torch.zeros(E + 1, B, device=dev)
         dz = [H.f32c(g) if g is not None else torch.zeros(B, D, device=dev) for g in dzs] if n_z else None
-        dpacked = [torch.empty_like(p) for p in packed]
+        sub = D != Dtot
+        dpacked = [(torch.zeros_like(p) if sub else torch.empty_like(p)) for p in packed]
         a = H.PoeBwdArgs()
         for e, p in enumerate(packed):
-            a.mu[e] = p.data_ptr()
-            a.lv[e] = p.data_ptr() + 4 * D
-            a.dmu[e] = dpacked[e].data_ptr()
-            a.dlv[e] = dpacked[e].data_ptr() + 4 * D
+            a.mu[e] = p.data_ptr() + 4 * col0
+            a.lv[e] = p.data_ptr() + 4 * (Dtot + col0)
+            a.dmu[e] = dpacked[e].data_ptr() + 4 * col0
+            a.dlv[e] = dpacked[e].data_ptr() + 4 * (Dtot + col0)
         for i in range(n_z if dz is not None else 0):
             a.eps[i] = eps[i].data_ptr()
             a.dz[i] = dz[i].data_ptr()
@@ -496,13 +499,13 @@ class PoeReparamKL(Function):
             acc = 0
         ws = H.workspace(H.lib().mmvae_poe_ws_floats(B, D), dev)
         _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws), E,
-              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * D, acc, H.stream())
-        return (ret, None, None, None, None, None, *dpacked, *([None] * n_z))
+              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, acc, H.stream())
+        return (ret, None, None, None, None, None, None, *dpacked, *([None] * n_z))
 
 
-def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None):
-    """-> joint (2,B,D), kl (E+1,B), [z_0 .. z_{n_z-1}] each (B,D)"""
-    out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), *packed, *eps)
+def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None, cols=None):
+    """-> joint (2,B,D), kl (E+1,B), [z_0 .. z_{n_z-1}] each (B,D); cols = (col0, D) selects expert columns"""
+    out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), cols, *packed, *eps)
     return out[0], out[1], list(out[2:])
 
 

@@ -17,11 +17,11 @@ def cdsprites_batch(B, T, seed=1, device="cpu", V=27):
             "mod_2": {"data": onehot.to(device), "masks": mask.to(device), "categorical": True}}
 
 
-def cdsprites_config(mixing="mopoe", n_latents=32, batch_size=128, beta=1, lr=1e-4):
+def cdsprites_config(mixing="mopoe", n_latents=32, batch_size=128, beta=1, lr=1e-4, private=None):
     """the reference's configs/config_cdspritesplus.yml schema with the CNN2 image tower"""
     return {"batch_size": batch_size, "beta": beta, "dataset_name": "cdspritesplus", "lr": lr, "mixing": mixing,
             "n_latents": n_latents, "obj": "elbo", "optimizer": "adam", "K": 1,
             "modality_1": {"decoder": "CNN", "encoder": "CNN2", "mod_type": "image", "recon_loss": "bce",
-                           "prior": "normal", "private_latents": None},
+                           "prior": "normal", "private_latents": private},
             "modality_2": {"decoder": "TxtTransformer", "encoder": "TxtTransformer", "mod_type": "text",
-                           "recon_loss": "category_ce", "prior": "normal", "private_latents": None}}
+                           "recon_loss": "category_ce", "prior": "normal", "private_latents": private}}

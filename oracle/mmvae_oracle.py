@@ -514,7 +514,56 @@ def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
     return {"loss": loss, "kld": kld, "reconstruction_loss": lpx, "_rows": torch.stack(rows), "_z": zs, "_enc": enc}
 
 
-OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective, "moe": moe_objective}
+def dmvae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+    """DMVAE.forward + objective, models/mmvae_models.py:436-503 (all modalities present, K = 1).
+
+    Encoder outputs (B, D+P) are split into shared [:D] / private [D:] AFTER the softmax over all D+P columns
+    (mmvae_base.py:152-156); joint = product of the shared experts WITHOUT a prior expert (:478-479); draws in the
+    reference's order: z_joint, then per modality z_shared, z_private and one fresh shared draw of every other
+    modality for the cross reconstruction (:486-502); three ELBOs per modality (:458-459):
+      -(sum lpx_own - beta sum KL(q_shared || p)) - (sum lpx_joint - beta sum KL(joint || p))
+      -(sum lpx_cross - beta sum_over_cross KL(q_private || N(0,1)))        p = N(0, softmax(theta) * D)."""
+    M, D = len(mods), n_latents
+    enc = [encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in range(M)]
+    B = enc[0][0].shape[0]
+    sh = [(mu[:, :D], lv[:, :D]) for mu, lv in enc]
+    pr = [(mu[:, D:], lv[:, D:]) for mu, lv in enc]
+    j_mu, j_var = product_of_experts(torch.stack([m for m, _ in sh]), torch.stack([l for _, l in sh]))
+    sig_p = prior_sigma(p["_pz_params.1"])
+    it = iter(eps)
+    nxt = lambda d: next(it).reshape(1, B, d)
+    z_joint = j_mu + j_var * nxt(D)
+    kld_joint = kl_normal(j_mu, j_var, 0.0, sig_p)
+    losses, ind, klds, inter = [], [], [], []
+    for i in range(M):
+        lam = float(mods[i].get("llik_scaling", 1.0))
+        tgt = batch[f"mod_{i + 1}"]
+        mask = tgt["masks"]
+        z_sh = sh[i][0] + sh[i][1] * nxt(D)
+        z_pr = pr[i][0] + pr[i][1] * nxt(pr[i][0].shape[1])
+        rec = lambda z: (-recon_loss(mods[i]["ltype"], decode(p, mods, i, torch.cat([z, z_pr], -1), mask, train), tgt) * lam).sum(-1)
+        lpx_own = rec(z_sh)
+        lpx_joint = rec(z_joint)
+        lpx_cross, kl_priv = [], []
+        for m in range(M):
+            if m != i:
+                z_c = sh[m][0] + sh[m][1] * nxt(D)
+                lpx_cross.append(rec(z_c))
+                kl_priv.append(kl_normal(pr[i][0], pr[i][1], 0.0, torch.ones(1, pr[i][0].shape[1])))
+        kld = kl_normal(sh[i][0], sh[i][1], 0.0, sig_p)
+        e1 = -(lpx_own.sum(-1) - beta * kld.sum(-1).sum()).sum()
+        e2 = -(lpx_joint.sum(-1) - beta * kld_joint.sum()).sum()
+        e3 = -(torch.stack(lpx_cross).sum() - beta * torch.stack(kl_priv).sum(-1).sum())
+        losses.append(e1 + e2 + e3)
+        ind.append(lpx_own)
+        klds.append(kld)
+        inter.append({"z_shared": z_sh, "z_private": z_pr})
+    rec_out = [-(m).sum() / float(mods[i].get("llik_scaling", 1.0)) for i, m in enumerate(ind)]
+    return {"loss": torch.stack(losses).sum(), "reconstruction_loss": rec_out, "kld": torch.stack(klds).mean(0).sum(),
+            "_joint": (j_mu, j_var), "_inter": inter}
+
+
+OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective, "moe": moe_objective, "dmvae": dmvae_objective}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -46,13 +46,16 @@ CASES = [
     ("poe_b4_t4_d16_BeqT", "poe", 4, 4, 16, [4, 1, 3, 2], "eval", 0.5),
     ("moe_b5_t6_d8", "moe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.0),
     ("moe_b6_t6_d16_BeqT", "moe", 6, 6, 16, [6, 5, 1, 3, 2, 4], "eval", 2.0),
+    ("dmvae_b5_t6_d8p4", "dmvae", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.0),
+    ("dmvae_b6_t6_d16p6_BeqT", "dmvae", 6, 6, 16, [6, 5, 1, 3, 2, 4], "eval", 0.5),
 ]
+PRIVATE = {"dmvae_b5_t6_d8p4": 4, "dmvae_b6_t6_d16p6_BeqT": 6}
 
 
-def build_reference(mixing, D, beta):
+def build_reference(mixing, D, beta, private=None):
     vaes = {}
     for i, m in enumerate(MODS):
-        vaes[f"mod_{i + 1}"] = VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], None, obj_fn="elbo", beta=beta,
+        vaes[f"mod_{i + 1}"] = VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], private, obj_fn="elbo", beta=beta,
                                    id_name=f"mod_{i + 1}", llik_scaling=m["llik_scaling"])
     return getattr(models, mixing)(nn.ModuleDict(vaes), D, {"obj": "elbo", "beta": beta, "K": 1}, {})
 
@@ -68,8 +71,10 @@ def make_batch(B, T, lengths, seed):
 
 
 def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
-    model = build_reference(mixing, D, beta)
-    shapes = orc.model_param_shapes(MODS, D)
+    private = PRIVATE.get(name)
+    mods = [dict(m, private=private) for m in MODS] if private else MODS
+    model = build_reference(mixing, D, beta, private)
+    shapes = orc.model_param_shapes(mods, D)
     ref_sd = model.state_dict()
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
     assert trainable == set(shapes), (trainable ^ set(shapes))
@@ -93,7 +98,7 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
 
     out = {"img": img.numpy(), "onehot": onehot.numpy(), "mask": mask.numpy()}
     meta = {"name": name, "mixing": mixing, "B": B, "T": T, "D": D, "beta": beta, "seed": seed, "mode": mode,
-            "mods": MODS, "lr": 1e-4}
+            "mods": mods, "lr": 1e-4}
 
     order = None
     if mixing == "poe":                     # record the hash-seed dependent subset order (utils.py:98)

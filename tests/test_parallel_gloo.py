@@ -66,7 +66,10 @@ def _worker(rank, world, port, q):
 def test_two_ranks_equal_one_rank_average():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    import socket
+    with socket.socket() as sk:          # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
