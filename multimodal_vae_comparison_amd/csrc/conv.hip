@@ -23,16 +23,11 @@ __global__ __launch_bounds__(256) void conv2d_bwd_fused_kernel(ConvScatterArgs a
   if ((int)blockIdx.x < n_w) conv_wgrad_body<32>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
   else conv_scatter_body<TM>(ad, blockIdx.x - n_w, smem);
 }
-template <int TM>
+template <typename G>
 __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax(GatherCfg<32>::SMEM, WgradCfg::SMEM)];
-  if ((int)blockIdx.x < n_w) conv_wgrad_body<32>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
-  else conv_gather_body<32, TM>(ad, blockIdx.x - n_w, smem);
-}
-__global__ __launch_bounds__(256) void convT3_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax(GatherCfg<3>::SMEM, WgradCfg::SMEM)];
-  if ((int)blockIdx.x < n_w) conv_wgrad_body<3>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
-  else conv_gather_body<3, 4>(ad, blockIdx.x - n_w, smem);
+  __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, WgradCfg::SMEM)];
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<G::CIN>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  else conv_gather_body<G>(ad, blockIdx.x - n_w, smem);
 }
 
 static inline int dact_ep(int act) {
@@ -95,18 +90,17 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
     return conv_gather_dispatch(dy, w, nullptr, x, dx, B, Cout, Cin, 2 * Hin, MMVAE_ACT_NONE, ep, st);
   }
   // input gradient = gather conv over dy (2Hin x 2Hin, Cout channels) -> (Hin x Hin, 32 channels)
-  ConvGatherArgs ad{dy, w, nullptr, x, dx, B, 2 * Hin, Hin, ilog2i(Hin), MMVAE_ACT_NONE, ep};
-  const int rows_per_tile = Hin >= 32 ? 1 : 32 / Hin;
+  ConvGatherArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep};
   const long tiles = ((long)B * Hin * Hin + 31) / 32;
-  const int TM = gather_tm(Cout, tiles);
-  const int n_d = (int)(((long)B * Hin + TM * rows_per_tile - 1) / (TM * rows_per_tile));
   const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
   ConvWgradArgs aw{x, dy, ws, B, Hin, ilog2i(Hin), x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro};
   const int n_w = nsplit * (Cout == 32 ? 4 : 1);
-  if (Cout == 3) hipLaunchKernelGGL(convT3_bwd_fused_kernel, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
-  else if (TM == 4) hipLaunchKernelGGL(convT_bwd_fused_kernel<4>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
-  else if (TM == 2) hipLaunchKernelGGL(convT_bwd_fused_kernel<2>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
-  else hipLaunchKernelGGL(convT_bwd_fused_kernel<1>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  if (!gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles), [&](auto g) {
+        using G = decltype(g);
+        const int n_d = (int)gather_grid(B, Hin, G::TM);
+        hipLaunchKernelGGL((convT_bwd_fused_kernel<G>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      }))
+    return MMVAE_ERR_UNSUPPORTED;
   int rc = mmvae_launch_status();
   if (rc) return rc;
   return conv_bwd_reduce(ws, dw, db, B, Cout, Hin, Cout, accumulate, stream);
