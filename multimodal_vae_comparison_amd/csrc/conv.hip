@@ -17,16 +17,16 @@
 // ------------------------------------------------------------------------------------------------
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int TM>
+template <typename G, typename W>
 __global__ __launch_bounds__(256) void conv2d_bwd_fused_kernel(ConvScatterArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax(ScatterCfg::SMEM, WgradCfg::SMEM)];
-  if ((int)blockIdx.x < n_w) conv_wgrad_body<32>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
-  else conv_scatter_body<TM>(ad, blockIdx.x - n_w, smem);
+  __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  else conv_scatter_body<G>(ad, blockIdx.x - n_w, smem);
 }
-template <typename G>
+template <typename G, typename W>
 __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, WgradCfg::SMEM)];
-  if ((int)blockIdx.x < n_w) conv_wgrad_body<G::CIN>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
   else conv_gather_body<G>(ad, blockIdx.x - n_w, smem);
 }
 
@@ -57,19 +57,23 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
     return conv_scatter_dispatch(dy, w, nullptr, x, dx, B, Cout, Cin, Hout, MMVAE_ACT_NONE, dact_ep(x_act), st);
   }
   const int ep = dact_ep(x_act);
-  ConvScatterArgs ad{dy, w, nullptr, x, dx, B, Hout, ilog2i(Hout), MMVAE_ACT_NONE, ep};
-  const int rows_per_tile = Hout >= 32 ? 1 : 32 / Hout;
+  ConvScatterArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep};
   const long tiles = ((long)B * Hout * Hout + 31) / 32;
-  int TM = 4;
-  if (tiles < 512 * 4) TM = 2;
-  if (tiles < 512 * 2) TM = 1;
-  const int n_d = (int)(((long)B * Hout + TM * rows_per_tile - 1) / (TM * rows_per_tile));
   const int n_macro = wgrad_n_macro(B, Hout), nsplit = wgrad_splits(n_macro, 32);
-  ConvWgradArgs aw{dy, x, ws, B, Hout, ilog2i(Hout), MMVAE_ACT_NONE, x_act, db ? 1 : 0, n_macro};
-  const int n_w = nsplit * 4;
-  if (TM == 4) hipLaunchKernelGGL(conv2d_bwd_fused_kernel<4>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
-  else if (TM == 2) hipLaunchKernelGGL(conv2d_bwd_fused_kernel<2>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
-  else hipLaunchKernelGGL(conv2d_bwd_fused_kernel<1>, dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+  ConvWgradArgs aw{dy, x, ws, B, MMVAE_ACT_NONE, x_act, db ? 1 : 0, n_macro};
+  // one instantiation per layer shape: the scatter plan is a function of the map size at a given batch, but both
+  // template arguments must be compile-time, so the (few) combinations are enumerated by the two visitors
+  bool launched = false;
+  scatter_visit(Hout, scatter_plan(tiles), [&](auto g) {
+    using G = decltype(g);
+    if constexpr (G::LGH <= 4) {
+      using W = WgradGeom<32, G::LGH>;
+      const int n_w = nsplit * W::NCH, n_d = (int)scatter_grid(B, Hout, G::TM);
+      hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      launched = true;
+    }
+  });
+  if (!launched) return MMVAE_ERR_UNSUPPORTED;
   int rc = mmvae_launch_status();
   if (rc) return rc;
   return conv_bwd_reduce(ws, dw, db, B, Cin, Hout, 32, accumulate, stream);
@@ -93,14 +97,18 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   ConvGatherArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep};
   const long tiles = ((long)B * Hin * Hin + 31) / 32;
   const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
-  ConvWgradArgs aw{x, dy, ws, B, Hin, ilog2i(Hin), x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro};
-  const int n_w = nsplit * (Cout == 32 ? 4 : 1);
-  if (!gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles), [&](auto g) {
-        using G = decltype(g);
-        const int n_d = (int)gather_grid(B, Hin, G::TM);
-        hipLaunchKernelGGL((convT_bwd_fused_kernel<G>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
-      }))
-    return MMVAE_ERR_UNSUPPORTED;
+  ConvWgradArgs aw{x, dy, ws, B, x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro};
+  bool launched = false;
+  gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles), [&](auto g) {
+    using G = decltype(g);
+    if constexpr (G::LGH >= 3 && (G::CIN == 32 || G::LGH == 6)) {
+      using W = WgradGeom<G::CIN, G::LGH - 1>;       // small map = the gather's output map
+      const int n_w = nsplit * W::NCH, n_d = (int)gather_grid(B, Hin, G::TM);
+      hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      launched = true;
+    }
+  });
+  if (!launched) return MMVAE_ERR_UNSUPPORTED;
   int rc = mmvae_launch_status();
   if (rc) return rc;
   return conv_bwd_reduce(ws, dw, db, B, Cout, Hin, Cout, accumulate, stream);

@@ -1,4 +1,4 @@
-"""Per-kernel timings on the GPU box (HIP events, back-to-back launches on the current stream)."""
+"""Per-kernel timings on the GPU box (HIP events around hipGraph replays of 20 back-to-back launches)."""
 import os
 import sys
 
@@ -11,17 +11,26 @@ from multimodal_vae_comparison_amd import ops
 dev = "cuda"
 
 
-def timeit(fn, reps=30, warm=5):
-    for _ in range(warm):
+def timeit(fn, reps=20, n=20):
+    """Average time of one call: n calls captured in a hipGraph (no host launch gaps), replayed reps times."""
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
         fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(n):
+                fn()
+    for _ in range(3):
+        g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        fn()
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    return e0.elapsed_time(e1) * 1e3 / reps / n
 
 
 out = {}
@@ -50,7 +59,7 @@ with torch.no_grad():
             db = torch.zeros(32, device=dev)
             ws = torch.empty(L.mmvae_conv_wgrad_ws_floats(B, 32, Q, Hs), device=dev)
             us = timeit(lambda: L.mmvae_conv2d_k4s2_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(),
-                                                           ws.data_ptr(), B, Q, 32, Hs, 1, 1, H.stream()))
+                                                           ws.data_ptr(), B, Q, 32, Hs, 1, 1, torch.cuda.current_stream().cuda_stream))
             fl = 2.0 * B * Hs * Hs * 32 * Q * 16
             out[f"{name} (+reduce) B={B}"] = (us, fl / us / 1e6)
     for M, K, N in ((128, 512, 512), (4096, 54, 162), (4096, 128, 54), (4096, 54, 128), (128, 32, 512), (131072, 54, 162)):
@@ -59,16 +68,5 @@ with torch.no_grad():
         b = torch.zeros(N, device=dev)
         us = timeit(lambda: ops.linear(x, w, b))
         out[f"linear fwd M={M} K={K} N={N}"] = (us, 2.0 * M * K * N / us / 1e6)
-    t = torch.zeros(64, device=dev)
-    out["eager launch of a trivial kernel"] = (timeit(lambda: ops.fill(t, 1.0), reps=200), 0)
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        ops.fill(t, 1.0)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g, stream=s):
-            for _ in range(100):
-                ops.fill(t, 1.0)
-    out["graph of 100 trivial kernels: us per kernel"] = (timeit(lambda: g.replay(), reps=50) / 100, 0)
 for k, v in out.items():
     print(f"{k:48s} {v[0]:10.2f} us" + (f"   {v[1]:8.2f} TFLOP/s" if v[1] else ""))
