@@ -17,6 +17,8 @@
 // and are summed by mmvae_reduce_rows (deterministic, no atomics).
 #include "common.hpp"
 
+#define GEMM_BK1 64   // K depth of a stage of the 128 x 32 tiling
+
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -30,77 +32,112 @@ struct GemmArgs {
   int a_act, b_act, ep, accumulate, kper;
 };
 
-template <int KSPLIT>
+// Staging of one operand tile [R rows (m or n)][BK] into LDS as [k][r] (pitch RP).  The tile is walked with a
+// per-thread base offset and a constant stride, so a slot costs one address add, one select and one LDS store
+// (the first version decoded (row, k) and did 64-bit index math per element: ~25 VALU per slot and 30 KB of code,
+// which at batch 128 is what the kernel's time went into).
+//   KMAJOR (k contiguous in memory):  slot i = (row r0 + i*RSTEP, k kl);   RSTEP = NT / BK
+//   else   (row contiguous):          slot i = (row rl, k kl0 + i*KSTEP);  KSTEP = NT / R
+template <int R, int BK, int NT, bool KMAJOR>
+struct OperandStage {
+  static constexpr int PER_T = R * BK / NT;
+  static constexpr int RSTEP = NT / BK, KSTEP = NT / R;
+  static constexpr int RP = R + 1;
+  int rl, kl;            // this thread's first (row, k) inside the tile
+  long rstride, kstride; // element strides of row / k in memory
+  unsigned rvalid;       // KMAJOR: per-slot row validity (stage independent)
+  int rows_left;         // rows valid in this tile
+  __device__ __forceinline__ void init(int tid, int row0, int nrows, long rs, long ks) {
+    if (KMAJOR) { kl = tid % BK; rl = tid / BK; } else { rl = tid % R; kl = tid / R; }
+    rstride = rs; kstride = ks;
+    rows_left = nrows - row0;
+    rvalid = 0;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int r = KMAJOR ? rl + i * RSTEP : rl;
+      rvalid |= (r < rows_left ? 1u : 0u) << i;
+    }
+  }
+  // Unconditional loads of stage [k0, kend) from clamped addresses (a predicated load makes hipcc wait vmcnt(0)
+  // per element); returns the validity mask that store() applies.
+  __device__ __forceinline__ unsigned load(const float* __restrict__ base, int k0, int kend, float (&v)[PER_T]) const {
+    unsigned ok = 0;
+    const long off = (long)rl * rstride + (long)(k0 + kl) * kstride;
+    if (KMAJOR) {
+      ok = (k0 + kl < kend) ? rvalid : 0u;
+      const long step = (long)RSTEP * rstride;
+#pragma unroll
+      for (int i = 0; i < PER_T; ++i) v[i] = base[(ok >> i & 1u) ? off + i * step : 0];
+    } else {
+      const bool rok = rl < rows_left;
+      const long step = (long)KSTEP * kstride;
+#pragma unroll
+      for (int i = 0; i < PER_T; ++i) {
+        const bool e = rok && (k0 + kl + i * KSTEP < kend);
+        ok |= (e ? 1u : 0u) << i;
+        v[i] = base[e ? off + i * step : 0];
+      }
+    }
+    return ok;
+  }
+  __device__ __forceinline__ void store(float* __restrict__ S, const float (&v)[PER_T], unsigned ok) const {
+    float* d = S + kl * RP + rl;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) d[KMAJOR ? i * RSTEP : i * KSTEP * RP] = (ok >> i & 1u) ? v[i] : 0.f;
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void act_inplace(float (&v)[N], int act) {
+  if (act == MMVAE_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dev_silu(v[i]);
+  } else if (act == MMVAE_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
+  } else if (act == MMVAE_ACT_GELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dev_gelu(v[i]);
+  }
+}
+
+template <int KSPLIT, bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, const int nz,
                                           float* __restrict__ As, float* __restrict__ Bs) {
   constexpr int NT = KSPLIT == 8 ? 512 : 256;  // threads
   constexpr int BM = KSPLIT == 1 ? 128 : 32;
   constexpr int BN = 32;
-  constexpr int BK = KSPLIT == 1 ? 32 : 32 * KSPLIT;  // every wave owns a 32-deep K slice of a stage
+  constexpr int BK = KSPLIT == 1 ? GEMM_BK1 : 32 * KSPLIT;  // KSPLIT > 1: every wave owns a 32-deep K slice of a stage
+  constexpr int KW = KSPLIT == 1 ? BK : 32;                 // K steps (x2) a wave walks per stage
   constexpr int AP = BM + 1;  // LDS row pitch of As (odd)
   constexpr int BP = BN + 1;
-  constexpr int A_PER_T = BM * BK / NT;  // 16
-  constexpr int B_PER_T = BK * BN / NT;  // 4 or 16
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  using StA = OperandStage<BM, BK, NT, A_KMAJOR>;
+  using StB = OperandStage<BN, BK, NT, B_KMAJOR>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * g.kper;
   const int kend = min(g.K, kbeg + g.kper);
-  const bool a_kmajor = (g.sak == 1);
-  const bool b_kmajor = (g.sbk == 1 && g.sbn != 1);
 
-  // Staging in two phases so that all of a stage's global loads are in flight together: (1) unconditional
-  // loads from clamped addresses into registers, (2) select/activation + LDS stores.  (A load followed by a
-  // data-dependent branch makes hipcc wait vmcnt(0) per element: measured 8 us per stage.)
-  float ra[A_PER_T], rb[B_PER_T];
-  unsigned va = 0, vb = 0;
-
+  // Staging in two phases so that all of a stage's global loads are in flight together: (1) predicated loads
+  // into registers, (2) activation + LDS stores.
+  StA sa;
+  StB sb;
+  sa.init(tid, 0, g.M - m0, g.sam, g.sak);
+  sb.init(tid, 0, g.N - n0, g.sbn, g.sbk);
+  const float* Abase = g.A + (long)m0 * g.sam;
+  const float* Bbase = g.B + (long)n0 * g.sbn;
+  float ra[StA::PER_T], rb[StB::PER_T];
+  unsigned oka = 0, okb = 0;
   auto load_stage = [&](int k0) {
-    va = vb = 0;
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int e = i * NT + tid;
-      int ml, kl;
-      if (a_kmajor) { kl = e % BK; ml = e / BK; } else { ml = e % BM; kl = e / BM; }
-      const int m = m0 + ml, k = k0 + kl;
-      const bool ok = m < g.M && k < kend;
-      va |= (ok ? 1u : 0u) << i;
-      ra[i] = g.A[ok ? (long)m * g.sam + (long)k * g.sak : 0];
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER_T; ++i) {
-      const int e = i * NT + tid;
-      int nl, kl;
-      if (b_kmajor) { kl = e % BK; nl = e / BK; } else { nl = e % BN; kl = e / BN; }
-      const int n = n0 + nl, k = k0 + kl;
-      const bool ok = n < g.N && k < kend;
-      vb |= (ok ? 1u : 0u) << i;
-      rb[i] = g.B[ok ? (long)k * g.sbk + (long)n * g.sbn : 0];
-    }
+    oka = sa.load(Abase, k0, kend, ra);
+    okb = sb.load(Bbase, k0, kend, rb);
   };
   auto store_stage = [&]() {
-    if (g.a_act != MMVAE_ACT_NONE) {
-#pragma unroll
-      for (int i = 0; i < A_PER_T; ++i) ra[i] = apply_in_act(ra[i], g.a_act);
-    }
-    if (g.b_act != MMVAE_ACT_NONE) {
-#pragma unroll
-      for (int i = 0; i < B_PER_T; ++i) rb[i] = apply_in_act(rb[i], g.b_act);
-    }
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int e = i * NT + tid;
-      int ml, kl;
-      if (a_kmajor) { kl = e % BK; ml = e / BK; } else { ml = e % BM; kl = e / BM; }
-      As[kl * AP + ml] = (va >> i & 1u) ? ra[i] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER_T; ++i) {
-      const int e = i * NT + tid;
-      int nl, kl;
-      if (b_kmajor) { kl = e % BK; nl = e / BK; } else { nl = e % BN; kl = e / BN; }
-      Bs[kl * BP + nl] = (vb >> i & 1u) ? rb[i] : 0.f;
-    }
+    if (g.a_act != MMVAE_ACT_NONE) act_inplace(ra, g.a_act);
+    if (g.b_act != MMVAE_ACT_NONE) act_inplace(rb, g.b_act);
+    sa.store(As, ra, oka);
+    sb.store(Bs, rb, okb);
   };
 
   f32x16 acc;
@@ -112,12 +149,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   const int k_off = (KSPLIT == 1 ? 0 : wave * 32) + lh;   // k within the staged tile
 
   if (kbeg < kend) load_stage(kbeg);
+#pragma unroll 1
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     store_stage();
     __syncthreads();
     if (k0 + BK < kend) load_stage(k0 + BK);
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
+    for (int kk = 0; kk < KW; kk += 2) {
       const float a = As[(k_off + kk) * AP + a_off];
       const float b = Bs[(k_off + kk) * BP + li];
       asum += a;
@@ -135,15 +173,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
   asum += __shfl_xor(asum, 32, 64);
 
+  const bool plain = ep == MMVAE_EP_NONE && !acc_out;   // the common case: no per-element branching
+  const float bias_v = (!partial && g.bias && n0 + li < g.N) ? g.bias[n0 + li] : 0.f;   // every emit of a lane has col n0+li
   auto emit = [&](int row, int col, float v) {
     if (row < g.M && col < g.N) {
-      if (!partial && g.bias) v += g.bias[col];
+      v += bias_v;
       const long o = (long)row * ldc + col;
-      float av = 0.f;
-      if (ep_reads_aux(ep)) av = g.aux[o];
-      if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
-      v = apply_epilogue(v, av, ep);
-      Cout[o] = acc_out ? Cout[o] + v : v;
+      if (!plain) {
+        float av = 0.f;
+        if (ep_reads_aux(ep)) av = g.aux[o];
+        if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
+        v = apply_epilogue(v, av, ep);
+        if (acc_out) v += Cout[o];
+      }
+      Cout[o] = v;
     }
   };
 
@@ -182,18 +225,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   }
 }
 
-template <int KSPLIT>
+template <int KSPLIT, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void gemm_kernel(GemmArgs g) {
   constexpr int BM = KSPLIT == 1 ? 128 : 32;
-  constexpr int BK = KSPLIT == 1 ? 32 : 32 * KSPLIT;
+  constexpr int BK = KSPLIT == 1 ? GEMM_BK1 : 32 * KSPLIT;
   __shared__ float As[BK * (BM + 1)];
   __shared__ float Bs[BK * 33];
-  gemm_body<KSPLIT>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, As, Bs);
+  gemm_body<KSPLIT, A_KMAJOR, B_KMAJOR>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, As, Bs);
 }
 
 // Several independent GEMMs in ONE launch (same tiling): workgroup id -> (problem, tile).  Used for the data- and
 // weight-gradient GEMMs of a Linear layer, which only share their inputs: each alone fills a fraction of the chip.
-#define GEMM_GROUP_MAX 4
+// Problem 0 is the data gradient (A k-major, B n-major), problem 1 the weight gradient (A m-major, B n-major).
+#define GEMM_GROUP_MAX 2
 struct GemmGroup {
   GemmArgs g[GEMM_GROUP_MAX];
   int blk0[GEMM_GROUP_MAX + 1];
@@ -203,12 +247,12 @@ struct GemmGroup {
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GemmGroup grp) {
   __shared__ float As[128 * 33];
   __shared__ float Bs[128 * 33];
-  int p = 0;
-  while (p + 1 < grp.n && (int)blockIdx.x >= grp.blk0[p + 1]) ++p;
+  const int p = ((int)blockIdx.x >= grp.blk0[1]) ? 1 : 0;
   const int local = blockIdx.x - grp.blk0[p];
   const int bx = local % grp.nx[p], t = local / grp.nx[p];
   const int by = t % grp.ny[p], bz = t / grp.ny[p];
-  gemm_body<4>(grp.g[p], bx, by, bz, grp.nz[p], As, Bs);
+  if (p == 0) gemm_body<4, true, false>(grp.g[0], bx, by, bz, grp.nz[0], As, Bs);
+  else gemm_body<4, false, false>(grp.g[1], bx, by, bz, grp.nz[1], As, Bs);
 }
 
 extern "C" size_t mmvae_gemm_ws_floats(int M, int N, int splitk) {
@@ -237,19 +281,30 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   int variant = 4;
   if (tiles128 >= 256) variant = 1;   // measured: below that the single-stage 32x32 tiles are faster
   else if (K >= 384 && tiles32 <= 512 && splitk == 1) variant = 8;
-  const int bk = variant == 1 ? 32 : 32 * variant;
+  const int bk = variant == 1 ? GEMM_BK1 : 32 * variant;
   int kper = (K + splitk - 1) / splitk;
   kper = (kper + bk - 1) / bk * bk;
   const int nz = (K + kper - 1) / kper;
   g.kper = kper;
   if (nz > 1 && !ws) return MMVAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (variant == 1)
-    hipLaunchKernelGGL(gemm_kernel<1>, dim3(ntn, (M + 127) / 128, nz), dim3(256), 0, st, g);
-  else if (variant == 8)
-    hipLaunchKernelGGL(gemm_kernel<8>, dim3(ntn, (M + 31) / 32, nz), dim3(512), 0, st, g);
-  else
-    hipLaunchKernelGGL(gemm_kernel<4>, dim3(ntn, (M + 31) / 32, nz), dim3(256), 0, st, g);
+  // operand orientation is a template argument (per-slot address stride folds to a constant): the three forms a
+  // Linear layer needs are  fwd: A k-major, B k-major;  dgrad: A k-major, B n-major;  wgrad: A m-major, B n-major
+  const bool ak = sak == 1, bk_major = (sbk == 1 && sbn != 1);
+  if (!ak && sam != 1) return MMVAE_ERR_UNSUPPORTED;
+  if (!bk_major && sbn != 1) return MMVAE_ERR_UNSUPPORTED;
+  const dim3 grid(ntn, variant == 1 ? (M + 127) / 128 : (M + 31) / 32, nz), block(variant == 8 ? 512 : 256);
+#define GEMM_LAUNCH(V)                                                                            \
+  do {                                                                                            \
+    if (ak && bk_major) hipLaunchKernelGGL((gemm_kernel<V, true, true>), grid, block, 0, st, g);   \
+    else if (ak) hipLaunchKernelGGL((gemm_kernel<V, true, false>), grid, block, 0, st, g);         \
+    else if (!bk_major) hipLaunchKernelGGL((gemm_kernel<V, false, false>), grid, block, 0, st, g); \
+    else hipLaunchKernelGGL((gemm_kernel<V, false, true>), grid, block, 0, st, g);                 \
+  } while (0)
+  if (variant == 1) GEMM_LAUNCH(1);
+  else if (variant == 8) GEMM_LAUNCH(8);
+  else GEMM_LAUNCH(4);
+#undef GEMM_LAUNCH
   int rc = mmvae_launch_status();
   if (rc) return rc;
   if (nz > 1 && accumulate != MMVAE_ACC_DEFER) {
@@ -291,7 +346,7 @@ extern "C" int mmvae_linear_bwd_weight_splits(int M, int N, int K) {
   int variant = 4;
   if (tiles128 >= 256) variant = 1;
   else if (M >= 384 && tiles32 <= 512 && sk == 1) variant = 8;
-  const int bk = variant == 1 ? 32 : 32 * variant;
+  const int bk = variant == 1 ? GEMM_BK1 : 32 * variant;
   int kper = (M + sk - 1) / sk;
   kper = (kper + bk - 1) / bk * bk;
   return (M + kper - 1) / kper;
