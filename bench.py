@@ -87,6 +87,11 @@ def cpu_baseline(B, T, D, budget_s):
                       f"{1e3 * dt / n:.1f} ms/step"}
 
 
+# HBM bytes per launch of the conv2 forward kernel at B=128 from the PMC passes of tools/gpu_pmc.sh
+# (2 * FETCH_SIZE 10059.9 KB + WRITE_SIZE 4096.0 KB); bench.py cannot collect counters itself.
+CONV2_FWD_HBM_BYTES_B128 = int((2 * 10059.9 + 4096.0) * 1024)
+
+
 def dominant_kernel_roofline(B, device):
     """Average duration of the dominant kernel at this workload's shape, measured live with HIP events on the
     launch stream: the 32->32 channel 4x4/s2 gather conv at 32x32 -> 16x16 (encoder conv2; the decoder's
@@ -112,7 +117,10 @@ def dominant_kernel_roofline(B, device):
     ach = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "conv_gather_kernel<32,*> (conv2 fwd shape)", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "avg_us": round(us, 2), "traffic": None}
+            "avg_us": round(us, 2), "traffic": CONV2_FWD_HBM_BYTES_B128 if B == 128 else None,
+            "traffic_unit": "bytes/launch",
+            "traffic_source": "profiles/r01_e_pmc_conv_b128.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                              "FETCH doubled per the gfx950 16-B/lane correction); algorithmic 21.0e6"}
 
 
 def main():
