@@ -275,6 +275,53 @@ int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float*
                        int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 size_t mmvae_embed_ws_floats(int B, int T, int V);
 
+/* ---- One Transformer layer of the text towers per launch (csrc/txtlayer.hip) --------------------------------
+ * torch.nn.TransformerEncoderLayer / TransformerDecoderLayer (post-norm, gelu, dropout p) as the reference builds
+ * them: models/encoders.py:806-812 (Enc_TxtTransformer, d = 2V = 54, ff 128, 2 heads) and models/decoders.py:686-692
+ * (Dec_TxtTransformer, d = n_latents, memory length 1).  One workgroup per sequence, L <= 32 tokens; activations are
+ * (L, N, D) time-major like the rest of the text path.  Shapes outside mmvae_txt_layer_supported() use the op-by-op
+ * entry points below (same arithmetic, same dropout masks).
+ *   fwd writes y and the tensors backward needs; bwd runs the whole data-gradient chain and leaves the output
+ *   gradient of every GEMM in HBM (d_*), from which the weight gradients are mmvae_linear_bwd_weight calls over the
+ *   (L*N)-row tensors:  in_proj (d_qkv, x) | out_proj (d_a, ao) | linear1 (d_h1, x1 or x2) | linear2 (d_f, g)
+ *   decoder: cross out_proj (d_ca, vb) | cross value projection (d_v (N,D), mem).
+ *   lnws (N, n_norms, 2, D): per-sequence partials of the LayerNorm gamma / beta gradients (norm order 1, [2,] last). */
+typedef struct {
+  const float *in_w, *in_b;     /* self-attention in_proj (3D, D), (3D) */
+  const float *out_w, *out_b;   /* self-attention out_proj (D, D), (D) */
+  const float *l1_w, *l1_b;     /* linear1 (FF, D), (FF) */
+  const float *l2_w, *l2_b;     /* linear2 (D, FF), (D) */
+  const float *n1_g, *n1_b, *n2_g, *n2_b, *n3_g, *n3_b; /* LayerNorm weight / bias; n3 decoder only */
+  const float *x_in_w, *x_in_b; /* decoder: VALUE rows of the cross-attention in_proj (D, D), (D) */
+  const float *x_out_w, *x_out_b; /* decoder: cross-attention out_proj */
+} mmvae_txt_layer_w_t;
+typedef struct {
+  float *qkv;                   /* (L,N,3D) */
+  float *probs;                 /* (N,H,L,L) normalised attention weights before dropout, or NULL */
+  float *ao;                    /* (L,N,D) attention output (input of out_proj) */
+  float *xhat1, *rstd1, *x1;    /* LayerNorm1: (L,N,D), (L,N), output (L,N,D) */
+  float *vproj, *vb;            /* decoder: value projection (N,D); its dropout-masked broadcast (L,N,D) */
+  float *xhat2, *rstd2, *x2;    /* decoder LayerNorm2 */
+  float *h1, *g;                /* linear1 output (L,N,FF); dropout(gelu(h1)) (L,N,FF) */
+  float *xhatf, *rstdf;         /* last LayerNorm */
+} mmvae_txt_layer_saved_t;
+typedef struct {
+  float *d_f, *d_h1, *d_ca, *d_v, *d_a, *d_qkv, *lnws;
+} mmvae_txt_layer_grads_t;
+typedef struct {
+  mmvae_dropout_t attn, drop1, xattn, drop2, ffn, drop3; /* encoder: attn, drop1, ffn, drop2 */
+} mmvae_txt_layer_drop_t;
+int mmvae_txt_layer_supported(int L, int D, int FF, int NH, int dec);
+size_t mmvae_txt_layer_lnws_floats(int N, int D, int dec);
+int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const float* mem, float* y,
+                        const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
+                        const mmvae_txt_layer_drop_t* drop, int L, int N, int D, int FF, int NH, int dec,
+                        mmvae_stream_t stream);
+int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float* dmem,
+                        const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
+                        const mmvae_txt_layer_grads_t* grads, const mmvae_txt_layer_drop_t* drop, int L, int N, int D,
+                        int FF, int NH, int dec, mmvae_stream_t stream);
+
 /* Scaled-dot-product attention with key padding mask for L,S <= 64 (nn.MultiheadAttention core).
  *   q (L*N, ldq) rows r = l*N+n, head h at columns [h*hd,(h+1)*hd); k, v (S*N, ld) likewise.
  *   kpm (N,S) bytes, 1 = ignore key (may be NULL); with mask_is_valid != 0 the bytes are the batch's validity

@@ -85,6 +85,10 @@ SIGNATURES = {
     "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_dp, c_p]),
     "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_dp, c_p]),
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_txt_layer_supported": (c_i, [c_i] * 5),
+    "mmvae_txt_layer_lnws_floats": (c_sz, [c_i] * 3),
+    "mmvae_txt_layer_fwd": (c_i, [c_p] * 7 + [c_i] * 6 + [c_p]),
+    "mmvae_txt_layer_bwd": (c_i, [c_p] * 8 + [c_i] * 6 + [c_p]),
     "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_i, c_dp, c_p]),
     "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_dp, c_p]),
     "mmvae_layernorm_residual_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_dp, c_p]),
@@ -119,6 +123,24 @@ SIGNATURES = {
 }
 ACC_DEFER = 2
 MAX_SEGMENTS = 64
+
+
+class TxtLayerW(ctypes.Structure):
+    _fields_ = [(k, c_p) for k in ("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_g", "n1_b",
+                                   "n2_g", "n2_b", "n3_g", "n3_b", "x_in_w", "x_in_b", "x_out_w", "x_out_b")]
+
+
+class TxtLayerSaved(ctypes.Structure):
+    _fields_ = [(k, c_p) for k in ("qkv", "probs", "ao", "xhat1", "rstd1", "x1", "vproj", "vb", "xhat2", "rstd2", "x2",
+                                   "h1", "g", "xhatf", "rstdf")]
+
+
+class TxtLayerGrads(ctypes.Structure):
+    _fields_ = [(k, c_p) for k in ("d_f", "d_h1", "d_ca", "d_v", "d_a", "d_qkv", "lnws")]
+
+
+class TxtLayerDrop(ctypes.Structure):
+    _fields_ = [(k, Dropout) for k in ("attn", "drop1", "xattn", "drop2", "ffn", "drop3")]
 
 
 class ReduceSegments(ctypes.Structure):

@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from .. import hipops as H
 from .. import ops
+from . import encoders
 from .NetworkTypes import NetworkRoles, NetworkTypes
 from .encoders import VaeComponent
 from .nn_modules import DropoutState, HipLayerNorm, HipLinear, HipSelfAttention, ModuleWrap, PositionalEncoding
@@ -79,7 +80,22 @@ class HipTransformerDecoderLayer(nn.Module):
         self.norm2 = HipLayerNorm(d)
         self.norm3 = HipLayerNorm(d)
 
+    def fused_params(self):
+        a, c = self.self_attn, self.multihead_attn
+        return {"in_w": a.in_proj_weight, "in_b": a.in_proj_bias, "out_w": a.out_proj.weight, "out_b": a.out_proj.bias,
+                "l1_w": self.linear1.weight, "l1_b": self.linear1.bias, "l2_w": self.linear2.weight,
+                "l2_b": self.linear2.bias, "n1_g": self.norm1.weight, "n1_b": self.norm1.bias,
+                "n2_g": self.norm2.weight, "n2_b": self.norm2.bias, "n3_g": self.norm3.weight, "n3_b": self.norm3.bias,
+                "x_in_w": c.in_proj_weight, "x_in_b": c.in_proj_bias, "x_out_w": c.out_proj.weight,
+                "x_out_b": c.out_proj.bias}
+
     def forward(self, x, mem, mask_u8, ds=None):
+        L, _, d = x.shape
+        ff, nh = self.linear1.out_features, self.self_attn.nhead
+        if encoders.FUSED_TXT_LAYERS and ops.txt_layer_supported(L, d, ff, nh, True):
+            p = self.fused_params()
+            return ops.txt_layer(x, mem, mask_u8, ops.TxtLayerMeta(d, ff, nh, True, ds), p,
+                                 {k: v.grad for k, v in p.items()})
         if ds is None:
             x = self.norm1(self.self_attn(x, mask_u8), x)
             x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time

@@ -4,6 +4,8 @@ enc_mu_logvar)`, looked up by string in models/vae.py; reference: models/encoder
 Same constructor signatures, attributes (latent_dim, data_dim, out_dim) and state_dict key names as the
 reference; the arithmetic runs on the gfx950 kernels of the C-ABI library (no torch.nn.functional compute).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -133,6 +135,9 @@ class Enc_CNN(VaeEncoder):
                                   "use encoder: CNN2 (see DESIGN.md, out of scope)")
 
 
+FUSED_TXT_LAYERS = os.environ.get("MMVAE_FUSED_TXT", "1") != "0"
+
+
 class HipTransformerEncoderLayer(nn.Module):
     """torch.nn.TransformerEncoderLayer (post-norm, gelu) parameter layout on the HIP kernels."""
 
@@ -144,8 +149,22 @@ class HipTransformerEncoderLayer(nn.Module):
         self.norm1 = HipLayerNorm(d)
         self.norm2 = HipLayerNorm(d)
 
+    def fused_params(self):
+        a = self.self_attn
+        return {"in_w": a.in_proj_weight, "in_b": a.in_proj_bias, "out_w": a.out_proj.weight, "out_b": a.out_proj.bias,
+                "l1_w": self.linear1.weight, "l1_b": self.linear1.bias, "l2_w": self.linear2.weight,
+                "l2_b": self.linear2.bias, "n1_g": self.norm1.weight, "n1_b": self.norm1.bias,
+                "n2_g": self.norm2.weight, "n2_b": self.norm2.bias}
+
     def forward(self, x, mask_u8, ds=None):
         """`ds`: dict of DropSpec for train mode (attn, drop1, ffn, drop2) or None"""
+        L, _, d = x.shape
+        ff, nh = self.linear1.out_features, self.self_attn.nhead
+        if FUSED_TXT_LAYERS and ops.txt_layer_supported(L, d, ff, nh, False):
+            # one workgroup per sequence runs the whole layer (csrc/txtlayer.hip); same arithmetic and dropout masks
+            p = self.fused_params()
+            return ops.txt_layer(x, None, mask_u8, ops.TxtLayerMeta(d, ff, nh, False, ds), p,
+                                 {k: v.grad for k, v in p.items()})
         if ds is None:
             x = self.norm1(self.self_attn(x, mask_u8), x)
             return self.norm2(self.linear2(self.linear1(x)), x)

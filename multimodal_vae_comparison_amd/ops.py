@@ -782,6 +782,182 @@ class Attention(Function):
         return dqkv, None, None, None, None
 
 
+def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
+    """dW (+)= dy2^T act(x2), db (+)= colsum(dy2) for dy2 (M,N), x2 (M,K): the weight half of Linear.backward.
+    Returns the tensors to hand back to autograd (None when accumulated into the preset gradient views)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dw, acc_w, ret_w = _new_like_param(w, gw)
+    db, ret_b = None, None
+    if b is not None:
+        if gb is not None:
+            db = gb
+        else:
+            db = ret_b = torch.empty(N, device=dy2.device)
+    nws = H.lib().mmvae_linear_bwd_weight_ws_floats(M, N, K)
+    nz = H.lib().mmvae_linear_bwd_weight_splits(M, N, K)
+    defer = _defer(gw, gb if b is not None else gw)
+    if defer:
+        ws = GradReducer.alloc(nws, dy2.device) if nz > 1 else None
+        acc = H.ACC_DEFER
+    else:
+        ws, acc = H.workspace(nws, dy2.device), acc_w
+    _call("mmvae_linear_bwd_weight", H.ptr(dy2), H.ptr(x2), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, x_act, acc,
+          H.stream())
+    if defer and nz > 1:
+        GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
+        if db is not None:
+            GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
+    return ret_w, ret_b
+
+
+class TxtLayerMeta:
+    """static description of one fused transformer layer call (shapes + the DropSpecs of its dropout sites)"""
+
+    def __init__(self, D, FF, NH, dec, drops):
+        self.D, self.FF, self.NH, self.dec, self.drops = D, FF, NH, bool(dec), drops or {}
+
+    def c_drop(self, L, N):
+        if not self.drops:
+            return None
+        t = H.TxtLayerDrop()
+        n_el = {"attn": N * self.NH * L * L, "drop1": L * N * self.D, "xattn": N * self.NH * L, "drop2": L * N * self.D,
+                "ffn": L * N * self.FF, "drop3": L * N * self.D}
+        for k, n in n_el.items():
+            d = self.drops.get(k)
+            if d is not None:
+                d.note(n)
+                setattr(t, k, H.Dropout(d.state.data_ptr(), d.slot, d.site, d.p))
+        return ctypes.byref(t)
+
+
+_TXT_ENC_PARAMS = ("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_g", "n1_b", "n2_g", "n2_b")
+_TXT_DEC_PARAMS = _TXT_ENC_PARAMS + ("n3_g", "n3_b", "x_in_w", "x_in_b", "x_out_w", "x_out_b")
+
+
+def txt_layer_supported(L, D, FF, NH, dec):
+    return bool(H.lib().mmvae_txt_layer_supported(int(L), int(D), int(FF), int(NH), int(bool(dec))))
+
+
+class TxtLayer(Function):
+    """One post-norm Transformer layer of the text towers in ONE launch per direction (csrc/txtlayer.hip):
+    torch.nn.TransformerEncoderLayer, or TransformerDecoderLayer over a length-1 memory (`mem` (N,D))."""
+
+    @staticmethod
+    def forward(ctx, x, mem, mask_u8, meta, grads, *params):
+        x = H.f32c(x)
+        L, N, D = x.shape
+        FF, NH, dec = meta.FF, meta.NH, meta.dec
+        names = _TXT_DEC_PARAMS if dec else _TXT_ENC_PARAMS
+        P = dict(zip(names, params))
+        dev = x.device
+        w = H.TxtLayerW()
+        for k in names:
+            setattr(w, k, P[k].data_ptr())
+        if dec:
+            mem = H.f32c(mem)
+            w.x_in_w = P["x_in_w"].data_ptr() + 4 * 2 * D * D       # value rows of the cross in_proj
+            w.x_in_b = P["x_in_b"].data_ptr() + 4 * 2 * D
+        e = lambda *sh: torch.empty(*sh, device=dev)
+        S = {"qkv": e(L, N, 3 * D), "ao": e(L, N, D), "xhat1": e(L, N, D), "rstd1": e(L, N), "x1": e(L, N, D),
+             "h1": e(L, N, FF), "g": e(L, N, FF), "xhatf": e(L, N, D), "rstdf": e(L, N)}
+        if dec:
+            S.update({"vproj": e(N, D), "vb": e(L, N, D), "xhat2": e(L, N, D), "rstd2": e(L, N), "x2": e(L, N, D)})
+        sv = H.TxtLayerSaved()
+        for k, t in S.items():
+            setattr(sv, k, t.data_ptr())
+        y = e(L, N, D)
+        _call("mmvae_txt_layer_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(mem) if dec else None, H.ptr(y), ctypes.byref(w),
+              ctypes.byref(sv), meta.c_drop(L, N), L, N, D, FF, NH, int(dec), H.stream())
+        ctx.meta, ctx.names, ctx.grads, ctx.S = meta, names, grads, S
+        ctx.save_for_backward(x, mem if dec else None, mask_u8, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mem, mask_u8, *params = ctx.saved_tensors
+        meta, names, G, S = ctx.meta, ctx.names, ctx.grads, ctx.S
+        L, N, D = x.shape
+        FF, NH, dec = meta.FF, meta.NH, meta.dec
+        P = dict(zip(names, params))
+        dev = x.device
+        dy = H.f32c(dy)
+        w = H.TxtLayerW()
+        for k in names:
+            setattr(w, k, P[k].data_ptr())
+        if dec:
+            w.x_in_w = P["x_in_w"].data_ptr() + 4 * 2 * D * D
+            w.x_in_b = P["x_in_b"].data_ptr() + 4 * 2 * D
+        sv = H.TxtLayerSaved()
+        for k, t in S.items():
+            setattr(sv, k, t.data_ptr())
+        e = lambda *sh: torch.empty(*sh, device=dev)
+        nln = 3 if dec else 2
+        ln_names = [("n1_g", "n1_b"), ("n2_g", "n2_b")] + ([("n3_g", "n3_b")] if dec else [])
+        ln_defer = all(_defer(G.get(g), G.get(b)) for g, b in ln_names)
+        lnws = GradReducer.alloc(N * nln * 2 * D, dev) if ln_defer else e(N * nln * 2 * D)
+        T = {"d_f": e(L, N, D), "d_h1": e(L, N, FF), "d_a": e(L, N, D), "d_qkv": e(L, N, 3 * D)}
+        if dec:
+            T.update({"d_ca": e(L, N, D), "d_v": e(N, D)})
+        gr = H.TxtLayerGrads()
+        for k, t in T.items():
+            setattr(gr, k, t.data_ptr())
+        gr.lnws = lnws.data_ptr()
+        dx = e(L, N, D)
+        dmem = e(N, D) if dec else None
+        drops = meta.drops
+        dstruct = None
+        if drops:
+            t = H.TxtLayerDrop()
+            for k, d in drops.items():
+                if d is not None:
+                    setattr(t, k, H.Dropout(d.state.data_ptr(), d.slot, d.site, d.p))
+            dstruct = ctypes.byref(t)
+        _call("mmvae_txt_layer_bwd", H.ptr(dy), H.ptr(mask_u8), H.ptr(dx), H.ptr(dmem), ctypes.byref(w),
+              ctypes.byref(sv), ctypes.byref(gr), dstruct, L, N, D, FF, NH, int(dec), H.stream())
+        M = L * N
+        ret = {}
+
+        def wg(dyt, xt, wn, bn, wsl=None):
+            wt, bt, gw, gb = P[wn], P[bn], G.get(wn), G.get(bn)
+            if wsl is not None:       # a row slice of the parameter (value rows of the cross in_proj)
+                wt, bt = wt[wsl], bt[wsl]
+                gw = gw[wsl] if gw is not None else None
+                gb = gb[wsl] if gb is not None else None
+            rw, rb = _linear_wgrad(dyt, xt, wt, bt, gw, gb)
+            if wsl is None:
+                ret[wn], ret[bn] = rw, rb
+            elif rw is not None:      # no preset gradient views: embed the slice gradient in a full-size zero tensor
+                fw, fb = torch.zeros_like(P[wn]), torch.zeros_like(P[bn])
+                fw[wsl], fb[wsl] = rw, rb
+                ret[wn], ret[bn] = fw, fb
+            else:
+                ret[wn], ret[bn] = None, None
+
+        wg(T["d_qkv"].view(M, 3 * D), x.view(M, D), "in_w", "in_b")
+        wg(T["d_a"].view(M, D), S["ao"].view(M, D), "out_w", "out_b")
+        wg(T["d_h1"].view(M, FF), (S["x2"] if dec else S["x1"]).view(M, D), "l1_w", "l1_b")
+        wg(T["d_f"].view(M, D), S["g"].view(M, FF), "l2_w", "l2_b")
+        if dec:
+            wg(T["d_ca"].view(M, D), S["vb"].view(M, D), "x_out_w", "x_out_b")
+            wg(T["d_v"], mem, "x_in_w", "x_in_b", slice(2 * D, 3 * D))
+        if ln_defer:
+            for k, (gn, bn) in enumerate(ln_names):
+                GradReducer.add(lnws.data_ptr() + 4 * (k * 2 * D), G[gn], N, D, nln * 2 * D)
+                GradReducer.add(lnws.data_ptr() + 4 * (k * 2 * D + D), G[bn], N, D, nln * 2 * D)
+                ret[gn], ret[bn] = None, None
+        else:
+            sums = lnws.view(N, nln, 2, D).sum(0)
+            for k, (gn, bn) in enumerate(ln_names):
+                ret[gn], ret[bn] = sums[k, 0].contiguous(), sums[k, 1].contiguous()
+        return (dx, dmem, None, None, None) + tuple(ret[k] for k in names)
+
+
+def txt_layer(x, mem, mask_u8, meta, params, grads):
+    names = _TXT_DEC_PARAMS if meta.dec else _TXT_ENC_PARAMS
+    return TxtLayer.apply(x, mem, mask_u8, meta, grads, *[params[k] for k in names])
+
+
 class LayerNormResidual(Function):
     """y = LayerNorm(x + r); r None, same shape, or (N,d) broadcast over the leading (time) axis"""
 

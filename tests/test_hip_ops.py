@@ -339,3 +339,51 @@ def test_adam_amsgrad_flat_matches_torch(ops):
         ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, 0, step_dev, 1.0, True)
         assert float(gd.abs().max()) == 0.0
         check(p, pr.detach(), 2e-6, f"adam step {it}")
+
+
+@pytest.mark.parametrize("dec,L,N,d,train", [(False, 32, 128, 54, False), (False, 32, 16, 54, True), (False, 5, 6, 54, True),
+                                             (True, 32, 128, 32, False), (True, 32, 16, 32, True), (True, 9, 7, 32, True),
+                                             (False, 6, 5, 32, True), (True, 6, 5, 54, True)])
+def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
+    """csrc/txtlayer.hip (one launch per layer and direction) against the op-by-op kernels (each checked against
+    torch above): outputs, input gradients and every parameter gradient, with identical dropout masks."""
+    from multimodal_vae_comparison_amd.models import decoders, encoders
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    torch.manual_seed(L * N + d + int(dec))
+    layer = (decoders.HipTransformerDecoderLayer if dec else encoders.HipTransformerEncoderLayer)(d, 2, 128).to(DEV)
+    for p in layer.parameters():          # non-trivial LayerNorm parameters and biases
+        p.data.add_(0.05 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(L + N)
+    x = torch.randn(L, N, d, generator=g).to(DEV)
+    mem = torch.randn(N, d, generator=g).to(DEV)
+    lens = torch.randint(1, L + 1, (N,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV)
+    dy = torch.randn(L, N, d, generator=g).to(DEV)
+    st = DropoutState().to(DEV)
+    sites = ("attn", "drop1", "xattn", "drop2", "ffn", "drop3") if dec else ("attn", "drop1", "ffn", "drop2")
+    ds = {k: st.spec(0, 0, i + 1, 0.1, k) for i, k in enumerate(sites)} if train else None
+
+    def run(fused):
+        encoders.FUSED_TXT_LAYERS = fused
+        for p in layer.parameters():
+            p.grad = None
+        xg, mg = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+        out = layer(xg, mg, mask, ds) if dec else layer(xg, mask, ds)
+        out.backward(dy)
+        return out.detach(), xg.grad, (mg.grad if dec else None), {k: p.grad.clone() for k, p in layer.named_parameters()
+                                                                    if p.grad is not None}
+
+    try:
+        assert ops.txt_layer_supported(L, d, 128, 2, dec)
+        yf, dxf, dmf, gf = run(True)
+        yu, dxu, dmu, gu = run(False)
+    finally:
+        encoders.FUSED_TXT_LAYERS = True
+    check(yf, yu, 2e-5, "layer out")
+    check(dxf, dxu, 5e-5, "layer dx")
+    if dec:
+        check(dmf, dmu, 5e-5, "layer dmem")
+    assert set(gf) == set(gu), set(gf) ^ set(gu)
+    for k in gu:
+        check(gf[k], gu[k], 5e-5, f"grad {k}")
