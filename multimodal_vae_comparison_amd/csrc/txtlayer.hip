@@ -55,17 +55,18 @@ __device__ __forceinline__ Lane lane_ids() {
   return l;
 }
 
-// C[32][N] = A_lds[32][K] * W^T, W [N][K] row-major in global memory (k contiguous).  Waves take N tiles round robin.
-// epi(n, nvalid, acc) consumes one 32 x 32 tile (column n = nt*32 + li).
-template <int K, typename Epi>
-__device__ __forceinline__ void gemm_kc(const float* __restrict__ A, const int PA, const float* __restrict__ W,
-                                        const int N, const Lane& l, Epi&& epi) {
-  constexpr int KQ = (K + 3) / 4;
-  for (int nt = l.wave; nt * 32 < N; nt += 4) {
+// Weight operand of one 32-column tile, held in registers.  The weights are not staged through LDS: every lane reads
+// its own column's K values straight from L2.  `load` is separate from `mma` so that a phase can issue the NEXT
+// GEMM's weight loads before its own barrier (the only thing a one-workgroup-per-sequence kernel can overlap).
+template <int K>
+struct WTile {
+  static constexpr int KQ = (K + 3) / 4;
+  float2 b[KQ];
+  // W [N][K] row-major (k contiguous): lane's row n, k = 4q + 2 lh + {0, 1}
+  __device__ __forceinline__ void load_kc(const float* __restrict__ W, const int N, const int nt, const Lane& l) {
     const int n = nt * 32 + l.li;
     const bool nv = n < N;
     const float* wr = W + (size_t)(nv ? n : 0) * K;
-    float2 b[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int k = 4 * q + 2 * l.lh;
@@ -73,6 +74,23 @@ __device__ __forceinline__ void gemm_kc(const float* __restrict__ A, const int P
       b[q] = *reinterpret_cast<const float2*>(wr + (kv ? k : 0));
       if (!kv || !nv) b[q] = make_float2(0.f, 0.f);
     }
+  }
+  // W [K][NJ] row-major (j contiguous): lane's column j
+  __device__ __forceinline__ void load_jc(const float* __restrict__ W, const int NJ, const int nt, const Lane& l) {
+    const int j = nt * 32 + l.li;
+    const bool jv = j < NJ;
+    const float* wc = W + (jv ? j : 0);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int k = 4 * q + 2 * l.lh;
+      const bool kv0 = (4 * q + 4 <= K) || (k < K), kv1 = (4 * q + 4 <= K) || (k + 1 < K);
+      b[q].x = wc[(size_t)(kv0 ? k : 0) * NJ];
+      b[q].y = wc[(size_t)(kv1 ? k + 1 : 0) * NJ];
+      if (!kv0 || !jv) b[q].x = 0.f;
+      if (!kv1 || !jv) b[q].y = 0.f;
+    }
+  }
+  __device__ __forceinline__ f32x16 mma(const float* __restrict__ A, const int PA, const Lane& l) const {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -83,40 +101,64 @@ __device__ __forceinline__ void gemm_kc(const float* __restrict__ A, const int P
       acc = mfma(a.x, b[q].x, acc);
       acc = mfma(a.y, b[q].y, acc);
     }
-    epi(n, nv, acc);
+    return acc;
+  }
+};
+
+// C[32][N] = A_lds[32][K] * (weights); waves take the 32-column tiles round robin; the first tile of every wave may
+// have been prefetched into `pre` (prefetch_* below).  epi(col, col_valid, acc) consumes one tile.
+template <int K, bool KC, typename Epi>
+__device__ __forceinline__ void gemm_tiles(const float* __restrict__ A, const int PA, const float* __restrict__ W,
+                                           const int N, const Lane& l, WTile<K>& pre, const bool have_pre, Epi&& epi) {
+  for (int nt = l.wave; nt * 32 < N; nt += 4) {
+    if (!(have_pre && nt == l.wave)) {
+      if (KC) pre.load_kc(W, N, nt, l);
+      else pre.load_jc(W, N, nt, l);
+    }
+    const f32x16 acc = pre.mma(A, PA, l);
+    const int col = nt * 32 + l.li;
+    epi(col, col < N, acc);
   }
 }
-
-// C[32][NJ] = A_lds[32][K] * W, W [K][NJ] row-major in global memory (j contiguous): data-gradient GEMMs
+template <int K, bool KC>
+__device__ __forceinline__ void prefetch_tile(WTile<K>& pre, const float* __restrict__ W, const int N, const Lane& l) {
+  if (l.wave * 32 < N) {
+    if (KC) pre.load_kc(W, N, l.wave, l);
+    else pre.load_jc(W, N, l.wave, l);
+  }
+}
+template <int K, typename Epi>
+__device__ __forceinline__ void gemm_kc(const float* __restrict__ A, const int PA, const float* __restrict__ W,
+                                        const int N, const Lane& l, Epi&& epi) {
+  WTile<K> w;
+  gemm_tiles<K, true>(A, PA, W, N, l, w, false, epi);
+}
 template <int K, typename Epi>
 __device__ __forceinline__ void gemm_jc(const float* __restrict__ A, const int PA, const float* __restrict__ W,
                                         const int NJ, const Lane& l, Epi&& epi) {
-  constexpr int KQ = (K + 3) / 4;
-  for (int nt = l.wave; nt * 32 < NJ; nt += 4) {
-    const int j = nt * 32 + l.li;
-    const bool jv = j < NJ;
-    const float* wc = W + (jv ? j : 0);
-    float b0[KQ], b1[KQ];
+  WTile<K> w;
+  gemm_tiles<K, false>(A, PA, W, NJ, l, w, false, epi);
+}
+
+// rows t < L of a (L, N, COLS) tensor for sequence n -> LDS [32][P]: all loads issued before the first store
+// (clamped addresses, no predicated loads), rows >= L zero.
+template <int COLS>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const int P, const float* __restrict__ src,
+                                           const size_t N, const int n, const int L, const Lane& l) {
+  constexpr int NIT = (T * COLS + 255) / 256;
+  float v[NIT];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      const int k = 4 * q + 2 * l.lh;
-      const bool kv0 = (4 * q + 4 <= K) || (k < K), kv1 = (4 * q + 4 <= K) || (k + 1 < K);
-      b0[q] = wc[(size_t)(kv0 ? k : 0) * NJ];
-      b1[q] = wc[(size_t)(kv1 ? k + 1 : 0) * NJ];
-      if (!kv0 || !jv) b0[q] = 0.f;
-      if (!kv1 || !jv) b1[q] = 0.f;
-    }
-    f32x16 acc;
+  for (int i = 0; i < NIT; ++i) {
+    const int e = l.tid + 256 * i;
+    const int t = e / COLS, c = e - t * COLS;
+    const int tc = t < L ? t : L - 1;
+    v[i] = src[((size_t)tc * N + n) * COLS + c];
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* ar = A + l.li * PA + 2 * l.lh;
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      const float2 a = *reinterpret_cast<const float2*>(ar + 4 * q);
-      acc = mfma(a.x, b0[q], acc);
-      acc = mfma(a.y, b1[q], acc);
-    }
-    epi(j, jv, acc);
+  for (int i = 0; i < NIT; ++i) {
+    const int e = l.tid + 256 * i;
+    const int t = e / COLS, c = e - t * COLS;
+    if (e < T * COLS) dst[t * P + c] = t < L ? v[i] : 0.f;
   }
 }
 
@@ -261,15 +303,15 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
 
   for (int i = l.tid; i < SMEM / 4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  for (int e = l.tid; e < T * D; e += 256) {
-    const int t = e / D, c = e - t * D;
-    if (t < L) XB[t * PX + c] = x[((size_t)t * LN + n) * D + c];
-  }
+  WTile<D> wd;       // prefetched first weight tile of the next K = D GEMM
+  WTile<FF> wf;      // ... of linear2
+  prefetch_tile<D, true>(wd, w.in_w, 3 * D, l);
+  stage_rows<D>(XB, PX, x, LN, n, L, l);
   if (l.tid < T) s_valid[l.tid] = (l.tid < L && valid[(size_t)n * L + l.tid] != 0) ? 1.f : 0.f;
   __syncthreads();
 
   // ---- QKV projection ----
-  gemm_kc<D>(XB, PX, w.in_w, 3 * D, l, [&](int col, bool cv, const f32x16& acc) {
+  gemm_tiles<D, true>(XB, PX, w.in_w, 3 * D, l, wd, true, [&](int col, bool cv, const f32x16& acc) {
     if (!cv) return;
     const float b = w.in_b[col];
 #pragma unroll
@@ -280,6 +322,7 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
       if (t < L) sv.qkv[((size_t)t * LN + n) * (3 * D) + col] = v;
     }
   });
+  prefetch_tile<D, true>(wd, w.out_w, D, l);
   __syncthreads();
 
   // ---- attention: one wave per head ----
@@ -315,7 +358,7 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
   // ---- out_proj, + x, dropout1 -> RB ----
   {
     const DropKey dk = drop_key(dr.drop1);
-    gemm_kc<D>(AB, PX, w.out_w, D, l, [&](int col, bool cv, const f32x16& acc) {
+    gemm_tiles<D, true>(AB, PX, w.out_w, D, l, wd, true, [&](int col, bool cv, const f32x16& acc) {
       if (!cv) return;
       const float b = w.out_b[col];
 #pragma unroll
@@ -326,6 +369,7 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
       }
     });
   }
+  if (!G::DEC) prefetch_tile<D, true>(wd, w.l1_w, FF, l);
   __syncthreads();
   layernorm_rows<D>(RB, PX, w.n1_g, w.n1_b, l,
                     [&](int t, int c, float xh, float yv) {
@@ -373,6 +417,7 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
         }
       });
     }
+    prefetch_tile<D, true>(wd, w.l1_w, FF, l);
     __syncthreads();
     layernorm_rows<D>(RB, PX, w.n2_g, w.n2_b, l,
                       [&](int t, int c, float xh, float yv) {
@@ -390,7 +435,7 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
   // ---- FFN: linear1 -> GELU, dropout -> linear2, + residual, dropout -> LayerNorm ----
   {
     const DropKey dk = drop_key(dr.ffn);
-    gemm_kc<D>(X2B, PX, w.l1_w, FF, l, [&](int col, bool cv, const f32x16& acc) {
+    gemm_tiles<D, true>(X2B, PX, w.l1_w, FF, l, wd, true, [&](int col, bool cv, const f32x16& acc) {
       if (!cv) return;
       const float b = w.l1_b[col];
 #pragma unroll
@@ -407,10 +452,11 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
       }
     });
   }
+  prefetch_tile<FF, true>(wf, w.l2_w, D, l);
   __syncthreads();
   {
     const DropKey dk = drop_key(G::DEC ? dr.drop3 : dr.drop2);
-    gemm_kc<FF>(HB, PH, w.l2_w, D, l, [&](int col, bool cv, const f32x16& acc) {
+    gemm_tiles<FF, true>(HB, PH, w.l2_w, D, l, wf, true, [&](int col, bool cv, const f32x16& acc) {
       if (!cv) return;
       const float b = w.l2_b[col];
 #pragma unroll
@@ -464,18 +510,11 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
 
   for (int i = l.tid; i < SMEM / 4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  for (int e = l.tid; e < T * D; e += 256) {
-    const int t = e / D, c = e - t * D;
-    if (t < L) {
-      const size_t o = ((size_t)t * LN + n) * D + c;
-      DYB[t * PX + c] = dy[o];
-      XHB[t * PX + c] = sv.xhatf[o];
-    }
-  }
-  for (int e = l.tid; e < T * 3 * D; e += 256) {
-    const int t = e / (3 * D), c = e - t * (3 * D);
-    if (t < L) QB[t * PQ + c] = sv.qkv[((size_t)t * LN + n) * (3 * D) + c];
-  }
+  WTile<D> wd;        // prefetched first weight tile of the next K = D data-gradient GEMM
+  prefetch_tile<D, false>(wd, w.l2_w, FF, l);
+  stage_rows<D>(DYB, PX, dy, LN, n, L, l);
+  stage_rows<D>(XHB, PX, sv.xhatf, LN, n, L, l);
+  stage_rows<3 * D>(QB, PQ, sv.qkv, LN, n, L, l);
   if (l.tid < T) {
     s_valid[l.tid] = (l.tid < L && valid[(size_t)n * L + l.tid] != 0) ? 1.f : 0.f;
     const size_t row = (size_t)l.tid * LN + n;
@@ -512,18 +551,26 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
       if (t < L) gr.d_f[o] = m;           // gradient of linear2's output
     });
   }
+  WTile<FF> wf;
+  prefetch_tile<FF, false>(wf, w.l1_w, D, l);
   __syncthreads();
   {
     const DropKey dk = drop_key(dr.ffn);
-    gemm_jc<D>(GAB, PX, w.l2_w, FF, l, [&](int col, bool cv, const f32x16& acc) {
+    gemm_tiles<D, false>(GAB, PX, w.l2_w, FF, l, wd, true, [&](int col, bool cv, const f32x16& acc) {
       if (!cv) return;
+      float hv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {      // all 16 loads in flight before the first use
+        const int t = acc_row(r, l.lh);
+        hv[r] = sv.h1[((size_t)(t < L ? t : L - 1) * LN + n) * FF + col];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int t = acc_row(r, l.lh);
         const size_t o = ((size_t)t * LN + n) * FF + col;
         float v = 0.f;
         if (t < L) {
-          v = acc[r] * drop_mul(dk, (uint32_t)o) * dev_gelu_grad(sv.h1[o]);
+          v = acc[r] * drop_mul(dk, (uint32_t)o) * dev_gelu_grad(hv[r]);
           gr.d_h1[o] = v;                 // gradient of linear1's output
         }
         DHB[t * PH + col] = v;
@@ -532,7 +579,7 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
   }
   __syncthreads();
   // d(FFN input) = DRB + DHB * W1  -> DYB (gradient of the previous LayerNorm's output)
-  gemm_jc<FF>(DHB, PH, w.l1_w, D, l, [&](int col, bool cv, const f32x16& acc) {
+  gemm_tiles<FF, false>(DHB, PH, w.l1_w, D, l, wf, true, [&](int col, bool cv, const f32x16& acc) {
     if (!cv) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -544,10 +591,7 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
 
   if (G::DEC) {
     // ================= cross-attention block =================
-    for (int e = l.tid; e < T * D; e += 256) {
-      const int t = e / D, c = e - t * D;
-      XHB[t * PX + c] = t < L ? sv.xhat2[((size_t)t * LN + n) * D + c] : 0.f;
-    }
+    stage_rows<D>(XHB, PX, sv.xhat2, LN, n, L, l);
     __syncthreads();
     ln_param_partials(1);
     {
@@ -591,10 +635,8 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
   }
 
   // ================= self-attention block =================
-  for (int e = l.tid; e < T * D; e += 256) {
-    const int t = e / D, c = e - t * D;
-    XHB[t * PX + c] = t < L ? sv.xhat1[((size_t)t * LN + n) * D + c] : 0.f;
-  }
+  stage_rows<D>(XHB, PX, sv.xhat1, LN, n, L, l);
+  prefetch_tile<D, false>(wd, w.out_w, D, l);
   __syncthreads();
   ln_param_partials(0);
   {
@@ -609,11 +651,13 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
   }
   __syncthreads();
   // d(attention output) -> XHB (reused)
-  gemm_jc<D>(GAB, PX, w.out_w, D, l, [&](int col, bool cv, const f32x16& acc) {
+  gemm_tiles<D, false>(GAB, PX, w.out_w, D, l, wd, true, [&](int col, bool cv, const f32x16& acc) {
     if (!cv) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) XHB[acc_row(r, l.lh) * PX + col] = acc[r];
   });
+  WTile<3 * D> wq;    // in_proj columns for the last GEMM: in flight under the attention backward
+  prefetch_tile<3 * D, false>(wq, w.in_w, D, l);
   __syncthreads();
 
   // attention backward, one wave per head; DO = XHB
@@ -727,7 +771,7 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
     if (t < L) gr.d_qkv[((size_t)t * LN + n) * (3 * D) + c] = DQB[t * PG + c];
   }
   // dx = DRB + DQB * W_in
-  gemm_jc<3 * D>(DQB, PG, w.in_w, D, l, [&](int col, bool cv, const f32x16& acc) {
+  gemm_tiles<3 * D, false>(DQB, PG, w.in_w, D, l, wq, true, [&](int col, bool cv, const f32x16& acc) {
     if (!cv) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
