@@ -145,7 +145,7 @@ def main():
     if world > 1:
         opt.grad_scale = 1.0 / world                       # all-reduce(sum) then average inside the Adam kernel
     batch = cdsprites_batch(a.batch, a.seq, seed=1 + rank, device=dev)
-    tr.capture(batch)
+    tr.capture(batch, world)      # world 1: the Adam step is part of the captured graph
 
     def barrier():
         if world > 1:

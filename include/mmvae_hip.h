@@ -250,6 +250,19 @@ int mmvae_lincomb_rows_fwd(const float* V, const float* W_host, float* out, int 
 int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, int n_rows, int B, int n_out,
                            mmvae_stream_t stream);
 
+/* The same with the rows in separate tensors (p[n] -> B floats) and one upstream-gradient scalar per output
+ * (g[k] device pointer or NULL = that output does not take part in backward); d rows are written to drows->p[n]. */
+typedef struct {
+  const float* p[16];
+} mmvae_rowptrs_t;
+typedef struct {
+  const float* g[4];
+} mmvae_gptrs_t;
+int mmvae_lincomb_rowptrs_fwd(const mmvae_rowptrs_t* rows, const float* W_host, float* out, int n_rows, int B,
+                              int n_out, mmvae_stream_t stream);
+int mmvae_lincomb_rowptrs_bwd(const mmvae_gptrs_t* gout, const float* W_host, const mmvae_rowptrs_t* drows,
+                              int n_rows, int B, int n_out, mmvae_stream_t stream);
+
 /* MoE ELBO (models/mmvae_models.py:61-77): wc = exp(lw) * r;  loss = (sum_n W_n rowsum_n + n_nz beta sum kld) / M
  * where n_nz counts the rows whose weighted sum is not exactly 0 (the reference's `lp.sum() != 0` filter and the
  * broadcast in BaseObjective.elbo).  out[0] = loss, out[1] = n_nz (kept for the backward). */
@@ -360,15 +373,22 @@ int mmvae_permute_mask_fwd(const float* x, const uint8_t* mask, float* y, int T,
 int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, float* dx, int T, int B, int V,
                            mmvae_stream_t stream);
 
+/* Standard-normal noise for the reparameterised samples (the reference draws it with torch.distributions rsample:
+ * models/mmvae_models.py:363-369).  state = {seed, call counter, ticket} (three uint32 on the device, ticket 0); the
+ * launch advances the call counter itself, so a captured graph replays with fresh noise and no host work. */
+int mmvae_randn(float* out, long n, uint32_t* state, mmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser + utilities
  * ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam(amsgrad=True) over one flat buffer (models/trainer.py:79-81); step is 1-based and is
  * read from *step_dev (device int) when step_dev != NULL, so that a captured hipGraph replays with the
- * right bias correction (mmvae_step_inc bumps it on the stream).  g is multiplied by grad_scale first
- * (1/world_size after a sum all-reduce); zero_grad != 0 clears g. */
+ * right bias correction (mmvae_step_inc bumps it on the stream).  With step < 0, step_dev is {count, ticket}
+ * (two ints, zero-initialised): the launch computes step count + 1 and stores it itself when its last workgroup
+ * finishes -- no separate launch.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce);
+ * zero_grad != 0 clears g. */
 int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
-                            float beta2, float eps, int step, const int* step_dev, float grad_scale,
+                            float beta2, float eps, int step, int* step_dev, float grad_scale,
                             int zero_grad, mmvae_stream_t stream);
 int mmvae_step_inc(int* step_dev, mmvae_stream_t stream);
 /* dst[i] (+)= sum_r src[r*stride + i],  i < len */

@@ -353,3 +353,41 @@ extern "C" int mmvae_normal_logratio_bwd(const float* packed_r, const float* z, 
                      packed_r, z, g, dpacked_r, B, D);
   return mmvae_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Standard-normal noise for the reparameterised samples (torch.distributions rsample -> _standard_normal in the
+// reference).  Counter-based (murmur3 finaliser over (seed, call counter, element)) + Box-Muller, two outputs per
+// thread.  torch.randn inside a captured hipGraph makes every replay run two extra fill kernels (the generator's
+// seed/offset tensors); this kernel keeps its state {seed, counter, ticket} on the device and bumps the counter
+// itself when its last workgroup finishes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long n, uint32_t* __restrict__ state) {
+  const uint32_t key = drop_fmix(state[0] ^ (state[1] * 0x9E3779B1u) ^ 0x632BE5ABu);
+  const long pairs = (n + 1) >> 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long)gridDim.x * 256) {
+    const uint32_t h1 = drop_fmix(key + (uint32_t)(2 * i) * 0x9E3779B1u);
+    const uint32_t h2 = drop_fmix(key + (uint32_t)(2 * i + 1) * 0x9E3779B1u);
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    out[2 * i] = r * cs;
+    if (2 * i + 1 < n) out[2 * i + 1] = r * sn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t ticket = atomicAdd(state + 2, 1u);
+    if (ticket == gridDim.x - 1) {
+      state[2] = 0u;
+      state[1] += 1u;
+    }
+  }
+}
+extern "C" int mmvae_randn(float* out, long n, uint32_t* state, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(out && state && n > 0);
+  long blocks = ((n + 1) / 2 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, state);
+  return mmvae_launch_status();
+}

@@ -323,6 +323,57 @@ extern "C" int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, fl
   return mmvae_launch_status();
 }
 
+// Row-pointer forms: the rows live in separate tensors (one per loss term) and the upstream gradients of the n_out
+// outputs arrive as separate scalars -- no cat / select / fill kernels around the two launches.
+__global__ __launch_bounds__(256) void lincomb_rowptrs_fwd_kernel(mmvae_rowptrs_t rows, lincomb_w W,
+                                                                  float* __restrict__ out, int n_rows, int B, int n_out) {
+  __shared__ float red[4];
+  __shared__ float rs[LC_MAX_ROWS];
+  for (int n = 0; n < n_rows; ++n) {
+    const float* V = rows.p[n];
+    float a = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) a += V[b];
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) rs[n] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < n_out) {
+    float o = 0.f;
+    for (int n = 0; n < n_rows; ++n) o += W.w[threadIdx.x * LC_MAX_ROWS + n] * rs[n];
+    out[threadIdx.x] = o;
+  }
+}
+__global__ __launch_bounds__(256) void lincomb_rowptrs_bwd_kernel(mmvae_gptrs_t g, lincomb_w W, mmvae_rowptrs_t drows,
+                                                                  int n_rows, int B, int n_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows * B) return;
+  const int n = i / B, b = i - n * B;
+  float v = 0.f;
+  for (int k = 0; k < n_out; ++k)
+    if (g.g[k]) v += g.g[k][0] * W.w[k * LC_MAX_ROWS + n];
+  const_cast<float*>(drows.p[n])[b] = v;
+}
+extern "C" int mmvae_lincomb_rowptrs_fwd(const mmvae_rowptrs_t* rows, const float* W_host, float* out, int n_rows,
+                                         int B, int n_out, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(rows && W_host && out && n_rows > 0 && B > 0 && n_out > 0);
+  lincomb_w w;
+  int rc = pack_w(W_host, n_rows, n_out, &w);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lincomb_rowptrs_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *rows, w, out, n_rows, B,
+                     n_out);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_lincomb_rowptrs_bwd(const mmvae_gptrs_t* gout, const float* W_host, const mmvae_rowptrs_t* drows,
+                                         int n_rows, int B, int n_out, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(gout && W_host && drows && n_rows > 0 && B > 0 && n_out > 0);
+  lincomb_w w;
+  int rc = pack_w(W_host, n_rows, n_out, &w);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lincomb_rowptrs_bwd_kernel, dim3((n_rows * B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     *gout, w, *drows, n_rows, B, n_out);
+  return mmvae_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // MoE ELBO assembly (models/mmvae_models.py:61-77 + BaseObjective.elbo objectives.py:54-67)
 //   wc[b] = exp(lw[b]) * r[b]                                  (importance-weighted cross term)

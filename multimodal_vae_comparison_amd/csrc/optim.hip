@@ -8,13 +8,14 @@
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ vmax, long n, float lr,
-                                                           int step, const int* __restrict__ step_dev, float b1,
+                                                           int step, int* __restrict__ step_dev, float b1,
                                                            float b2, float eps, float gscale, int zero_grad) {
   // bias corrections from the step count; the count lives in device memory when the launch is replayed
   // from a captured graph (kernel arguments are frozen at capture time).
   __shared__ float bc[2];
   if (threadIdx.x == 0) {
-    const int st = step_dev ? *step_dev : step;
+    // step < 0 with a device counter: this launch IS step (*step_dev + 1); the last workgroup to finish stores it
+    const int st = step_dev ? step_dev[0] + (step < 0 ? 1 : 0) : step;
     const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
     bc[0] = (float)((double)lr / bc1);
     bc[1] = (float)(1.0 / sqrt(bc2));
@@ -58,10 +59,20 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
     vmax[i] = xi;
     if (zero_grad) g[i] = 0.f;
   }
+  if (step_dev && step < 0) {     // {count, finished-workgroup ticket}: no separate counter-bump launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int ticket = atomicAdd(step_dev + 1, 1);
+      if (ticket == (int)gridDim.x - 1) {
+        step_dev[1] = 0;
+        step_dev[0] += 1;
+      }
+    }
+  }
 }
 
 extern "C" int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr,
-                                       float beta1, float beta2, float eps, int step, const int* step_dev,
+                                       float beta1, float beta2, float eps, int step, int* step_dev,
                                        float grad_scale, int zero_grad, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(p && g && m && v && vmax && n > 0 && (step > 0 || step_dev));
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) != 0) return MMVAE_ERR_ARG;

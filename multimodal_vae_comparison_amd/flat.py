@@ -67,16 +67,16 @@ class FlatAdam(torch.optim.Optimizer):
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
         self.vmax = torch.zeros_like(flat.data)
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.data.device)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=flat.data.device)   # {count, kernel ticket}
         self.grad_scale = grad_scale
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
-        ops.step_inc(self.step_dev)
+        # step = -1: the kernel takes step_dev[0] + 1 and stores it itself (one launch per step)
         ops.adam_amsgrad_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]),
-                              g["betas"][0], g["betas"][1], g["eps"], 0, self.step_dev, self.grad_scale, True)
+                              g["betas"][0], g["betas"][1], g["eps"], -1, self.step_dev, self.grad_scale, True)
         return loss
 
     def zero_grad(self, set_to_none=False):

@@ -82,6 +82,9 @@ SIGNATURES = {
     "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_p]),
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_randn": (c_i, [c_p, c_l, c_p, c_p]),
+    "mmvae_lincomb_rowptrs_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_lincomb_rowptrs_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_dp, c_p]),
     "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_dp, c_p]),
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
@@ -123,6 +126,14 @@ SIGNATURES = {
 }
 ACC_DEFER = 2
 MAX_SEGMENTS = 64
+
+
+class RowPtrs(ctypes.Structure):
+    _fields_ = [("p", c_p * 16)]
+
+
+class GPtrs(ctypes.Structure):
+    _fields_ = [("g", c_p * 4)]
 
 
 class TxtLayerW(ctypes.Structure):

@@ -49,6 +49,9 @@ class TorchMMVAE(nn.Module):
                 if st is not None:
                     st.prefix = f"vaes.{name}.{part}"
         self.eps_override = None    # list of (K,B,D) noise tensors consumed in draw order (parity tests)
+        # counter-based device noise generator {seed, call counter, ticket} (ops.randn)
+        self.register_buffer("_rng_state", torch.tensor([torch.initial_seed() & 0x7FFFFFFF, 0, 0], dtype=torch.int32),
+                             persistent=False)
 
     def set_likelihood_scales(self):
         """mmvae_base.py:41-47"""
@@ -77,7 +80,13 @@ class TorchMMVAE(nn.Module):
         if self.eps_override is not None:
             e = self.eps_override.pop(0)
             return e.reshape(B, D).to(device=device, dtype=torch.float32).contiguous()
-        return torch.randn(B, D, device=device)
+        return ops.randn((B, D), self._rng_state)
+
+    def _draw_many(self, n, B, D, device):
+        """n draws of shape (B, D) in one launch (`eps_override`: n consecutive recorded draws)"""
+        if self.eps_override is not None:
+            return [self._draw(B, D, device) for _ in range(n)]
+        return list(ops.randn((n, B, D), self._rng_state).unbind(0))
 
     # ---- tower-level concurrency -------------------------------------------------------------------
     def _tower_streams(self, device):

@@ -3,6 +3,7 @@
 `objective()` is the per-step hot path: towers -> ONE fused latent kernel (product of experts, reparameterised
 samples, analytic KL rows) -> decoders -> fused per-sample reconstruction sums -> ONE ELBO assembly kernel.
 No host synchronisation anywhere (the reference forces >= 6 per step)."""
+import os
 from itertools import chain, combinations
 
 import torch
@@ -55,22 +56,29 @@ class MoPOE(TorchMMVAE):
         streams = self._tower_streams(dev)
         self._fork(streams, dev)
         enc = []
+        B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
+        eps = None
         for n, st in zip(names, streams):
             with torch.cuda.stream(st):
+                if st is not None and eps is None:      # noise does not depend on anything: off the main stream
+                    eps = self._draw_many(M, B, D, dev)                    # one rsample per modality (:363-369)
                 enc.append(self.vaes[n].enc(mods[n]))
         self._join(streams, dev)
+        if eps is None:
+            eps = self._draw_many(M, B, D, dev)
         packed = [packed_head(mu, lv) for mu, lv in enc]
-        B, D = packed[0].shape[0], self.n_latents
-        eps = [self._draw(B, D, dev) for _ in names]                       # one rsample per modality (:363-369)
         theta = self._pz_params[1]
         _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad)
         self._fork(streams, dev)
-        recs = []
-        for i, (n, st) in enumerate(zip(names, streams)):
+        recs = [None] * M
+        order = list(enumerate(zip(names, streams)))
+        if os.environ.get("MMVAE_DEC_ORDER", "rev") == "rev":
+            order = order[::-1]     # autograd runs the LAST recorded tower's backward first: see DESIGN.md section 5
+        for i, (n, st) in order:
             vae = self.vaes[n]
             with torch.cuda.stream(st):
                 out, _ = vae.dec({"latents": z[i].unsqueeze(0), "masks": mods[n]["masks"]})
-                recs.append(recon_rowsum(vae.ltype, out, mods[n]))         # (B,) = -lpx_z / llik_scaling
+                recs[i] = recon_rowsum(vae.ltype, out, mods[n])            # (B,) = -lpx_z / llik_scaling
         self._join(streams, dev)
         w_kl = 1.0 / (M + 1)
         lam = [float(self.vaes[n].llik_scaling) for n in names]

@@ -66,24 +66,31 @@ class MultimodalVAE(nn.Module):
         return loss_d["loss"]
 
     # ---- MI355X fast path ------------------------------------------------------------------------
-    def capture(self, batch):
-        """Capture objective + backward for `batch`'s shapes into a hipGraph.  `batch` tensors become the static
-        input buffers: copy new data into them (`load_batch`) before each replay."""
+    def capture(self, batch, world_size=1):
+        """Capture objective + backward (+ the Adam step when there is no collective between them, world_size 1) for
+        `batch`'s shapes into a hipGraph.  `batch` tensors become the static input buffers: copy new data into them
+        (`load_batch`) before each replay."""
         assert self.optimizer is not None, "call configure_optimizers() first"
         self._static_batch = batch
+        self._one = torch.ones((), device=self.flat.data.device)     # loss.backward() seed: no fill kernel per step
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):                       # warm-up: sizes the shared workspace, loads code objects
-                self.model.objective(batch)["loss"].backward()
+                self.model.objective(batch)["loss"].backward(self._one)
             self.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        self._adam_in_graph = world_size == 1
         with torch.cuda.graph(self._graph):
             out = self.model.objective(batch)
-            out["loss"].backward()
+            out["loss"].backward(self._one)
+            if self._adam_in_graph:
+                self.optimizer.step()
         self._static_out = out
+        if self._adam_in_graph:                      # the capture pass does not execute: nothing to undo
+            pass
         self.flat.zero_grad()
         return out
 
@@ -96,6 +103,9 @@ class MultimodalVAE(nn.Module):
     def fused_step(self, world_size=1):
         """one optimisation step on the static batch: graph replay -> (all-reduce) -> fused Adam"""
         self._graph.replay()
+        if self._adam_in_graph:
+            assert world_size == 1, "captured with the optimiser step inside the graph"
+            return self._static_out
         if world_size > 1:
             torch.distributed.all_reduce(self.flat.grad)       # ONE RCCL collective over the 3.95 MB flat buffer
         self.optimizer.step()

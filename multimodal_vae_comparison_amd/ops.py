@@ -581,8 +581,9 @@ class CeOverTime(Function):
 
 
 class LincombRows(Function):
-    """out[k] = sum_n W[k][n] * sum_b rows_n[b]  -- ELBO assembly with host-side constant weights.
-    `blocks`: tensors of shape (B,) or (r,B); their rows are concatenated logically (no cat/stack kernel)."""
+    """out_k = sum_n W[k][n] * sum_b rows_n[b]  -- ELBO assembly with host-side constant weights.
+    `blocks`: tensors of shape (B,) or (r,B); their rows are addressed in place (no cat/stack kernel).  Returns the
+    k outputs as k scalar tensors, so backward receives one upstream scalar per output (no select / fill kernels)."""
 
     @staticmethod
     def forward(ctx, W, *blocks):
@@ -590,24 +591,39 @@ class LincombRows(Function):
         B = blocks[0].shape[-1]
         rows = [t.numel() // B for t in blocks]
         n, k = sum(rows), len(W)
-        V = torch.empty(n, B, device=blocks[0].device)
-        torch.cat([t.reshape(-1, B) for t in blocks], dim=0, out=V)
+        assert n <= 16 and k <= 4
+        rp = H.RowPtrs()
+        i = 0
+        for t, r in zip(blocks, rows):
+            for j in range(r):
+                rp.p[i] = t.data_ptr() + 4 * j * B
+                i += 1
         flat = (H.c_f * (k * n))(*[float(x) for row in W for x in row])
-        out = torch.empty(k, device=V.device)
-        _call("mmvae_lincomb_rows_fwd", H.ptr(V), flat, H.ptr(out), n, B, k, H.stream())
+        out = torch.empty(k, device=blocks[0].device)
+        _call("mmvae_lincomb_rowptrs_fwd", ctypes.byref(rp), flat, H.ptr(out), n, B, k, H.stream())
         ctx.cfg = (flat, n, B, k, rows, [tuple(t.shape) for t in blocks])
-        return out
+        ctx.keep = blocks
+        return tuple(out.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         flat, n, B, k, rows, shapes = ctx.cfg
-        g = H.f32c(g)
-        dV = torch.empty(n, B, device=g.device)
-        _call("mmvae_lincomb_rows_bwd", H.ptr(g), flat, H.ptr(dV), n, B, k, H.stream())
-        outs, r0 = [], 0
+        dev = ctx.keep[0].device
+        gp = H.GPtrs()
+        held = []
+        for i, g in enumerate(gs):
+            if g is not None:
+                g = H.f32c(g)
+                held.append(g)
+                gp.g[i] = g.data_ptr()
+        outs, dp, i = [], H.RowPtrs(), 0
         for r, shp in zip(rows, shapes):
-            outs.append(dV[r0:r0 + r].view(shp))
-            r0 += r
+            d = torch.empty(shp, device=dev)
+            outs.append(d)
+            for j in range(r):
+                dp.p[i] = d.data_ptr() + 4 * j * B
+                i += 1
+        _call("mmvae_lincomb_rowptrs_bwd", ctypes.byref(gp), flat, ctypes.byref(dp), n, B, k, H.stream())
         return (None, *outs)
 
 
@@ -1154,6 +1170,13 @@ def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=No
 
 def step_inc(step_dev):
     _call("mmvae_step_inc", H.ptr(step_dev), H.stream())
+
+
+def randn(shape, state):
+    """standard-normal tensor from the counter-based device generator (`state`: int32[3] = seed, counter, ticket)"""
+    out = torch.empty(shape, device=state.device)
+    _call("mmvae_randn", H.ptr(out), out.numel(), H.ptr(state), H.stream())
+    return out
 
 
 def fill(t, value):

@@ -215,10 +215,16 @@ def test_lincomb_rows(ops):
     ref.backward(torch.tensor([1.5, -0.5], dtype=torch.float64))
     Vg = V.to(DEV).requires_grad_(True)
     Va, Vb = Vg[:2], Vg[2:]
-    out = ops.lincomb_rows([Va[0], Va[1], Vb], W)
-    out.backward(torch.tensor([1.5, -0.5], device=DEV))
-    check(out, ref, 1e-5, "lincomb")
+    out = ops.lincomb_rows([Va[0], Va[1], Vb], W)          # tuple of scalars, one per row of W
+    torch.autograd.backward(list(out), [torch.tensor(1.5, device=DEV), torch.tensor(-0.5, device=DEV)])
+    check(torch.stack(out), ref, 1e-5, "lincomb")
     check(Vg.grad, Vr.grad, 1e-6, "lincomb dV")
+    # only the first output takes part in backward (the training step: loss.backward(), kld is logged)
+    Vg2 = V.to(DEV).requires_grad_(True)
+    out2 = ops.lincomb_rows([Vg2], W)
+    out2[0].backward(torch.tensor(2.0, device=DEV))
+    ref2 = 2.0 * torch.tensor(W[0], dtype=torch.float64)[:, None].expand(5, 130)
+    check(Vg2.grad, ref2, 1e-6, "lincomb dV, one output")
 
 
 @pytest.mark.parametrize("B,T", [(6, 5), (5, 5), (1, 7), (128, 32)])
@@ -320,7 +326,9 @@ def test_time_reduce_and_permute_mask(ops):
     check(yg.grad, yr.grad, 1e-6, "permute_mask dx")
 
 
-def test_adam_amsgrad_flat_matches_torch(ops):
+@pytest.mark.parametrize("self_counting", [False, True])
+def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
+    """self_counting: step = -1, the kernel bumps the device step counter itself (what FlatAdam uses)"""
     g = torch.Generator().manual_seed(11)
     n = 10007
     p0 = torch.randn(n, generator=g)
@@ -329,14 +337,18 @@ def test_adam_amsgrad_flat_matches_torch(ops):
     p = p0.to(DEV)
     # the flat kernel needs 16-byte aligned bases; torch allocations are
     m, v, vm = (torch.zeros(n, device=DEV) for _ in range(3))
-    step_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    step_dev = torch.zeros(2, dtype=torch.int32, device=DEV)
     for it in range(1, 6):
         gr = torch.randn(n, generator=g) * (0.1 if it != 3 else 10.0)
         pr.grad = gr.clone()
         opt.step()
         gd = gr.to(DEV)
-        ops.step_inc(step_dev)
-        ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, 0, step_dev, 1.0, True)
+        if self_counting:
+            ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, -1, step_dev, 1.0, True)
+            assert step_dev.tolist() == [it, 0]
+        else:
+            ops.step_inc(step_dev)
+            ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, 0, step_dev, 1.0, True)
         assert float(gd.abs().max()) == 0.0
         check(p, pr.detach(), 2e-6, f"adam step {it}")
 

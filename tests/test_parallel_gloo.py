@@ -58,7 +58,8 @@ def _worker(rank, world, port, q):
     parallel.broadcast_flat_parameters(flat.data)   # -> rank 0's parameters everywhere
     _local_grads(r, holder)
     scale = parallel.allreduce_flat_gradients(flat.grad, w)
-    q.put((rank, flat.data.clone(), (flat.grad * scale).clone()))
+    # numpy copies are pickled by value (torch tensors travel as shared-memory handles that die with this process)
+    q.put((rank, flat.data.detach().numpy().copy(), (flat.grad * scale).detach().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,7 +77,7 @@ def test_two_ranks_equal_one_rank_average():
     res = {}
     for _ in range(2):
         rank, data, grad = q.get(timeout=300)
-        res[rank] = (data, grad)
+        res[rank] = (torch.from_numpy(data), torch.from_numpy(grad))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
