@@ -40,6 +40,7 @@ import torch.nn.functional as F
 ETA = 1e-6          # utils.py:254  Constants.eta
 DROPOUT_P = 0.1     # models/encoders.py:790, models/decoders.py:669 (ctor defaults)
 LN_EPS = 1e-5       # torch.nn.LayerNorm default
+ENC_TRANSFORMER_LAYERS, DEC_TRANSFORMER_LAYERS, TRANSFORMER_FF = 8, 4, 1024   # encoders.py:659, decoders.py:542
 
 
 # ----------------------------------------------------------------------------------------------
@@ -84,6 +85,29 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
         s[f"{prefix}.enc.mu_layer.module.bias"] = (Dp,)
         s[f"{prefix}.enc.logvar_layer.module.weight"] = (Dp, d)
         s[f"{prefix}.enc.logvar_layer.module.bias"] = (Dp,)
+    elif enc == "Transformer":
+        # Enc_Transformer ctor, models/encoders.py:659-700: d_model = out_dim, 8 layers, ff 1024, 2 heads
+        feats = data_dim[1] * (data_dim[2] if len(data_dim) > 2 else 1)
+        d = Dp
+        s[f"{prefix}.enc.mu_layer.module.weight"] = (Dp, Dp)
+        s[f"{prefix}.enc.mu_layer.module.bias"] = (Dp,)
+        s[f"{prefix}.enc.logvar_layer.module.weight"] = (Dp, Dp)
+        s[f"{prefix}.enc.logvar_layer.module.bias"] = (Dp,)
+        s[f"{prefix}.enc.skel_Embedding.module.weight"] = (d, feats)
+        s[f"{prefix}.enc.skel_Embedding.module.bias"] = (d,)
+        for li in range(ENC_TRANSFORMER_LAYERS):
+            L = f"{prefix}.enc.seqTransEncoder.layers.{li}"
+            s[f"{L}.self_attn.in_proj_weight"] = (3 * d, d)
+            s[f"{L}.self_attn.in_proj_bias"] = (3 * d,)
+            s[f"{L}.self_attn.out_proj.weight"] = (d, d)
+            s[f"{L}.self_attn.out_proj.bias"] = (d,)
+            s[f"{L}.linear1.weight"] = (TRANSFORMER_FF, d)
+            s[f"{L}.linear1.bias"] = (TRANSFORMER_FF,)
+            s[f"{L}.linear2.weight"] = (d, TRANSFORMER_FF)
+            s[f"{L}.linear2.bias"] = (d,)
+            for n in ("norm1", "norm2"):
+                s[f"{L}.{n}.weight"] = (d,)
+                s[f"{L}.{n}.bias"] = (d,)
     else:
         raise NotImplementedError(enc)
     if dec == "CNN":
@@ -113,6 +137,26 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
         for n in ("norm1", "norm2", "norm3"):
             s[f"{L}.{n}.weight"] = (d,)
             s[f"{L}.{n}.bias"] = (d,)
+        s[f"{prefix}.dec.finallayer.module.weight"] = (feats, d)
+        s[f"{prefix}.dec.finallayer.module.bias"] = (feats,)
+    elif dec == "Transformer":
+        # Dec_Transformer ctor, models/decoders.py:542-588: 4 layers, ff 1024, 2 heads
+        d = Dp
+        feats = data_dim[1] * (data_dim[2] if len(data_dim) > 2 else 1)
+        for li in range(DEC_TRANSFORMER_LAYERS):
+            L = f"{prefix}.dec.seqTransDecoder.layers.{li}"
+            for a in ("self_attn", "multihead_attn"):
+                s[f"{L}.{a}.in_proj_weight"] = (3 * d, d)
+                s[f"{L}.{a}.in_proj_bias"] = (3 * d,)
+                s[f"{L}.{a}.out_proj.weight"] = (d, d)
+                s[f"{L}.{a}.out_proj.bias"] = (d,)
+            s[f"{L}.linear1.weight"] = (TRANSFORMER_FF, d)
+            s[f"{L}.linear1.bias"] = (TRANSFORMER_FF,)
+            s[f"{L}.linear2.weight"] = (d, TRANSFORMER_FF)
+            s[f"{L}.linear2.bias"] = (d,)
+            for n in ("norm1", "norm2", "norm3"):
+                s[f"{L}.{n}.weight"] = (d,)
+                s[f"{L}.{n}.bias"] = (d,)
         s[f"{prefix}.dec.finallayer.module.weight"] = (feats, d)
         s[f"{prefix}.dec.finallayer.module.bias"] = (feats,)
     else:
@@ -288,8 +332,55 @@ def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
     return out.permute(1, 0, 2) * mask.unsqueeze(-1).float()    # (B,T,V), zero at padding
 
 
+def enc_transformer(p, pre, data, mask, train=False):
+    """Enc_Transformer.forward, models/encoders.py:702-729 (ACTOR-style encoder for sequences of (joints, feats)):
+    Linear(joints*feats -> d) -> + pe[t] (PositionalEncoding's try-branch: a true time encoding here) -> dropout ->
+    8 post-norm encoder layers with src_key_padding_mask = ~mask -> mean over ALL time steps -> heads."""
+    x = data
+    if x.dim() == 3:
+        x = x.unsqueeze(-1)
+    B, T = x.shape[0], x.shape[1]
+    if mask is None:
+        mask = torch.ones(B, T, dtype=torch.bool)
+    x = x.permute(1, 0, 2, 3).reshape(T, B, -1).float()
+    x = F.linear(x, p[f"{pre}.enc.skel_Embedding.module.weight"], p[f"{pre}.enc.skel_Embedding.module.bias"])
+    d = x.shape[-1]
+    x = x + positional_table(d, T).reshape(T, 1, d)
+    nm = _tower_call(train, f"{pre}.enc")
+    x = _dropout(x, train, nm("pe"))
+    for li in range(ENC_TRANSFORMER_LAYERS):
+        x = transformer_encoder_layer(x, p, f"{pre}.enc.seqTransEncoder.layers.{li}", 2, ~mask, train, nm, li)
+    z = x.mean(dim=0)
+    return process_output(z, p[f"{pre}.enc.mu_layer.module.weight"], p[f"{pre}.enc.mu_layer.module.bias"],
+                          p[f"{pre}.enc.logvar_layer.module.weight"], p[f"{pre}.enc.logvar_layer.module.bias"])
+
+
+def dec_transformer(p, pre, z, mask, data_dim, train=False):
+    """Dec_Transformer.forward, models/decoders.py:590-616: memory = z reshaped to (1, K*B, D'); queries = PE(zeros);
+    4 post-norm decoder layers; Linear(d -> joints*feats); padded steps zeroed; (B, T, joints, feats)."""
+    D = z.shape[-1]
+    z = z.reshape(-1, D).unsqueeze(0)
+    B = z.shape[1]
+    if mask is None:
+        mask = torch.ones(B, data_dim[0], dtype=torch.bool)
+    T = mask.shape[1]
+    joints = data_dim[1]
+    feats = data_dim[2] if len(data_dim) > 2 else 1
+    tq = torch.zeros(T, B, D) + positional_table(D, T).reshape(T, 1, D)
+    nm = _tower_call(train, f"{pre}.dec")
+    out = _dropout(tq, train, nm("pe"))
+    for li in range(DEC_TRANSFORMER_LAYERS):
+        out = transformer_decoder_layer(out, z, p, f"{pre}.dec.seqTransDecoder.layers.{li}", 2, ~mask, train, nm, li)
+    out = F.linear(out, p[f"{pre}.dec.finallayer.module.weight"], p[f"{pre}.dec.finallayer.module.bias"])
+    # `output[~mask.T] = 0`: an in-place masked write -- padded steps are exactly 0 AND receive exactly zero gradient
+    # (a multiplication by the mask would turn the NaN gradients lprob produces there into NaN * 0 = NaN)
+    out = out.reshape(T, B, joints, feats).masked_fill(~mask.T.reshape(T, B, 1, 1), 0.0)
+    return out.permute(1, 0, 2, 3)
+
+
 _ENC = {"CNN2": lambda p, pre, d, train: enc_cnn2(p, pre, d["data"]),
-        "TxtTransformer": lambda p, pre, d, train: enc_txt_transformer(p, pre, d["data"], d["masks"], train)}
+        "TxtTransformer": lambda p, pre, d, train: enc_txt_transformer(p, pre, d["data"], d["masks"], train),
+        "Transformer": lambda p, pre, d, train: enc_transformer(p, pre, d["data"], d["masks"], train)}
 
 
 def encode(p, mods, i, inp, train=False):
@@ -303,6 +394,8 @@ def decode(p, mods, i, z, mask, train=False):
         return dec_cnn(p, pre, z, tuple(m["data_dim"]))
     if m["dec"] == "TxtTransformer":
         return dec_txt_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
+    if m["dec"] == "Transformer":
+        return dec_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
     raise NotImplementedError(m["dec"])
 
 
@@ -362,14 +455,53 @@ def recon_category_ce(logits, target):
     return -(target.float().detach() * lsm).sum(dim=1)
 
 
-_RECON = {"bce": recon_bce, "category_ce": recon_category_ce}
+PX_SCALE = 0.75     # the decoders' second return value: Normal(loc, 0.75), models/decoders.py:98,616,723
+
+
+def recon_lprob(loc, target, scale=None, laplace=False):
+    """ReconLoss.lprob, models/objectives.py:409-424: -log p(target) under Normal (or Laplace)(loc, scale) evaluated in
+    fp32 by torch.distributions, THEN cast to float64, NaN -> 0 (an in-place masked write: those elements carry no
+    gradient).  scale = 0.75, or `loc` itself when the modality has masks (`output.scale = output.loc`, :43-45)."""
+    B = target.shape[0]
+    t = target.float().reshape(loc.shape).detach()
+    sc = torch.full_like(loc, PX_SCALE) if scale is None else scale
+    if laplace:
+        lp = -torch.log(2 * sc) - torch.abs(t - loc) / sc                     # torch.distributions.Laplace.log_prob
+    else:
+        lp = -((t - loc) ** 2) / (2 * sc ** 2) - sc.log() - math.log(math.sqrt(2 * math.pi))   # Normal.log_prob
+    out = lp.reshape(B, -1).double()
+    out = torch.where(torch.isnan(out), torch.zeros_like(out), out)
+    return -out
+
+
+def softclip(t, lo):
+    """utils.softclip, utils.py:66-69"""
+    return lo + F.softplus((t - lo).float())
+
+
+def recon_optimal_sigma(loc, target):
+    """ReconLoss.optimal_sigma, models/objectives.py:503-509 (sigma-VAE): ONE log sigma = softclip(log sqrt(mean over
+    every element of (t - x)^2), -6) per call; the squared term is `.clone().detach()`-ed, so the only gradient path
+    into the decoder is through log sigma."""
+    B = target.shape[0]
+    t = target.float().reshape(loc.shape).detach()
+    log_sigma = softclip(((t - loc) ** 2).mean().sqrt().log(), -6.0)
+    sq = (((t - loc) / log_sigma.exp()) ** 2).detach()
+    return (sq + log_sigma + 0.5 * math.log(2 * math.pi)).reshape(B, -1)
+
+
+_RECON = {"bce": lambda o, t, sc: recon_bce(o, t), "category_ce": lambda o, t, sc: recon_category_ce(o, t),
+          "lprob": lambda o, t, sc: recon_lprob(o, t, sc), "optimal_sigma": lambda o, t, sc: recon_optimal_sigma(o, t)}
 
 
 def recon_loss(ltype, out, target):
-    """BaseObjective.recon_loss_fn, models/objectives.py:30-52: slice to the mask length, positive loss."""
+    """BaseObjective.recon_loss_fn, models/objectives.py:30-52: slice to the mask length (and, with masks, the
+    likelihood's scale becomes its loc), positive loss."""
+    scale = None
     if target["masks"] is not None:
         out = out[:, : target["masks"].shape[1]]
-    return _RECON[ltype](out, target["data"])
+        scale = out
+    return _RECON[ltype](out, target["data"], scale)
 
 
 # ----------------------------------------------------------------------------------------------

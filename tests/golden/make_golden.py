@@ -51,10 +51,21 @@ CASES = [
 ]
 PRIVATE = {"dmvae_b5_t6_d8p4": 4, "dmvae_b6_t6_d16p6_BeqT": 6}
 
+# cases with their own modality lists: the action Transformer towers, lprob (a21), optimal_sigma (a23)
+ACTIONS = {"enc": "Transformer", "dec": "Transformer", "data_dim": [6, 4, 1], "llik_scaling": 1.0}
+CASE_MODS = {
+    "mopoe3_b5_t6_d8_actions_optsigma": [MODS[0], MODS[1], dict(ACTIONS, ltype="optimal_sigma")],
+    "poe3_b4_t5_d8_actions_lprob": [dict(MODS[0], ltype="lprob"), MODS[1], dict(ACTIONS, ltype="lprob")],
+}
+CASES += [
+    ("mopoe3_b5_t6_d8_actions_optsigma", "mopoe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.0),
+    ("poe3_b4_t5_d8_actions_lprob", "poe", 4, 5, 8, [5, 2, 3, 4], "eval", 1.0),
+]
 
-def build_reference(mixing, D, beta, private=None):
+
+def build_reference(mixing, D, beta, private=None, mods=None):
     vaes = {}
-    for i, m in enumerate(MODS):
+    for i, m in enumerate(mods or MODS):
         vaes[f"mod_{i + 1}"] = VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], private, obj_fn="elbo", beta=beta,
                                    id_name=f"mod_{i + 1}", llik_scaling=m["llik_scaling"])
     return getattr(models, mixing)(nn.ModuleDict(vaes), D, {"obj": "elbo", "beta": beta, "K": 1}, {})
@@ -72,8 +83,9 @@ def make_batch(B, T, lengths, seed):
 
 def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     private = PRIVATE.get(name)
-    mods = [dict(m, private=private) for m in MODS] if private else MODS
-    model = build_reference(mixing, D, beta, private)
+    base = CASE_MODS.get(name, MODS)
+    mods = [dict(m, private=private) for m in base] if private else base
+    model = build_reference(mixing, D, beta, private, mods)
     shapes = orc.model_param_shapes(mods, D)
     ref_sd = model.state_dict()
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
@@ -97,6 +109,16 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
              "mod_2": {"data": onehot, "masks": mask, "categorical": True}}
 
     out = {"img": img.numpy(), "onehot": onehot.numpy(), "mask": mask.numpy()}
+    if len(mods) == 3:      # action sequences (B, Ta, joints, feats) with their own ragged lengths
+        ga = torch.Generator().manual_seed(seed + 5)
+        Ta, J, Fe = mods[2]["data_dim"]
+        act = torch.randn(B, Ta, J, Fe, generator=ga)
+        alen = torch.randint(1, Ta + 1, (B,), generator=ga)
+        alen[0] = Ta
+        amask = torch.arange(Ta)[None, :] < alen[:, None]
+        act = act * amask[:, :, None, None]
+        batch["mod_3"] = {"data": act, "masks": amask, "categorical": False}
+        out["act"], out["amask"] = act.numpy(), amask.numpy()
     meta = {"name": name, "mixing": mixing, "B": B, "T": T, "D": D, "beta": beta, "seed": seed, "mode": mode,
             "mods": mods, "lr": 1e-4}
 
@@ -104,7 +126,7 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     if mixing == "poe":                     # record the hash-seed dependent subset order (utils.py:98)
         from utils import subsample_input_modalities
         subs = subsample_input_modalities(batch)
-        order = [[i for i in range(len(MODS)) if s[f"mod_{i + 1}"]["data"] is not None] for s in subs]
+        order = [[i for i in range(len(mods)) if s[f"mod_{i + 1}"]["data"] is not None] for s in subs]
         meta["order"] = order
 
     torch.manual_seed(seed + 2)
@@ -127,7 +149,7 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     with torch.no_grad():
         if mixing == "mopoe":
             lat = model.modality_mixing(batch)
-            for i in range(len(MODS)):
+            for i in range(len(mods)):
                 mu, lv = lat["modalities"][f"mod_{i + 1}"]["shared"]
                 out[f"enc_mu_{i}"], out[f"enc_lv_{i}"] = mu.numpy(), lv.numpy()
             out["joint_mu"], out["joint_var"] = lat["joint"][0].numpy(), lat["joint"][1].numpy()
@@ -135,12 +157,12 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
                 out[f"subset_mu/{k}"], out[f"subset_var/{k}"] = mu.squeeze(0).numpy(), var.squeeze(0).numpy()
             with ref_harness.EpsTape(replay=tape.draws):
                 fw = model.forward(batch)
-            for i in range(len(MODS)):
+            for i in range(len(mods)):
                 o = fw.mods[f"mod_{i + 1}"]
                 out[f"z_{i}"] = o.latent_samples["latents"].numpy()
                 out[f"recon_{i}"] = gw.summarize(o.decoder_dist.loc, 256)
         else:
-            for i in range(len(MODS)):
+            for i in range(len(mods)):
                 mu, lv = model.vaes[f"mod_{i + 1}"].enc(batch[f"mod_{i + 1}"])
                 out[f"enc_mu_{i}"], out[f"enc_lv_{i}"] = mu.numpy(), lv.numpy()
 

@@ -11,8 +11,11 @@ from oracle import mmvae_oracle as orc
 
 
 def _batch(g):
-    return {"mod_1": {"data": torch.from_numpy(g["img"]), "masks": None, "categorical": False},
-            "mod_2": {"data": torch.from_numpy(g["onehot"]), "masks": torch.from_numpy(g["mask"]), "categorical": True}}
+    b = {"mod_1": {"data": torch.from_numpy(g["img"]), "masks": None, "categorical": False},
+         "mod_2": {"data": torch.from_numpy(g["onehot"]), "masks": torch.from_numpy(g["mask"]), "categorical": True}}
+    if "act" in g:       # third modality: action sequences (B, T, joints, feats)
+        b["mod_3"] = {"data": torch.from_numpy(g["act"]), "masks": torch.from_numpy(g["amask"]), "categorical": False}
+    return b
 
 
 def _run(meta, g):
