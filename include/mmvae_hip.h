@@ -243,8 +243,26 @@ int mmvae_ce_over_time_fwd(const float* logits, const float* target, float* loss
 int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float* g, const float* g_row,
                            float* dlogits, int B, int T, int V, mmvae_stream_t stream);
 
+/* ReconLoss.lprob (models/objectives.py:409-424): row[b] = sum_f -log p(target[b,f]) under Normal (laplace = 0) or
+ * Laplace(loc[b,f], scale); elements in fp32, the row sum in fp64 (the reference sums the elements as doubles), NaN
+ * elements count 0 and get zero gradient.  scale <= 0: scale := loc (BaseObjective.recon_loss_fn, objectives.py:43-45,
+ * when the modality has masks). */
+int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F, float scale,
+                           int laplace, mmvae_stream_t stream);
+int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, const float* g_row, float* dloc, int B, int F,
+                           float scale, int laplace, mmvae_stream_t stream);
+/* ReconLoss.optimal_sigma (models/objectives.py:503-509) + utils.softclip (utils.py:66-69): one log sigma per call
+ * from the mean squared error over all B*F elements; row[b] = sum_f ((t-x)/sigma)^2 + F (log sigma + log sqrt(2 pi)).
+ * stats (3 floats, written by fwd, read by bwd) = {mean square, log sigma, unclipped log sigma}.  Gradient flows only
+ * through log sigma (the squared term is detached in the reference). */
+size_t mmvae_optimal_sigma_ws_floats(int B, int F);
+int mmvae_optimal_sigma_fwd(const float* loc, const float* target, float* row_loss, float* stats, float* ws, int B,
+                            int F, mmvae_stream_t stream);
+int mmvae_optimal_sigma_bwd(const float* loc, const float* target, const float* g_row, const float* stats,
+                            float* dloc, int B, int F, mmvae_stream_t stream);
+
 /* out[k] = sum_n W[k,n] * sum_b V[n,b]   (ELBO assembly: BaseObjective.elbo objectives.py:54-67,
- * MoPOE.objective mmvae_models.py:315-319).  W is passed by value (<= 4 x 16 host floats). */
+ * MoPOE.objective mmvae_models.py:315-319).  W is passed by value (<= 4 x 32 host floats). */
 int mmvae_lincomb_rows_fwd(const float* V, const float* W_host, float* out, int n_rows, int B, int n_out,
                            mmvae_stream_t stream);
 int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, int n_rows, int B, int n_out,
@@ -253,7 +271,7 @@ int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, in
 /* The same with the rows in separate tensors (p[n] -> B floats) and one upstream-gradient scalar per output
  * (g[k] device pointer or NULL = that output does not take part in backward); d rows are written to drows->p[n]. */
 typedef struct {
-  const float* p[16];
+  const float* p[32];
 } mmvae_rowptrs_t;
 typedef struct {
   const float* g[4];
@@ -334,6 +352,12 @@ int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float*
                         const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                         const mmvae_txt_layer_grads_t* grads, const mmvae_txt_layer_drop_t* drop, int L, int N, int D,
                         int FF, int NH, int dec, mmvae_stream_t stream);
+
+/* y[t,b,:] = dropout(x[t,b,:] + pe[t,:]) -- Enc_Transformer / Dec_Transformer positional encoding
+ * (models/encoders.py:721-723, models/decoders.py:607-608; PositionalEncoding try-branch nn_modules.py:430-438).
+ * x may be NULL (time queries PE(zeros)).  Backward: mmvae_dropout_act_bwd with MMVAE_ACT_NONE. */
+int mmvae_add_pe_dropout_fwd(const float* x, const float* pe, float* y, int T, int B, int D,
+                             const mmvae_dropout_t* drop, mmvae_stream_t stream);
 
 /* Scaled-dot-product attention with key padding mask for L,S <= 64 (nn.MultiheadAttention core).
  *   q (L*N, ldq) rows r = l*N+n, head h at columns [h*hd,(h+1)*hd); k, v (S*N, ld) likewise.

@@ -120,6 +120,161 @@ extern "C" int mmvae_bce_sigmoid_clamp_bwd(const float* x_hat, const float* targ
 }
 
 // ---------------------------------------------------------------------------------------------
+// lprob (objectives.py:409-424): -log p(t) under Normal / Laplace(loc, scale); elements in fp32 as torch.distributions
+// computes them, row sums accumulated in fp64 (the reference casts the elements to double before summing), NaN
+// elements count as 0 and carry no gradient.  scale <= 0 selects the reference's masked-modality quirk scale := loc.
+// ---------------------------------------------------------------------------------------------
+#define HALF_LOG_2PI 0.9189385332046727f
+__device__ __forceinline__ float lprob_logp(float x, float t, float s, int laplace) {
+  if (laplace) return -logf(2.0f * s) - fabsf(t - x) / s;
+  const float d = t - x;
+  return -(d * d) / (2.0f * (s * s)) - logf(s) - HALF_LOG_2PI;
+}
+__global__ __launch_bounds__(256) void lprob_rowsum_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                           float* __restrict__ row, int F, float scale, int laplace) {
+  __shared__ double red[4];
+  const size_t base = (size_t)blockIdx.x * F;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < F; i += 256) {
+    const float x = loc[base + i];
+    const float lp = lprob_logp(x, tg[base + i], scale > 0.f ? scale : x, laplace);
+    if (lp == lp) acc -= (double)lp;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) row[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void lprob_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                        const float* __restrict__ grow, float* __restrict__ dl, int F,
+                                                        float scale, int laplace) {
+  const size_t base = (size_t)blockIdx.y * F;
+  const float g = grow[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F) return;
+  const float x = loc[base + i], t = tg[base + i], d = t - x;
+  const bool own = !(scale > 0.f);
+  const float s = own ? x : scale;
+  const float lp = lprob_logp(x, t, s, laplace);
+  float v;   // d(-log p)/d loc
+  if (laplace) {
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    v = -sg / s;
+    if (own) v += 1.0f / s - fabsf(d) / (s * s);
+  } else {
+    v = -d / (s * s);
+    if (own) v += 1.0f / s - (d * d) / (s * s * s);
+  }
+  dl[base + i] = (lp == lp && v == v) ? g * v : 0.f;
+}
+extern "C" int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F, float scale,
+                                      int laplace, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && row_loss && B > 0 && F > 0);
+  hipLaunchKernelGGL(lprob_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, target, row_loss, F, scale,
+                     laplace);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, const float* g_row, float* dloc, int B,
+                                      int F, float scale, int laplace, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && g_row && dloc && B > 0 && F > 0);
+  hipLaunchKernelGGL(lprob_bwd_kernel, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, loc, target, g_row,
+                     dloc, F, scale, laplace);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimal_sigma (objectives.py:503-509, sigma-VAE): log_sigma = softclip(log sqrt(mean_all (t-x)^2), -6), ONE scalar
+// per call; loss[b,f] = detach(((t-x)/sigma)^2) + log_sigma + log sqrt(2 pi).  The only gradient path is log_sigma.
+// stats = {mean square, log_sigma, raw log sigma}.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqerr_partial_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                            float* __restrict__ ws, long n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = tg[i] - loc[i];
+    acc += d * d;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+__device__ __forceinline__ void optsig_stats(const float* __restrict__ ws, int nparts, long n, float* red, float* msq,
+                                             float* ls_raw, float* log_sigma) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += ws[i];
+  a = block_sum_256(a, red);
+  const float m = a / (float)n;
+  const float r = 0.5f * logf(m);                       // log sqrt(mean)
+  const float y = r + 6.0f;
+  *msq = m;
+  *ls_raw = r;
+  *log_sigma = -6.0f + (y > 20.0f ? y : log1pf(expf(y)));   // utils.softclip: min + softplus(x - min)
+}
+__global__ __launch_bounds__(256) void optsig_rows_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                          const float* __restrict__ ws, int nparts,
+                                                          float* __restrict__ row, float* __restrict__ stats, int B,
+                                                          int F) {
+  __shared__ float red[4];
+  float msq, ls_raw, ls;
+  optsig_stats(ws, nparts, (long)B * F, red, &msq, &ls_raw, &ls);
+  const float inv = expf(-ls);
+  const size_t base = (size_t)blockIdx.x * F;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < F; i += 256) {
+    const float q = (tg[base + i] - loc[base + i]) * inv;
+    acc += q * q;
+  }
+  __syncthreads();
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) {
+    row[blockIdx.x] = acc + (float)F * (ls + HALF_LOG_2PI);
+    if (blockIdx.x == 0) {
+      stats[0] = msq;
+      stats[1] = ls;
+      stats[2] = ls_raw;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void optsig_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                         const float* __restrict__ grow, const float* __restrict__ stats,
+                                                         float* __restrict__ dl, int B, int F) {
+  __shared__ float red[4];
+  float gs = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) gs += grow[b];
+  gs = block_sum_256(gs, red);
+  const long n = (long)B * F;
+  // d loss / d log_sigma = F * sum_b g_b;  d log_sigma / d raw = sigmoid(raw + 6);  d raw / d x_i = -(t_i - x_i) / (n * msq)
+  const float coef = -(gs * (float)F) * dev_sigmoid(stats[2] + 6.0f) / ((float)n * stats[0]);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dl[i] = coef * (tg[i] - loc[i]);
+}
+static inline int optsig_parts(long n) {
+  long p = (n + 4095) / 4096;
+  return (int)(p < 1 ? 1 : (p > 1024 ? 1024 : p));
+}
+extern "C" size_t mmvae_optimal_sigma_ws_floats(int B, int F) { return (size_t)optsig_parts((long)B * F); }
+extern "C" int mmvae_optimal_sigma_fwd(const float* loc, const float* target, float* row_loss, float* stats, float* ws,
+                                       int B, int F, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && row_loss && stats && ws && B > 0 && F > 0);
+  const long n = (long)B * F;
+  const int parts = optsig_parts(n);
+  hipLaunchKernelGGL(sqerr_partial_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, loc, target, ws, n);
+  hipLaunchKernelGGL(optsig_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, target, ws, parts, row_loss,
+                     stats, B, F);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_optimal_sigma_bwd(const float* loc, const float* target, const float* g_row, const float* stats,
+                                       float* dloc, int B, int F, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && g_row && stats && dloc && B > 0 && F > 0);
+  const long n = (long)B * F;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(optsig_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, loc, target, g_row,
+                     stats, dloc, B, F);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // category_ce: softmax over TIME (objectives.py:499-500).  One 64-thread block per
 // sample; lanes over the vocabulary (coalesced rows of V floats), serial loop over T (<= a few hundred).
 // ---------------------------------------------------------------------------------------------
@@ -264,7 +419,7 @@ extern "C" int mmvae_ce_over_time_bwd(const float* logits, const float* target, 
 // ---------------------------------------------------------------------------------------------
 // ELBO assembly: out[k] = sum_n W[k,n] * sum_b V[n,b]
 // ---------------------------------------------------------------------------------------------
-#define LC_MAX_ROWS 16
+#define LC_MAX_ROWS 32
 #define LC_MAX_OUT 4
 struct lincomb_w {
   float w[LC_MAX_OUT * LC_MAX_ROWS];

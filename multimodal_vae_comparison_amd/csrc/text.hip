@@ -513,8 +513,10 @@ __global__ __launch_bounds__(256) void permute_mask_kernel(const float* __restri
     const long bt = i / V;
     const int t = (int)(bt % T), b = (int)(bt / T);
     const long j = ((long)t * B + b) * V + v;  // (T,B,V) side
-    const float mk = m[bt] ? 1.f : 0.f;
-    if (fwd) y[i] = x[j] * mk; else y[j] = x[i] * mk;
+    // `output[~mask.T] = 0` is a masked WRITE (decoders.py:612,720): exact zeros forward, exact zero gradient backward
+    // even where the incoming value is NaN / inf -- a select, not a multiplication
+    const bool keep = m[bt] != 0;
+    if (fwd) y[i] = keep ? x[j] : 0.f; else y[j] = keep ? x[i] : 0.f;
   }
 }
 extern "C" int mmvae_permute_mask_fwd(const float* x, const uint8_t* mask, float* y, int T, int B, int V,
@@ -612,6 +614,30 @@ __global__ __launch_bounds__(256) void head_bcast_dropout_kernel(const float* __
     }
   }
 }
+// y[t,b,:] = dropout(x[t,b,:] + pe[t,:]): the time positional encoding of the action Transformer towers
+// (PositionalEncoding.forward's try-branch, models/nn_modules.py:430-438); x == NULL: the decoders' time queries
+// PE(zeros).  Backward is mmvae_dropout_act_bwd with MMVAE_ACT_NONE (same element index).
+__global__ __launch_bounds__(256) void add_pe_dropout_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                             float* __restrict__ y, int T, long BD, int D,
+                                                             mmvae_dropout_t drop) {
+  const DropKey dk = drop_key(drop);
+  const long n = (long)T * BD;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int t = (int)(i / BD), d = (int)(i % D);
+    y[i] = ((x ? x[i] : 0.f) + pe[(size_t)t * D + d]) * drop_mul(dk, (uint32_t)i);
+  }
+}
+extern "C" int mmvae_add_pe_dropout_fwd(const float* x, const float* pe, float* y, int T, int B, int D,
+                                        const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(pe && y && T > 0 && B > 0 && D > 0);
+  const long n = (long)T * B * D;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add_pe_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, pe, y, T,
+                     (long)B * D, D, drop_arg(drop));
+  return mmvae_launch_status();
+}
+
 extern "C" int mmvae_head_bcast_dropout_fwd(const float* v, float* out, int L, int N, int H, int hd,
                                             const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(v && out && L > 0 && N > 0 && H > 0 && hd > 0);

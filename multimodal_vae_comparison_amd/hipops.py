@@ -83,6 +83,12 @@ SIGNATURES = {
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_randn": (c_i, [c_p, c_l, c_p, c_p]),
+    "mmvae_lprob_rowsum_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
+    "mmvae_lprob_rowsum_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
+    "mmvae_optimal_sigma_ws_floats": (c_sz, [c_i, c_i]),
+    "mmvae_optimal_sigma_fwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
+    "mmvae_optimal_sigma_bwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
+    "mmvae_add_pe_dropout_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_dp, c_p]),
     "mmvae_lincomb_rowptrs_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rowptrs_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_dp, c_p]),
@@ -129,7 +135,7 @@ MAX_SEGMENTS = 64
 
 
 class RowPtrs(ctypes.Structure):
-    _fields_ = [("p", c_p * 16)]
+    _fields_ = [("p", c_p * 32)]
 
 
 class GPtrs(ctypes.Structure):

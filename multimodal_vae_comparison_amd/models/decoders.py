@@ -179,3 +179,58 @@ class Dec_TxtTransformer(VaeDecoder):
         out = self.finallayer(x)                                              # (T, bs, V)
         out = ops.permute_mask(out, mask_u8)                                  # (bs, T, V), zero at padding
         return out, self._scale
+
+
+class Dec_Transformer(VaeDecoder):
+    """models/decoders.py:541-616: time queries PE(zeros) + dropout, `num_layers` post-norm decoder layers over the
+    length-1 memory z (d = D', ff 1024, 2 heads), Linear(D' -> joints*feats), padded steps zeroed, (B, T, joints, feats)."""
+
+    def __init__(self, latent_dim, data_dim, latent_private, ff_size=1024, num_layers=4, num_heads=2, dropout=0.1,
+                 activation="gelu"):
+        super().__init__(latent_dim, data_dim, latent_private, net_type=NetworkTypes.TRANSFORMER)
+        assert activation == "gelu"
+        self.net_type = "Transformer"
+        self.njoints = data_dim[1]
+        self.nfeats = data_dim[2] if len(data_dim) > 2 else 1
+        self.data_dim = data_dim
+        self.latent_dim = latent_dim
+        self.ff_size, self.num_layers, self.num_heads, self.dropout = ff_size, num_layers, num_heads, dropout
+        self.activation = activation
+        self.input_feats = self.njoints * self.nfeats
+        self.sequence_pos_encoder = ModuleWrap(PositionalEncoding(self.out_dim, self.dropout))
+        self.seqTransDecoder = HipTransformerDecoderStack(
+            [HipTransformerDecoderLayer(self.out_dim, num_heads, ff_size) for _ in range(num_layers)])
+        self.finallayer = ModuleWrap(HipLinear(self.out_dim, self.input_feats))
+        self.register_buffer("_scale", torch.tensor(0.75), persistent=False)
+        self.drop_state = DropoutState()
+
+    def forward(self, batch):
+        z, mask = batch["latents"], batch["masks"]
+        D = self.out_dim
+        z = z.reshape(-1, D)                       # memory of length 1: (K*B, D')
+        bs = z.shape[0]
+        if mask is not None:
+            if bs > mask.shape[0]:
+                mask = mask.repeat(int(bs / mask.shape[0]), 1)
+            mask = mask.to(z.device)
+        else:
+            mask = torch.ones(bs, self.data_dim[0], dtype=torch.bool, device=z.device)
+        T = mask.shape[1]
+        mask_u8 = ops.as_u8(mask)
+        nl = len(self.seqTransDecoder.layers)
+        if self.training and self.dropout > 0:    # nn.Dropout sites: PE + 6 per layer
+            slot, call = self.drop_state.begin()
+            sp = lambda site, name: self.drop_state.spec(slot, call, site, self.dropout, name)
+            d_pe = sp(0, "pe")
+            ds = [{"attn": sp(1 + 6 * i, f"l{i}.attn"), "drop1": sp(2 + 6 * i, f"l{i}.drop1"),
+                   "xattn": sp(3 + 6 * i, f"l{i}.xattn"), "drop2": sp(4 + 6 * i, f"l{i}.drop2"),
+                   "ffn": sp(5 + 6 * i, f"l{i}.ffn"), "drop3": sp(6 + 6 * i, f"l{i}.drop3")} for i in range(nl)]
+        else:
+            d_pe, ds = None, [None] * nl
+        pe = self.sequence_pos_encoder.module.pe[:T].reshape(T, D)
+        x = ops.add_pe_dropout(None, pe, T, bs, D, d_pe)
+        for layer, d in zip(self.seqTransDecoder.layers, ds):
+            x = layer(x, z, mask_u8, d)
+        out = self.finallayer(x)                                              # (T, bs, joints*feats)
+        out = ops.permute_mask(out, mask_u8)                                  # (bs, T, .), padded steps zero
+        return out.view(bs, T, self.njoints, self.nfeats), self._scale

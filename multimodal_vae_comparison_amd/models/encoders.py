@@ -226,3 +226,53 @@ class Enc_TxtTransformer(VaeEncoder):
             h = layer(h, mask_u8, d)
         z = ops.mean_over_time(h)
         return self.process_output(z)
+
+
+class Enc_Transformer(VaeEncoder):
+    """models/encoders.py:656-729 (ACTOR-style encoder for action sequences (B, T, joints, feats)):
+    Linear(joints*feats -> D') + time positional encoding + dropout, `num_layers` post-norm encoder layers
+    (d = D', ff 1024, 2 heads, gelu), mean over time, heads Linear(D' -> D')."""
+
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar, ff_size=1024, num_layers=8, num_heads=2,
+                 dropout=0.1, activation="gelu"):
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.TRANSFORMER)
+        assert activation == "gelu" and num_layers >= 1
+        self.net_type = "Transformer"
+        self.njoints, self.nfeats = data_dim[1], (data_dim[2] if len(data_dim) > 2 else 1)
+        self.ff_size, self.num_layers, self.num_heads, self.dropout = ff_size, num_layers, num_heads, dropout
+        self.activation = activation
+        self.input_feats = self.njoints * self.nfeats
+        d = self.out_dim
+        self.mu_layer = ModuleWrap(HipLinear(d, d))
+        self.logvar_layer = ModuleWrap(HipLinear(d, d))
+        self.skel_Embedding = ModuleWrap(HipLinear(self.input_feats, d))
+        self.sequence_pos_encoder = PositionalEncoding(d, self.dropout)
+        self.seqTransEncoder = HipTransformerStack([HipTransformerEncoderLayer(d, num_heads, ff_size)
+                                                    for _ in range(num_layers)])
+        self.drop_state = DropoutState()
+
+    def forward(self, batch):
+        x, mask = batch["data"], batch["masks"]
+        if x.dim() == 3:
+            x = x.unsqueeze(-1)
+        bs, nframes = x.shape[0], x.shape[1]
+        if mask is None:
+            mask = torch.ones(bs, nframes, dtype=torch.bool, device=x.device)
+        mask_u8 = ops.as_u8(mask)
+        d = self.out_dim
+        x = x.permute(1, 0, 2, 3).reshape(nframes, bs, self.input_feats).float().contiguous()
+        nl = len(self.seqTransEncoder.layers)
+        if self.training and self.dropout > 0:    # nn.Dropout sites: PE + 4 per layer
+            slot, call = self.drop_state.begin()
+            sp = lambda site, name: self.drop_state.spec(slot, call, site, self.dropout, name)
+            d_pe = sp(0, "pe")
+            ds = [{"attn": sp(1 + 4 * i, f"l{i}.attn"), "drop1": sp(2 + 4 * i, f"l{i}.drop1"),
+                   "ffn": sp(3 + 4 * i, f"l{i}.ffn"), "drop2": sp(4 + 4 * i, f"l{i}.drop2")} for i in range(nl)]
+        else:
+            d_pe, ds = None, [None] * nl
+        h = self.skel_Embedding(x)
+        pe = self.sequence_pos_encoder.pe[:nframes].reshape(nframes, d)
+        h = ops.add_pe_dropout(h, pe, nframes, bs, d, d_pe)
+        for layer, dd in zip(self.seqTransEncoder.layers, ds):
+            h = layer(h, mask_u8, dd)
+        return self.process_output(ops.mean_over_time(h))

@@ -23,18 +23,39 @@ class ReconLoss:
         return ops.ce_over_time(output.loc, target.float().detach(), per_v=True).reshape(bs, -1)
 
 
+    @staticmethod
+    def lprob(output, target, bs):
+        """objectives.py:409-424: -log_prob, NaN -> 0.  Per-sample sums only on the hot path (recon_rowsum); the
+        element-wise fp64 tensor is evaluation API and not built."""
+        raise NotImplementedError("ReconLoss.lprob: use objectives.recon_rowsum (per-sample sums)")
+
+    @staticmethod
+    def optimal_sigma(output, target, bs):
+        """objectives.py:503-509 (sigma-VAE): see recon_rowsum"""
+        raise NotImplementedError("ReconLoss.optimal_sigma: use objectives.recon_rowsum (per-sample sums)")
+
+
+PX_SCALE = 0.75     # the decoders return (recon, 0.75): px_z = Normal / Laplace(recon, 0.75)
+
+
 # per-sample sums  sum_f ReconLoss.<ltype>(...)[b, f]  in one kernel
-def recon_rowsum(ltype, out, target):
+def recon_rowsum(ltype, out, target, laplace=False):
     """`out`: decoder output tensor; `target`: {"data", "masks"} (BaseObjective.recon_loss_fn, objectives.py:30-52:
-    slice to the mask length, reshape target like the output)."""
-    if target["masks"] is not None:
+    slice to the mask length -- and then the likelihood's scale := its loc --, reshape target like the output)."""
+    masked = target["masks"] is not None
+    if masked:
         out = out[:, : target["masks"].shape[1]]
     data = target["data"]
+    if ltype == "lprob":
+        return ops.lprob_rowsum(out, data.float().reshape(out.shape), None if masked else PX_SCALE, laplace)
+    if ltype == "optimal_sigma":
+        return ops.optimal_sigma_rowsum(out, data.float().reshape(out.shape))
     if ltype == "bce":
         return ops.bce_rowsum(out, data.float().reshape(out.shape))
     if ltype == "category_ce":
         return ops.ce_over_time(out, data.float(), per_v=False)
-    raise NotImplementedError(f"recon_loss {ltype} is not on the MI355X hot path yet (bce, category_ce are)")
+    raise NotImplementedError(f"recon_loss {ltype} is not on the MI355X hot path (bce, category_ce, lprob, "
+                              f"optimal_sigma are)")
 
 
 class BaseObjective:

@@ -553,6 +553,92 @@ class BceElem(Function):
         return H.f32c(g) * (x_hat - target) / ((1 - x_hat) * x_hat).clamp_min(1e-12), None
 
 
+class LprobRowsum(Function):
+    """row[b] = sum_f -log p(target[b,f]) under Normal / Laplace(loc, scale); `scale` None = scale := loc (masked
+    modalities).  ReconLoss.lprob summed per sample (models/objectives.py:409-424)."""
+
+    @staticmethod
+    def forward(ctx, loc, target, scale, laplace):
+        loc, target = H.f32c(loc), H.f32c(target)
+        B = loc.shape[0]
+        F_ = loc.numel() // B
+        row = torch.empty(B, device=loc.device)
+        sc = -1.0 if scale is None else float(scale)
+        _call("mmvae_lprob_rowsum_fwd", H.ptr(loc), H.ptr(target), H.ptr(row), B, F_, sc, int(laplace), H.stream())
+        ctx.save_for_backward(loc, target)
+        ctx.cfg = (sc, int(laplace))
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, target = ctx.saved_tensors
+        B = loc.shape[0]
+        d = torch.empty_like(loc)
+        _call("mmvae_lprob_rowsum_bwd", H.ptr(loc), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(d), B, loc.numel() // B,
+              ctx.cfg[0], ctx.cfg[1], H.stream())
+        return d, None, None, None
+
+
+class OptimalSigmaRowsum(Function):
+    """ReconLoss.optimal_sigma summed per sample (models/objectives.py:503-509): one log sigma per call."""
+
+    @staticmethod
+    def forward(ctx, loc, target):
+        loc, target = H.f32c(loc), H.f32c(target)
+        B = loc.shape[0]
+        F_ = loc.numel() // B
+        row = torch.empty(B, device=loc.device)
+        stats = torch.empty(4, device=loc.device)
+        ws = torch.empty(H.lib().mmvae_optimal_sigma_ws_floats(B, F_), device=loc.device)
+        _call("mmvae_optimal_sigma_fwd", H.ptr(loc), H.ptr(target), H.ptr(row), H.ptr(stats), H.ptr(ws), B, F_,
+              H.stream())
+        ctx.save_for_backward(loc, target, stats)
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, target, stats = ctx.saved_tensors
+        B = loc.shape[0]
+        d = torch.empty_like(loc)
+        _call("mmvae_optimal_sigma_bwd", H.ptr(loc), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(stats), H.ptr(d), B,
+              loc.numel() // B, H.stream())
+        return d, None
+
+
+def lprob_rowsum(loc, target, scale=0.75, laplace=False):
+    return LprobRowsum.apply(loc, target, scale, laplace)
+
+
+def optimal_sigma_rowsum(loc, target):
+    return OptimalSigmaRowsum.apply(loc, target)
+
+
+class AddPEDropout(Function):
+    """dropout(x + pe[t]) for x (T,B,D), pe (T,D); x None: the decoders' time queries dropout(pe[t]) broadcast"""
+
+    @staticmethod
+    def forward(ctx, x, pe, T, B, D, drop):
+        y = torch.empty(T, B, D, device=pe.device)
+        _call("mmvae_add_pe_dropout_fwd", H.ptr(H.f32c(x)) if x is not None else None, H.ptr(pe), H.ptr(y), T, B, D,
+              _dp(drop, y.numel()), H.stream())
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None
+        dy = H.f32c(dy)
+        dx = torch.empty_like(dy)
+        _call("mmvae_dropout_act_bwd", H.ptr(dy), H.ptr(dy), H.ptr(dx), dy.numel(), H.ACT_NONE,
+              ctx.drop.c() if ctx.drop is not None else None, H.stream())
+        return dx, None, None, None, None, None
+
+
+def add_pe_dropout(x, pe, T, B, D, drop=None):
+    return AddPEDropout.apply(x, pe, T, B, D, drop)
+
+
 class CeOverTime(Function):
     """category_ce with the softmax over TIME (models/objectives.py:486-500): logits/target (B,T,V) ->
     loss (B,V) [per_v=True] or its row sums (B,)."""
@@ -591,7 +677,7 @@ class LincombRows(Function):
         B = blocks[0].shape[-1]
         rows = [t.numel() // B for t in blocks]
         n, k = sum(rows), len(W)
-        assert n <= 16 and k <= 4
+        assert n <= 32 and k <= 4
         rp = H.RowPtrs()
         i = 0
         for t, r in zip(blocks, rows):

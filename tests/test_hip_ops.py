@@ -206,6 +206,47 @@ def test_bce_and_ce(ops):
         check(lgg.grad, lr_.grad, 2e-5, f"ce dlogits per_v={per_v}")
 
 
+@pytest.mark.parametrize("B,F_,own,laplace", [(7, 33, False, False), (128, 12288, False, False), (5, 24, True, False),
+                                              (6, 40, False, True), (5, 24, True, True)])
+def test_lprob_rowsum(ops, B, F_, own, laplace):
+    """-log_prob sums vs torch.distributions in fp32 -> double, NaN -> 0 (ReconLoss.lprob); `own`: scale := loc"""
+    g = torch.Generator().manual_seed(B + F_)
+    loc = torch.randn(B, F_, generator=g)
+    if own:
+        loc[0, :5] = 0.0                        # exact zeros as in padded steps: 0/0 -> NaN -> dropped
+    tgt = torch.randn(B, F_, generator=g)
+    tgt[0, :5] = 0.0
+    gr = torch.randn(B, generator=g)
+    lr_ = loc.clone().requires_grad_(True)
+    sc = lr_ if own else torch.tensor(0.75)
+    dist = torch.distributions.Laplace if laplace else torch.distributions.Normal
+    out = dist(lr_, sc, validate_args=False).log_prob(tgt).double()
+    out = torch.where(torch.isnan(out), torch.zeros_like(out), out)
+    ref = (-out).sum(1)
+    ref.backward(gr.double())
+    lg = loc.to(DEV).requires_grad_(True)
+    row = ops.lprob_rowsum(lg, tgt.to(DEV), None if own else 0.75, laplace)
+    row.backward(gr.to(DEV))
+    check(row, ref, 2e-6, "lprob rows")
+    rg = torch.where(torch.isnan(lr_.grad), torch.zeros_like(lr_.grad), lr_.grad)
+    check(lg.grad, rg, 2e-5, "lprob dloc")
+
+
+@pytest.mark.parametrize("B,F_", [(5, 24), (128, 128), (64, 12288)])
+def test_optimal_sigma_rowsum(ops, B, F_):
+    g = torch.Generator().manual_seed(B * 3 + F_)
+    loc, tgt, gr = torch.randn(B, F_, generator=g), torch.randn(B, F_, generator=g), torch.randn(B, generator=g)
+    lr_ = loc.double().requires_grad_(True)
+    ls = -6 + F.softplus(((tgt.double() - lr_) ** 2).mean().sqrt().log() + 6)
+    ref = ((((tgt.double() - lr_) / ls.exp()) ** 2).detach() + ls + 0.5 * math.log(2 * math.pi)).sum(1)
+    ref.backward(gr.double())
+    lg = loc.to(DEV).requires_grad_(True)
+    row = ops.optimal_sigma_rowsum(lg, tgt.to(DEV))
+    row.backward(gr.to(DEV))
+    check(row, ref, 1e-5, "optimal_sigma rows")
+    check(lg.grad, lr_.grad, 5e-5, "optimal_sigma dloc")
+
+
 def test_lincomb_rows(ops):
     g = torch.Generator().manual_seed(4)
     V = torch.randn(5, 130, generator=g)
