@@ -45,7 +45,8 @@ enum {
   MMVAE_EP_MUL_SILU_GRAD = 3, /* y = acc * silu'(aux)       (dgrad through a SiLU, aux = saved u)   */
   MMVAE_EP_GELU = 4,          /* y = gelu(acc + bias); aux (if non-null) RECEIVES acc + bias        */
   MMVAE_EP_MUL_GELU_GRAD = 5, /* y = acc * gelu'(aux)                                              */
-  MMVAE_EP_SIGMOID_CLAMP = 6  /* y = clamp(sigmoid(acc + bias), 1e-6, 1 - 1e-6)                     */
+  MMVAE_EP_SIGMOID_CLAMP = 6, /* y = clamp(sigmoid(acc + bias), 1e-6, 1 - 1e-6)  (Dec_CNN, decoders.py:96-97) */
+  MMVAE_EP_SIGMOID = 7        /* y = sigmoid(acc + bias)                          (Dec_SVHN, decoders.py:144) */
 };
 
 /* Inverted dropout (train mode of the text towers: nn.Dropout(0.1) in PositionalEncoding and in every
@@ -401,6 +402,31 @@ int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, float* dx, int 
  * models/mmvae_models.py:363-369).  state = {seed, call counter, ticket} (three uint32 on the device, ticket 0); the
  * launch advances the call counter itself, so a captured graph replays with fresh noise and no host work. */
 int mmvae_randn(float* out, long n, uint32_t* state, mmvae_stream_t stream);
+
+/* ---- Generic convolutions (csrc/conv_generic.hip): any channel counts, K <= 4, stride S, padding P -------------
+ * First correct path for Enc_SVHN / Dec_SVHN (models/encoders.py:434-478, models/decoders.py:101-147); plain fp32 FMA.
+ * Same conventions as the k4-s2-p1 entry points above: layers emit pre-activations, `in_act` is applied to the
+ * input, `ep_mode` to the output (`aux` = the tensor a MUL_* epilogue differentiates through).
+ *   Conv2d          w [Cout][Cin][K][K], Hout = (Hin + 2P - K) / S + 1
+ *   ConvTranspose2d w [Cin][Cout][K][K], Hout = (Hin - 1) S - 2P + K                                            */
+int mmvae_conv2d_generic_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y, int B,
+                             int Cin, int Cout, int Hin, int Win, int K, int S, int P, int in_act, int ep_mode,
+                             mmvae_stream_t stream);
+int mmvae_conv2d_generic_dgrad(const float* dy, const float* w, const float* aux, float* dx, int B, int Cin, int Cout,
+                               int Hin, int Win, int K, int S, int P, int ep_mode, mmvae_stream_t stream);
+int mmvae_conv2d_generic_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Cin, int Cout, int Hin,
+                               int Win, int K, int S, int P, int x_act, int accumulate, mmvae_stream_t stream);
+int mmvae_convT2d_generic_fwd(const float* x, const float* w, const float* bias, const float* aux, float* y, int B,
+                              int Cin, int Cout, int Hin, int Win, int K, int S, int P, int in_act, int ep_mode,
+                              mmvae_stream_t stream);
+int mmvae_convT2d_generic_dgrad(const float* dy, const float* w, const float* aux, float* dx, int B, int Cin, int Cout,
+                                int Hin, int Win, int K, int S, int P, int ep_mode, mmvae_stream_t stream);
+int mmvae_convT2d_generic_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Cin, int Cout,
+                                int Hin, int Win, int K, int S, int P, int x_act, int accumulate,
+                                mmvae_stream_t stream);
+/* y = sigmoid(x); dx = dy y (1 - y)   (Dec_MNIST, models/decoders.py:266; backward of MMVAE_EP_SIGMOID outputs) */
+int mmvae_sigmoid_fwd(const float* x, float* y, long n, mmvae_stream_t stream);
+int mmvae_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser + utilities

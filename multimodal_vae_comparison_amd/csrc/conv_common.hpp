@@ -46,10 +46,11 @@ __device__ __forceinline__ float conv_epilogue(float v, float aux_v, int ep) {
     case MMVAE_EP_MUL_RELU_MASK: return aux_v > 0.0f ? v : 0.0f;
     case MMVAE_EP_MUL_SILU_GRAD: return v * dev_silu_grad(aux_v);
     case MMVAE_EP_SIGMOID_CLAMP: return fminf(fmaxf(dev_sigmoid(v), 1e-6f), 1.0f - 1e-6f);
+    case MMVAE_EP_SIGMOID: return dev_sigmoid(v);
     default: return v;
   }
 }
 __host__ __device__ __forceinline__ bool conv_ep_supported(int ep) {
   return ep == MMVAE_EP_NONE || ep == MMVAE_EP_RELU || ep == MMVAE_EP_MUL_RELU_MASK || ep == MMVAE_EP_MUL_SILU_GRAD ||
-         ep == MMVAE_EP_SIGMOID_CLAMP;
+         ep == MMVAE_EP_SIGMOID_CLAMP || ep == MMVAE_EP_SIGMOID;
 }

@@ -23,7 +23,7 @@ c_sz = ctypes.c_size_t
 MAX_EXPERTS = 8
 
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
-EP_NONE, EP_RELU, EP_MUL_RELU_MASK, EP_MUL_SILU_GRAD, EP_GELU, EP_MUL_GELU_GRAD, EP_SIGMOID_CLAMP = range(7)
+EP_NONE, EP_RELU, EP_MUL_RELU_MASK, EP_MUL_SILU_GRAD, EP_GELU, EP_MUL_GELU_GRAD, EP_SIGMOID_CLAMP, EP_SIGMOID = range(8)
 
 _ERR = {1: "invalid argument", 2: "unsupported shape", 3: "kernel launch failed"}
 
@@ -83,6 +83,14 @@ SIGNATURES = {
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_randn": (c_i, [c_p, c_l, c_p, c_p]),
+    "mmvae_conv2d_generic_fwd": (c_i, [c_p] * 5 + [c_i] * 10 + [c_p]),
+    "mmvae_conv2d_generic_dgrad": (c_i, [c_p] * 4 + [c_i] * 9 + [c_p]),
+    "mmvae_conv2d_generic_wgrad": (c_i, [c_p] * 4 + [c_i] * 10 + [c_p]),
+    "mmvae_convT2d_generic_fwd": (c_i, [c_p] * 5 + [c_i] * 10 + [c_p]),
+    "mmvae_convT2d_generic_dgrad": (c_i, [c_p] * 4 + [c_i] * 9 + [c_p]),
+    "mmvae_convT2d_generic_wgrad": (c_i, [c_p] * 4 + [c_i] * 10 + [c_p]),
+    "mmvae_sigmoid_fwd": (c_i, [c_p, c_p, c_l, c_p]),
+    "mmvae_sigmoid_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "mmvae_lprob_rowsum_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
     "mmvae_lprob_rowsum_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
     "mmvae_optimal_sigma_ws_floats": (c_sz, [c_i, c_i]),

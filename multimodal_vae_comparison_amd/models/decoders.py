@@ -234,3 +234,55 @@ class Dec_Transformer(VaeDecoder):
         out = self.finallayer(x)                                              # (T, bs, joints*feats)
         out = ops.permute_mask(out, mask_u8)                                  # (bs, T, .), padded steps zero
         return out.view(bs, T, self.njoints, self.nfeats), self._scale
+
+
+class Dec_MNIST(VaeDecoder):
+    """models/decoders.py:230-270: D' -> 400 -> 400 (ReLU) -> 784, sigmoid, reshaped to data_dim and permuted to NCHW"""
+
+    def __init__(self, latent_dim, data_dim, latent_private):
+        super().__init__(latent_dim, data_dim, latent_private, net_type=NetworkTypes.FNN)
+        self.data_dim = data_dim
+        self.net_type = "CNN"
+        self.hidden_dim = 400
+        self.dec = nn.ModuleList([nn.ModuleList([HipLinear(self.out_dim, self.hidden_dim)]),
+                                  nn.ModuleList([HipLinear(self.hidden_dim, self.hidden_dim, H.ACT_RELU)])])
+        self.fc3 = HipLinear(self.hidden_dim, 784, H.ACT_RELU)
+        self.register_buffer("_scale", torch.tensor(0.75), persistent=False)
+
+    def forward(self, z):
+        z = z["latents"]
+        lead = z.shape[:-1]
+        h = self.fc3(self.dec[1][0](self.dec[0][0](z.reshape(-1, z.shape[-1]))))
+        x_hat = ops.sigmoid(h)
+        d = x_hat.reshape(*lead, *self.data_dim)
+        if d.dim() == 5:
+            d = d.squeeze(0)
+        d = d.permute(0, 3, 1, 2) if d.dim() == 4 else d.permute(0, 1, 4, 2, 3)
+        return d, self._scale
+
+
+class Dec_SVHN(VaeDecoder):
+    """models/decoders.py:101-147: Linear(D', 128), ReLU, ConvT k4 128->64 (s1 p0), 64->64, 64->32, 32->3 (s2 p1),
+    sigmoid, output permuted to (B, 32, 32, 3)"""
+
+    def __init__(self, latent_dim, data_dim, latent_private):
+        super().__init__(latent_dim, data_dim, latent_private, net_type=NetworkTypes.CNN)
+        self.data_dim = data_dim
+        self.net_type = "CNN"
+        HC = encoders.HipConv
+        self.linear = HipLinear(self.out_dim, 128)
+        self.conv1 = HC(128, 64, 4, 1, 0, H.ACT_RELU, transposed=True)
+        self.conv2 = HC(64, 64, 4, 2, 1, H.ACT_RELU, transposed=True)
+        self.conv3 = HC(64, 32, 4, 2, 1, H.ACT_RELU, transposed=True)
+        self.conv4 = HC(32, 3, 4, 2, 1, H.ACT_RELU, transposed=True, out_ep=H.EP_SIGMOID)
+        self.register_buffer("_scale", torch.tensor(0.75), persistent=False)
+
+    def forward(self, z):
+        zs = z["latents"]
+        bs = zs.shape[:2] if (zs.dim() == 3 and zs.shape[0] > 1) else None
+        zs = zs.reshape(-1, zs.shape[-1])
+        h = self.linear(zs).reshape(-1, 128, 1, 1)
+        d = self.conv4(self.conv3(self.conv2(self.conv1(h)))).permute(0, 2, 3, 1)
+        if bs:
+            d = d.reshape(*bs, *d.shape[1:])
+        return d, self._scale

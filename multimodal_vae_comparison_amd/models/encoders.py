@@ -44,9 +44,9 @@ class VaeComponent(nn.Module):
         return mu, lv
 
     def flat_groups(self):
-        if self.mu_layer is None or self.logvar_layer is None:
-            return []
         mu, lv = self._heads()
+        if mu is None or lv is None:
+            return []
         return [[mu.weight, lv.weight], [mu.bias, lv.bias]]
 
     def process_output(self, data, in_act=H.ACT_NONE):
@@ -123,6 +123,71 @@ class Enc_CNN2(VaeEncoder):
         u = self.conv4(self.conv3(self.conv2(self.conv1(x.float()))))
         o5 = self.lin1(u.view(bs, -1))
         return self.process_output(o5)
+
+
+class HipConv(nn.Module):
+    """nn.Conv2d / nn.ConvTranspose2d parameters (torch default init) for any (channels, k, stride, pad): ops.conv2d /
+    ops.convT2d pick the MFMA kernel when the shape is one of theirs, the generic kernel otherwise."""
+
+    def __init__(self, cin, cout, k, stride, pad, in_act=H.ACT_NONE, transposed=False, out_ep=H.EP_NONE):
+        super().__init__()
+        ref = (nn.ConvTranspose2d if transposed else nn.Conv2d)(cin, cout, k, stride=stride, padding=pad)
+        self.weight, self.bias = ref.weight, ref.bias
+        self.cfg = (stride, pad, in_act, transposed, out_ep)
+
+    def flat_groups(self):
+        return [[self.weight, self.bias]]
+
+    def forward(self, x):
+        stride, pad, in_act, transposed, out_ep = self.cfg
+        if transposed:
+            return ops.convT2d(x, self.weight, self.bias, stride, pad, in_act, out_ep, self.weight.grad, self.bias.grad)
+        return ops.conv2d(x, self.weight, self.bias, stride, pad, in_act, self.weight.grad, self.bias.grad)
+
+
+class _HiddenHeads:
+    """the MNIST / SVHN towers name their heads hidden_mu / hidden_logvar (models/encoders.py:246-247,455-456)"""
+
+    def _heads(self):
+        return self.hidden_mu, self.hidden_logvar
+
+
+class Enc_MNIST(_HiddenHeads, VaeEncoder):
+    """models/encoders.py:226-265: 784 -> 400 -> 400 (ReLU) MLP, heads.  state_dict keys enc.{0,1}.0.*, hidden_*."""
+
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar):
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.FNN)
+        self.net_type = "CNN"
+        self.hidden_dim = 400
+        self.enc = nn.ModuleList([nn.ModuleList([HipLinear(784, self.hidden_dim)]),
+                                  nn.ModuleList([HipLinear(self.hidden_dim, self.hidden_dim, H.ACT_RELU)])])
+        self.hidden_mu = HipLinear(self.hidden_dim, self.out_dim)
+        self.hidden_logvar = HipLinear(self.hidden_dim, self.out_dim)
+
+    def forward(self, x):
+        x = x["data"] if isinstance(x, dict) else x
+        h = x.reshape(x.shape[0], -1).float()
+        h = self.enc[1][0](self.enc[0][0](h))            # the ReLUs are applied by the consumers
+        return self.process_output(h, H.ACT_RELU)
+
+
+class Enc_SVHN(_HiddenHeads, VaeEncoder):
+    """models/encoders.py:434-478: Conv2d k4 3->32->64->64 (s2 p1), 64->128 (s2 p0), ReLU, heads on the 128 features"""
+
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar):
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.CNN)
+        self.net_type = "CNN"
+        self.conv1 = HipConv(3, 32, 4, 2, 1)
+        self.conv2 = HipConv(32, 64, 4, 2, 1, H.ACT_RELU)
+        self.conv3 = HipConv(64, 64, 4, 2, 1, H.ACT_RELU)
+        self.conv4 = HipConv(64, 128, 4, 2, 0, H.ACT_RELU)
+        self.hidden_mu = HipLinear(128, self.out_dim)
+        self.hidden_logvar = HipLinear(128, self.out_dim)
+
+    def forward(self, x):
+        x = x["data"] if isinstance(x, dict) else x
+        h = self.conv4(self.conv3(self.conv2(self.conv1(x.float()))))
+        return self.process_output(h.reshape(h.shape[0], -1), H.ACT_RELU)
 
 
 class Enc_CNN(VaeEncoder):

@@ -43,21 +43,25 @@ class GradReducer:
         key = device.index if device.index is not None else torch.cuda.current_device()
         st = cls._state.get(key)
         if st is None:
-            st = {"off": 0, "segs": [], "armed": False, "device": device, "keep": [], "used": set(), "pending": []}
+            st = {"off": 0, "segs": [], "armed": False, "device": device, "keep": [], "used": set(), "pending": [],
+                  "spill": [], "spilled": 0}
             cls._state[key] = st
         return key, st
 
     @classmethod
     def alloc(cls, n_floats, device):
+        """a private slice of the step arena.  The arena never moves or gets folded in the middle of a backward pass
+        (kernels on several streams are writing into it): when it is full a further chunk is chained for the rest of
+        the step, and the next step starts with one arena of the combined size."""
         key, st = cls._st(device)
         n = (int(n_floats) + 63) // 64 * 64
         ar = cls._arena.get(key)
         if ar is None or st["off"] + n > ar.numel():
-            if st["segs"]:
-                cls.flush(device)              # cannot grow under pending segments: fold what we have first
-            if ar is None or n > ar.numel():
-                ar = torch.empty(max(n, 16 << 20), dtype=torch.float32, device=device)   # 64 MB
-                cls._arena[key] = ar
+            if ar is not None:
+                st["spill"].append(ar)          # keep the full chunk alive until the end-of-backward fold
+                st["spilled"] += ar.numel()
+            ar = torch.empty(max(n, 16 << 20), dtype=torch.float32, device=device)   # 64 MB chunks
+            cls._arena[key] = ar
             st["off"] = 0
         out = ar[st["off"]:st["off"] + n]
         st["off"] += n
@@ -111,7 +115,8 @@ class GradReducer:
                 cur.wait_stream(side)
         st["used"] = set()
         st["keep"] = []
-        segs, st["segs"], st["armed"], st["off"] = st["segs"], [], False, 0
+        segs, st["segs"], st["armed"] = st["segs"], [], False
+        need, st["off"] = st["spilled"] + st["off"], 0
         for i in range(0, len(segs), H.MAX_SEGMENTS):
             chunk = segs[i:i + H.MAX_SEGMENTS]
             t = H.ReduceSegments()
@@ -119,6 +124,11 @@ class GradReducer:
                 t.src[j], t.dst[j], t.rows[j], t.len[j], t.stride[j] = sp, dp, r, ln, sd
             t.n = len(chunk)
             _call("mmvae_reduce_segments", ctypes.byref(t), H.stream())
+        if st["spill"]:        # the step did not fit one chunk: one arena of the full size from the next step on
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            st["spill"], st["spilled"] = [], 0
+            if not torch.cuda.is_current_stream_capturing():
+                cls._arena[key] = torch.empty(need + (1 << 20), dtype=torch.float32, device=device)
 
 
 class StreamPlan:
@@ -287,7 +297,7 @@ class ConvT2dK4S2(Function):
         y = torch.empty(B, Cout, 2 * Hin, 2 * Hin, device=x.device, dtype=torch.float32)
         _call("mmvae_convT2d_k4s2_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), B, Cin, Cout, Hin, in_act,
               out_ep, H.stream())
-        ctx.save_for_backward(x, w, y if out_ep == H.EP_SIGMOID_CLAMP else None)
+        ctx.save_for_backward(x, w, y if out_ep in (H.EP_SIGMOID_CLAMP, H.EP_SIGMOID) else None)
         ctx.cfg = (in_act, out_ep, gw, gb, b is not None)
         return y
 
@@ -301,6 +311,10 @@ class ConvT2dK4S2(Function):
         if out_ep == H.EP_SIGMOID_CLAMP:
             dl = torch.empty_like(dy)
             _call("mmvae_sigmoid_clamp_bwd", H.ptr(dy), H.ptr(y), H.ptr(dl), dy.numel(), H.stream())
+            dy = dl
+        elif out_ep == H.EP_SIGMOID:
+            dl = torch.empty_like(dy)
+            _call("mmvae_sigmoid_bwd", H.ptr(dy), H.ptr(y), H.ptr(dl), dy.numel(), H.stream())
             dy = dl
         dw, acc_w, ret_w = _new_like_param(w, gw)
         db, ret_b = None, None
@@ -324,6 +338,83 @@ class ConvT2dK4S2(Function):
         if defer:
             _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
         return dx, ret_w, ret_b, None, None, None, None
+
+
+class ConvGeneric(Function):
+    """Conv2d (transposed = False) or ConvTranspose2d (True) with any channel counts, K <= 4, stride, padding, on the
+    generic kernels of csrc/conv_generic.hip (Enc_SVHN / Dec_SVHN layers outside the k4-s2-p1 3/32-channel shapes)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, transposed, stride, pad, in_act, out_ep, gw, gb):
+        x = H.f32c(x)
+        B, Cin, Hin, Win = x.shape
+        K = w.shape[-1]
+        if transposed:
+            Cout = w.shape[1]
+            Ho, Wo = (Hin - 1) * stride - 2 * pad + K, (Win - 1) * stride - 2 * pad + K
+        else:
+            Cout = w.shape[0]
+            Ho, Wo = (Hin + 2 * pad - K) // stride + 1, (Win + 2 * pad - K) // stride + 1
+        y = torch.empty(B, Cout, Ho, Wo, device=x.device)
+        _call("mmvae_convT2d_generic_fwd" if transposed else "mmvae_conv2d_generic_fwd", H.ptr(x), H.ptr(w), H.ptr(b),
+              None, H.ptr(y), B, Cin, Cout, Hin, Win, K, stride, pad, in_act, out_ep, H.stream())
+        ctx.save_for_backward(x, w, y if out_ep in (H.EP_SIGMOID_CLAMP, H.EP_SIGMOID) else None)
+        ctx.cfg = (transposed, stride, pad, in_act, out_ep, gw, gb, b is not None, Cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        transposed, stride, pad, in_act, out_ep, gw, gb, has_b, Cout = ctx.cfg
+        dy = H.f32c(dy)
+        B, Cin, Hin, Win = x.shape
+        K = w.shape[-1]
+        if out_ep in (H.EP_SIGMOID_CLAMP, H.EP_SIGMOID):
+            dl = torch.empty_like(dy)
+            _call("mmvae_sigmoid_clamp_bwd" if out_ep == H.EP_SIGMOID_CLAMP else "mmvae_sigmoid_bwd", H.ptr(dy), H.ptr(y),
+                  H.ptr(dl), dy.numel(), H.stream())
+            dy = dl
+        dw, acc_w, ret_w = _new_like_param(w, gw)
+        db, ret_b = None, None
+        if has_b:
+            if gb is not None:
+                db = gb
+            else:
+                db = ret_b = torch.empty(Cout, device=x.device)
+        pre = "mmvae_convT2d_generic" if transposed else "mmvae_conv2d_generic"
+        _call(pre + "_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), B, Cin, Cout, Hin, Win, K, stride, pad, in_act,
+              acc_w, H.stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ep = _DACT[in_act]
+            _call(pre + "_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout, Hin, Win, K,
+                  stride, pad, ep, H.stream())
+        return dx, ret_w, ret_b, None, None, None, None, None, None, None
+
+
+def _pow2(v, lo, hi):
+    return lo <= v <= hi and (v & (v - 1)) == 0
+
+
+def conv2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, gw=None, gb=None):
+    """nn.Conv2d on act(x): the MFMA kernels for the k4-s2-p1 3/32 -> 32 channel layers, the generic kernel otherwise"""
+    Cout, Cin, K, _ = w.shape
+    Hin = x.shape[-1]
+    if (K == 4 and stride == 2 and pad == 1 and Cout == 32 and x.shape[-2] == Hin and
+            ((Cin == 32 and _pow2(Hin, 8, 32)) or (Cin == 3 and _pow2(Hin, 8, 64)))):
+        return Conv2dK4S2.apply(x, w, b, in_act, gw, gb)
+    return ConvGeneric.apply(x, w, b, False, stride, pad, in_act, H.EP_NONE, gw, gb)
+
+
+def convT2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None):
+    """nn.ConvTranspose2d on act(x), optional sigmoid epilogue"""
+    Cin, Cout, K, _ = w.shape
+    Hin = x.shape[-1]
+    if (K == 4 and stride == 2 and pad == 1 and Cin == 32 and x.shape[-2] == Hin and
+            ((Cout == 32 and _pow2(Hin, 4, 16) and out_ep == H.EP_NONE) or (Cout == 3 and Hin in (16, 32)))):
+        return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+    return ConvGeneric.apply(x, w, b, True, stride, pad, in_act, out_ep, gw, gb)
 
 
 def _conv_segments(ws, dw, db, B, c_small, c_large, h_small, n_bias):
@@ -1256,6 +1347,27 @@ def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=No
 
 def step_inc(step_dev):
     _call("mmvae_step_inc", H.ptr(step_dev), H.stream())
+
+
+class Sigmoid(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = H.f32c(x)
+        y = torch.empty_like(x)
+        _call("mmvae_sigmoid_fwd", H.ptr(x), H.ptr(y), x.numel(), H.stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        _call("mmvae_sigmoid_bwd", H.ptr(H.f32c(dy)), H.ptr(y), H.ptr(dx), y.numel(), H.stream())
+        return dx
+
+
+def sigmoid(x):
+    return Sigmoid.apply(x)
 
 
 def randn(shape, state):

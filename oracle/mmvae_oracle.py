@@ -85,6 +85,23 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
         s[f"{prefix}.enc.mu_layer.module.bias"] = (Dp,)
         s[f"{prefix}.enc.logvar_layer.module.weight"] = (Dp, d)
         s[f"{prefix}.enc.logvar_layer.module.bias"] = (Dp,)
+    elif enc == "MNIST":
+        # Enc_MNIST ctor, models/encoders.py:226-250: 784 -> 400 -> 400 (ReLU), heads hidden_mu / hidden_logvar
+        s[f"{prefix}.enc.enc.0.0.weight"] = (400, 784)
+        s[f"{prefix}.enc.enc.0.0.bias"] = (400,)
+        s[f"{prefix}.enc.enc.1.0.weight"] = (400, 400)
+        s[f"{prefix}.enc.enc.1.0.bias"] = (400,)
+        for h in ("hidden_mu", "hidden_logvar"):
+            s[f"{prefix}.enc.{h}.weight"] = (Dp, 400)
+            s[f"{prefix}.enc.{h}.bias"] = (Dp,)
+    elif enc == "SVHN":
+        # Enc_SVHN ctor, models/encoders.py:434-456: 4 convs k4 (s2 p1, s2 p1, s2 p1, s2 p0), ReLU
+        for i, (co, ci) in enumerate(((32, 3), (64, 32), (64, 64), (128, 64))):
+            s[f"{prefix}.enc.conv{i + 1}.weight"] = (co, ci, 4, 4)
+            s[f"{prefix}.enc.conv{i + 1}.bias"] = (co,)
+        for h in ("hidden_mu", "hidden_logvar"):
+            s[f"{prefix}.enc.{h}.weight"] = (Dp, 128)
+            s[f"{prefix}.enc.{h}.bias"] = (Dp,)
     elif enc == "Transformer":
         # Enc_Transformer ctor, models/encoders.py:659-700: d_model = out_dim, 8 layers, ff 1024, 2 heads
         feats = data_dim[1] * (data_dim[2] if len(data_dim) > 2 else 1)
@@ -139,6 +156,21 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
             s[f"{L}.{n}.bias"] = (d,)
         s[f"{prefix}.dec.finallayer.module.weight"] = (feats, d)
         s[f"{prefix}.dec.finallayer.module.bias"] = (feats,)
+    elif dec == "MNIST":
+        # Dec_MNIST ctor, models/decoders.py:230-250
+        s[f"{prefix}.dec.dec.0.0.weight"] = (400, Dp)
+        s[f"{prefix}.dec.dec.0.0.bias"] = (400,)
+        s[f"{prefix}.dec.dec.1.0.weight"] = (400, 400)
+        s[f"{prefix}.dec.dec.1.0.bias"] = (400,)
+        s[f"{prefix}.dec.fc3.weight"] = (784, 400)
+        s[f"{prefix}.dec.fc3.bias"] = (784,)
+    elif dec == "SVHN":
+        # Dec_SVHN ctor, models/decoders.py:101-116: Linear(D', 128), ConvT k4 s1 p0, then 3 x ConvT k4 s2 p1
+        s[f"{prefix}.dec.linear.weight"] = (128, Dp)
+        s[f"{prefix}.dec.linear.bias"] = (128,)
+        for i, (ci, co) in enumerate(((128, 64), (64, 64), (64, 32), (32, 3))):
+            s[f"{prefix}.dec.conv{i + 1}.weight"] = (ci, co, 4, 4)
+            s[f"{prefix}.dec.conv{i + 1}.bias"] = (co,)
     elif dec == "Transformer":
         # Dec_Transformer ctor, models/decoders.py:542-588: 4 layers, ff 1024, 2 heads
         d = Dp
@@ -332,6 +364,49 @@ def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
     return out.permute(1, 0, 2) * mask.unsqueeze(-1).float()    # (B,T,V), zero at padding
 
 
+def enc_mnist(p, pre, x):
+    """Enc_MNIST.forward, models/encoders.py:252-265"""
+    h = x.reshape(x.shape[0], -1).float()
+    h = F.relu(F.linear(h, p[f"{pre}.enc.enc.0.0.weight"], p[f"{pre}.enc.enc.0.0.bias"]))
+    h = F.relu(F.linear(h, p[f"{pre}.enc.enc.1.0.weight"], p[f"{pre}.enc.enc.1.0.bias"]))
+    return process_output(h, p[f"{pre}.enc.hidden_mu.weight"], p[f"{pre}.enc.hidden_mu.bias"],
+                          p[f"{pre}.enc.hidden_logvar.weight"], p[f"{pre}.enc.hidden_logvar.bias"])
+
+
+def dec_mnist(p, pre, z, data_dim=(28, 28, 1)):
+    """Dec_MNIST.forward, models/decoders.py:252-270: (K=1,B,D') -> sigmoid MLP -> reshape (B,28,28,1) -> permute to
+    (B,1,28,28)"""
+    h = F.relu(F.linear(z, p[f"{pre}.dec.dec.0.0.weight"], p[f"{pre}.dec.dec.0.0.bias"]))
+    h = F.relu(F.linear(h, p[f"{pre}.dec.dec.1.0.weight"], p[f"{pre}.dec.dec.1.0.bias"]))
+    x = torch.sigmoid(F.linear(h, p[f"{pre}.dec.fc3.weight"], p[f"{pre}.dec.fc3.bias"]))
+    d = x.reshape(*z.shape[:-1], *data_dim)
+    if d.dim() == 5:
+        d = d.squeeze(0)
+    return d.permute(0, 3, 1, 2)
+
+
+def enc_svhn(p, pre, x):
+    """Enc_SVHN.forward, models/encoders.py:458-478"""
+    h = x.float()
+    for i, pad in enumerate((1, 1, 1, 0)):
+        h = F.relu(F.conv2d(h, p[f"{pre}.enc.conv{i + 1}.weight"], p[f"{pre}.enc.conv{i + 1}.bias"], stride=2, padding=pad))
+    h = h.reshape(h.shape[0], -1)
+    return process_output(h, p[f"{pre}.enc.hidden_mu.weight"], p[f"{pre}.enc.hidden_mu.bias"],
+                          p[f"{pre}.enc.hidden_logvar.weight"], p[f"{pre}.enc.hidden_logvar.bias"])
+
+
+def dec_svhn(p, pre, z):
+    """Dec_SVHN.forward, models/decoders.py:118-147: the output is permuted to (B,32,32,3) -- the loss then RESHAPES
+    the NCHW target to that shape (objectives.py:120), it does not permute it"""
+    zs = z.squeeze(0) if z.dim() == 3 else z
+    h = F.relu(F.linear(zs, p[f"{pre}.dec.linear.weight"], p[f"{pre}.dec.linear.bias"])).reshape(-1, 128, 1, 1)
+    h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv1.weight"], p[f"{pre}.dec.conv1.bias"], stride=1, padding=0))
+    h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv2.weight"], p[f"{pre}.dec.conv2.bias"], stride=2, padding=1))
+    h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv3.weight"], p[f"{pre}.dec.conv3.bias"], stride=2, padding=1))
+    h = F.conv_transpose2d(h, p[f"{pre}.dec.conv4.weight"], p[f"{pre}.dec.conv4.bias"], stride=2, padding=1)
+    return torch.sigmoid(h).permute(0, 2, 3, 1)
+
+
 def enc_transformer(p, pre, data, mask, train=False):
     """Enc_Transformer.forward, models/encoders.py:702-729 (ACTOR-style encoder for sequences of (joints, feats)):
     Linear(joints*feats -> d) -> + pe[t] (PositionalEncoding's try-branch: a true time encoding here) -> dropout ->
@@ -380,7 +455,9 @@ def dec_transformer(p, pre, z, mask, data_dim, train=False):
 
 _ENC = {"CNN2": lambda p, pre, d, train: enc_cnn2(p, pre, d["data"]),
         "TxtTransformer": lambda p, pre, d, train: enc_txt_transformer(p, pre, d["data"], d["masks"], train),
-        "Transformer": lambda p, pre, d, train: enc_transformer(p, pre, d["data"], d["masks"], train)}
+        "Transformer": lambda p, pre, d, train: enc_transformer(p, pre, d["data"], d["masks"], train),
+        "MNIST": lambda p, pre, d, train: enc_mnist(p, pre, d["data"]),
+        "SVHN": lambda p, pre, d, train: enc_svhn(p, pre, d["data"])}
 
 
 def encode(p, mods, i, inp, train=False):
@@ -396,6 +473,10 @@ def decode(p, mods, i, z, mask, train=False):
         return dec_txt_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
     if m["dec"] == "Transformer":
         return dec_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
+    if m["dec"] == "MNIST":
+        return dec_mnist(p, pre, z, tuple(m["data_dim"]))
+    if m["dec"] == "SVHN":
+        return dec_svhn(p, pre, z)
     raise NotImplementedError(m["dec"])
 
 

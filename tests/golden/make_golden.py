@@ -57,9 +57,17 @@ CASE_MODS = {
     "mopoe3_b5_t6_d8_actions_optsigma": [MODS[0], MODS[1], dict(ACTIONS, ltype="optimal_sigma")],
     "poe3_b4_t5_d8_actions_lprob": [dict(MODS[0], ltype="lprob"), MODS[1], dict(ACTIONS, ltype="lprob")],
 }
+# MNIST MLP towers + SVHN conv towers with lprob (the reference's mnist_svhn feature dims)
+MS = [{"enc": "MNIST", "dec": "MNIST", "data_dim": [28, 28, 1], "ltype": "lprob", "llik_scaling": 1.0},
+      {"enc": "SVHN", "dec": "SVHN", "data_dim": [32, 32, 3], "ltype": "lprob", "llik_scaling": 1.0}]
+CASE_MODS["dmvae_ms_b5_d8p4_lprob"] = MS
+CASE_MODS["mopoe_ms_b6_d8_lprob"] = MS
+PRIVATE["dmvae_ms_b5_d8p4_lprob"] = 4
 CASES += [
     ("mopoe3_b5_t6_d8_actions_optsigma", "mopoe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.0),
     ("poe3_b4_t5_d8_actions_lprob", "poe", 4, 5, 8, [5, 2, 3, 4], "eval", 1.0),
+    ("dmvae_ms_b5_d8p4_lprob", "dmvae", 5, 0, 8, None, "eval", 1.0),
+    ("mopoe_ms_b6_d8_lprob", "mopoe", 6, 0, 8, None, "eval", 2.0),
 ]
 
 
@@ -104,11 +112,17 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
                 mod.p = 0.0
             if isinstance(mod, nn.MultiheadAttention):
                 mod.dropout = 0.0
-    img, onehot, mask = make_batch(B, T, lengths, seed + 1)
-    batch = {"mod_1": {"data": img, "masks": None, "categorical": False},
-             "mod_2": {"data": onehot, "masks": mask, "categorical": True}}
-
-    out = {"img": img.numpy(), "onehot": onehot.numpy(), "mask": mask.numpy()}
+    if mods[0]["enc"] == "MNIST":       # image pair (B,1,28,28) / (B,3,32,32) in [0,1], no masks
+        gm = torch.Generator().manual_seed(seed + 1)
+        mn, sv = torch.rand(B, 1, 28, 28, generator=gm), torch.rand(B, 3, 32, 32, generator=gm)
+        batch = {"mod_1": {"data": mn, "masks": None, "categorical": False},
+                 "mod_2": {"data": sv, "masks": None, "categorical": False}}
+        out = {"mnist": mn.numpy(), "svhn": sv.numpy()}
+    else:
+        img, onehot, mask = make_batch(B, T, lengths, seed + 1)
+        batch = {"mod_1": {"data": img, "masks": None, "categorical": False},
+                 "mod_2": {"data": onehot, "masks": mask, "categorical": True}}
+        out = {"img": img.numpy(), "onehot": onehot.numpy(), "mask": mask.numpy()}
     if len(mods) == 3:      # action sequences (B, Ta, joints, feats) with their own ragged lengths
         ga = torch.Generator().manual_seed(seed + 5)
         Ta, J, Fe = mods[2]["data_dim"]

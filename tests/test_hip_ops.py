@@ -206,6 +206,38 @@ def test_bce_and_ce(ops):
         check(lgg.grad, lr_.grad, 2e-5, f"ce dlogits per_v={per_v}")
 
 
+@pytest.mark.parametrize("transposed,B,Cin,Cout,Hin,S,P,act,ep", [
+    (False, 5, 32, 64, 16, 2, 1, 2, 0), (False, 3, 64, 64, 8, 2, 1, 2, 0), (False, 4, 64, 128, 4, 2, 0, 2, 0),
+    (False, 2, 3, 32, 32, 2, 1, 0, 0), (True, 4, 128, 64, 1, 1, 0, 2, 0), (True, 3, 64, 64, 4, 2, 1, 2, 0),
+    (True, 3, 64, 32, 8, 2, 1, 2, 0), (True, 2, 32, 3, 16, 2, 1, 2, 7), (True, 2, 16, 5, 6, 2, 1, 1, 7)])
+def test_conv_generic(ops, transposed, B, Cin, Cout, Hin, S, P, act, ep):
+    """ops.conv2d / ops.convT2d (generic kernels, or the MFMA kernels when the shape is theirs) vs torch fp64: the
+    SVHN tower layers (channels 64 / 128, k4 s2 p0, k4 s1 p0) and the plain-sigmoid epilogue"""
+    g = torch.Generator().manual_seed(Cin * Cout + Hin)
+    x = torch.randn(B, Cin, Hin, Hin, generator=g)
+    w = torch.randn(*((Cin, Cout) if transposed else (Cout, Cin)), 4, 4, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    f = F.conv_transpose2d if transposed else F.conv2d
+    ref = f(_act(xr, act), wr, br, stride=S, padding=P)
+    if ep == 7:
+        ref = torch.sigmoid(ref)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    if transposed:
+        out = ops.convT2d(xg, wg, bg, S, P, act, ep)
+    else:
+        out = ops.conv2d(xg, wg, bg, S, P, act)
+    out.backward(dy.to(DEV))
+    check(out, ref, 2e-5, "conv out")
+    # the op emits d/d(pre-activation input): compare through act'
+    gx = xr.grad
+    check(xg.grad, gx, 5e-5, "conv dx")
+    check(wg.grad, wr.grad, 5e-5, "conv dw")
+    check(bg.grad, br.grad, 5e-5, "conv db")
+
+
 @pytest.mark.parametrize("B,F_,own,laplace", [(7, 33, False, False), (128, 12288, False, False), (5, 24, True, False),
                                               (6, 40, False, True), (5, 24, True, True)])
 def test_lprob_rowsum(ops, B, F_, own, laplace):

@@ -11,6 +11,9 @@ from oracle import mmvae_oracle as orc
 
 
 def _batch(g):
+    if "mnist" in g:     # MNIST / SVHN image pair
+        return {"mod_1": {"data": torch.from_numpy(g["mnist"]), "masks": None, "categorical": False},
+                "mod_2": {"data": torch.from_numpy(g["svhn"]), "masks": None, "categorical": False}}
     b = {"mod_1": {"data": torch.from_numpy(g["img"]), "masks": None, "categorical": False},
          "mod_2": {"data": torch.from_numpy(g["onehot"]), "masks": torch.from_numpy(g["mask"]), "categorical": True}}
     if "act" in g:       # third modality: action sequences (B, T, joints, feats)
