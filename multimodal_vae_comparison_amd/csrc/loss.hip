@@ -6,7 +6,8 @@
 
 __device__ __forceinline__ float bce_term(float x, float t) {
   // torch.nn.functional.binary_cross_entropy clamps each log at -100 (ReconLoss.bce, objectives.py:405)
-  float lx = fmaxf(logf(x), -100.0f), l1x = fmaxf(logf(1.0f - x), -100.0f);
+  // (v_log_f32: ~1e-7 absolute error per term, 1e-7 relative on a row sum; logf costs ~20 VALU instructions more per call)
+  float lx = fmaxf(__logf(x), -100.0f), l1x = fmaxf(__logf(1.0f - x), -100.0f);
   return -(t * lx + (1.0f - t) * l1x);
 }
 
@@ -19,7 +20,20 @@ __global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict
   if ((F & 3) == 0) {
     const float4* x4 = reinterpret_cast<const float4*>(xh + base);
     const float4* t4 = reinterpret_cast<const float4*>(tg + base);
-    for (int i = threadIdx.x; i < F / 4; i += 256) {
+    const int n4 = F / 4;
+    int i = threadIdx.x;
+    for (; i + 3 * 256 < n4; i += 4 * 256) {       // 8 independent 16-byte loads in flight per thread
+      float4 x[4], t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = x4[i + u * 256];
+        t[u] = t4[i + u * 256];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc += bce_term(x[u].x, t[u].x) + bce_term(x[u].y, t[u].y) + bce_term(x[u].z, t[u].z) + bce_term(x[u].w, t[u].w);
+    }
+    for (; i < n4; i += 256) {
       float4 x = x4[i], t = t4[i];
       acc += bce_term(x.x, t.x) + bce_term(x.y, t.y) + bce_term(x.z, t.z) + bce_term(x.w, t.w);
     }

@@ -162,7 +162,7 @@ class Dec_TxtTransformer(VaeDecoder):
         T = mask.shape[1]
         mask_u8 = ops.as_u8(mask)
         x = self._timequeries(T, bs, D, z.device)
-        mem = z[0]
+        mem = z.reshape(bs, D)                     # K = 1: a view (z[0] would cost a select-backward fill + copy)
         p = self.dropout
         nl = len(self.seqTransDecoder.layers)
         if self.training and p > 0:       # nn.Dropout sites of the reference: PE + 6 per layer

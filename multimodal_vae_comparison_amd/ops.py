@@ -558,6 +558,7 @@ class PoeReparamKL(Function):
         ctx.save_for_backward(theta, *packed, *eps)
         ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0)
         ctx.mark_non_differentiable(joint)
+        ctx.set_materialize_grads(False)
         return (joint, kl, *zs)
 
     @staticmethod
@@ -780,6 +781,7 @@ class LincombRows(Function):
         _call("mmvae_lincomb_rowptrs_fwd", ctypes.byref(rp), flat, H.ptr(out), n, B, k, H.stream())
         ctx.cfg = (flat, n, B, k, rows, [tuple(t.shape) for t in blocks])
         ctx.keep = blocks
+        ctx.set_materialize_grads(False)      # an unused output (kld is only logged) must not cost a zero-fill kernel
         return tuple(out.unbind(0))
 
     @staticmethod
