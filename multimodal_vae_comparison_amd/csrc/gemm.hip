@@ -374,7 +374,8 @@ extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w,
   // problem 0 (data):   C[M,K] = dy[M,N] W[N,K]            reduction N
   // problem 1 (weight): C[N,K] = dy^T[N,M] act(x)[M,K]     reduction M, split over workgroups
   const long t128_d = (long)((M + 127) / 128) * ((K + 31) / 32), t32_d = (long)((M + 31) / 32) * ((K + 31) / 32);
-  const bool d_ok = t128_d < 256 && !(N >= 384 && t32_d <= 512);
+  // (a 512-deep data gradient alone prefers the 8-wave tiling, but one grouped launch beats two: +4 % on the step)
+  const bool d_ok = t128_d < 256;
   const int nz = mmvae_linear_bwd_weight_splits(M, N, K);
   const long t128_w = (long)((N + 127) / 128) * ((K + 31) / 32), t32_w = (long)((N + 31) / 32) * ((K + 31) / 32);
   const int sk = wgrad_splitk(M, N, K);

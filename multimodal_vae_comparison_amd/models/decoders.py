@@ -31,8 +31,9 @@ class HipConvT2d(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x):
-        return ops.convT2d_k4s2(x, self.weight, self.bias, self.in_act, self.out_ep, self.weight.grad, self.bias.grad)
+    def forward(self, x, ep_bwd=True):
+        return ops.convT2d_k4s2(x, self.weight, self.bias, self.in_act, self.out_ep, self.weight.grad, self.bias.grad,
+                                ep_bwd)
 
 
 class Dec_CNN(VaeDecoder):
@@ -61,9 +62,14 @@ class Dec_CNN(VaeDecoder):
         K, bs = z.shape[0], z.shape[1]
         u = self.lin3(self.lin2(self.lin1(z.reshape(K * bs, -1))))
         u = u.view(bs * K, *self.reshape)
-        d = self.convT3(self.convT2(self.convT1(self.convT_64(u))))        # (K*B,3,64,64) clamped sigmoid
+        # (K*B,3,64,64) clamped sigmoid.  `raw` holds the same values, but its gradient is the LOGITS' gradient; `d` goes
+        # through SigmoidClampOut.  A bce loss takes the fused closed-form path via `out._bce_src` (objectives.py).
+        raw = self.convT3.module(self.convT2(self.convT1(self.convT_64(u))), ep_bwd=False)
+        d = ops.sigmoid_clamp_out(raw)
         d = d.view(*z.size()[:-1], *self.data_dim)                          # decoders.py:96 (view, no permute)
-        return d.squeeze().reshape(-1, *self.data_dim), self._scale
+        out = d.squeeze().reshape(-1, *self.data_dim)
+        out._bce_src = raw
+        return out, self._scale
 
 
 class HipTransformerDecoderLayer(nn.Module):

@@ -51,6 +51,9 @@ def recon_rowsum(ltype, out, target, laplace=False):
     if ltype == "optimal_sigma":
         return ops.optimal_sigma_rowsum(out, data.float().reshape(out.shape))
     if ltype == "bce":
+        raw = getattr(out, "_bce_src", None)       # Dec_CNN: the producing layer's raw output (gradient = d logits)
+        if raw is not None and raw.numel() == out.numel():
+            return ops.bce_sigmoid_rowsum(raw, data.float().reshape(raw.shape))
         return ops.bce_rowsum(out, data.float().reshape(out.shape))
     if ltype == "category_ce":
         return ops.ce_over_time(out, data.float(), per_v=False)

@@ -290,13 +290,16 @@ class ConvT2dK4S2(Function):
     out_ep: EP_NONE or EP_SIGMOID_CLAMP (decoders.py:96-97)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, in_act, out_ep, gw, gb):
+    def forward(ctx, x, w, b, in_act, out_ep, gw, gb, ep_bwd=True):
+        """ep_bwd False: the incoming gradient is already the gradient of the PRE-epilogue value (see SigmoidClampOut)"""
         x = H.f32c(x)
         B, Cin, Hin, _ = x.shape
         Cout = w.shape[1]
         y = torch.empty(B, Cout, 2 * Hin, 2 * Hin, device=x.device, dtype=torch.float32)
         _call("mmvae_convT2d_k4s2_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), B, Cin, Cout, Hin, in_act,
               out_ep, H.stream())
+        if not ep_bwd:
+            out_ep = H.EP_NONE
         ctx.save_for_backward(x, w, y if out_ep in (H.EP_SIGMOID_CLAMP, H.EP_SIGMOID) else None)
         ctx.cfg = (in_act, out_ep, gw, gb, b is not None)
         return y
@@ -337,7 +340,50 @@ class ConvT2dK4S2(Function):
                   in_act, acc, H.stream())
         if defer:
             _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
-        return dx, ret_w, ret_b, None, None, None, None
+        return dx, ret_w, ret_b, None, None, None, None, None
+
+
+class SigmoidClampOut(Function):
+    """Identity on the forward values of a layer whose kernel already applied clamp(sigmoid(.)); in backward it turns
+    the gradient of that output into the gradient of the logits.  Splitting the epilogue's backward off the layer
+    lets a loss that knows the logits' gradient in closed form (BceSigmoidRowsum) feed the layer directly."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = H.f32c(dy)
+        dl = torch.empty_like(dy)
+        _call("mmvae_sigmoid_clamp_bwd", H.ptr(dy), H.ptr(y), H.ptr(dl), dy.numel(), H.stream())
+        return dl
+
+
+class BceSigmoidRowsum(Function):
+    """BceRowsum on x_hat = clamp(sigmoid(logits)) given as the layer's raw output (whose gradient is taken with
+    respect to the LOGITS): backward is the closed form g (x_hat - t) [clamp inactive] in one kernel."""
+
+    @staticmethod
+    def forward(ctx, y_raw, target):
+        y_raw, target = H.f32c(y_raw), H.f32c(target)
+        B = y_raw.shape[0]
+        F_ = y_raw.numel() // B
+        row = torch.empty(B, device=y_raw.device)
+        _call("mmvae_bce_rowsum_fwd", H.ptr(y_raw), H.ptr(target), H.ptr(row), B, F_, H.stream())
+        ctx.save_for_backward(y_raw, target)
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        y, target = ctx.saved_tensors
+        B = y.shape[0]
+        dl = torch.empty_like(y)
+        _call("mmvae_bce_sigmoid_clamp_bwd", H.ptr(y), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(dl), B, y.numel() // B,
+              H.stream())
+        return dl, None
 
 
 class ConvGeneric(Function):
@@ -430,8 +476,16 @@ def conv2d_k4s2(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
     return Conv2dK4S2.apply(x, w, b, in_act, gw, gb)
 
 
-def convT2d_k4s2(x, w, b, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None):
-    return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+def convT2d_k4s2(x, w, b, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None, ep_bwd=True):
+    return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb, ep_bwd)
+
+
+def sigmoid_clamp_out(y_raw):
+    return SigmoidClampOut.apply(y_raw)
+
+
+def bce_sigmoid_rowsum(y_raw, target):
+    return BceSigmoidRowsum.apply(y_raw, target)
 
 
 # ----------------------------------------------------------------------------------------------
