@@ -27,7 +27,7 @@ template <typename G, typename W>
 __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
   if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
-  else conv_gather_body<G>(ad, blockIdx.x - n_w, smem);
+  else conv_gather_body<G, G::RWONLY>(ad, blockIdx.x - n_w, smem);
 }
 
 static inline int dact_ep(int act) {
