@@ -270,15 +270,17 @@ int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, float* dV, in
                            mmvae_stream_t stream);
 
 /* The same with the rows in separate tensors (p[n] -> B floats) and one upstream-gradient scalar per output
- * (g[k] device pointer or NULL = that output does not take part in backward); d rows are written to drows->p[n]. */
+ * (g[k] device pointer or NULL = that output does not take part in backward); d rows are written to drows->p[n].
+ * d_unit (may be NULL): fwd also writes the row gradients of output 0 for a unit upstream gradient (the constants
+ * W[0][n]) -- a training step seeds loss.backward() with ones, so its backward needs no launch at all. */
 typedef struct {
   const float* p[32];
 } mmvae_rowptrs_t;
 typedef struct {
   const float* g[4];
 } mmvae_gptrs_t;
-int mmvae_lincomb_rowptrs_fwd(const mmvae_rowptrs_t* rows, const float* W_host, float* out, int n_rows, int B,
-                              int n_out, mmvae_stream_t stream);
+int mmvae_lincomb_rowptrs_fwd(const mmvae_rowptrs_t* rows, const float* W_host, float* out,
+                              const mmvae_rowptrs_t* d_unit, int n_rows, int B, int n_out, mmvae_stream_t stream);
 int mmvae_lincomb_rowptrs_bwd(const mmvae_gptrs_t* gout, const float* W_host, const mmvae_rowptrs_t* drows,
                               int n_rows, int B, int n_out, mmvae_stream_t stream);
 

@@ -495,7 +495,8 @@ extern "C" int mmvae_lincomb_rows_bwd(const float* gout, const float* W_host, fl
 // Row-pointer forms: the rows live in separate tensors (one per loss term) and the upstream gradients of the n_out
 // outputs arrive as separate scalars -- no cat / select / fill kernels around the two launches.
 __global__ __launch_bounds__(256) void lincomb_rowptrs_fwd_kernel(mmvae_rowptrs_t rows, lincomb_w W,
-                                                                  float* __restrict__ out, int n_rows, int B, int n_out) {
+                                                                  float* __restrict__ out, mmvae_rowptrs_t dunit,
+                                                                  int has_dunit, int n_rows, int B, int n_out) {
   __shared__ float red[4];
   __shared__ float rs[LC_MAX_ROWS];
   for (int n = 0; n < n_rows; ++n) {
@@ -504,6 +505,11 @@ __global__ __launch_bounds__(256) void lincomb_rowptrs_fwd_kernel(mmvae_rowptrs_
     for (int b = threadIdx.x; b < B; b += 256) a += V[b];
     a = block_sum_256(a, red);
     if (threadIdx.x == 0) rs[n] = a;
+    // gradient of output 0 with respect to this row for a unit upstream gradient: the constant W[0][n]
+    if (has_dunit) {
+      float* d = const_cast<float*>(dunit.p[n]);
+      for (int b = threadIdx.x; b < B; b += 256) d[b] = W.w[n];
+    }
   }
   __syncthreads();
   if (threadIdx.x < n_out) {
@@ -522,14 +528,17 @@ __global__ __launch_bounds__(256) void lincomb_rowptrs_bwd_kernel(mmvae_gptrs_t 
     if (g.g[k]) v += g.g[k][0] * W.w[k * LC_MAX_ROWS + n];
   const_cast<float*>(drows.p[n])[b] = v;
 }
-extern "C" int mmvae_lincomb_rowptrs_fwd(const mmvae_rowptrs_t* rows, const float* W_host, float* out, int n_rows,
-                                         int B, int n_out, mmvae_stream_t stream) {
+extern "C" int mmvae_lincomb_rowptrs_fwd(const mmvae_rowptrs_t* rows, const float* W_host, float* out,
+                                         const mmvae_rowptrs_t* d_unit, int n_rows, int B, int n_out,
+                                         mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(rows && W_host && out && n_rows > 0 && B > 0 && n_out > 0);
   lincomb_w w;
   int rc = pack_w(W_host, n_rows, n_out, &w);
   if (rc) return rc;
-  hipLaunchKernelGGL(lincomb_rowptrs_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *rows, w, out, n_rows, B,
-                     n_out);
+  mmvae_rowptrs_t du;
+  if (d_unit) du = *d_unit;
+  hipLaunchKernelGGL(lincomb_rowptrs_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *rows, w, out, du,
+                     d_unit ? 1 : 0, n_rows, B, n_out);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_lincomb_rowptrs_bwd(const mmvae_gptrs_t* gout, const float* W_host, const mmvae_rowptrs_t* drows,

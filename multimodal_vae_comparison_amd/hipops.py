@@ -97,7 +97,7 @@ SIGNATURES = {
     "mmvae_optimal_sigma_fwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
     "mmvae_optimal_sigma_bwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
     "mmvae_add_pe_dropout_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_dp, c_p]),
-    "mmvae_lincomb_rowptrs_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_lincomb_rowptrs_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rowptrs_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_dp, c_p]),
     "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_dp, c_p]),

@@ -73,6 +73,8 @@ class MultimodalVAE(nn.Module):
         assert self.optimizer is not None, "call configure_optimizers() first"
         self._static_batch = batch
         self._one = torch.ones((), device=self.flat.data.device)     # loss.backward() seed: no fill kernel per step
+        from .. import ops
+        ops.LincombRows.unit_seed_ptr = self._one.data_ptr()         # ... and the ELBO assembly's backward is free
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

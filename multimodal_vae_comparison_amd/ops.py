@@ -813,6 +813,8 @@ class CeOverTime(Function):
 
 
 class LincombRows(Function):
+    unit_seed_ptr = None      # data_ptr of the trainer's persistent backward seed (a ones scalar), see backward()
+
     """out_k = sum_n W[k][n] * sum_b rows_n[b]  -- ELBO assembly with host-side constant weights.
     `blocks`: tensors of shape (B,) or (r,B); their rows are addressed in place (no cat/stack kernel).  Returns the
     k outputs as k scalar tensors, so backward receives one upstream scalar per output (no select / fill kernels)."""
@@ -832,7 +834,19 @@ class LincombRows(Function):
                 i += 1
         flat = (H.c_f * (k * n))(*[float(x) for row in W for x in row])
         out = torch.empty(k, device=blocks[0].device)
-        _call("mmvae_lincomb_rowptrs_fwd", ctypes.byref(rp), flat, H.ptr(out), n, B, k, H.stream())
+        ctx.unit = None
+        du = None
+        if LincombRows.unit_seed_ptr is not None and any(t.requires_grad for t in blocks):
+            # the trainer seeds backward with a persistent ones scalar: the row gradients are then constants, written
+            # here, and backward() hands them out without a launch
+            ctx.unit = [torch.empty(t.shape, device=t.device) for t in blocks]
+            dp, i = H.RowPtrs(), 0
+            for t, r in zip(ctx.unit, rows):
+                for j in range(r):
+                    dp.p[i] = t.data_ptr() + 4 * j * B
+                    i += 1
+            du = ctypes.byref(dp)
+        _call("mmvae_lincomb_rowptrs_fwd", ctypes.byref(rp), flat, H.ptr(out), du, n, B, k, H.stream())
         ctx.cfg = (flat, n, B, k, rows, [tuple(t.shape) for t in blocks])
         ctx.keep = blocks
         ctx.set_materialize_grads(False)      # an unused output (kld is only logged) must not cost a zero-fill kernel
@@ -842,6 +856,9 @@ class LincombRows(Function):
     def backward(ctx, *gs):
         flat, n, B, k, rows, shapes = ctx.cfg
         dev = ctx.keep[0].device
+        if (ctx.unit is not None and gs[0] is not None and gs[0].data_ptr() == LincombRows.unit_seed_ptr
+                and all(g is None for g in gs[1:])):
+            return (None, *ctx.unit)
         gp = H.GPtrs()
         held = []
         for i, g in enumerate(gs):
