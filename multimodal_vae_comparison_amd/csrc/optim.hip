@@ -127,15 +127,21 @@ extern "C" int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long 
 // Used at the end of backward: every weight-gradient kernel of the step leaves its split partials in a private
 // region of the step arena and registers a segment; a single launch folds all of them into the flat gradient
 // buffer (40 tiny reduce launches per step otherwise).  Same 64-column x 4-row-slice blocks as reduce_rows.
+// A block covers RS_COLS = 256 columns of one head segment: 64 lanes x float4 (16-byte loads when the whole chain is
+// 16-byte aligned and a multiple of 4 long, else four dword columns per lane) x 4 row slices, 8 loads in flight.
+#define RS_COLS 256
 __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t) {
-  __shared__ float part[4][64];
+  __shared__ float4 part[4][64];
   int sg = 0;
   while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan over head segments, n <= 64
   float* __restrict__ dst = t.dst[sg];
   const long len = t.len[sg];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const long i = ((long)blockIdx.x - t.blk0[sg]) * 64 + cx;
-  float a = 0.f;
+  const long i = ((long)blockIdx.x - t.blk0[sg]) * RS_COLS + 4 * cx;
+  bool vec = (len & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
+  for (int cur = sg; cur >= 0; cur = t.next[cur])
+    vec = vec && (((uintptr_t)t.src[cur]) & 15) == 0 && (t.stride[cur] & 3) == 0;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   // a parameter used several times in one backward (PoE re-runs its towers per subset) has several partial
   // regions with the SAME destination: they are chained (`next`) and summed by the same block -- two blocks
   // doing dst += concurrently would race.
@@ -143,21 +149,54 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segme
     const float* __restrict__ src = t.src[cur];
     const int n_rows = t.rows[cur];
     const long stride = t.stride[cur];
-    if (i < len) {
+    if (vec) {
+      if (i < len) {
+        int r = ry;
+        for (; r + 28 < n_rows; r += 32) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + 4 * u) * stride + i);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; r < n_rows; r += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * stride + i);
+          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+      }
+    } else if (i < len) {     // unaligned chain: the same 4 columns as dwords, still 32 independent loads in flight
+      float* ap = &a.x;
       int r = ry;
       for (; r + 28 < n_rows; r += 32) {
-        float v[8];
+        float v[8][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + 4 * u) * stride + i];
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += v[u];
+          for (int c = 0; c < 4; ++c) v[u][c] = src[(size_t)(r + 4 * u) * stride + (i + c < len ? i + c : i)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ap[c] += v[u][c];
       }
-      for (; r < n_rows; r += 4) a += src[(size_t)r * stride + i];
+      for (; r < n_rows; r += 4) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = src[(size_t)r * stride + (i + c < len ? i + c : i)];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ap[c] += v[c];
+      }
     }
   }
   part[ry][cx] = a;
   __syncthreads();
-  if (ry == 0 && i < len) dst[i] += part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+  if (ry == 0) {
+    const float4 p0 = part[0][cx], p1 = part[1][cx], p2 = part[2][cx], p3 = part[3][cx];
+    const float s[4] = {p0.x + p1.x + p2.x + p3.x, p0.y + p1.y + p2.y + p3.y, p0.z + p1.z + p2.z + p3.z,
+                        p0.w + p1.w + p2.w + p3.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (i + c < len) dst[i + c] += s[c];
+  }
 }
 extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(table && table->n > 0 && table->n <= MMVAE_MAX_SEGMENTS);
@@ -194,7 +233,7 @@ extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae
   int blocks = 0;
   for (int k = 0; k < n_heads; ++k) {
     o.blk0[k] = blocks;
-    blocks += (o.len[k] + 63) / 64;
+    blocks += (o.len[k] + RS_COLS - 1) / RS_COLS;
   }
   t = o;
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);

@@ -399,6 +399,31 @@ def test_time_reduce_and_permute_mask(ops):
     check(yg.grad, yr.grad, 1e-6, "permute_mask dx")
 
 
+def test_reduce_segments(ops, hip_lib):
+    """dst_s += sum_r src_s[r]: aligned / unaligned lengths and bases, chained segments sharing a destination"""
+    import ctypes
+    from multimodal_vae_comparison_amd import hipops as H
+    g = torch.Generator().manual_seed(3)
+    arena = torch.randn(1 << 22, generator=g).to(DEV)
+    flat = torch.randn(40000, generator=g).to(DEV)
+    ref = flat.clone()
+    specs = [  # (src offset, dst offset, rows, len, stride)
+        (0, 0, 128, 16384, 16416), (16384, 16384, 128, 32, 16416),          # conv partial: weights then bias columns
+        (128 * 16416, 16416, 33, 8748, 8748 + 162), (128 * 16416 + 8748, 25164, 33, 162, 8748 + 162),
+        (3000001, 30001, 7, 1001, 1003),                                       # nothing aligned
+        (3100000, 0, 5, 16384, 16384),                                         # chained onto segment 0 (same dst, len)
+        (3300000, 33000, 1, 64, 64)]
+    t = H.ReduceSegments()
+    for j, (so, do, r, ln, sd) in enumerate(specs):
+        t.src[j], t.dst[j] = arena.data_ptr() + 4 * so, flat.data_ptr() + 4 * do
+        t.rows[j], t.len[j], t.stride[j] = r, ln, sd
+        rows = torch.stack([arena[so + k * sd: so + k * sd + ln] for k in range(r)])
+        ref[do:do + ln] += rows.double().sum(0).float()
+    t.n = len(specs)
+    H.check(hip_lib.mmvae_reduce_segments(ctypes.byref(t), H.stream()), "mmvae_reduce_segments")
+    check(flat, ref, 2e-6, "reduce_segments")
+
+
 @pytest.mark.parametrize("self_counting", [False, True])
 def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
     """self_counting: step = -1, the kernel bumps the device step counter itself (what FlatAdam uses)"""
