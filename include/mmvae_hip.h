@@ -187,6 +187,9 @@ int mmvae_head_softmax_bwd(const float* h, float* dh, int B, int D, mmvae_stream
  *                  row E    : sum_d KL(N(mu_J, sigma=var_J) || p) if kl_mask bit E set; p = N(0, softmax(theta)*D)
  *   joint (2,B,D): mu_J, var_J (always written).
  * bwd: dz[i] (B,D), dkl (E+1,B)  ->  dmu[e], dlv[e] (B,D), dtheta (D) (+)=; ws: mmvae_poe_ws_floats(B,D).
+ *   raw_heads    : != 0: lv[e] points at the RAW logvar-head outputs u and the kernels apply
+ *                  lv = softmax(u, -1) + 1e-6 themselves (process_output, encoders.py:52-53), forward and backward
+ *                  (dlv[e] then receives d/du) -- no mmvae_head_softmax_* launch per tower and direction.
  * ---------------------------------------------------------------------------------------------- */
 #define MMVAE_MAX_EXPERTS 8
 typedef struct {
@@ -204,11 +207,11 @@ typedef struct {
   float* dlv[MMVAE_MAX_EXPERTS];
 } mmvae_poe_bwd_args;
 int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl, int E,
-                             int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
+                             int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in, int raw_heads,
                              mmvae_stream_t stream);
 int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl, float* dtheta,
                              float* ws, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
-                             int accumulate, mmvae_stream_t stream);
+                             int raw_heads, int accumulate, mmvae_stream_t stream);
 size_t mmvae_poe_ws_floats(int B, int D);
 
 /* MoE importance weights, models/mmvae_models.py:56-62:  lw[b] = sum_d [log N(z; mu_r, s_r) - log N(z; mu_o, s_o)]

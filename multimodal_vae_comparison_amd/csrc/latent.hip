@@ -76,6 +76,28 @@ __device__ __forceinline__ void prior_sigma(const float* __restrict__ theta, int
   }
 }
 
+// statistics of softmax(u[0..D)) for one row: max and 1 / sum exp  (raw heads: lv = softmax(u) + 1e-6 computed here
+// instead of by a head_softmax launch per tower and direction)
+__device__ __forceinline__ void row_softmax_stats(const float* __restrict__ u, int D, int lane, float* mx_out,
+                                                  float* inv_out) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    const int d = lane + 64 * s;
+    if (d < D) mx = fmaxf(mx, u[d]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < POE_SLOTS; ++s) {
+    const int d = lane + 64 * s;
+    if (d < D) sum += expf(u[d] - mx);
+  }
+  sum = wave_sum(sum);
+  *mx_out = mx;
+  *inv_out = 1.0f / sum;
+}
+
 __device__ __forceinline__ float kl_elem(float mu, float s, float sp) {
   float r = s / sp, m = mu / sp;
   float vr = r * r;
@@ -84,7 +106,8 @@ __device__ __forceinline__ float kl_elem(float mu, float s, float sp) {
 
 __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, const float* __restrict__ theta,
                                                       float* __restrict__ joint, float* __restrict__ kl, int E,
-                                                      int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld) {
+                                                      int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
+                                                      int raw) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -94,6 +117,12 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
     float klacc[MMVAE_MAX_EXPERTS + 1];
 #pragma unroll
     for (int j = 0; j <= MMVAE_MAX_EXPERTS; ++j) klacc[j] = 0.f;
+    float umx[MMVAE_MAX_EXPERTS], uinv[MMVAE_MAX_EXPERTS];
+    if (raw) {
+#pragma unroll
+      for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e)
+        if (e < E) row_softmax_stats(a.lv[e] + (size_t)b * ld, D, lane, &umx[e], &uinv[e]);
+    }
 #pragma unroll
     for (int s = 0; s < POE_SLOTS; ++s) {
       const int d = lane + 64 * s;
@@ -104,7 +133,9 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
 #pragma unroll
       for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e) {
         if (e >= E) continue;
-        const float mu = a.mu[e][oi], lv = a.lv[e][oi];
+        const float mu = a.mu[e][oi];
+        float lv = a.lv[e][oi];
+        if (raw) lv = expf(lv - umx[e]) * uinv[e] + 1e-6f;
         const float T = 1.0f / (expf(lv) + 1e-8f);
         P += T;
         S += mu * T;
@@ -145,7 +176,8 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
 //   dsp  += sum_j gk_j * (1 - (s_j^2 + mu_j^2) / sp^2) / sp
 __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, const float* __restrict__ theta,
                                                       const float* __restrict__ dkl, float* __restrict__ ws, int E,
-                                                      int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld) {
+                                                      int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
+                                                      int raw) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -158,6 +190,14 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
 #pragma unroll
     for (int j = 0; j <= MMVAE_MAX_EXPERTS; ++j)
       gk[j] = (j <= E && dkl && (kl_mask & (1u << j))) ? dkl[(size_t)j * B + b] : 0.f;
+    float umx[MMVAE_MAX_EXPERTS], uinv[MMVAE_MAX_EXPERTS], udot[MMVAE_MAX_EXPERTS];
+#pragma unroll
+    for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e) udot[e] = 0.f;
+    if (raw) {
+#pragma unroll
+      for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e)
+        if (e < E) row_softmax_stats(a.lv[e] + (size_t)b * ld, D, lane, &umx[e], &uinv[e]);
+    }
 #pragma unroll
     for (int s = 0; s < POE_SLOTS; ++s) {
       const int d = lane + 64 * s;
@@ -172,6 +212,7 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
         if (e >= E) continue;
         mu[e] = a.mu[e][oi];
         lv[e] = a.lv[e][oi];
+        if (raw) lv[e] = expf(lv[e] - umx[e]) * uinv[e] + 1e-6f;
         T[e] = 1.0f / (expf(lv[e]) + 1e-8f);
         P += T[e];
         S += mu[e] * T[e];
@@ -213,8 +254,25 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
         }
         a.dmu[e][oi] = dmu;
         a.dlv[e][oi] = dlv;
+        udot[e] += (lv[e] - 1e-6f) * dlv;
       }
       dsp[s] += dspe;
+      }
+    }
+    if (raw) {      // through lv = softmax(u) + 1e-6:  du = s (dlv - sum(s dlv)),  s = lv - 1e-6
+#pragma unroll
+      for (int e = 0; e < MMVAE_MAX_EXPERTS; ++e) {
+        if (e >= E) continue;
+        const float dot = wave_sum(udot[e]);
+#pragma unroll
+        for (int s = 0; s < POE_SLOTS; ++s) {
+          const int d = lane + 64 * s;
+          if (d < D) {
+            const size_t oi = (size_t)b * ld + d;
+            const float sv = expf(a.lv[e][oi] - umx[e]) * uinv[e];
+            a.dlv[e][oi] = sv * (a.dlv[e][oi] - dot);
+          }
+        }
       }
     }
   }
@@ -279,24 +337,25 @@ extern "C" size_t mmvae_poe_ws_floats(int B, int D) { return (size_t)poe_blocks(
 
 extern "C" int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl,
                                         int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
-                                        mmvae_stream_t stream) {
+                                        int raw_heads, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && joint && B > 0 && D > 0 && E > 0 && ld_in >= D);
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   if (with_prior == 2 && E != 1) return MMVAE_ERR_ARG;
   if (kl_mask && !kl) return MMVAE_ERR_ARG;
   hipLaunchKernelGGL(poe_fwd_kernel, dim3(poe_blocks(B)), dim3(256), 0, (hipStream_t)stream, *a, theta, joint, kl, E,
-                     with_prior, n_z, kl_mask, B, D, ld_in);
+                     with_prior, n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0);
   return mmvae_launch_status();
 }
 
 extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl,
                                         float* dtheta, float* ws, int E, int with_prior, int n_z, unsigned kl_mask,
-                                        int B, int D, int ld_in, int accumulate, mmvae_stream_t stream) {
+                                        int B, int D, int ld_in, int raw_heads, int accumulate,
+                                        mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && ws && B > 0 && D > 0 && E > 0 && ld_in >= D);
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   const int nb = poe_blocks(B);
   hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
-                     n_z, kl_mask, B, D, ld_in);
+                     n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0);
   if (dtheta)
     hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
                        accumulate);

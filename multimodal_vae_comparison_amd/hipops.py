@@ -69,9 +69,9 @@ SIGNATURES = {
     "mmvae_head_softmax_fwd": (c_i, [c_p, c_i, c_i, c_p]),
     "mmvae_head_softmax_bwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "mmvae_poe_reparam_kl_fwd": (c_i, [ctypes.POINTER(PoeFwdArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i, c_i,
-                                       c_p]),
+                                       c_i, c_p]),
     "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
-                                       c_i, c_i, c_p]),
+                                       c_i, c_i, c_i, c_p]),
     "mmvae_poe_ws_floats": (c_sz, [c_i, c_i]),
     "mmvae_bce_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 2 + [c_p]),
     "mmvae_bce_sigmoid_clamp_bwd": (c_i, [c_p] * 4 + [c_i] * 2 + [c_p]),

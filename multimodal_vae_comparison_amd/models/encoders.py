@@ -31,6 +31,7 @@ class VaeComponent(nn.Module):
         self.net_type = net_type
         self.mu_layer = None
         self.logvar_layer = None
+        self.raw_heads = False      # set by a mixer's objective(): return [mu | raw logvar head], softmax in the PoE kernel
 
     def init_final_layers(self, in_feats):
         self.mu_layer = HipLinear(in_feats, self.out_dim)
@@ -74,7 +75,8 @@ class VaeComponent(nn.Module):
             h = ops.linear(data, w, b, in_act, gw, gb)
         else:
             h = torch.cat([mu_l(data, in_act), lv_l(data, in_act)], dim=-1)
-        h = ops.head_softmax(h)
+        if not self.raw_heads:
+            h = ops.head_softmax(h)
         return h[:, :D], h[:, D:]
 
 

@@ -62,13 +62,18 @@ class MoPOE(TorchMMVAE):
             with torch.cuda.stream(st):
                 if st is not None and eps is None:      # noise does not depend on anything: off the main stream
                     eps = self._draw_many(M, B, D, dev)                    # one rsample per modality (:363-369)
-                enc.append(self.vaes[n].enc(mods[n]))
+                tower = self.vaes[n].enc
+                tower.raw_heads = True      # lv = softmax(u) + eta is applied by the fused latent kernel
+                try:
+                    enc.append(tower(mods[n]))
+                finally:
+                    tower.raw_heads = False
         self._join(streams, dev)
         if eps is None:
             eps = self._draw_many(M, B, D, dev)
         packed = [packed_head(mu, lv) for mu, lv in enc]
         theta = self._pz_params[1]
-        _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad)
+        _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad, raw=True)
         self._fork(streams, dev)
         recs = [None] * M
         order = list(enumerate(zip(names, streams)))

@@ -590,7 +590,8 @@ class PoeReparamKL(Function):
     [not differentiable], kl (E+1,B), then n_z tensors z_i (B,D)."""
 
     @staticmethod
-    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, cols, *tensors):
+    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, cols, raw, *tensors):
+        """raw: the logvar halves of `packed` are the raw head outputs; softmax + 1e-6 happens inside the kernels"""
         packed = [H.f32c(t) for t in tensors[:E]]
         eps = [H.f32c(t) for t in tensors[E:E + n_z]]
         B, D2 = packed[0].shape
@@ -608,16 +609,16 @@ class PoeReparamKL(Function):
             a.eps[i] = t.data_ptr()
             a.z[i] = zs[i].data_ptr()
         _call("mmvae_poe_reparam_kl_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(joint), H.ptr(kl), E, int(with_prior),
-              n_z, kl_mask, B, D, D2, H.stream())
+              n_z, kl_mask, B, D, D2, int(bool(raw)), H.stream())
         ctx.save_for_backward(theta, *packed, *eps)
-        ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0)
+        ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0, int(bool(raw)))
         ctx.mark_non_differentiable(joint)
         ctx.set_materialize_grads(False)
         return (joint, kl, *zs)
 
     @staticmethod
     def backward(ctx, _dj, dkl, *dzs):
-        gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0 = ctx.cfg
+        gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0, raw = ctx.cfg
         # batch point: every decoder's backward is done, so the queued decoder weight-gradient kernels can run on
         # the side stream underneath the encoder backward chains
         GradReducer.launch_pending(ctx.saved_tensors[0].device)
@@ -645,13 +646,15 @@ class PoeReparamKL(Function):
             acc = 0
         ws = H.workspace(H.lib().mmvae_poe_ws_floats(B, D), dev)
         _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws), E,
-              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, acc, H.stream())
-        return (ret, None, None, None, None, None, None, *dpacked, *([None] * n_z))
+              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, H.stream())
+        return (ret, None, None, None, None, None, None, None, *dpacked, *([None] * n_z))
 
 
-def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None, cols=None):
-    """-> joint (2,B,D), kl (E+1,B), [z_0 .. z_{n_z-1}] each (B,D); cols = (col0, D) selects expert columns"""
-    out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), cols, *packed, *eps)
+def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None, cols=None, raw=False):
+    """-> joint (2,B,D), kl (E+1,B), [z_0 .. z_{n_z-1}] each (B,D); cols = (col0, D) selects expert columns;
+    raw: packed = [mu | raw logvar-head output] (VaeComponent.process_output(raw=True))"""
+    assert not (raw and cols is not None), "raw heads: the softmax runs over the full head width"
+    out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), cols, raw, *packed, *eps)
     return out[0], out[1], list(out[2:])
 
 
