@@ -408,6 +408,11 @@ int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, float* dx, int 
  * launch advances the call counter itself, so a captured graph replays with fresh noise and no host work. */
 int mmvae_randn(float* out, long n, uint32_t* state, mmvae_stream_t stream);
 
+/* debug: store the device wall clock (100 MHz ticks) into *slot, in stream order (phase timelines of a graph replay) */
+int mmvae_debug_timestamp(long long* slot, mmvae_stream_t stream);
+/* debug: one thread spins for `ticks` device wall-clock ticks, then stores {start, end} ticks into slot[0..1] */
+int mmvae_debug_spin(long long* slot, long long ticks, mmvae_stream_t stream);
+
 /* ---- Generic convolutions (csrc/conv_generic.hip): any channel counts, K <= 4, stride S, padding P -------------
  * First correct path for Enc_SVHN / Dec_SVHN (models/encoders.py:434-478, models/decoders.py:101-147); plain fp32 FMA.
  * Same conventions as the k4-s2-p1 entry points above: layers emit pre-activations, `in_act` is applied to the
@@ -473,6 +478,9 @@ int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows
 /* linear weight gradient: `splits` partial (N*K) slabs followed by `splits` partial (N) bias rows; splits == 1
  * means the kernel accumulated directly (nothing to reduce) */
 int mmvae_linear_bwd_weight_splits(int M, int N, int K);
+/* ... and by mmvae_linear_bwd (1 = written straight to dW/db: <= 256 rows with N % 4 == 0 take the register-operand
+ * kernel, which needs dy 16-byte aligned) */
+int mmvae_linear_bwd_splits(int M, int N, int K);
 int mmvae_layernorm_bwd_rows(int rows, int d); /* partial rows of length 2*d: [dgamma | dbeta] */
 int mmvae_embed_bwd_rows(int B, int T, int V);  /* partial rows of length 4 */
 

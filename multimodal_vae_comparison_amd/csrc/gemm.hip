@@ -101,6 +101,73 @@ __device__ __forceinline__ void act_inplace(float (&v)[N], int act) {
   }
 }
 
+// Output phase shared by the staged and the register-operand bodies: (KSPLIT > 1) sum the waves' partial accumulators
+// through LDS (`red`: KSPLIT x 16 x 64 floats, `rsr`: KSPLIT x 32), then bias / epilogue / accumulate / store.
+template <int KSPLIT>
+__device__ __forceinline__ void gemm_finish(const GemmArgs& g, const int bx, const int m0, const int n0, const int bz,
+                                            const int nz, const f32x16& acc, float asum, float* __restrict__ red,
+                                            float* __restrict__ rsr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const bool partial = nz > 1;
+  float* Cout = partial ? g.ws + (size_t)bz * g.M * g.N : g.C;
+  const long ldc = partial ? g.N : g.ldc;
+  float* rs_out = partial ? g.ws + (size_t)nz * g.M * g.N + (size_t)bz * g.M : g.a_rowsum;
+  const int ep = partial ? MMVAE_EP_NONE : g.ep;
+  const bool acc_out = !partial && g.accumulate;
+
+  asum += __shfl_xor(asum, 32, 64);
+
+  const bool plain = ep == MMVAE_EP_NONE && !acc_out;   // the common case: no per-element branching
+  const float bias_v = (!partial && g.bias && n0 + li < g.N) ? g.bias[n0 + li] : 0.f;   // every emit of a lane has col n0+li
+  auto emit = [&](int row, int col, float v) {
+    if (row < g.M && col < g.N) {
+      v += bias_v;
+      const long o = (long)row * ldc + col;
+      if (!plain) {
+        float av = 0.f;
+        if (ep_reads_aux(ep)) av = g.aux[o];
+        if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
+        v = apply_epilogue(v, av, ep);
+        if (acc_out) v += Cout[o];
+      }
+      Cout[o] = v;
+    }
+  };
+
+  if (KSPLIT == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) emit(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, acc[r]);
+    if (g.a_rowsum && bx == 0 && lh == 0) {
+      const int row = m0 + wave * 32 + li;
+      if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + asum : asum;
+    }
+  } else {
+    #pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    if (lh == 0) rsr[wave * 32 + li] = asum;
+    __syncthreads();
+    constexpr int RPW = 16 / KSPLIT > 0 ? 16 / KSPLIT : 1;  // accumulator registers summed and emitted per wave
+    if (wave < 16 / RPW) {
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave * RPW + q;
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < KSPLIT; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
+        emit(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, v);
+      }
+    }
+    if (g.a_rowsum && bx == 0 && wave == 0 && lh == 0) {
+      const int row = m0 + li;
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < KSPLIT; ++w2) v += rsr[w2 * 32 + li];
+      if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + v : v;
+    }
+  }
+}
+
 template <int KSPLIT, bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, const int nz,
                                           float* __restrict__ As, float* __restrict__ Bs) {
@@ -164,65 +231,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     __syncthreads();
   }
 
-  const bool partial = nz > 1;
-  float* Cout = partial ? g.ws + (size_t)bz * g.M * g.N : g.C;
-  const long ldc = partial ? g.N : g.ldc;
-  float* rs_out = partial ? g.ws + (size_t)nz * g.M * g.N + (size_t)bz * g.M : g.a_rowsum;
-  const int ep = partial ? MMVAE_EP_NONE : g.ep;
-  const bool acc_out = !partial && g.accumulate;
-
-  asum += __shfl_xor(asum, 32, 64);
-
-  const bool plain = ep == MMVAE_EP_NONE && !acc_out;   // the common case: no per-element branching
-  const float bias_v = (!partial && g.bias && n0 + li < g.N) ? g.bias[n0 + li] : 0.f;   // every emit of a lane has col n0+li
-  auto emit = [&](int row, int col, float v) {
-    if (row < g.M && col < g.N) {
-      v += bias_v;
-      const long o = (long)row * ldc + col;
-      if (!plain) {
-        float av = 0.f;
-        if (ep_reads_aux(ep)) av = g.aux[o];
-        if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
-        v = apply_epilogue(v, av, ep);
-        if (acc_out) v += Cout[o];
-      }
-      Cout[o] = v;
-    }
-  };
-
-  if (KSPLIT == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) emit(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, acc[r]);
-    if (g.a_rowsum && bx == 0 && lh == 0) {
-      const int row = m0 + wave * 32 + li;
-      if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + asum : asum;
-    }
-  } else {
-    float* red = As;  // KSPLIT waves x 16 regs x 64 lanes floats <= BK*AP
-    float* rsr = Bs;  // KSPLIT x 32 row sums
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-    if (lh == 0) rsr[wave * 32 + li] = asum;
-    __syncthreads();
-    constexpr int RPW = 16 / KSPLIT > 0 ? 16 / KSPLIT : 1;  // accumulator registers summed and emitted per wave
-    if (wave < 16 / RPW) {
-#pragma unroll
-      for (int q = 0; q < RPW; ++q) {
-        const int r = wave * RPW + q;
-        float v = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < KSPLIT; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
-        emit(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + li, v);
-      }
-    }
-    if (g.a_rowsum && bx == 0 && wave == 0 && lh == 0) {
-      const int row = m0 + li;
-      float v = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < KSPLIT; ++w2) v += rsr[w2 * 32 + li];
-      if (row < g.M) rs_out[row] = acc_out ? rs_out[row] + v : v;
-    }
-  }
+  gemm_finish<KSPLIT>(g, bx, m0, n0, bz, nz, acc, asum, As, Bs);
 }
 
 template <int KSPLIT, bool A_KMAJOR, bool B_KMAJOR>
@@ -253,6 +262,216 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GemmGroup grp) {
   const int by = t % grp.ny[p], bz = t / grp.ny[p];
   if (p == 0) gemm_body<4, true, false>(grp.g[0], bx, by, bz, grp.nz[0], As, Bs);
   else gemm_body<4, false, false>(grp.g[1], bx, by, bz, grp.nz[1], As, Bs);
+}
+
+// ---- register-operand body (batch-128 linears) -------------------------------------------------------------
+// With <= 256 output rows a Linear layer is a handful of 32x32 tiles with a 512-deep reduction: the staged body
+// above spends its time in the global -> register -> LDS -> register round trip and two barriers per stage, not in
+// its 16 MFMAs.  fp32 MFMA wants ONE row per lane (A[i = li][k], B[k][j = li]) so here every lane loads its own
+// operand slots straight from L2 into registers -- float4 along k for k-contiguous operands, coalesced dwords for
+// row-contiguous ones -- all of a slice's loads in flight at once, no LDS and no barrier before the MFMAs.  The 8
+// waves of a workgroup take interleaved DEPTH-deep slices of the reduction; gemm_finish sums them.
+// Reduction slot of lane (li, lh), register (q, j): k = k0 + 8 q + 4 lh + j.
+// Requires (checked by the dispatcher): k-contiguous operands 16-byte aligned with K and the row stride % 4 == 0.
+template <int DEPTH, bool KMAJOR>
+__device__ __forceinline__ void rgemm_load(const float* __restrict__ rowp, const long kstride, const int k0,
+                                           const int kend, const int K, const int lh, float (&v)[DEPTH / 8][4]) {
+#pragma unroll
+  for (int q = 0; q < DEPTH / 8; ++q) {
+    const int kq = k0 + 8 * q + 4 * lh;
+    if (KMAJOR) {
+      const float4 t = *reinterpret_cast<const float4*>(rowp + min(kq, K - 4));
+      const bool ok = kq < kend;
+      v[q][0] = ok ? t.x : 0.f; v[q][1] = ok ? t.y : 0.f; v[q][2] = ok ? t.z : 0.f; v[q][3] = ok ? t.w : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = rowp[(long)min(kq + j, K - 1) * kstride];
+        v[q][j] = kq + j < kend ? t : 0.f;
+      }
+    }
+  }
+}
+
+template <int DEPTH, bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void rgemm_body(const GemmArgs& g, const int bx, const int by, const int bz, const int nz,
+                                           float* __restrict__ red, float* __restrict__ rsr) {
+  constexpr int NW = 8, NQ = DEPTH / 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = by * 32, n0 = bx * 32;
+  const int kbeg = bz * g.kper;
+  const int kend = min(g.K, kbeg + g.kper);
+  // rows / columns past the edge are clamped, not zeroed: they only feed accumulator rows / columns that are never
+  // written.  The reduction tail is zeroed.
+  const float* Ap = g.A + (long)min(m0 + li, g.M - 1) * g.sam;
+  const float* Bp = g.B + (long)min(n0 + li, g.N - 1) * g.sbn;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float asum = 0.f;
+#ifdef GEMM_PROBE
+  long stamps[8];
+  int nst = 0;
+#define GSTAMP() stamps[nst++] = clock64()
+#else
+#define GSTAMP()
+#endif
+  GSTAMP();
+#pragma unroll 1
+  for (int k0 = kbeg + wave * DEPTH; k0 < kend; k0 += NW * DEPTH) {
+    float a[NQ][4], b[NQ][4];
+    rgemm_load<DEPTH, A_KMAJOR>(Ap, g.sak, k0, kend, g.K, lh, a);
+    rgemm_load<DEPTH, B_KMAJOR>(Bp, g.sbk, k0, kend, g.K, lh, b);
+    GSTAMP();
+#ifdef GEMM_PROBE
+    __builtin_amdgcn_s_waitcnt(0);
+    GSTAMP();
+#endif
+    if (g.a_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) act_inplace(a[q], g.a_act);
+    }
+    if (g.b_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) act_inplace(b[q], g.b_act);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asum += a[q][j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b[q][j], acc, 0, 0, 0);
+      }
+  }
+  GSTAMP();
+  gemm_finish<NW>(g, bx, m0, n0, bz, nz, acc, asum, red, rsr);
+#ifdef GEMM_PROBE
+  GSTAMP();
+  if (g.ws && lane == 0) {
+    long* o = reinterpret_cast<long*>(g.ws) + ((long)(by * gridDim.x + bx) * NW + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = i < nst ? stamps[i] : 0;
+  }
+#endif
+}
+
+// 16 x 16 tiles on v_mfma_f32_16x16x4_f32 for outputs of <= 128 32x32 tiles (a 128 x 512 layer: 256 workgroups
+// instead of 64, so the MFMA phase and the operand loads spread over the whole chip).  The texture unit walks about
+// one 128-byte line per clock per CU: a float4 load of 16 rows x 64 contiguous bytes touches 16 lines per kilobyte
+// where the 32-row form touches 32, and a workgroup only pulls 64 KB.
+// Operand layout: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; accumulator register r of
+// lane l is C[4 (l >> 4) + r][l & 15].  Reduction slot of lane (l & 15, kq = l >> 4), register (q, j):
+// k = k0 + 16 q + 4 kq + j.
+template <int DEPTH, bool KMAJOR>
+__device__ __forceinline__ void rgemm16_load(const float* __restrict__ rowp, const long kstride, const int k0,
+                                             const int kend, const int K, const int kq4, float (&v)[DEPTH / 16][4]) {
+#pragma unroll
+  for (int q = 0; q < DEPTH / 16; ++q) {
+    const int kq = k0 + 16 * q + 4 * kq4;
+    if (KMAJOR) {
+      const float4 t = *reinterpret_cast<const float4*>(rowp + min(kq, K - 4));
+      const bool ok = kq < kend;
+      v[q][0] = ok ? t.x : 0.f; v[q][1] = ok ? t.y : 0.f; v[q][2] = ok ? t.z : 0.f; v[q][3] = ok ? t.w : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = rowp[(long)min(kq + j, K - 1) * kstride];
+        v[q][j] = kq + j < kend ? t : 0.f;
+      }
+    }
+  }
+}
+
+template <int DEPTH, bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void rgemm16_body(const GemmArgs& g, const int bx, const int by, float* __restrict__ red) {
+  constexpr int NW = 8, NQ = DEPTH / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, kq4 = lane >> 4;
+  const int m0 = by * 16, n0 = bx * 16;
+  const int kend = g.K;
+  const float* Ap = g.A + (long)min(m0 + l16, g.M - 1) * g.sam;
+  const float* Bp = g.B + (long)min(n0 + l16, g.N - 1) * g.sbn;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int k0 = wave * DEPTH; k0 < kend; k0 += NW * DEPTH) {
+    float a[NQ][4], b[NQ][4];
+    rgemm16_load<DEPTH, A_KMAJOR>(Ap, g.sak, k0, kend, g.K, kq4, a);
+    rgemm16_load<DEPTH, B_KMAJOR>(Bp, g.sbk, k0, kend, g.K, kq4, b);
+    if (g.a_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) act_inplace(a[q], g.a_act);
+    }
+    if (g.b_act != MMVAE_ACT_NONE) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) act_inplace(b[q], g.b_act);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], b[q][j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int r = tid >> 6;
+    float v = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) v += red[(w2 * 4 + r) * 64 + lane];
+    const int row = m0 + 4 * kq4 + r, col = n0 + l16;
+    if (row < g.M && col < g.N) {
+      if (g.bias) v += g.bias[col];
+      const long o = (long)row * g.ldc + col;
+      const int ep = g.ep;
+      if (ep != MMVAE_EP_NONE || g.accumulate) {
+        float av = 0.f;
+        if (ep_reads_aux(ep)) av = g.aux[o];
+        if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
+        v = apply_epilogue(v, av, ep);
+        if (g.accumulate) v += g.C[o];
+      }
+      g.C[o] = v;
+    }
+  }
+}
+
+template <int DEPTH, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(512) void rgemm16_kernel(GemmArgs g) {
+  __shared__ float red[8 * 4 * 64];
+  rgemm16_body<DEPTH, A_KMAJOR, B_KMAJOR>(g, blockIdx.x, blockIdx.y, red);
+}
+
+template <int DEPTH, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(512) void rgemm_kernel(GemmArgs g) {
+  __shared__ float red[8 * 16 * 64];
+  __shared__ float rsr[8 * 32];
+  rgemm_body<DEPTH, A_KMAJOR, B_KMAJOR>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, red, rsr);
+}
+
+// data + weight gradient of one Linear layer in one launch (see gemm_grouped_kernel), register-operand bodies
+template <int D0, int D1, bool T16>
+__global__ __launch_bounds__(512) void rgemm_grouped_kernel(GemmGroup grp) {
+  __shared__ float red[8 * 16 * 64];
+  __shared__ float rsr[8 * 32];
+  const int p = ((int)blockIdx.x >= grp.blk0[1]) ? 1 : 0;
+  const int local = blockIdx.x - grp.blk0[p];
+  const int bx = local % grp.nx[p], t = local / grp.nx[p];
+  const int by = t % grp.ny[p], bz = t / grp.ny[p];
+  if (p == 0) {
+    if (T16) rgemm16_body<D0, true, false>(grp.g[0], bx, by, red);
+    else rgemm_body<D0, true, false>(grp.g[0], bx, by, bz, grp.nz[0], red, rsr);
+  } else {
+    rgemm_body<D1, false, false>(grp.g[1], bx, by, bz, grp.nz[1], red, rsr);
+  }
+}
+
+static inline bool rgemm_aligned(const float* p, long row_stride, int K) {
+  return ((uintptr_t)p & 15) == 0 && (row_stride & 3) == 0 && (K & 3) == 0 && K >= 4;
+}
+static inline int rgemm_depth(int K) { return K >= 384 ? 64 : 16; }
+static bool rgemm_enabled() {
+  static const int v = [] { const char* e = getenv("MMVAE_RGEMM"); return e ? atoi(e) : 1; }();
+  return v != 0;
 }
 
 extern "C" size_t mmvae_gemm_ws_floats(int M, int N, int splitk) {
@@ -293,6 +512,37 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   const bool ak = sak == 1, bk_major = (sbk == 1 && sbn != 1);
   if (!ak && sam != 1) return MMVAE_ERR_UNSUPPORTED;
   if (!bk_major && sbn != 1) return MMVAE_ERR_UNSUPPORTED;
+  // few tiles, short reduction: register-operand kernel (no LDS staging)
+  if (rgemm_enabled() && splitk == 1 && tiles32 <= 1024 && K <= 2048 && (!ak || rgemm_aligned(A, sam, K)) &&
+      (!bk_major || rgemm_aligned(Bm, sbn, K))) {
+    g.kper = K;
+    const dim3 rgrid(ntn, (M + 31) / 32, 1);
+#define RGEMM_LAUNCH(D)                                                                                  \
+  do {                                                                                                   \
+    if (ak && bk_major) hipLaunchKernelGGL((rgemm_kernel<D, true, true>), rgrid, dim3(512), 0, st, g);    \
+    else if (ak) hipLaunchKernelGGL((rgemm_kernel<D, true, false>), rgrid, dim3(512), 0, st, g);          \
+    else if (!bk_major) hipLaunchKernelGGL((rgemm_kernel<D, false, false>), rgrid, dim3(512), 0, st, g);  \
+    else hipLaunchKernelGGL((rgemm_kernel<D, false, true>), rgrid, dim3(512), 0, st, g);                  \
+  } while (0)
+    if (tiles32 <= 128 && !a_rowsum) {   // 16 x 16 tiles
+      const dim3 grid16((N + 15) / 16, (M + 15) / 16, 1);
+#define RGEMM16_LAUNCH(D)                                                                                   \
+  do {                                                                                                      \
+    if (ak && bk_major) hipLaunchKernelGGL((rgemm16_kernel<D, true, true>), grid16, dim3(512), 0, st, g);    \
+    else if (ak) hipLaunchKernelGGL((rgemm16_kernel<D, true, false>), grid16, dim3(512), 0, st, g);          \
+    else if (!bk_major) hipLaunchKernelGGL((rgemm16_kernel<D, false, false>), grid16, dim3(512), 0, st, g);  \
+    else hipLaunchKernelGGL((rgemm16_kernel<D, false, true>), grid16, dim3(512), 0, st, g);                  \
+  } while (0)
+      if (rgemm_depth(K) == 64) RGEMM16_LAUNCH(64);
+      else RGEMM16_LAUNCH(16);
+#undef RGEMM16_LAUNCH
+      return mmvae_launch_status();
+    }
+    if (rgemm_depth(K) == 64) RGEMM_LAUNCH(64);
+    else RGEMM_LAUNCH(16);
+#undef RGEMM_LAUNCH
+    return mmvae_launch_status();
+  }
   const dim3 grid(ntn, variant == 1 ? (M + 127) / 128 : (M + 31) / 32, nz), block(variant == 8 ? 512 : 256);
 #define GEMM_LAUNCH(V)                                                                            \
   do {                                                                                            \
@@ -365,7 +615,13 @@ extern "C" int mmvae_linear_bwd_weight(const float* dy, const float* x, float* d
 
 // Fused nn.Linear backward: dx = ep(dy W) and dW (+)= dy^T act(x), db (+)= colsum(dy) in ONE grouped launch.
 // Falls back to two launches when either problem wants a different tiling.
-extern "C" size_t mmvae_linear_bwd_ws_floats(int M, int N, int K) { return mmvae_linear_bwd_weight_ws_floats(M, N, K); }
+static inline bool linear_bwd_rgemm(int M, int N) { return rgemm_enabled() && M <= 256 && (N & 3) == 0 && N >= 4; }
+extern "C" size_t mmvae_linear_bwd_ws_floats(int M, int N, int K) {
+  return linear_bwd_rgemm(M, N) ? 0 : mmvae_linear_bwd_weight_ws_floats(M, N, K);
+}
+extern "C" int mmvae_linear_bwd_splits(int M, int N, int K) {
+  return linear_bwd_rgemm(M, N) ? 1 : mmvae_linear_bwd_weight_splits(M, N, K);
+}
 extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const float* aux, float* dx,
                                 float* dw, float* db, float* ws, int M, int N, int K, long ldx, int x_act, int ep_mode,
                                 int accumulate, mmvae_stream_t stream) {
@@ -373,6 +629,34 @@ extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w,
   if (ep_reads_aux(ep_mode) && !aux) return MMVAE_ERR_ARG;
   // problem 0 (data):   C[M,K] = dy[M,N] W[N,K]            reduction N
   // problem 1 (weight): C[N,K] = dy^T[N,M] act(x)[M,K]     reduction M, split over workgroups
+  if (linear_bwd_rgemm(M, N)) {
+    if (!rgemm_aligned(dy, N, N)) return MMVAE_ERR_ARG;   // this regime needs a 16-byte aligned dy
+    GemmGroup grp;
+    GemmArgs& gd = grp.g[0];
+    gd.A = dy; gd.B = w; gd.bias = nullptr; gd.aux = const_cast<float*>(aux); gd.C = dx; gd.a_rowsum = nullptr; gd.ws = nullptr;
+    gd.M = M; gd.N = K; gd.K = N; gd.sam = N; gd.sak = 1; gd.sbk = K; gd.sbn = 1; gd.ldc = K;
+    gd.a_act = MMVAE_ACT_NONE; gd.b_act = MMVAE_ACT_NONE; gd.ep = ep_mode; gd.accumulate = 0; gd.kper = N;
+    GemmArgs& gw = grp.g[1];
+    gw.A = dy; gw.B = x; gw.bias = nullptr; gw.aux = nullptr; gw.C = dw; gw.a_rowsum = db; gw.ws = nullptr;
+    gw.M = N; gw.N = K; gw.K = M; gw.sam = 1; gw.sak = N; gw.sbk = ldx; gw.sbn = 1; gw.ldc = K;
+    gw.a_act = MMVAE_ACT_NONE; gw.b_act = x_act; gw.ep = MMVAE_EP_NONE; gw.accumulate = accumulate ? 1 : 0; gw.kper = M;
+    grp.n = 2;
+    const bool t16 = (long)((M + 31) / 32) * ((K + 31) / 32) <= 128;   // data gradient on 16 x 16 tiles
+    const int td = t16 ? 16 : 32;
+    grp.nx[0] = (K + td - 1) / td; grp.ny[0] = (M + td - 1) / td; grp.nz[0] = 1;
+    grp.nx[1] = (K + 31) / 32; grp.ny[1] = (N + 31) / 32; grp.nz[1] = 1;
+    grp.blk0[0] = 0;
+    grp.blk0[1] = grp.nx[0] * grp.ny[0];
+    grp.blk0[2] = grp.blk0[1] + grp.nx[1] * grp.ny[1];
+    const dim3 rgrid(grp.blk0[2]);
+    hipStream_t st = (hipStream_t)stream;
+    const bool deep = rgemm_depth(N) == 64;
+    if (deep && t16) hipLaunchKernelGGL((rgemm_grouped_kernel<64, 16, true>), rgrid, dim3(512), 0, st, grp);
+    else if (deep) hipLaunchKernelGGL((rgemm_grouped_kernel<64, 16, false>), rgrid, dim3(512), 0, st, grp);
+    else if (t16) hipLaunchKernelGGL((rgemm_grouped_kernel<16, 16, true>), rgrid, dim3(512), 0, st, grp);
+    else hipLaunchKernelGGL((rgemm_grouped_kernel<16, 16, false>), rgrid, dim3(512), 0, st, grp);
+    return mmvae_launch_status();
+  }
   const long t128_d = (long)((M + 127) / 128) * ((K + 31) / 32), t32_d = (long)((M + 31) / 32) * ((K + 31) / 32);
   // (a 512-deep data gradient alone prefers the 8-wave tiling, but one grouped launch beats two: +4 % on the step)
   const bool d_ok = t128_d < 256;

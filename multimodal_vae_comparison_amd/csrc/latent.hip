@@ -450,3 +450,29 @@ extern "C" int mmvae_randn(float* out, long n, uint32_t* state, mmvae_stream_t s
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, state);
   return mmvae_launch_status();
 }
+
+// ---- debug: device wall-clock marker ---------------------------------------------------------------------------
+// One-thread kernel that stores the 100 MHz device wall clock into `slot`: dropped into a captured step at phase
+// boundaries (tools/phase_timeline.py) it gives the true per-stream timeline of a graph replay, which a profiler's
+// per-dispatch instrumentation distorts at this kernel size.
+__global__ void timestamp_kernel(long long* slot) { *slot = (long long)wall_clock64(); }
+extern "C" int mmvae_debug_timestamp(long long* slot, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(slot);
+  hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+  return mmvae_launch_status();
+}
+
+// debug: one thread that spins for `ticks` wall-clock ticks (10 ns each), then stamps slot[0] = start, slot[1] = end.
+// Synthetic DAGs of these (tools/probe/graph_sched.py) show how a captured multi-stream graph is really scheduled.
+__global__ void spin_kernel(long long* slot, long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  long long t = t0;
+  while (t - t0 < ticks) t = (long long)wall_clock64();
+  slot[0] = t0;
+  slot[1] = t;
+}
+extern "C" int mmvae_debug_spin(long long* slot, long long ticks, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(slot);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot, ticks);
+  return mmvae_launch_status();
+}

@@ -83,6 +83,8 @@ SIGNATURES = {
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_randn": (c_i, [c_p, c_l, c_p, c_p]),
+    "mmvae_debug_timestamp": (c_i, [c_p, c_p]),
+    "mmvae_debug_spin": (c_i, [c_p, ctypes.c_longlong, c_p]),
     "mmvae_conv2d_generic_fwd": (c_i, [c_p] * 5 + [c_i] * 10 + [c_p]),
     "mmvae_conv2d_generic_dgrad": (c_i, [c_p] * 4 + [c_i] * 9 + [c_p]),
     "mmvae_conv2d_generic_wgrad": (c_i, [c_p] * 4 + [c_i] * 10 + [c_p]),
@@ -135,6 +137,7 @@ SIGNATURES = {
     "mmvae_head_bcast_dropout_bwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_dp, c_p]),
     "mmvae_conv_wgrad_layout": (c_i, [c_i] * 4 + [c_p] * 3),
     "mmvae_linear_bwd_weight_splits": (c_i, [c_i] * 3),
+    "mmvae_linear_bwd_splits": (c_i, [c_i] * 3),
     "mmvae_layernorm_bwd_rows": (c_i, [c_i, c_i]),
     "mmvae_embed_bwd_rows": (c_i, [c_i] * 3),
 }

@@ -14,6 +14,13 @@ from .mmvae_base import TorchMMVAE, normal, packed_head
 from .objectives import recon_rowsum
 
 
+def _uses(t, stream):
+    """`t` (allocated on another stream) is read by kernels queued on `stream`"""
+    if t is not None and t.is_cuda and stream is not None:
+        base = t._base if t._base is not None else t
+        base.record_stream(stream)
+
+
 class MoPOE(TorchMMVAE):
     """Generalised multimodal ELBO (mmvae_models.py:253-410).
 
@@ -47,49 +54,94 @@ class MoPOE(TorchMMVAE):
         return subsets
 
     # ---- hot path --------------------------------------------------------------------------------
-    def objective(self, mods):
-        """mmvae_models.py:296-320 + weighted_group_kld (objectives.py:184-201)"""
+    def _elbo_terms(self, mods):
+        """Forward pass up to the per-row ELBO terms (mmvae_models.py:296-320 + weighted_group_kld,
+        objectives.py:184-201): returns (recs, kl, W, streams, device) and leaves the tower streams un-joined.
+
+        Stream choreography (every cross-stream wait costs ~9 us at this kernel size, a wait whose event has already
+        fired costs nothing): tower i encodes on stream i; the fusion kernel runs on the LAST tower's stream -- the
+        text encoder, the longer of the two -- after that stream has waited for the others; the decoders then rotate
+        by one stream, so modality 0's decoder (the image ConvT stack, the longer one) continues on the fusion stream
+        without a wait.  autograd replays every node on its forward stream, so the backward pass mirrors this."""
         self._begin_step()
         names = list(self.vaes.keys())
         M = len(names)
         dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
         streams = self._tower_streams(dev)
+        cur = torch.cuda.current_stream(dev)
+        real = [cur if st is None else st for st in streams]
         self._fork(streams, dev)
         enc = []
         B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
-        eps = None
+        eps = self._draw_many(M, B, D, dev)            # one rsample per modality (:363-369), ahead of tower 0
         for n, st in zip(names, streams):
             with torch.cuda.stream(st):
-                if st is not None and eps is None:      # noise does not depend on anything: off the main stream
-                    eps = self._draw_many(M, B, D, dev)                    # one rsample per modality (:363-369)
                 tower = self.vaes[n].enc
                 tower.raw_heads = True      # lv = softmax(u) + eta is applied by the fused latent kernel
+                ops.Marks.mark(f"enc {n} start")
                 try:
-                    enc.append(tower(mods[n]))
+                    mu_lv = tower(mods[n])
                 finally:
                     tower.raw_heads = False
-        self._join(streams, dev)
-        if eps is None:
-            eps = self._draw_many(M, B, D, dev)
-        packed = [packed_head(mu, lv) for mu, lv in enc]
+                enc.append(tuple(ops.mark_tensor(t, f"enc {n} out[{j}]") for j, t in enumerate(mu_lv)))
+        rotate = os.environ.get("MMVAE_ROTATE", "1") == "1"
+        fuse = real[-1] if rotate else real[0]
+        for st in real:
+            if st != fuse:
+                fuse.wait_stream(st)
         theta = self._pz_params[1]
-        _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad, raw=True)
-        self._fork(streams, dev)
+        # tensors that cross streams are registered with the consuming stream: the caching allocator must not hand
+        # their memory to the producing stream again while the consumer's kernels are still queued
+        for t in list(eps) + [t for pair in enc for t in pair]:
+            _uses(t, fuse)
+        with torch.cuda.stream(fuse):
+            packed = [packed_head(mu, lv) for mu, lv in enc]
+            _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad, raw=True)
+        _uses(kl, cur)
+        for st in real:
+            if st != fuse:
+                st.wait_stream(fuse)
         recs = [None] * M
-        order = list(enumerate(zip(names, streams)))
-        if os.environ.get("MMVAE_DEC_ORDER", "rev") == "rev":
-            order = order[::-1]     # autograd runs the LAST recorded tower's backward first: see DESIGN.md section 5
-        for i, (n, st) in order:
+        order = [(i, names[i], real[(i + M - 1) % M] if rotate else real[i]) for i in range(M)]
+        if os.environ.get("MMVAE_DEC_ORDER", "fwd") == "rev":
+            order = order[::-1]
+        for i, n, st in order:
             vae = self.vaes[n]
+            _uses(z[i], st)
             with torch.cuda.stream(st):
-                out, _ = vae.dec({"latents": z[i].unsqueeze(0), "masks": mods[n]["masks"]})
-                recs[i] = recon_rowsum(vae.ltype, out, mods[n])            # (B,) = -lpx_z / llik_scaling
-        self._join(streams, dev)
+                zi = ops.mark_tensor(z[i], f"dec {n} z")
+                out, _ = vae.dec({"latents": zi.unsqueeze(0), "masks": mods[n]["masks"]})
+                recs[i] = ops.mark_tensor(recon_rowsum(vae.ltype, out, mods[n]), f"dec {n} recon")   # (B,) = -lpx_z / llik_scaling
+            _uses(recs[i], cur)
         w_kl = 1.0 / (M + 1)
         lam = [float(self.vaes[n].llik_scaling) for n in names]
         W = [[l / B for l in lam] + [self.obj_fn.beta * w_kl / B] * (M + 1),
              [0.0] * M + [w_kl / B] * (M + 1)]
+        return recs, kl, W, streams, dev
+
+    def objective(self, mods):
+        recs, kl, W, streams, dev = self._elbo_terms(mods)
+        self._join(streams, dev)
+        ops.Marks.mark("joined decoders")
         out = ops.lincomb_rows(recs + [kl], W)                              # rows: M recon sums, M+1 KL rows
+        return {"loss": out[0], "kld": out[1], "reconstruction_loss": recs}
+
+    def objective_backward(self, mods):
+        """objective(mods)["loss"].backward() without the join in the middle: the loss is LINEAR in the per-row terms
+        (recs, kl) with host-side constant weights, so every tower's backward is seeded with those constants as soon as
+        its own forward is done -- no tower waits for the other one's decoder or for the loss kernel.  The loss values
+        are assembled afterwards, off the critical path.  Used by the captured training step (trainer.capture)."""
+        recs, kl, W, streams, dev = self._elbo_terms(mods)
+        key = (tuple(W[0]), tuple(kl.shape), tuple(recs[0].shape), str(dev))
+        if getattr(self, "_seed_key", None) != key:
+            M = len(recs)
+            self._seeds = [torch.full(r.shape, W[0][i], device=dev) for i, r in enumerate(recs)]
+            self._seeds.append(torch.tensor(W[0][M:], device=dev).reshape(-1, 1).expand(kl.shape).contiguous())
+            self._seed_key = key
+        torch.autograd.backward(recs + [kl], self._seeds)
+        self._join(streams, dev)
+        with torch.no_grad():
+            out = ops.lincomb_rows([r.detach() for r in recs] + [kl.detach()], W)
         return {"loss": out[0], "kld": out[1], "reconstruction_loss": recs}
 
     # ---- API surface (inference / evaluation) ------------------------------------------------------

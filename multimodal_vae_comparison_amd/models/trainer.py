@@ -3,6 +3,8 @@ dependency: `get_model`, `training_step(batch, idx) -> loss`, `configure_optimiz
 drive it unchanged (nn.Module + the same hook names); `fused_step()` is the MI355X fast path used by bench.py:
 forward + backward of the whole objective replayed from ONE hipGraph, optional RCCL all-reduce of the flat
 gradient buffer, ONE fused Adam kernel."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -79,21 +81,32 @@ class MultimodalVAE(nn.Module):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):                       # warm-up: sizes the shared workspace, loads code objects
-                self.model.objective(batch)["loss"].backward(self._one)
+                self._fwd_bwd(batch)
             self.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         self._adam_in_graph = world_size == 1
         with torch.cuda.graph(self._graph):
-            out = self.model.objective(batch)
-            out["loss"].backward(self._one)
+            ops.Marks.mark("step start")
+            out = self._fwd_bwd(batch)
+            ops.Marks.mark("backward done")
             if self._adam_in_graph:
                 self.optimizer.step()
+                ops.Marks.mark("adam done")
         self._static_out = out
         if self._adam_in_graph:                      # the capture pass does not execute: nothing to undo
             pass
         self.flat.zero_grad()
+        return out
+
+    def _fwd_bwd(self, batch):
+        """forward + backward of the objective; mixers whose loss is linear in per-tower terms provide
+        `objective_backward`, which seeds every tower's backward without joining the towers first"""
+        if hasattr(self.model, "objective_backward") and os.environ.get("MMVAE_SPLIT_BACKWARD", "1") == "1":
+            return self.model.objective_backward(batch)
+        out = self.model.objective(batch)
+        out["loss"].backward(self._one)
         return out
 
     def load_batch(self, batch):

@@ -131,6 +131,43 @@ class GradReducer:
                 cls._arena[key] = torch.empty(need + (1 << 20), dtype=torch.float32, device=device)
 
 
+class Marks:
+    """debug phase markers (MMVAE_MARKS=1): device wall-clock stamps in stream order, see tools/phase_timeline.py"""
+    enabled = os.environ.get("MMVAE_MARKS", "0") == "1"
+    names = []
+    buf = None
+
+    @classmethod
+    def mark(cls, name):
+        if not cls.enabled:
+            return
+        if cls.buf is None:
+            cls.buf = torch.zeros(256, dtype=torch.int64, device="cuda")
+        if name not in cls.names:
+            cls.names.append(name)
+        i = cls.names.index(name)
+        _call("mmvae_debug_timestamp", cls.buf.data_ptr() + 8 * i, H.stream())
+
+
+class Mark(Function):
+    """identity that stamps `fwd:name` in forward and `bwd:name` in backward (on the stream each runs on)"""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        Marks.mark("fwd:" + name)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        Marks.mark("bwd:" + ctx.name)
+        return g, None
+
+
+def mark_tensor(x, name):
+    return Mark.apply(x, name) if Marks.enabled else x
+
+
 class StreamPlan:
     """Overlap on separate HIP streams (captured into one hipGraph as parallel branches).
 
@@ -522,13 +559,16 @@ class Linear(Function):
                 db = gb
             else:
                 db = ret_b = torch.empty(N, device=x.device)
-        nws = H.lib().mmvae_linear_bwd_weight_ws_floats(M, N, K)
         need_dx = ctx.needs_input_grad[0]
+        if dy.data_ptr() % 16:
+            dy = dy.clone()
+        lib = H.lib()
+        nws = lib.mmvae_linear_bwd_ws_floats(M, N, K) if need_dx else lib.mmvae_linear_bwd_weight_ws_floats(M, N, K)
         dx = torch.empty_like(x) if need_dx else None
         ep = _DACT[in_act]
         aux = H.ptr(x) if ep else None
         defer = _defer(gw, gb if has_b else gw)
-        nz = H.lib().mmvae_linear_bwd_weight_splits(M, N, K)
+        nz = lib.mmvae_linear_bwd_splits(M, N, K) if need_dx else lib.mmvae_linear_bwd_weight_splits(M, N, K)
         if defer:
             ws = GradReducer.alloc(nws, x.device) if nz > 1 else None
             acc = H.ACC_DEFER
