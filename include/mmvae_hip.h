@@ -350,14 +350,16 @@ typedef struct {
 } mmvae_txt_layer_drop_t;
 int mmvae_txt_layer_supported(int L, int D, int FF, int NH, int dec);
 size_t mmvae_txt_layer_lnws_floats(int N, int D, int dec);
+/* time_mean != 0: y / dy are (N, D), the mean of the layer output over the L frames and its gradient -- the pooling
+ * `x.mean(0)` that follows the last encoder layer (models/encoders.py:552), folded into the layer's launch */
 int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const float* mem, float* y,
                         const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                         const mmvae_txt_layer_drop_t* drop, int L, int N, int D, int FF, int NH, int dec,
-                        mmvae_stream_t stream);
+                        int time_mean, mmvae_stream_t stream);
 int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float* dmem,
                         const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                         const mmvae_txt_layer_grads_t* grads, const mmvae_txt_layer_drop_t* drop, int L, int N, int D,
-                        int FF, int NH, int dec, mmvae_stream_t stream);
+                        int FF, int NH, int dec, int time_mean, mmvae_stream_t stream);
 
 /* y[t,b,:] = dropout(x[t,b,:] + pe[t,:]) -- Enc_Transformer / Dec_Transformer positional encoding
  * (models/encoders.py:721-723, models/decoders.py:607-608; PositionalEncoding try-branch nn_modules.py:430-438).
@@ -443,9 +445,9 @@ int mmvae_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, mmvae_
  * ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam(amsgrad=True) over one flat buffer (models/trainer.py:79-81); step is 1-based and is
  * read from *step_dev (device int) when step_dev != NULL, so that a captured hipGraph replays with the
- * right bias correction (mmvae_step_inc bumps it on the stream).  With step < 0, step_dev is {count, ticket}
- * (two ints, zero-initialised): the launch computes step count + 1 and stores it itself when its last workgroup
- * finishes -- no separate launch.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce);
+ * right bias correction (mmvae_step_inc bumps it on the stream).  With step < 0, step_dev is a zero-initialised,
+ * 8-byte aligned 24-byte block {int count, int ticket, double beta1^count, double beta2^count}: the launch is step
+ * count + 1 and stores the new count and powers itself when its last workgroup finishes -- no separate launch.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce);
  * zero_grad != 0 clears g. */
 int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
                             float beta2, float eps, int step, int* step_dev, float grad_scale,

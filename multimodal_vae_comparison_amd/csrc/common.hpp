@@ -109,3 +109,25 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
+
+// ---- debug build only (-DMMVAE_TRACE, tools/probe/trace_step.py): thread 0 of workgroup 0 of the instrumented kernels
+// stores the device wall clock into a per-module table, so the start time of every phase of a REAL captured step can
+// be read back without adding graph nodes (markers change the graph's topology and with it hipGraph's scheduling) or
+// a profiler (which changes the timing).  Compiles to nothing in the product build.
+#ifdef MMVAE_TRACE
+static __device__ long long* mmvae_trace_table __attribute__((unused)) = nullptr;
+#define MMVAE_TRACE_STAMP(id)                                                      \
+  do {                                                                             \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
+      long long* t__ = mmvae_trace_table;                                          \
+      if (t__) t__[id] = (long long)wall_clock64();                                \
+    }                                                                              \
+  } while (0)
+#define MMVAE_TRACE_SETTER(module)                                                          \
+  extern "C" int mmvae_trace_set_##module(long long* table) {                               \
+    return hipMemcpyToSymbol(HIP_SYMBOL(mmvae_trace_table), &table, sizeof(table)) == hipSuccess ? 0 : 1; \
+  }
+#else
+#define MMVAE_TRACE_STAMP(id)
+#define MMVAE_TRACE_SETTER(module)
+#endif

@@ -19,12 +19,14 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <typename G, typename W>
 __global__ __launch_bounds__(256) void conv2d_bwd_fused_kernel(ConvScatterArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  MMVAE_TRACE_STAMP(10 + G::LGH);
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
   if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
   else conv_scatter_body<G>(ad, blockIdx.x - n_w, smem);
 }
 template <typename G, typename W>
 __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  MMVAE_TRACE_STAMP(14 - G::LGH);
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
   if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
   else conv_gather_body<G, G::RWONLY>(ad, blockIdx.x - n_w, smem);
@@ -165,3 +167,5 @@ extern "C" int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall
   conv_wgrad_layout(B, Clarge, Hsmall, rows, rowlen, bias_col);
   return MMVAE_OK;
 }
+
+MMVAE_TRACE_SETTER(conv)

@@ -513,24 +513,25 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   if (!ak && sam != 1) return MMVAE_ERR_UNSUPPORTED;
   if (!bk_major && sbn != 1) return MMVAE_ERR_UNSUPPORTED;
   // few tiles, short reduction: register-operand kernel (no LDS staging)
-  if (rgemm_enabled() && splitk == 1 && tiles32 <= 1024 && K <= 2048 && (!ak || rgemm_aligned(A, sam, K)) &&
-      (!bk_major || rgemm_aligned(Bm, sbn, K))) {
+  if (rgemm_enabled() && splitk == 1 && tiles32 <= 1024 && K <= 1024) {
+    // k-contiguous operands that are not float4-aligned take the strided (dword) loads with a k stride of 1
+    const bool ak4 = ak && rgemm_aligned(A, sam, K), bk4 = bk_major && rgemm_aligned(Bm, sbn, K);
     g.kper = K;
     const dim3 rgrid(ntn, (M + 31) / 32, 1);
 #define RGEMM_LAUNCH(D)                                                                                  \
   do {                                                                                                   \
-    if (ak && bk_major) hipLaunchKernelGGL((rgemm_kernel<D, true, true>), rgrid, dim3(512), 0, st, g);    \
-    else if (ak) hipLaunchKernelGGL((rgemm_kernel<D, true, false>), rgrid, dim3(512), 0, st, g);          \
-    else if (!bk_major) hipLaunchKernelGGL((rgemm_kernel<D, false, false>), rgrid, dim3(512), 0, st, g);  \
+    if (ak4 && bk4) hipLaunchKernelGGL((rgemm_kernel<D, true, true>), rgrid, dim3(512), 0, st, g);        \
+    else if (ak4) hipLaunchKernelGGL((rgemm_kernel<D, true, false>), rgrid, dim3(512), 0, st, g);         \
+    else if (!bk4) hipLaunchKernelGGL((rgemm_kernel<D, false, false>), rgrid, dim3(512), 0, st, g);       \
     else hipLaunchKernelGGL((rgemm_kernel<D, false, true>), rgrid, dim3(512), 0, st, g);                  \
   } while (0)
     if (tiles32 <= 128 && !a_rowsum) {   // 16 x 16 tiles
       const dim3 grid16((N + 15) / 16, (M + 15) / 16, 1);
 #define RGEMM16_LAUNCH(D)                                                                                   \
   do {                                                                                                      \
-    if (ak && bk_major) hipLaunchKernelGGL((rgemm16_kernel<D, true, true>), grid16, dim3(512), 0, st, g);    \
-    else if (ak) hipLaunchKernelGGL((rgemm16_kernel<D, true, false>), grid16, dim3(512), 0, st, g);          \
-    else if (!bk_major) hipLaunchKernelGGL((rgemm16_kernel<D, false, false>), grid16, dim3(512), 0, st, g);  \
+    if (ak4 && bk4) hipLaunchKernelGGL((rgemm16_kernel<D, true, true>), grid16, dim3(512), 0, st, g);        \
+    else if (ak4) hipLaunchKernelGGL((rgemm16_kernel<D, true, false>), grid16, dim3(512), 0, st, g);         \
+    else if (!bk4) hipLaunchKernelGGL((rgemm16_kernel<D, false, false>), grid16, dim3(512), 0, st, g);       \
     else hipLaunchKernelGGL((rgemm16_kernel<D, false, true>), grid16, dim3(512), 0, st, g);                  \
   } while (0)
       if (rgemm_depth(K) == 64) RGEMM16_LAUNCH(64);

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
                                                       float* __restrict__ joint, float* __restrict__ kl, int E,
                                                       int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
                                                       int raw) {
+  MMVAE_TRACE_STAMP(22);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
                                                       const float* __restrict__ dkl, float* __restrict__ ws, int E,
                                                       int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
                                                       int raw) {
+  MMVAE_TRACE_STAMP(23);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -476,3 +478,5 @@ extern "C" int mmvae_debug_spin(long long* slot, long long ticks, mmvae_stream_t
   hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot, ticks);
   return mmvae_launch_status();
 }
+
+MMVAE_TRACE_SETTER(latent)

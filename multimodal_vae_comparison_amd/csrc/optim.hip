@@ -10,26 +10,38 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
                                                            float* __restrict__ vmax, long n, float lr,
                                                            int step, int* __restrict__ step_dev, float b1,
                                                            float b2, float eps, float gscale, int zero_grad) {
+  MMVAE_TRACE_STAMP(20);
   // bias corrections from the step count; the count lives in device memory when the launch is replayed
   // from a captured graph (kernel arguments are frozen at capture time).
   __shared__ float bc[2];
+  __shared__ double pw[2];
   if (threadIdx.x == 0) {
-    // step < 0 with a device counter: this launch IS step (*step_dev + 1); the last workgroup to finish stores it
+    // step < 0 with a device counter: this launch IS step (*step_dev + 1); the last workgroup to finish stores it.
+    // In that mode the buffer also carries beta1^count, beta2^count as doubles (bytes 8..23; zero = not there yet):
+    // one multiply per step instead of two double-precision pow() in front of every launch (~2 us of a ~15 us kernel).
     const int st = step_dev ? step_dev[0] + (step < 0 ? 1 : 0) : step;
-    const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
-    bc[0] = (float)((double)lr / bc1);
-    bc[1] = (float)(1.0 / sqrt(bc2));
+    double p1, p2;
+    if (step_dev && step < 0) {
+      const double* run = reinterpret_cast<const double*>(step_dev + 2);
+      const double r1 = run[0], r2 = run[1];
+      p1 = st == 1 ? (double)b1 : (r1 > 0.0 ? r1 * (double)b1 : pow((double)b1, (double)st));
+      p2 = st == 1 ? (double)b2 : (r2 > 0.0 ? r2 * (double)b2 : pow((double)b2, (double)st));
+      pw[0] = p1;
+      pw[1] = p2;
+    } else {
+      p1 = pow((double)b1, (double)st);
+      p2 = pow((double)b2, (double)st);
+    }
+    bc[0] = (float)((double)lr / (1.0 - p1));
+    bc[1] = (float)(1.0 / sqrt(1.0 - p2));
   }
   __syncthreads();
   const float lr_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
-    float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
-    float4 X = reinterpret_cast<float4*>(vmax)[i];
+  auto update4 = [&](float4& P, const float4& G, float4& M, float4& Vv, float4& X) {
     float* pp = &P.x;
-    float* gg = &G.x;
+    const float* gg = &G.x;
     float* mm = &M.x;
     float* vv = &Vv.x;
     float* xx = &X.x;
@@ -41,11 +53,30 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
       xx[k] = fmaxf(xx[k], vv[k]);
       pp[k] -= lr_bc1 * mm[k] / (sqrtf(xx[k]) * inv_sqrt_bc2 + eps);
     }
-    reinterpret_cast<float4*>(p)[i] = P;
-    reinterpret_cast<float4*>(m)[i] = M;
-    reinterpret_cast<float4*>(v)[i] = Vv;
-    reinterpret_cast<float4*>(vmax)[i] = X;
-    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  float4* x4 = reinterpret_cast<float4*>(vmax);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // two float4 per array per thread and iteration: ten 16-byte loads in flight before the first use
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const long j = i + stride;
+    float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i], X0 = x4[i];
+    float4 P1 = p4[j], G1 = g4[j], M1 = m4[j], V1 = v4[j], X1 = x4[j];
+    update4(P0, G0, M0, V0, X0);
+    update4(P1, G1, M1, V1, X1);
+    p4[i] = P0; m4[i] = M0; v4[i] = V0; x4[i] = X0;
+    p4[j] = P1; m4[j] = M1; v4[j] = V1; x4[j] = X1;
+    if (zero_grad) { g4[i] = zero4; g4[j] = zero4; }
+  }
+  if (i < n4) {
+    float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i], X0 = x4[i];
+    update4(P0, G0, M0, V0, X0);
+    p4[i] = P0; m4[i] = M0; v4[i] = V0; x4[i] = X0;
+    if (zero_grad) g4[i] = zero4;
   }
   // tail
   for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -66,6 +97,9 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
       if (ticket == (int)gridDim.x - 1) {
         step_dev[1] = 0;
         step_dev[0] += 1;
+        double* run = reinterpret_cast<double*>(step_dev + 2);
+        run[0] = pw[0];
+        run[1] = pw[1];
       }
     }
   }
@@ -76,7 +110,8 @@ extern "C" int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, f
                                        float grad_scale, int zero_grad, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(p && g && m && v && vmax && n > 0 && (step > 0 || step_dev));
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) != 0) return MMVAE_ERR_ARG;
-  long blocks = ((n >> 2) + 255) / 256;
+  if (step < 0 && (((uintptr_t)step_dev) & 7) != 0) return MMVAE_ERR_ARG;
+  long blocks = ((n >> 3) + 255) / 256;    // two float4 per thread
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
@@ -131,6 +166,7 @@ extern "C" int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long 
 // 16-byte aligned and a multiple of 4 long, else four dword columns per lane) x 4 row slices, 8 loads in flight.
 #define RS_COLS 256
 __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t) {
+  MMVAE_TRACE_STAMP(21);
   __shared__ float4 part[4][64];
   int sg = 0;
   while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan over head segments, n <= 64
@@ -261,3 +297,5 @@ extern "C" int mmvae_step_inc(int* step_dev, mmvae_stream_t stream) {
 
 extern "C" int mmvae_version(void) { return 1; }
 extern "C" const char* mmvae_arch(void) { return "gfx950"; }
+
+MMVAE_TRACE_SETTER(optim)

@@ -283,7 +283,9 @@ template <typename G>
 __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ valid,
                                                             const float* __restrict__ mem, float* __restrict__ y,
                                                             const mmvae_txt_layer_w_t w, const mmvae_txt_layer_saved_t sv,
-                                                            const mmvae_txt_layer_drop_t dr, const int L, const int N) {
+                                                            const mmvae_txt_layer_drop_t dr, const int L, const int N,
+                                                            const int time_mean) {
+  MMVAE_TRACE_STAMP(16 + (G::DEC ? 1 : 0));
   constexpr int D = G::D, FF = G::FF, NH = G::NH, HD = G::HD, PX = G::PX, PH = G::PH, PQ = G::PQ;
   constexpr int NBUF = G::DEC ? 5 : 4;
   constexpr int SMEM = NBUF * T * PX + T * PQ + T * PH + 64 + 64;
@@ -473,10 +475,19 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
                       if (t < L) {
                         const size_t o = ((size_t)t * LN + n) * D + c;
                         sv.xhatf[o] = xh;
-                        y[o] = yv;
+                        if (time_mean) RB[t * PX + c] = yv;   // same lane read this element: in-place is safe
+                        else y[o] = yv;
                       }
                     },
                     [&](int t, float rs) { if (t < L) sv.rstdf[(size_t)t * LN + n] = rs; });
+  if (time_mean) {   // y (N, D) = mean over the L frames (the encoder's pooling): no (L, N, D) round trip, no launch
+    __syncthreads();
+    if (l.tid < D) {
+      float a = 0.f;
+      for (int t = 0; t < L; ++t) a += RB[t * PX + l.tid];
+      y[(size_t)n * D + l.tid] = a * (1.0f / (float)L);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -487,7 +498,9 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, float* __restrict__ dmem,
                                                             const mmvae_txt_layer_w_t w, const mmvae_txt_layer_saved_t sv,
                                                             const mmvae_txt_layer_grads_t gr,
-                                                            const mmvae_txt_layer_drop_t dr, const int L, const int N) {
+                                                            const mmvae_txt_layer_drop_t dr, const int L, const int N,
+                                                            const int time_mean) {
+  MMVAE_TRACE_STAMP(18 + (G::DEC ? 1 : 0));
   constexpr int D = G::D, FF = G::FF, NH = G::NH, HD = G::HD, PX = G::PX, PH = G::PH, PQ = G::PQ, PG = G::PG;
   constexpr int NLN = G::DEC ? 3 : 2;
   constexpr int PP = 33;
@@ -512,7 +525,14 @@ __global__ __launch_bounds__(256) void txt_layer_bwd_kernel(const float* __restr
   __syncthreads();
   WTile<D> wd;        // prefetched first weight tile of the next K = D data-gradient GEMM
   prefetch_tile<D, false>(wd, w.l2_w, FF, l);
-  stage_rows<D>(DYB, PX, dy, LN, n, L, l);
+  if (time_mean) {   // dy (N, D) is the gradient of the mean over frames: every row gets dy / L
+    for (int e = l.tid; e < T * D; e += 256) {
+      const int t = e / D, c = e - t * D;
+      DYB[t * PX + c] = t < L ? dy[(size_t)n * D + c] * (1.0f / (float)L) : 0.f;
+    }
+  } else {
+    stage_rows<D>(DYB, PX, dy, LN, n, L, l);
+  }
   stage_rows<D>(XHB, PX, sv.xhatf, LN, n, L, l);
   stage_rows<3 * D>(QB, PQ, sv.qkv, LN, n, L, l);
   if (l.tid < T) {
@@ -801,7 +821,7 @@ extern "C" size_t mmvae_txt_layer_lnws_floats(int N, int D, int dec) { return (s
 extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const float* mem, float* y,
                                    const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                                    const mmvae_txt_layer_drop_t* drop, int L, int N, int D, int FF, int NH, int dec,
-                                   mmvae_stream_t stream) {
+                                   int time_mean, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && valid && y && w && saved && N > 0);
   if (dec && !mem) return MMVAE_ERR_ARG;
   if (L < 1 || L > tl::T) return MMVAE_ERR_UNSUPPORTED;
@@ -816,7 +836,7 @@ extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const f
   if (!txt_layer_visit(D, FF, NH, dec, [&](auto g) {
         using G = decltype(g);
         hipLaunchKernelGGL((txt_layer_fwd_kernel<G>), dim3(N), dim3(256), 0, (hipStream_t)stream, x, valid, mem, y, wv, sv,
-                           d, L, N);
+                           d, L, N, time_mean);
       }))
     return MMVAE_ERR_UNSUPPORTED;
   return mmvae_launch_status();
@@ -825,7 +845,7 @@ extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const f
 extern "C" int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float* dmem,
                                    const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                                    const mmvae_txt_layer_grads_t* grads, const mmvae_txt_layer_drop_t* drop, int L, int N,
-                                   int D, int FF, int NH, int dec, mmvae_stream_t stream) {
+                                   int D, int FF, int NH, int dec, int time_mean, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(dy && valid && dx && w && saved && grads && N > 0);
   if (dec && !dmem) return MMVAE_ERR_ARG;
   if (L < 1 || L > tl::T) return MMVAE_ERR_UNSUPPORTED;
@@ -841,8 +861,10 @@ extern "C" int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float*
   if (!txt_layer_visit(D, FF, NH, dec, [&](auto g) {
         using G = decltype(g);
         hipLaunchKernelGGL((txt_layer_bwd_kernel<G>), dim3(N), dim3(256), 0, (hipStream_t)stream, dy, valid, dx, dmem, wv,
-                           sv, gv, d, L, N);
+                           sv, gv, d, L, N, time_mean);
       }))
     return MMVAE_ERR_UNSUPPORTED;
   return mmvae_launch_status();
 }
+
+MMVAE_TRACE_SETTER(txtlayer)

@@ -67,7 +67,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
         self.vmax = torch.zeros_like(flat.data)
-        self.step_dev = torch.zeros(2, dtype=torch.int32, device=flat.data.device)   # {count, kernel ticket}
+        self.step_dev = torch.zeros(6, dtype=torch.int32, device=flat.data.device)   # {count, ticket, b1^count, b2^count}
         self.grad_scale = grad_scale
 
     @torch.no_grad()

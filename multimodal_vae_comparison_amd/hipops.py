@@ -106,8 +106,8 @@ SIGNATURES = {
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_txt_layer_supported": (c_i, [c_i] * 5),
     "mmvae_txt_layer_lnws_floats": (c_sz, [c_i] * 3),
-    "mmvae_txt_layer_fwd": (c_i, [c_p] * 7 + [c_i] * 6 + [c_p]),
-    "mmvae_txt_layer_bwd": (c_i, [c_p] * 8 + [c_i] * 6 + [c_p]),
+    "mmvae_txt_layer_fwd": (c_i, [c_p] * 7 + [c_i] * 7 + [c_p]),
+    "mmvae_txt_layer_bwd": (c_i, [c_p] * 8 + [c_i] * 7 + [c_p]),
     "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_i, c_dp, c_p]),
     "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_dp, c_p]),
     "mmvae_layernorm_residual_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_dp, c_p]),
@@ -186,7 +186,8 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "
                 f"`make -C multimodal_vae_comparison_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
-        L = ctypes.CDLL(LIB_PATH)
+        # MMVAE_HIP_LIB: an alternative build of the SAME library (the -DMMVAE_TRACE debug build of tools/probe)
+        L = ctypes.CDLL(os.environ.get("MMVAE_HIP_LIB", LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

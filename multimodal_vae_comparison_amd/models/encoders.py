@@ -223,15 +223,19 @@ class HipTransformerEncoderLayer(nn.Module):
                 "l2_b": self.linear2.bias, "n1_g": self.norm1.weight, "n1_b": self.norm1.bias,
                 "n2_g": self.norm2.weight, "n2_b": self.norm2.bias}
 
-    def forward(self, x, mask_u8, ds=None):
-        """`ds`: dict of DropSpec for train mode (attn, drop1, ffn, drop2) or None"""
+    def forward(self, x, mask_u8, ds=None, time_mean=False):
+        """`ds`: dict of DropSpec for train mode (attn, drop1, ffn, drop2) or None.  `time_mean`: return the mean of
+        the output over the frames, (N, d) -- the pooling that follows the LAST encoder layer, folded into the fused
+        layer's launch when that path is taken"""
         L, _, d = x.shape
         ff, nh = self.linear1.out_features, self.self_attn.nhead
         if FUSED_TXT_LAYERS and ops.txt_layer_supported(L, d, ff, nh, False):
             # one workgroup per sequence runs the whole layer (csrc/txtlayer.hip); same arithmetic and dropout masks
             p = self.fused_params()
-            return ops.txt_layer(x, None, mask_u8, ops.TxtLayerMeta(d, ff, nh, False, ds), p,
+            return ops.txt_layer(x, None, mask_u8, ops.TxtLayerMeta(d, ff, nh, False, ds, time_mean), p,
                                  {k: v.grad for k, v in p.items()})
+        if time_mean:
+            return ops.mean_over_time(self.forward(x, mask_u8, ds))
         if ds is None:
             x = self.norm1(self.self_attn(x, mask_u8), x)
             return self.norm2(self.linear2(self.linear1(x)), x)
@@ -289,10 +293,10 @@ class Enc_TxtTransformer(VaeEncoder):
         else:
             d_pe, ds = None, [None] * len(self.seqTransEncoder.layers)
         h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad, d_pe)   # (T, B, 2V)
-        for layer, d in zip(self.seqTransEncoder.layers, ds):
-            h = layer(h, mask_u8, d)
-        z = ops.mean_over_time(h)
-        return self.process_output(z)
+        last = len(self.seqTransEncoder.layers) - 1
+        for i, (layer, d) in enumerate(zip(self.seqTransEncoder.layers, ds)):
+            h = layer(h, mask_u8, d, time_mean=(i == last))      # z = h.mean(0) folded into the last layer
+        return self.process_output(h)
 
 
 class Enc_Transformer(VaeEncoder):
@@ -340,6 +344,6 @@ class Enc_Transformer(VaeEncoder):
         h = self.skel_Embedding(x)
         pe = self.sequence_pos_encoder.pe[:nframes].reshape(nframes, d)
         h = ops.add_pe_dropout(h, pe, nframes, bs, d, d_pe)
-        for layer, dd in zip(self.seqTransEncoder.layers, ds):
-            h = layer(h, mask_u8, dd)
-        return self.process_output(ops.mean_over_time(h))
+        for i, (layer, dd) in enumerate(zip(self.seqTransEncoder.layers, ds)):
+            h = layer(h, mask_u8, dd, time_mean=(i == nl - 1))
+        return self.process_output(h)

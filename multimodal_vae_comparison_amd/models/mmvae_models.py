@@ -138,11 +138,35 @@ class MoPOE(TorchMMVAE):
             self._seeds = [torch.full(r.shape, W[0][i], device=dev) for i, r in enumerate(recs)]
             self._seeds.append(torch.tensor(W[0][M:], device=dev).reshape(-1, 1).expand(kl.shape).contiguous())
             self._seed_key = key
+        cur = torch.cuda.current_stream(dev)
+        side = next((st for st in streams[::-1] if st is not None), None)
+        mode = os.environ.get("MMVAE_LOSS_SIDE", "0")
+
+        def assemble(stream):
+            with torch.cuda.stream(stream), torch.no_grad():
+                return ops.lincomb_rows([r.detach() for r in recs] + [kl.detach()], W)
+
+        out = None
+        if mode == "2" and side is not None:
+            # the logged values are assembled on the fusion stream between its decoder's forward and backward: that
+            # stream has slack until the fusion backward (the other decoder's backward is the longer one)
+            side.wait_stream(cur)
+            out = assemble(side)
         torch.autograd.backward(recs + [kl], self._seeds)
-        self._join(streams, dev)
-        with torch.no_grad():
-            out = ops.lincomb_rows([r.detach() for r in recs] + [kl.detach()], W)
+        if out is None and mode == "1" and side is not None:
+            side.wait_stream(cur)
+            out = assemble(side)
+        if out is None:
+            self._join(streams, dev)
+            out = assemble(None)
+        self._unjoined = (streams, dev)
         return {"loss": out[0], "kld": out[1], "reconstruction_loss": recs}
+
+    def finish_step(self):
+        """join the streams objective_backward() left running (call after the optimiser step has been queued)"""
+        pending, self._unjoined = getattr(self, "_unjoined", None), None
+        if pending is not None:
+            self._join(*pending)
 
     # ---- API surface (inference / evaluation) ------------------------------------------------------
     def modality_mixing(self, input_batch):

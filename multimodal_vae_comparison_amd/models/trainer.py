@@ -82,6 +82,7 @@ class MultimodalVAE(nn.Module):
         with torch.cuda.stream(s):
             for _ in range(2):                       # warm-up: sizes the shared workspace, loads code objects
                 self._fwd_bwd(batch)
+                self._finish_step()
             self.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -94,6 +95,7 @@ class MultimodalVAE(nn.Module):
             if self._adam_in_graph:
                 self.optimizer.step()
                 ops.Marks.mark("adam done")
+            self._finish_step()
         self._static_out = out
         if self._adam_in_graph:                      # the capture pass does not execute: nothing to undo
             pass
@@ -108,6 +110,10 @@ class MultimodalVAE(nn.Module):
         out = self.model.objective(batch)
         out["loss"].backward(self._one)
         return out
+
+    def _finish_step(self):
+        if hasattr(self.model, "finish_step"):
+            self.model.finish_step()
 
     def load_batch(self, batch):
         for k, v in batch.items():

@@ -1123,8 +1123,9 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
 class TxtLayerMeta:
     """static description of one fused transformer layer call (shapes + the DropSpecs of its dropout sites)"""
 
-    def __init__(self, D, FF, NH, dec, drops):
+    def __init__(self, D, FF, NH, dec, drops, time_mean=False):
         self.D, self.FF, self.NH, self.dec, self.drops = D, FF, NH, bool(dec), drops or {}
+        self.time_mean = bool(time_mean)      # output (N, D): mean over the L frames (the encoder's pooling)
 
     def c_drop(self, L, N):
         if not self.drops:
@@ -1175,9 +1176,9 @@ class TxtLayer(Function):
         sv = H.TxtLayerSaved()
         for k, t in S.items():
             setattr(sv, k, t.data_ptr())
-        y = e(L, N, D)
+        y = e(N, D) if meta.time_mean else e(L, N, D)
         _call("mmvae_txt_layer_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(mem) if dec else None, H.ptr(y), ctypes.byref(w),
-              ctypes.byref(sv), meta.c_drop(L, N), L, N, D, FF, NH, int(dec), H.stream())
+              ctypes.byref(sv), meta.c_drop(L, N), L, N, D, FF, NH, int(dec), int(meta.time_mean), H.stream())
         ctx.meta, ctx.names, ctx.grads, ctx.S = meta, names, grads, S
         ctx.save_for_backward(x, mem if dec else None, mask_u8, *params)
         return y
@@ -1223,7 +1224,7 @@ class TxtLayer(Function):
                     setattr(t, k, H.Dropout(d.state.data_ptr(), d.slot, d.site, d.p))
             dstruct = ctypes.byref(t)
         _call("mmvae_txt_layer_bwd", H.ptr(dy), H.ptr(mask_u8), H.ptr(dx), H.ptr(dmem), ctypes.byref(w),
-              ctypes.byref(sv), ctypes.byref(gr), dstruct, L, N, D, FF, NH, int(dec), H.stream())
+              ctypes.byref(sv), ctypes.byref(gr), dstruct, L, N, D, FF, NH, int(dec), int(meta.time_mean), H.stream())
         M = L * N
         ret = {}
 

@@ -435,7 +435,7 @@ def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
     p = p0.to(DEV)
     # the flat kernel needs 16-byte aligned bases; torch allocations are
     m, v, vm = (torch.zeros(n, device=DEV) for _ in range(3))
-    step_dev = torch.zeros(2, dtype=torch.int32, device=DEV)
+    step_dev = torch.zeros(6, dtype=torch.int32, device=DEV)      # {count, ticket, beta1^count, beta2^count}
     for it in range(1, 6):
         gr = torch.randn(n, generator=g) * (0.1 if it != 3 else 10.0)
         pr.grad = gr.clone()
@@ -443,7 +443,7 @@ def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
         gd = gr.to(DEV)
         if self_counting:
             ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, -1, step_dev, 1.0, True)
-            assert step_dev.tolist() == [it, 0]
+            assert step_dev[:2].tolist() == [it, 0]
         else:
             ops.step_inc(step_dev)
             ops.adam_amsgrad_flat(p, gd, m, v, vm, 1e-3, 0.9, 0.999, 1e-8, 0, step_dev, 1.0, True)
@@ -453,12 +453,14 @@ def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
 
 @pytest.mark.parametrize("dec,L,N,d,train", [(False, 32, 128, 54, False), (False, 32, 16, 54, True), (False, 5, 6, 54, True),
                                              (True, 32, 128, 32, False), (True, 32, 16, 32, True), (True, 9, 7, 32, True),
-                                             (False, 6, 5, 32, True), (True, 6, 5, 54, True)])
+                                             (False, 6, 5, 32, True), (True, 6, 5, 54, True),
+                                             (False, 32, 128, 54, "mean"), (False, 7, 6, 54, "mean")])
 def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
     """csrc/txtlayer.hip (one launch per layer and direction) against the op-by-op kernels (each checked against
     torch above): outputs, input gradients and every parameter gradient, with identical dropout masks."""
     from multimodal_vae_comparison_amd.models import decoders, encoders
     from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    pooled = train == "mean"      # encoder layer with the time pooling folded in (train mode)
     torch.manual_seed(L * N + d + int(dec))
     layer = (decoders.HipTransformerDecoderLayer if dec else encoders.HipTransformerEncoderLayer)(d, 2, 128).to(DEV)
     for p in layer.parameters():          # non-trivial LayerNorm parameters and biases
@@ -469,7 +471,7 @@ def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
     lens = torch.randint(1, L + 1, (N,), generator=g)
     lens[0] = L
     mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV)
-    dy = torch.randn(L, N, d, generator=g).to(DEV)
+    dy = (torch.randn(N, d, generator=g) if pooled else torch.randn(L, N, d, generator=g)).to(DEV)
     st = DropoutState().to(DEV)
     sites = ("attn", "drop1", "xattn", "drop2", "ffn", "drop3") if dec else ("attn", "drop1", "ffn", "drop2")
     ds = {k: st.spec(0, 0, i + 1, 0.1, k) for i, k in enumerate(sites)} if train else None
@@ -479,7 +481,7 @@ def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
         for p in layer.parameters():
             p.grad = None
         xg, mg = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
-        out = layer(xg, mg, mask, ds) if dec else layer(xg, mask, ds)
+        out = layer(xg, mg, mask, ds) if dec else layer(xg, mask, ds, time_mean=pooled)
         out.backward(dy)
         return out.detach(), xg.grad, (mg.grad if dec else None), {k: p.grad.clone() for k, p in layer.named_parameters()
                                                                     if p.grad is not None}

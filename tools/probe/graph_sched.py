@@ -120,3 +120,51 @@ def fuse_on_side(first):
 
 run("R -> A(main)|B(side) -> P(side) -> C(side)|D(main) -> J   (C captured first)", fuse_on_side(0))
 run("R -> A(main)|B(side) -> P(side) -> C(side)|D(main) -> J   (D captured first)", fuse_on_side(1))
+
+
+def satisfied_wait(with_wait):
+    """main: P, A0..A7; side: B0 (short).  Optionally A4 additionally waits for B0, which finished long before."""
+    def build(main, _):
+        spin("P", 5)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            spin("B0", 5)
+        for i in range(8):
+            if i == 4 and with_wait:
+                main.wait_stream(side)
+            spin(f"A{i}", 10)
+        main.wait_stream(side)
+        spin("J", 5)
+    return build
+
+
+run("main chain A0..A7, side B0; no extra wait", satisfied_wait(False))
+run("main chain A0..A7, side B0; A4 waits for (long finished) B0", satisfied_wait(True))
+
+
+def late_side_work(n_extra):
+    """like the end of a training step: main tail T0,T1 after a join; side gets `n_extra` small kernels after the join
+    event, which need one more join at the very end"""
+    def build(main, _):
+        spin("P", 5)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for i in range(3):
+                spin(f"B{i}", 10)
+        for i in range(3):
+            spin(f"A{i}", 10)
+        main.wait_stream(side)
+        if n_extra:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                spin("L", 5)
+        spin("T0", 15)
+        spin("T1", 15)
+        if n_extra:
+            main.wait_stream(side)
+        spin("E", 1)
+    return build
+
+
+run("tail after join, nothing on side", late_side_work(0))
+run("tail after join, one side kernel beside the tail + final join", late_side_work(1))

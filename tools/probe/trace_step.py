@@ -1,0 +1,53 @@
+"""Start times of the instrumented kernels inside a REAL captured training step (no extra graph nodes, no profiler):
+run with the -DMMVAE_TRACE build of the library,
+    MMVAE_HIP_LIB=tools/probe/libmmvae_trace.so python tools/probe/trace_step.py
+(build: every csrc/*.hip with -DMMVAE_TRACE linked into tools/probe/libmmvae_trace.so)."""
+import ctypes
+import os
+import sys
+
+here = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("MMVAE_HIP_LIB", os.path.join(here, "libmmvae_trace.so"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
+import torch
+
+from multimodal_vae_comparison_amd import hipops as H
+from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
+from multimodal_vae_comparison_amd.synthetic import cdsprites_batch, cdsprites_config
+
+NAMES = {0: "img enc conv1", 1: "img enc conv2", 2: "img enc conv3", 3: "img enc conv4",
+         4: "img dec convT(4x4)", 5: "img dec convT(8x8)", 6: "img dec convT(16x16)", 7: "img dec convT3 (last fwd)",
+         8: "img dec bwd convT3", 9: "img dec bwd convT(16)", 10: "img dec bwd convT(8)", 11: "img dec bwd convT(4)",
+         12: "img enc bwd conv4", 13: "img enc bwd conv3", 14: "img enc bwd conv2", 15: "img enc bwd conv1 wgrad",
+         16: "txt enc layer fwd", 17: "txt dec layer fwd", 18: "txt enc layer bwd", 19: "txt dec layer bwd",
+         20: "adam", 21: "reduce_segments", 22: "poe fwd", 23: "poe bwd"}
+dev = torch.device("cuda", 0)
+B = int(os.environ.get("TRACE_BATCH", 128))
+torch.manual_seed(0)
+tr = MultimodalVAE(cdsprites_config("mopoe", 32, batch_size=B), device=dev)
+tr.model.train()
+tr.configure_optimizers()
+batch = cdsprites_batch(B, 32, seed=1, device=dev)
+table = torch.zeros(64, dtype=torch.int64, device=dev)
+L = ctypes.CDLL(os.environ["MMVAE_HIP_LIB"])
+for m in ("conv", "txtlayer", "optim", "latent"):
+    fn = getattr(L, f"mmvae_trace_set_{m}")
+    fn.argtypes = [ctypes.c_void_p]
+    assert fn(table.data_ptr()) == 0
+tr.capture(batch, 1)
+for _ in range(30):
+    tr.fused_step(1)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(100):
+    tr.fused_step(1)
+e1.record()
+torch.cuda.synchronize()
+print(f"step: {e0.elapsed_time(e1) * 10:.1f} us")
+v = table.cpu().tolist()
+ev = sorted((v[i], n) for i, n in NAMES.items() if v[i])
+t0 = ev[0][0]
+for t, n in ev:
+    print(f"{(t - t0) / 100.0:8.2f} us  {n}")
+print(f"(adam start + ~18 us = end of step; next step's first kernel follows)")
