@@ -89,14 +89,17 @@ class TorchMMVAE(nn.Module):
         return list(ops.randn((n, B, D), self._rng_state).unbind(0))
 
     # ---- tower-level concurrency -------------------------------------------------------------------
-    def _tower_streams(self, device):
-        """stream per modality: modality 0 stays on the current stream, the others get side streams (ops.StreamPlan)
-        so that independent towers overlap -- each of them alone cannot fill the chip at batch 128"""
+    def _tower_streams(self, device, main=0):
+        """stream per modality: modality `main` stays on the current stream (None), the others get side streams
+        (ops.StreamPlan) so that independent towers overlap -- each of them alone cannot fill the chip at batch 128"""
         names = list(self.vaes.keys())
         if not (ops.StreamPlan.enabled and device.type == "cuda") or len(names) < 2:
             return [None] * len(names)
-        out = [None]
-        for i in range(1, len(names)):
+        out = []
+        for i in range(len(names)):
+            if i == main % len(names):
+                out.append(None)
+                continue
             s = ops.StreamPlan.get(f"tower{i}", device)
             ops.GradReducer.note_stream(device, s)
             out.append(s)

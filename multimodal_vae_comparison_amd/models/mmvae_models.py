@@ -67,14 +67,21 @@ class MoPOE(TorchMMVAE):
         names = list(self.vaes.keys())
         M = len(names)
         dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
-        streams = self._tower_streams(dev)
+        # (which tower keeps the capture stream, and the capture order of the towers, decide how hipGraph partitions the
+        # step into queues: measured, see DESIGN.md section 5 -- tower 0 on the capture stream, captured first)
+        main_tower = int(os.environ.get("MMVAE_MAIN_TOWER", "0"))
+        streams = self._tower_streams(dev, main_tower)
         cur = torch.cuda.current_stream(dev)
         real = [cur if st is None else st for st in streams]
         self._fork(streams, dev)
-        enc = []
         B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
-        eps = self._draw_many(M, B, D, dev)            # one rsample per modality (:363-369), ahead of tower 0
-        for n, st in zip(names, streams):
+        eps_first = os.environ.get("MMVAE_EPS", "after") == "first"
+        eps = self._draw_many(M, B, D, dev) if eps_first else None
+        enc = [None] * M
+        enc_order = list(enumerate(zip(names, streams)))
+        if os.environ.get("MMVAE_ENC_ORDER", "fwd") == "rev":
+            enc_order = enc_order[::-1]
+        for i, (n, st) in enc_order:
             with torch.cuda.stream(st):
                 tower = self.vaes[n].enc
                 tower.raw_heads = True      # lv = softmax(u) + eta is applied by the fused latent kernel
@@ -83,7 +90,11 @@ class MoPOE(TorchMMVAE):
                     mu_lv = tower(mods[n])
                 finally:
                     tower.raw_heads = False
-                enc.append(tuple(ops.mark_tensor(t, f"enc {n} out[{j}]") for j, t in enumerate(mu_lv)))
+                enc[i] = tuple(ops.mark_tensor(t, f"enc {n} out[{j}]") for j, t in enumerate(mu_lv))
+                if eps is None and i == 0:
+                    # one rsample per modality (:363-369), behind tower 0's encoder: that stream idles until the
+                    # fusion anyway
+                    eps = self._draw_many(M, B, D, dev)
         rotate = os.environ.get("MMVAE_ROTATE", "1") == "1"
         fuse = real[-1] if rotate else real[0]
         for st in real:
