@@ -209,9 +209,11 @@ typedef struct {
 int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl, int E,
                              int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in, int raw_heads,
                              mmvae_stream_t stream);
+/* ticket: NULL, or a zero-initialised device int owned by the calling stream: the prior-parameter gradient is then
+ * folded by the last workgroup of the same launch (the kernel leaves the int at zero) instead of a second launch */
 int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl, float* dtheta,
-                             float* ws, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
-                             int raw_heads, int accumulate, mmvae_stream_t stream);
+                             float* ws, int* ticket, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D,
+                             int ld_in, int raw_heads, int accumulate, mmvae_stream_t stream);
 size_t mmvae_poe_ws_floats(int B, int D);
 
 /* MoE importance weights, models/mmvae_models.py:56-62:  lw[b] = sum_d [log N(z; mu_r, s_r) - log N(z; mu_o, s_o)]
@@ -238,6 +240,15 @@ int mmvae_bce_rowsum_bwd(const float* x_hat, const float* target, const float* g
 int mmvae_sigmoid_clamp_bwd(const float* dy, const float* y, float* dl, long n, mmvae_stream_t stream);
 /* elementwise bce (B,F) for the ReconLoss.bce API */
 int mmvae_bce_elem_fwd(const float* x_hat, const float* target, float* loss, long n, mmvae_stream_t stream);
+
+/* Loss terms whose upstream gradient is a known constant (the ELBO is linear in them: seed = llik_scaling / B):
+ * row sums AND the logit gradient seed * d(row)/d(logit) from one pass, so the loss backward costs no launch.
+ * bce: x_hat = clamp(sigmoid(logit)), dlogit = seed (x_hat - t) where the clamp is inactive.
+ * ce_over_time: MMVAE_ERR_UNSUPPORTED when T*V > 4096 or V > 256 (use fwd + bwd). */
+int mmvae_bce_rowsum_seeded(const float* x_hat, const float* target, float* row_loss, float seed, float* dlogit,
+                            int B, int F, mmvae_stream_t stream);
+int mmvae_ce_over_time_seeded(const float* logits, const float* target, float* row_loss, float seed, float* dlogits,
+                              int B, int T, int V, mmvae_stream_t stream);
 
 /* category_ce (objectives.py:486-500): softmax over TIME.  logits/target (B,T,V) ->
  *   loss (B,V) = -sum_t tgt * log_softmax_t(logits);  row_loss[b] = sum_v loss[b,v]  (either may be NULL) */

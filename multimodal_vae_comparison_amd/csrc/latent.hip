@@ -175,10 +175,14 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
 //   dmu_e = G_mu * T_e * varJ                                  + gk_e * mu_e / sp^2
 //   dlv_e = [G_mu (mu_e - muJ) varJ - G_var varJ^2] * (-exp(lv_e) T_e^2)  + gk_e * (lv_e / sp^2 - 1 / lv_e)
 //   dsp  += sum_j gk_j * (1 - (s_j^2 + mu_j^2) / sp^2) / sp
+__device__ __forceinline__ void poe_theta_body(const float* __restrict__ theta, const float* __restrict__ ws,
+                                               float* __restrict__ dtheta, int nrows, int D, int accumulate,
+                                               float (*part)[64 * POE_SLOTS]);
 __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, const float* __restrict__ theta,
                                                       const float* __restrict__ dkl, float* __restrict__ ws, int E,
                                                       int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
-                                                      int raw) {
+                                                      int raw, float* __restrict__ dtheta, int* __restrict__ ticket,
+                                                      int accumulate) {
   MMVAE_TRACE_STAMP(23);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -283,13 +287,30 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
     const int d = lane + 64 * s;
     if (d < D) ws[(size_t)wave * D + d] = dsp[s];
   }
+  if (ticket) {
+    // the prior-parameter gradient in the same launch: the last workgroup to finish folds every wave's partial row
+    // (a second one-workgroup launch sat on the backward critical path between the fusion and the encoders)
+    __shared__ float part[4][64 * POE_SLOTS];
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(ticket, 1);
+      last = t == (int)gridDim.x - 1;
+      if (last) *ticket = 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    poe_theta_body(theta, ws, dtheta, nwaves, D, accumulate, part);
+  }
 }
 
 // dtheta_d (+)= D * s_d * (dsp_d - sum_k s_k dsp_k), dsp = sum over the per-wave partial rows.
 // 4 waves split the rows, 8 independent loads in flight per lane, LDS combine (D <= 256).
-__global__ __launch_bounds__(256) void poe_theta_kernel(const float* __restrict__ theta, const float* __restrict__ ws,
-                                                        float* __restrict__ dtheta, int nrows, int D, int accumulate) {
-  __shared__ float part[4][64 * POE_SLOTS];
+__device__ __forceinline__ void poe_theta_body(const float* __restrict__ theta, const float* __restrict__ ws,
+                                               float* __restrict__ dtheta, int nrows, int D, int accumulate,
+                                               float (*part)[64 * POE_SLOTS]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int s = 0; s < POE_SLOTS; ++s) {
@@ -329,6 +350,11 @@ __global__ __launch_bounds__(256) void poe_theta_kernel(const float* __restrict_
     }
   }
 }
+__global__ __launch_bounds__(256) void poe_theta_kernel(const float* __restrict__ theta, const float* __restrict__ ws,
+                                                        float* __restrict__ dtheta, int nrows, int D, int accumulate) {
+  __shared__ float part[4][64 * POE_SLOTS];
+  poe_theta_body(theta, ws, dtheta, nrows, D, accumulate, part);
+}
 
 static inline int poe_blocks(int B) {
   int waves = B < POE_MAX_WAVES ? B : POE_MAX_WAVES;
@@ -350,15 +376,17 @@ extern "C" int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float
 }
 
 extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl,
-                                        float* dtheta, float* ws, int E, int with_prior, int n_z, unsigned kl_mask,
-                                        int B, int D, int ld_in, int raw_heads, int accumulate,
+                                        float* dtheta, float* ws, int* ticket, int E, int with_prior, int n_z,
+                                        unsigned kl_mask, int B, int D, int ld_in, int raw_heads, int accumulate,
                                         mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && ws && B > 0 && D > 0 && E > 0 && ld_in >= D);
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   const int nb = poe_blocks(B);
+  const bool one_launch = dtheta && ticket;
   hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
-                     n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0);
-  if (dtheta)
+                     n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, one_launch ? dtheta : nullptr,
+                     one_launch ? ticket : nullptr, accumulate);
+  if (dtheta && !one_launch)
     hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
                        accumulate);
   return mmvae_launch_status();

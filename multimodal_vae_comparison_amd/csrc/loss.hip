@@ -12,14 +12,23 @@ __device__ __forceinline__ float bce_term(float x, float t) {
 }
 
 // one 256-thread block per sample row
+// d(row)/d(logit) for x_hat = clamp(sigmoid(logit)): g (x_hat - t) where the clamp is inactive
+__device__ __forceinline__ float bce_dlogit(float x, float t, float g) {
+  return (x > BCE_ETA && x < 1.0f - BCE_ETA) ? g * (x - t) : 0.f;
+}
+// SEEDED: the upstream gradient of every row is the known constant `seed` (the ELBO weight of this term), so the
+// logit gradient is written by the same pass over x_hat and target -- backward of the loss costs no launch.
+template <bool SEEDED>
 __global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
-                                                         float* __restrict__ row, int F) {
+                                                         float* __restrict__ row, int F, float seed,
+                                                         float* __restrict__ dl) {
   __shared__ float red[4];
   const size_t base = (size_t)blockIdx.x * F;
   float acc = 0.f;
   if ((F & 3) == 0) {
     const float4* x4 = reinterpret_cast<const float4*>(xh + base);
     const float4* t4 = reinterpret_cast<const float4*>(tg + base);
+    float4* d4 = reinterpret_cast<float4*>(dl + base);
     const int n4 = F / 4;
     int i = threadIdx.x;
     for (; i + 3 * 256 < n4; i += 4 * 256) {       // 8 independent 16-byte loads in flight per thread
@@ -30,15 +39,26 @@ __global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict
         t[u] = t4[i + u * 256];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 4; ++u) {
         acc += bce_term(x[u].x, t[u].x) + bce_term(x[u].y, t[u].y) + bce_term(x[u].z, t[u].z) + bce_term(x[u].w, t[u].w);
+        if (SEEDED)
+          d4[i + u * 256] = make_float4(bce_dlogit(x[u].x, t[u].x, seed), bce_dlogit(x[u].y, t[u].y, seed),
+                                        bce_dlogit(x[u].z, t[u].z, seed), bce_dlogit(x[u].w, t[u].w, seed));
+      }
     }
     for (; i < n4; i += 256) {
       float4 x = x4[i], t = t4[i];
       acc += bce_term(x.x, t.x) + bce_term(x.y, t.y) + bce_term(x.z, t.z) + bce_term(x.w, t.w);
+      if (SEEDED)
+        d4[i] = make_float4(bce_dlogit(x.x, t.x, seed), bce_dlogit(x.y, t.y, seed), bce_dlogit(x.z, t.z, seed),
+                            bce_dlogit(x.w, t.w, seed));
     }
   } else {
-    for (int i = threadIdx.x; i < F; i += 256) acc += bce_term(xh[base + i], tg[base + i]);
+    for (int i = threadIdx.x; i < F; i += 256) {
+      const float x = xh[base + i], t = tg[base + i];
+      acc += bce_term(x, t);
+      if (SEEDED) dl[base + i] = bce_dlogit(x, t, seed);
+    }
   }
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) row[blockIdx.x] = acc;
@@ -113,7 +133,16 @@ extern "C" int mmvae_sigmoid_clamp_bwd(const float* dy, const float* y, float* d
 extern "C" int mmvae_bce_rowsum_fwd(const float* x_hat, const float* target, float* row_loss, int B, int F,
                                     mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x_hat && target && row_loss && B > 0 && F > 0);
-  hipLaunchKernelGGL(bce_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x_hat, target, row_loss, F);
+  hipLaunchKernelGGL(bce_rowsum_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, x_hat, target, row_loss, F,
+                     0.f, nullptr);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_bce_rowsum_seeded(const float* x_hat, const float* target, float* row_loss, float seed,
+                                       float* dlogit, int B, int F, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && row_loss && dlogit && B > 0 && F > 0);
+  if ((F & 3) == 0 && (((uintptr_t)dlogit) & 15) != 0) return MMVAE_ERR_ARG;
+  hipLaunchKernelGGL(bce_rowsum_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, x_hat, target, row_loss, F,
+                     seed, dlogit);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_bce_elem_fwd(const float* x_hat, const float* target, float* loss, long n,
@@ -345,8 +374,11 @@ __global__ __launch_bounds__(64) void ce_time_bwd_kernel(const float* __restrict
 #define CE_TILE 4096
 __global__ __launch_bounds__(256) void ce_time_fwd_tile_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
                                                               float* __restrict__ loss, float* __restrict__ row, int T,
-                                                              int V) {
+                                                              int V, float seed, float* __restrict__ dl) {
+  // dl != NULL: every row's upstream gradient is the constant `seed`; the logit gradient is written from the same
+  // staged tile (see bce_rowsum_kernel<true>)
   __shared__ float sl[CE_TILE], st[CE_TILE];
+  __shared__ float s_mx[256], s_k[256];
   __shared__ float red[4];
   const int b = blockIdx.x, n = T * V;
   const float* L = lg + (size_t)b * n;
@@ -370,9 +402,20 @@ __global__ __launch_bounds__(256) void ce_time_fwd_tile_kernel(const float* __re
     const float ls = (mx + logf(se)) * ts - dot;
     if (loss) loss[(size_t)b * V + v] = ls;
     rsum += ls;
+    if (dl) {
+      s_mx[v] = mx;
+      s_k[v] = ts / se;
+    }
   }
   rsum = block_sum_256(rsum, red);
   if (row && threadIdx.x == 0) row[b] = rsum;
+  if (dl) {     // (block_sum_256 synchronised the workgroup: s_mx / s_k are visible)
+    float* D = dl + (size_t)b * n;
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int v = e % V;
+      D[e] = seed * (expf(sl[e] - s_mx[v]) * s_k[v] - st[e]);
+    }
+  }
 }
 __global__ __launch_bounds__(256) void ce_time_bwd_tile_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
                                                               const float* __restrict__ g, const float* __restrict__ grow,
@@ -412,10 +455,20 @@ extern "C" int mmvae_ce_over_time_fwd(const float* logits, const float* target, 
   MMVAE_CHECK_ARG(logits && target && (loss || row_loss) && B > 0 && T > 0 && V > 0);
   if (T * V <= CE_TILE && V <= 256)
     hipLaunchKernelGGL(ce_time_fwd_tile_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, loss,
-                       row_loss, T, V);
+                       row_loss, T, V, 0.f, nullptr);
   else
     hipLaunchKernelGGL(ce_time_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss, row_loss, T,
                        V);
+  return mmvae_launch_status();
+}
+/* row sums + logit gradient for a constant upstream gradient `seed` in one launch; MMVAE_ERR_UNSUPPORTED when the
+ * (T, V) tile does not fit the single-workgroup kernel (use fwd + bwd) */
+extern "C" int mmvae_ce_over_time_seeded(const float* logits, const float* target, float* row_loss, float seed,
+                                         float* dlogits, int B, int T, int V, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(logits && target && row_loss && dlogits && B > 0 && T > 0 && V > 0);
+  if (!(T * V <= CE_TILE && V <= 256)) return MMVAE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ce_time_fwd_tile_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target,
+                     (float*)nullptr, row_loss, T, V, seed, dlogits);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float* g, const float* g_row,

@@ -70,7 +70,7 @@ SIGNATURES = {
     "mmvae_head_softmax_bwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "mmvae_poe_reparam_kl_fwd": (c_i, [ctypes.POINTER(PoeFwdArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i, c_i,
                                        c_i, c_p]),
-    "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
+    "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
                                        c_i, c_i, c_i, c_p]),
     "mmvae_poe_ws_floats": (c_sz, [c_i, c_i]),
     "mmvae_bce_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 2 + [c_p]),
@@ -78,6 +78,8 @@ SIGNATURES = {
     "mmvae_bce_rowsum_bwd": (c_i, [c_p] * 4 + [c_i] * 2 + [c_p]),
     "mmvae_sigmoid_clamp_bwd": (c_i, [c_p] * 3 + [c_l] + [c_p]),
     "mmvae_bce_elem_fwd": (c_i, [c_p] * 3 + [c_l] + [c_p]),
+    "mmvae_bce_rowsum_seeded": (c_i, [c_p] * 3 + [c_f] + [c_p] + [c_i] * 2 + [c_p]),
+    "mmvae_ce_over_time_seeded": (c_i, [c_p] * 3 + [c_f] + [c_p] + [c_i] * 3 + [c_p]),
     "mmvae_ce_over_time_fwd": (c_i, [c_p] * 4 + [c_i] * 3 + [c_p]),
     "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_p]),
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),

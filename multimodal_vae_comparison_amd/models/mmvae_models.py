@@ -54,7 +54,16 @@ class MoPOE(TorchMMVAE):
         return subsets
 
     # ---- hot path --------------------------------------------------------------------------------
-    def _elbo_terms(self, mods):
+    def _elbo_weights(self, B):
+        """rows of the ELBO assembly (loss, kld) over [M recon rows, M+1 KL rows] (weighted_group_kld, objectives.py:184-201)"""
+        names = list(self.vaes.keys())
+        M = len(names)
+        w_kl = 1.0 / (M + 1)
+        lam = [float(self.vaes[n].llik_scaling) for n in names]
+        return [[l / B for l in lam] + [self.obj_fn.beta * w_kl / B] * (M + 1),
+                [0.0] * M + [w_kl / B] * (M + 1)]
+
+    def _elbo_terms(self, mods, seeds=None):
         """Forward pass up to the per-row ELBO terms (mmvae_models.py:296-320 + weighted_group_kld,
         objectives.py:184-201): returns (recs, kl, W, streams, device) and leaves the tower streams un-joined.
 
@@ -75,6 +84,7 @@ class MoPOE(TorchMMVAE):
         real = [cur if st is None else st for st in streams]
         self._fork(streams, dev)
         B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
+        W = self._elbo_weights(B)
         eps_first = os.environ.get("MMVAE_EPS", "after") == "first"
         eps = self._draw_many(M, B, D, dev) if eps_first else None
         enc = [None] * M
@@ -122,12 +132,13 @@ class MoPOE(TorchMMVAE):
             with torch.cuda.stream(st):
                 zi = ops.mark_tensor(z[i], f"dec {n} z")
                 out, _ = vae.dec({"latents": zi.unsqueeze(0), "masks": mods[n]["masks"]})
-                recs[i] = ops.mark_tensor(recon_rowsum(vae.ltype, out, mods[n]), f"dec {n} recon")   # (B,) = -lpx_z / llik_scaling
+                if seeds is not None:      # the term's upstream gradient is known: its kernel also writes its backward
+                    with ops.ConstSeed(seeds[i], W[0][i]):
+                        r = recon_rowsum(vae.ltype, out, mods[n])
+                else:
+                    r = recon_rowsum(vae.ltype, out, mods[n])
+                recs[i] = ops.mark_tensor(r, f"dec {n} recon")   # (B,) = -lpx_z / llik_scaling
             _uses(recs[i], cur)
-        w_kl = 1.0 / (M + 1)
-        lam = [float(self.vaes[n].llik_scaling) for n in names]
-        W = [[l / B for l in lam] + [self.obj_fn.beta * w_kl / B] * (M + 1),
-             [0.0] * M + [w_kl / B] * (M + 1)]
         return recs, kl, W, streams, dev
 
     def objective(self, mods):
@@ -142,13 +153,15 @@ class MoPOE(TorchMMVAE):
         (recs, kl) with host-side constant weights, so every tower's backward is seeded with those constants as soon as
         its own forward is done -- no tower waits for the other one's decoder or for the loss kernel.  The loss values
         are assembled afterwards, off the critical path.  Used by the captured training step (trainer.capture)."""
-        recs, kl, W, streams, dev = self._elbo_terms(mods)
-        key = (tuple(W[0]), tuple(kl.shape), tuple(recs[0].shape), str(dev))
-        if getattr(self, "_seed_key", None) != key:
-            M = len(recs)
-            self._seeds = [torch.full(r.shape, W[0][i], device=dev) for i, r in enumerate(recs)]
-            self._seeds.append(torch.tensor(W[0][M:], device=dev).reshape(-1, 1).expand(kl.shape).contiguous())
+        first = next(v["data"] for v in mods.values() if v["data"] is not None)
+        B, dev, M = first.shape[0], first.device, len(self.vaes)
+        W = self._elbo_weights(B)
+        key = (tuple(W[0]), B, str(dev))
+        if getattr(self, "_seed_key", None) != key:      # persistent: their addresses identify them in backward
+            self._seeds = [torch.full((B,), W[0][i], device=dev) for i in range(M)]
+            self._seeds.append(torch.tensor(W[0][M:], device=dev).reshape(-1, 1).expand(M + 1, B).contiguous())
             self._seed_key = key
+        recs, kl, W, streams, dev = self._elbo_terms(mods, self._seeds)
         cur = torch.cuda.current_stream(dev)
         side = next((st for st in streams[::-1] if st is not None), None)
         mode = os.environ.get("MMVAE_LOSS_SIDE", "0")

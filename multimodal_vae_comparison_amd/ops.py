@@ -399,6 +399,24 @@ class SigmoidClampOut(Function):
         return dl
 
 
+class ConstSeed:
+    """`with ConstSeed(seed, value):` -- the loss rows created inside are known to receive the persistent tensor `seed`
+    (every element == `value`: the ELBO is linear in them) as their upstream gradient.  Their forward kernels then
+    write the input gradient in the same pass and backward hands it out without a launch when it is indeed called
+    with `seed` (any other upstream gradient takes the ordinary backward kernel)."""
+    current = None
+
+    def __init__(self, seed, value):
+        self.seed, self.value = seed, float(value)
+
+    def __enter__(self):
+        self.prev, ConstSeed.current = ConstSeed.current, self
+        return self
+
+    def __exit__(self, *exc):
+        ConstSeed.current = self.prev
+
+
 class BceSigmoidRowsum(Function):
     """BceRowsum on x_hat = clamp(sigmoid(logits)) given as the layer's raw output (whose gradient is taken with
     respect to the LOGITS): backward is the closed form g (x_hat - t) [clamp inactive] in one kernel."""
@@ -409,12 +427,22 @@ class BceSigmoidRowsum(Function):
         B = y_raw.shape[0]
         F_ = y_raw.numel() // B
         row = torch.empty(B, device=y_raw.device)
-        _call("mmvae_bce_rowsum_fwd", H.ptr(y_raw), H.ptr(target), H.ptr(row), B, F_, H.stream())
+        cs = ConstSeed.current
+        ctx.seeded = None
+        if cs is not None and y_raw.requires_grad:
+            dl = torch.empty_like(y_raw)
+            _call("mmvae_bce_rowsum_seeded", H.ptr(y_raw), H.ptr(target), H.ptr(row), cs.value, H.ptr(dl), B, F_,
+                  H.stream())
+            ctx.seeded = (cs.seed.data_ptr(), dl)
+        else:
+            _call("mmvae_bce_rowsum_fwd", H.ptr(y_raw), H.ptr(target), H.ptr(row), B, F_, H.stream())
         ctx.save_for_backward(y_raw, target)
         return row
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.seeded is not None and g.data_ptr() == ctx.seeded[0]:
+            return ctx.seeded[1], None
         y, target = ctx.saved_tensors
         B = y.shape[0]
         dl = torch.empty_like(y)
@@ -622,6 +650,23 @@ def head_softmax(h):
 # ----------------------------------------------------------------------------------------------
 # fused latent op
 # ----------------------------------------------------------------------------------------------
+_POE_TICKETS = {}      # device -> (zeroed int pool, {stream: slot}): the fusion backward's last-workgroup tickets
+
+
+def _poe_ticket(dev):
+    """device int owned by the current stream (two fusion backwards may run on different streams at once); the pool
+    is allocated by the first call -- a warm-up pass -- so that a stream first seen during graph capture costs no
+    allocation or memset node"""
+    pool = _POE_TICKETS.get(dev.index)
+    if pool is None:
+        pool = _POE_TICKETS[dev.index] = (torch.zeros(64, dtype=torch.int32, device=dev), {})
+    buf, slots = pool
+    slot = slots.setdefault(H.stream(), len(slots))
+    if slot >= buf.numel():
+        return None           # more streams than slots: the two-launch path
+    return buf.data_ptr() + 4 * slot
+
+
 class PoeReparamKL(Function):
     """Product of experts -> n_z reparameterised samples -> analytic KL rows.
 
@@ -685,7 +730,8 @@ class PoeReparamKL(Function):
             dth = ret = torch.empty_like(theta)
             acc = 0
         ws = H.workspace(H.lib().mmvae_poe_ws_floats(B, D), dev)
-        _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws), E,
+        _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws),
+              _poe_ticket(dev), E,
               int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, H.stream())
         return (ret, None, None, None, None, None, None, None, *dpacked, *([None] * n_z))
 
@@ -839,13 +885,23 @@ class CeOverTime(Function):
         dev = logits.device
         loss = torch.empty(B, V, device=dev) if per_v else None
         row = None if per_v else torch.empty(B, device=dev)
-        _call("mmvae_ce_over_time_fwd", H.ptr(logits), H.ptr(target), H.ptr(loss), H.ptr(row), B, T, V, H.stream())
+        cs = ConstSeed.current
+        ctx.seeded = None
+        if cs is not None and not per_v and logits.requires_grad and T * V <= 4096 and V <= 256:
+            dl = torch.empty_like(logits)
+            _call("mmvae_ce_over_time_seeded", H.ptr(logits), H.ptr(target), H.ptr(row), cs.value, H.ptr(dl), B, T, V,
+                  H.stream())
+            ctx.seeded = (cs.seed.data_ptr(), dl)
+        else:
+            _call("mmvae_ce_over_time_fwd", H.ptr(logits), H.ptr(target), H.ptr(loss), H.ptr(row), B, T, V, H.stream())
         ctx.save_for_backward(logits, target)
         ctx.per_v = per_v
         return loss if per_v else row
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.seeded is not None and g.data_ptr() == ctx.seeded[0]:
+            return ctx.seeded[1], None, None
         logits, target = ctx.saved_tensors
         B, T, V = logits.shape
         g = H.f32c(g)

@@ -206,6 +206,39 @@ def test_bce_and_ce(ops):
         check(lgg.grad, lr_.grad, 2e-5, f"ce dlogits per_v={per_v}")
 
 
+@pytest.mark.parametrize("B,Fd", [(9, 3 * 64 * 64), (5, 37)])
+def test_seeded_losses_write_their_own_backward(ops, B, Fd):
+    """ops.ConstSeed: with a known constant upstream gradient the loss kernel writes the logit gradient in the same
+    pass (bce on clamp(sigmoid) outputs, category_ce over time) and backward launches nothing -- same numbers as the
+    two-kernel path; any other upstream gradient still takes the ordinary backward kernel."""
+    g = torch.Generator().manual_seed(B + Fd)
+    val = 1.7 / B
+    seed = torch.full((B,), val, device=DEV)
+    other = torch.randn(B, generator=g).to(DEV)
+    y = torch.sigmoid(torch.randn(B, Fd, generator=g) * 6).clamp(1e-6, 1 - 1e-6).to(DEV)
+    t = torch.rand(B, Fd, generator=g).to(DEV)
+    T, V = 7, 27
+    lg = (torch.randn(B, T, V, generator=g) * 2).to(DEV)
+    tg = F.one_hot(torch.randint(0, V, (B, T), generator=g), V).float().to(DEV)
+    for name, fn, x in (("bce", lambda a: ops.bce_sigmoid_rowsum(a, t), y), ("ce", lambda a: ops.ce_over_time(a, tg, False), lg)):
+        a0 = x.clone().requires_grad_(True)
+        r0 = fn(a0)
+        r0.backward(seed)
+        for up in (seed, other):
+            a1 = x.clone().requires_grad_(True)
+            with ops.ConstSeed(seed, val):
+                r1 = fn(a1)
+            assert r1.grad_fn.seeded is not None, name
+            r1.backward(up)
+            assert torch.equal(r1, r0), name
+            if up is seed:
+                check(a1.grad, a0.grad, 1e-6, f"{name} seeded grad")
+            else:
+                a2 = x.clone().requires_grad_(True)
+                fn(a2).backward(up)
+                assert torch.equal(a1.grad, a2.grad), name
+
+
 @pytest.mark.parametrize("transposed,B,Cin,Cout,Hin,S,P,act,ep", [
     (False, 5, 32, 64, 16, 2, 1, 2, 0), (False, 3, 64, 64, 8, 2, 1, 2, 0), (False, 4, 64, 128, 4, 2, 0, 2, 0),
     (False, 2, 3, 32, 32, 2, 1, 0, 0), (True, 4, 128, 64, 1, 1, 0, 2, 0), (True, 3, 64, 64, 4, 2, 1, 2, 0),
