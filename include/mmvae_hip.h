@@ -206,9 +206,12 @@ typedef struct {
   float* dmu[MMVAE_MAX_EXPERTS];
   float* dlv[MMVAE_MAX_EXPERTS];
 } mmvae_poe_bwd_args;
+/* rng_state: NULL (a->eps are inputs), or the mmvae_randn generator state: the n_z draws are then generated by this
+ * launch -- element i*B*D + b*D + d of the current draw, the values mmvae_randn would put into a (n_z,B,D) tensor --
+ * written to a->eps[i] (outputs, kept for the backward pass), and the generator advances by one draw */
 int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl, int E,
                              int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in, int raw_heads,
-                             mmvae_stream_t stream);
+                             uint32_t* rng_state, mmvae_stream_t stream);
 /* ticket: NULL, or a zero-initialised device int owned by the calling stream: the prior-parameter gradient is then
  * folded by the last workgroup of the same launch (the kernel leaves the int at zero) instead of a second launch */
 int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl, float* dtheta,
@@ -363,10 +366,14 @@ int mmvae_txt_layer_supported(int L, int D, int FF, int NH, int dec);
 size_t mmvae_txt_layer_lnws_floats(int N, int D, int dec);
 /* time_mean != 0: y / dy are (N, D), the mean of the layer output over the L frames and its gradient -- the pooling
  * `x.mean(0)` that follows the last encoder layer (models/encoders.py:552), folded into the layer's launch */
+/* head_w (HN, D), head_b (HN) non-NULL (needs time_mean): additionally heads (N, HN) = y head_w^T + head_b, the
+ * packed posterior heads on the pooled feature (VaeComponent.process_output, models/encoders.py:49-54); their
+ * backward is an ordinary mmvae_linear_bwd on (heads gradient, y) */
 int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const float* mem, float* y,
                         const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                         const mmvae_txt_layer_drop_t* drop, int L, int N, int D, int FF, int NH, int dec,
-                        int time_mean, mmvae_stream_t stream);
+                        int time_mean, const float* head_w, const float* head_b, float* heads, int HN,
+                        mmvae_stream_t stream);
 int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float* dmem,
                         const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                         const mmvae_txt_layer_grads_t* grads, const mmvae_txt_layer_drop_t* drop, int L, int N, int D,

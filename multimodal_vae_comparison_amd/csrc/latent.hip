@@ -98,6 +98,34 @@ __device__ __forceinline__ void row_softmax_stats(const float* __restrict__ u, i
   *inv_out = 1.0f / sum;
 }
 
+// element e of the counter-based standard-normal stream `key` (see randn_kernel: Box-Muller over the hash pair of
+// element pair e >> 1; the even element takes the cosine branch)
+__device__ __forceinline__ uint32_t randn_key(const uint32_t* __restrict__ state) {
+  return drop_fmix(state[0] ^ (state[1] * 0x9E3779B1u) ^ 0x632BE5ABu);
+}
+__device__ __forceinline__ float randn_elem(uint32_t key, long e) {
+  const long i = e >> 1;
+  const uint32_t h1 = drop_fmix(key + (uint32_t)(2 * i) * 0x9E3779B1u);
+  const uint32_t h2 = drop_fmix(key + (uint32_t)(2 * i + 1) * 0x9E3779B1u);
+  const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+  const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  return (e & 1) ? r * sn : r * cs;
+}
+// the last workgroup of a launch that consumed the stream advances its counter
+__device__ __forceinline__ void randn_advance(uint32_t* __restrict__ state) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t ticket = atomicAdd(state + 2, 1u);
+    if (ticket == gridDim.x - 1) {
+      state[2] = 0u;
+      state[1] += 1u;
+    }
+  }
+}
+
 __device__ __forceinline__ float kl_elem(float mu, float s, float sp) {
   float r = s / sp, m = mu / sp;
   float vr = r * r;
@@ -107,8 +135,12 @@ __device__ __forceinline__ float kl_elem(float mu, float s, float sp) {
 __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, const float* __restrict__ theta,
                                                       float* __restrict__ joint, float* __restrict__ kl, int E,
                                                       int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
-                                                      int raw) {
+                                                      int raw, uint32_t* __restrict__ rng) {
   MMVAE_TRACE_STAMP(22);
+  // rng != NULL: the noise is drawn HERE (element i*B*D + b*D + d of the generator's current draw, exactly what
+  // mmvae_randn would have put into a (n_z, B, D) tensor) and written to a.eps for the backward pass -- one launch
+  // less in front of the fusion
+  const uint32_t rkey = rng ? randn_key(rng) : 0u;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -154,7 +186,14 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
 #pragma unroll
       for (int i = 0; i < MMVAE_MAX_EXPERTS; ++i) {
         if (i >= n_z) continue;
-        a.z[i][o] = muJ + varJ * a.eps[i][o];
+        float ev;
+        if (rng) {
+          ev = randn_elem(rkey, (long)i * B * D + (long)o);
+          const_cast<float*>(a.eps[i])[o] = ev;
+        } else {
+          ev = a.eps[i][o];
+        }
+        a.z[i][o] = muJ + varJ * ev;
       }
       }
     }
@@ -167,6 +206,7 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
       }
     }
   }
+  if (rng) randn_advance(rng);
 }
 
 // Backward.  Per element (all for fixed b,d):
@@ -365,13 +405,13 @@ extern "C" size_t mmvae_poe_ws_floats(int B, int D) { return (size_t)poe_blocks(
 
 extern "C" int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, float* joint, float* kl,
                                         int E, int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld_in,
-                                        int raw_heads, mmvae_stream_t stream) {
+                                        int raw_heads, uint32_t* rng_state, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && joint && B > 0 && D > 0 && E > 0 && ld_in >= D);
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   if (with_prior == 2 && E != 1) return MMVAE_ERR_ARG;
   if (kl_mask && !kl) return MMVAE_ERR_ARG;
   hipLaunchKernelGGL(poe_fwd_kernel, dim3(poe_blocks(B)), dim3(256), 0, (hipStream_t)stream, *a, theta, joint, kl, E,
-                     with_prior, n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0);
+                     with_prior, n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, rng_state);
   return mmvae_launch_status();
 }
 
@@ -451,7 +491,7 @@ extern "C" int mmvae_normal_logratio_bwd(const float* packed_r, const float* z, 
 // itself when its last workgroup finishes.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long n, uint32_t* __restrict__ state) {
-  const uint32_t key = drop_fmix(state[0] ^ (state[1] * 0x9E3779B1u) ^ 0x632BE5ABu);
+  const uint32_t key = randn_key(state);
   const long pairs = (n + 1) >> 1;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long)gridDim.x * 256) {
     const uint32_t h1 = drop_fmix(key + (uint32_t)(2 * i) * 0x9E3779B1u);
@@ -464,14 +504,7 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, lon
     out[2 * i] = r * cs;
     if (2 * i + 1 < n) out[2 * i + 1] = r * sn;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t ticket = atomicAdd(state + 2, 1u);
-    if (ticket == gridDim.x - 1) {
-      state[2] = 0u;
-      state[1] += 1u;
-    }
-  }
+  randn_advance(state);
 }
 extern "C" int mmvae_randn(float* out, long n, uint32_t* state, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(out && state && n > 0);

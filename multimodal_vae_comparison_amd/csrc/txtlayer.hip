@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
                                                             const float* __restrict__ mem, float* __restrict__ y,
                                                             const mmvae_txt_layer_w_t w, const mmvae_txt_layer_saved_t sv,
                                                             const mmvae_txt_layer_drop_t dr, const int L, const int N,
-                                                            const int time_mean) {
+                                                            const int time_mean, const float* __restrict__ head_w,
+                                                            const float* __restrict__ head_b,
+                                                            float* __restrict__ heads, const int HN) {
   MMVAE_TRACE_STAMP(16 + (G::DEC ? 1 : 0));
   constexpr int D = G::D, FF = G::FF, NH = G::NH, HD = G::HD, PX = G::PX, PH = G::PH, PQ = G::PQ;
   constexpr int NBUF = G::DEC ? 5 : 4;
@@ -482,10 +484,26 @@ __global__ __launch_bounds__(256) void txt_layer_fwd_kernel(const float* __restr
                     [&](int t, float rs) { if (t < L) sv.rstdf[(size_t)t * LN + n] = rs; });
   if (time_mean) {   // y (N, D) = mean over the L frames (the encoder's pooling): no (L, N, D) round trip, no launch
     __syncthreads();
+    float zc = 0.f;
     if (l.tid < D) {
       float a = 0.f;
       for (int t = 0; t < L; ++t) a += RB[t * PX + l.tid];
-      y[(size_t)n * D + l.tid] = a * (1.0f / (float)L);
+      zc = a * (1.0f / (float)L);
+      y[(size_t)n * D + l.tid] = zc;
+    }
+    if (head_w) {   // the posterior heads on the pooled feature: heads[n, j] = head_w[j, :] . z + head_b[j] (a 54 x 64
+                    // GEMV per sequence: cheaper here than one more launch between the encoder and the fusion)
+      __syncthreads();
+      if (l.tid < D) RB[l.tid] = zc;
+      __syncthreads();
+      const int q = l.tid & 3;
+      for (int j = l.tid >> 2; j < HN; j += 64) {
+        float a = 0.f;
+        for (int c = q; c < D; c += 4) a += head_w[(size_t)j * D + c] * RB[c];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (q == 0) heads[(size_t)n * HN + j] = a + head_b[j];
+      }
     }
   }
 }
@@ -821,8 +839,10 @@ extern "C" size_t mmvae_txt_layer_lnws_floats(int N, int D, int dec) { return (s
 extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const float* mem, float* y,
                                    const mmvae_txt_layer_w_t* w, const mmvae_txt_layer_saved_t* saved,
                                    const mmvae_txt_layer_drop_t* drop, int L, int N, int D, int FF, int NH, int dec,
-                                   int time_mean, mmvae_stream_t stream) {
+                                   int time_mean, const float* head_w, const float* head_b, float* heads, int HN,
+                                   mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && valid && y && w && saved && N > 0);
+  if (head_w && !(time_mean && head_b && heads && HN > 0)) return MMVAE_ERR_ARG;
   if (dec && !mem) return MMVAE_ERR_ARG;
   if (L < 1 || L > tl::T) return MMVAE_ERR_UNSUPPORTED;
   mmvae_txt_layer_drop_t d;
@@ -836,7 +856,7 @@ extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const f
   if (!txt_layer_visit(D, FF, NH, dec, [&](auto g) {
         using G = decltype(g);
         hipLaunchKernelGGL((txt_layer_fwd_kernel<G>), dim3(N), dim3(256), 0, (hipStream_t)stream, x, valid, mem, y, wv, sv,
-                           d, L, N, time_mean);
+                           d, L, N, time_mean, head_w, head_b, heads, HN);
       }))
     return MMVAE_ERR_UNSUPPORTED;
   return mmvae_launch_status();

@@ -69,7 +69,7 @@ SIGNATURES = {
     "mmvae_head_softmax_fwd": (c_i, [c_p, c_i, c_i, c_p]),
     "mmvae_head_softmax_bwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "mmvae_poe_reparam_kl_fwd": (c_i, [ctypes.POINTER(PoeFwdArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i, c_i,
-                                       c_i, c_p]),
+                                       c_i, c_p, c_p]),
     "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
                                        c_i, c_i, c_i, c_p]),
     "mmvae_poe_ws_floats": (c_sz, [c_i, c_i]),
@@ -108,7 +108,7 @@ SIGNATURES = {
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_txt_layer_supported": (c_i, [c_i] * 5),
     "mmvae_txt_layer_lnws_floats": (c_sz, [c_i] * 3),
-    "mmvae_txt_layer_fwd": (c_i, [c_p] * 7 + [c_i] * 7 + [c_p]),
+    "mmvae_txt_layer_fwd": (c_i, [c_p] * 7 + [c_i] * 7 + [c_p] * 3 + [c_i] + [c_p]),
     "mmvae_txt_layer_bwd": (c_i, [c_p] * 8 + [c_i] * 7 + [c_p]),
     "mmvae_attn_fwd": (c_i, [c_p] * 6 + [c_i] * 5 + [c_l] * 3 + [c_i, c_dp, c_p]),
     "mmvae_attn_bwd": (c_i, [c_p] * 8 + [c_i] * 5 + [c_l] * 3 + [c_dp, c_p]),

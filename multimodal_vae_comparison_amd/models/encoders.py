@@ -55,29 +55,40 @@ class VaeComponent(nn.Module):
         Returns views of one packed (B, 2*out_dim) tensor; `mu._base` is that tensor (used by the fused
         latent kernel)."""
         mu_l, lv_l = self._heads()
-        D = self.out_dim
         if not self.enc_mu_logvar:
             return mu_l(data, in_act)
-        w_mu, w_lv, b_mu, b_lv = mu_l.weight, lv_l.weight, mu_l.bias, lv_l.bias
-        gw_mu, gw_lv, gb_mu, gb_lv = w_mu.grad, w_lv.grad, b_mu.grad, b_lv.grad
-        fused = (w_lv.data_ptr() == w_mu.data_ptr() + 4 * w_mu.numel()
-                 and b_lv.data_ptr() == b_mu.data_ptr() + 4 * b_mu.numel()
-                 and None not in (gw_mu, gw_lv, gb_mu, gb_lv)
-                 and gw_lv.data_ptr() == gw_mu.data_ptr() + 4 * w_mu.numel()
-                 and gb_lv.data_ptr() == gb_mu.data_ptr() + 4 * b_mu.numel()
-                 and data.requires_grad)
-        if fused:   # flat layout (flat.py): one (2D, F) GEMM, gradients accumulated in place
-            F = w_mu.shape[1]
-            w = torch.as_strided(w_mu.detach(), (2 * D, F), (F, 1))
-            b = torch.as_strided(b_mu.detach(), (2 * D,), (1,))
-            gw = torch.as_strided(gw_mu, (2 * D, F), (F, 1))
-            gb = torch.as_strided(gb_mu, (2 * D,), (1,))
-            h = ops.linear(data, w, b, in_act, gw, gb)
+        packed = self.packed_heads() if data.requires_grad else None
+        if packed is not None:   # flat layout (flat.py): one (2D, F) GEMM, gradients accumulated in place
+            h = ops.linear(data, packed[0], packed[1], in_act, packed[2], packed[3])
         else:
             h = torch.cat([mu_l(data, in_act), lv_l(data, in_act)], dim=-1)
+        return self.finish_heads(h)
+
+    def finish_heads(self, h):
+        """packed head outputs (B, 2D) -> (mu, "logvar") views (softmax unless the fused latent kernel applies it)"""
+        D = self.out_dim
         if not self.raw_heads:
             h = ops.head_softmax(h)
         return h[:, :D], h[:, D:]
+
+    def packed_heads(self):
+        """(w (2D, F), b (2D), gw, gb): the mu and logvar heads as ONE linear layer when their parameters and preset
+        gradient views are adjacent in the flat buffers (flat.py lays them out that way), else None"""
+        if not self.enc_mu_logvar:
+            return None
+        mu_l, lv_l = self._heads()
+        D = self.out_dim
+        w_mu, w_lv, b_mu, b_lv = mu_l.weight, lv_l.weight, mu_l.bias, lv_l.bias
+        gw_mu, gw_lv, gb_mu, gb_lv = w_mu.grad, w_lv.grad, b_mu.grad, b_lv.grad
+        if not (w_lv.data_ptr() == w_mu.data_ptr() + 4 * w_mu.numel()
+                and b_lv.data_ptr() == b_mu.data_ptr() + 4 * b_mu.numel()
+                and None not in (gw_mu, gw_lv, gb_mu, gb_lv)
+                and gw_lv.data_ptr() == gw_mu.data_ptr() + 4 * w_mu.numel()
+                and gb_lv.data_ptr() == gb_mu.data_ptr() + 4 * b_mu.numel()):
+            return None
+        F = w_mu.shape[1]
+        return (torch.as_strided(w_mu.detach(), (2 * D, F), (F, 1)), torch.as_strided(b_mu.detach(), (2 * D,), (1,)),
+                torch.as_strided(gw_mu, (2 * D, F), (F, 1)), torch.as_strided(gb_mu, (2 * D,), (1,)))
 
 
 class VaeEncoder(VaeComponent):
@@ -203,6 +214,7 @@ class Enc_CNN(VaeEncoder):
 
 
 FUSED_TXT_LAYERS = os.environ.get("MMVAE_FUSED_TXT", "1") != "0"
+FUSED_HEADS = os.environ.get("MMVAE_FUSED_HEADS", "1") != "0"     # text encoder: heads inside the last layer's launch
 
 
 class HipTransformerEncoderLayer(nn.Module):
@@ -223,17 +235,21 @@ class HipTransformerEncoderLayer(nn.Module):
                 "l2_b": self.linear2.bias, "n1_g": self.norm1.weight, "n1_b": self.norm1.bias,
                 "n2_g": self.norm2.weight, "n2_b": self.norm2.bias}
 
-    def forward(self, x, mask_u8, ds=None, time_mean=False):
+    def forward(self, x, mask_u8, ds=None, time_mean=False, heads=None):
         """`ds`: dict of DropSpec for train mode (attn, drop1, ffn, drop2) or None.  `time_mean`: return the mean of
         the output over the frames, (N, d) -- the pooling that follows the LAST encoder layer, folded into the fused
-        layer's launch when that path is taken"""
+        layer's launch when that path is taken.  `heads` (VaeComponent.packed_heads()): additionally apply the packed
+        posterior heads to the pooled feature, returning (N, 2D')."""
         L, _, d = x.shape
         ff, nh = self.linear1.out_features, self.self_attn.nhead
         if FUSED_TXT_LAYERS and ops.txt_layer_supported(L, d, ff, nh, False):
             # one workgroup per sequence runs the whole layer (csrc/txtlayer.hip); same arithmetic and dropout masks
             p = self.fused_params()
-            return ops.txt_layer(x, None, mask_u8, ops.TxtLayerMeta(d, ff, nh, False, ds, time_mean), p,
+            return ops.txt_layer(x, None, mask_u8, ops.TxtLayerMeta(d, ff, nh, False, ds, time_mean, heads), p,
                                  {k: v.grad for k, v in p.items()})
+        if heads is not None:
+            z = ops.mean_over_time(self.forward(x, mask_u8, ds))
+            return ops.linear(z, heads[0], heads[1], H.ACT_NONE, heads[2], heads[3])
         if time_mean:
             return ops.mean_over_time(self.forward(x, mask_u8, ds))
         if ds is None:
@@ -294,9 +310,11 @@ class Enc_TxtTransformer(VaeEncoder):
             d_pe, ds = None, [None] * len(self.seqTransEncoder.layers)
         h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad, d_pe)   # (T, B, 2V)
         last = len(self.seqTransEncoder.layers) - 1
+        heads = self.packed_heads() if (FUSED_HEADS and torch.is_grad_enabled()) else None
         for i, (layer, d) in enumerate(zip(self.seqTransEncoder.layers, ds)):
-            h = layer(h, mask_u8, d, time_mean=(i == last))      # z = h.mean(0) folded into the last layer
-        return self.process_output(h)
+            # z = h.mean(0) -- and the posterior heads when they are one packed layer -- folded into the last layer
+            h = layer(h, mask_u8, d, time_mean=(i == last), heads=heads if i == last else None)
+        return self.finish_heads(h) if heads is not None else self.process_output(h)
 
 
 class Enc_Transformer(VaeEncoder):

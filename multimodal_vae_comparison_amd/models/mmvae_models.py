@@ -85,8 +85,11 @@ class MoPOE(TorchMMVAE):
         self._fork(streams, dev)
         B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
         W = self._elbo_weights(B)
-        eps_first = os.environ.get("MMVAE_EPS", "after") == "first"
-        eps = self._draw_many(M, B, D, dev) if eps_first else None
+        # the M rsamples (:363-369): drawn by the fusion kernel itself unless the noise is replayed (`eps_override`)
+        eps_mode = os.environ.get("MMVAE_EPS", "fused")
+        if self.eps_override is not None and eps_mode == "fused":
+            eps_mode = "after"
+        eps = self._draw_many(M, B, D, dev) if eps_mode == "first" else None
         enc = [None] * M
         enc_order = list(enumerate(zip(names, streams)))
         if os.environ.get("MMVAE_ENC_ORDER", "fwd") == "rev":
@@ -101,7 +104,7 @@ class MoPOE(TorchMMVAE):
                 finally:
                     tower.raw_heads = False
                 enc[i] = tuple(ops.mark_tensor(t, f"enc {n} out[{j}]") for j, t in enumerate(mu_lv))
-                if eps is None and i == 0:
+                if eps is None and i == 0 and eps_mode == "after":
                     # one rsample per modality (:363-369), behind tower 0's encoder: that stream idles until the
                     # fusion anyway
                     eps = self._draw_many(M, B, D, dev)
@@ -113,11 +116,15 @@ class MoPOE(TorchMMVAE):
         theta = self._pz_params[1]
         # tensors that cross streams are registered with the consuming stream: the caching allocator must not hand
         # their memory to the producing stream again while the consumer's kernels are still queued
-        for t in list(eps) + [t for pair in enc for t in pair]:
+        for t in list(eps or []) + [t for pair in enc for t in pair]:
             _uses(t, fuse)
         with torch.cuda.stream(fuse):
             packed = [packed_head(mu, lv) for mu, lv in enc]
-            _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad, raw=True)
+            if eps is None:
+                _, kl, z = ops.poe_reparam_kl(theta, packed, M, True, (1 << (M + 1)) - 1, theta.grad, raw=True,
+                                              rng=self._rng_state)
+            else:
+                _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, (1 << (M + 1)) - 1, theta.grad, raw=True)
         _uses(kl, cur)
         for st in real:
             if st != fuse:

@@ -675,11 +675,16 @@ class PoeReparamKL(Function):
     [not differentiable], kl (E+1,B), then n_z tensors z_i (B,D)."""
 
     @staticmethod
-    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, cols, raw, *tensors):
-        """raw: the logvar halves of `packed` are the raw head outputs; softmax + 1e-6 happens inside the kernels"""
+    def forward(ctx, theta, gtheta, with_prior, n_z, kl_mask, E, cols, raw, rng, *tensors):
+        """raw: the logvar halves of `packed` are the raw head outputs; softmax + 1e-6 happens inside the kernels.
+        rng: None (the n_z noise tensors follow `packed`), or the device generator state: the kernel draws the noise"""
         packed = [H.f32c(t) for t in tensors[:E]]
-        eps = [H.f32c(t) for t in tensors[E:E + n_z]]
         B, D2 = packed[0].shape
+        if rng is not None:
+            col_d = cols[1] if cols is not None else D2 // 2
+            eps = list(torch.empty(n_z, B, col_d, device=packed[0].device).unbind(0))
+        else:
+            eps = [H.f32c(t) for t in tensors[E:E + n_z]]
         Dtot = D2 // 2
         col0, D = cols if cols is not None else (0, Dtot)
         dev = packed[0].device
@@ -694,8 +699,9 @@ class PoeReparamKL(Function):
             a.eps[i] = t.data_ptr()
             a.z[i] = zs[i].data_ptr()
         _call("mmvae_poe_reparam_kl_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(joint), H.ptr(kl), E, int(with_prior),
-              n_z, kl_mask, B, D, D2, int(bool(raw)), H.stream())
+              n_z, kl_mask, B, D, D2, int(bool(raw)), H.ptr(rng), H.stream())
         ctx.save_for_backward(theta, *packed, *eps)
+        ctx.n_eps_in = 0 if rng is not None else n_z
         ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0, int(bool(raw)))
         ctx.mark_non_differentiable(joint)
         ctx.set_materialize_grads(False)
@@ -733,14 +739,20 @@ class PoeReparamKL(Function):
         _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws),
               _poe_ticket(dev), E,
               int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, H.stream())
-        return (ret, None, None, None, None, None, None, None, *dpacked, *([None] * n_z))
+        return (ret, None, None, None, None, None, None, None, None, *dpacked, *([None] * ctx.n_eps_in))
 
 
-def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None, cols=None, raw=False):
+def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None, cols=None, raw=False, rng=None):
     """-> joint (2,B,D), kl (E+1,B), [z_0 .. z_{n_z-1}] each (B,D); cols = (col0, D) selects expert columns;
-    raw: packed = [mu | raw logvar-head output] (VaeComponent.process_output(raw=True))"""
+    raw: packed = [mu | raw logvar-head output] (VaeComponent.process_output(raw=True)).
+    eps: the n_z noise tensors, or -- with rng = the device generator state (ops.randn) -- their NUMBER: the fusion
+    kernel then draws them itself (same values as ops.randn((n_z, B, D), rng))"""
     assert not (raw and cols is not None), "raw heads: the softmax runs over the full head width"
-    out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), cols, raw, *packed, *eps)
+    if rng is not None:
+        out = PoeReparamKL.apply(theta, gtheta, with_prior, int(eps), kl_mask, len(packed), cols, raw, rng, *packed)
+    else:
+        out = PoeReparamKL.apply(theta, gtheta, with_prior, len(eps), kl_mask, len(packed), cols, raw, None, *packed,
+                                 *eps)
     return out[0], out[1], list(out[2:])
 
 
@@ -1179,9 +1191,13 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
 class TxtLayerMeta:
     """static description of one fused transformer layer call (shapes + the DropSpecs of its dropout sites)"""
 
-    def __init__(self, D, FF, NH, dec, drops, time_mean=False):
+    def __init__(self, D, FF, NH, dec, drops, time_mean=False, heads=None):
         self.D, self.FF, self.NH, self.dec, self.drops = D, FF, NH, bool(dec), drops or {}
         self.time_mean = bool(time_mean)      # output (N, D): mean over the L frames (the encoder's pooling)
+        # (w (HN, D), b (HN), gw, gb): the packed posterior heads applied to the pooled feature in the same launch;
+        # gw / gb are the preset gradient views they accumulate into.  The output is then (N, HN).
+        self.heads = heads
+        assert heads is None or self.time_mean
 
     def c_drop(self, L, N):
         if not self.drops:
@@ -1233,11 +1249,19 @@ class TxtLayer(Function):
         for k, t in S.items():
             setattr(sv, k, t.data_ptr())
         y = e(N, D) if meta.time_mean else e(L, N, D)
+        hw = hb = hout = None
+        HN = 0
+        if meta.heads is not None:
+            hw, hb = meta.heads[0], meta.heads[1]
+            HN = hw.shape[0]
+            hout = e(N, HN)
+            S["z"] = y
         _call("mmvae_txt_layer_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(mem) if dec else None, H.ptr(y), ctypes.byref(w),
-              ctypes.byref(sv), meta.c_drop(L, N), L, N, D, FF, NH, int(dec), int(meta.time_mean), H.stream())
+              ctypes.byref(sv), meta.c_drop(L, N), L, N, D, FF, NH, int(dec), int(meta.time_mean), H.ptr(hw), H.ptr(hb),
+              H.ptr(hout), HN, H.stream())
         ctx.meta, ctx.names, ctx.grads, ctx.S = meta, names, grads, S
         ctx.save_for_backward(x, mem if dec else None, mask_u8, *params)
-        return y
+        return y if hout is None else hout
 
     @staticmethod
     def backward(ctx, dy):
@@ -1248,6 +1272,23 @@ class TxtLayer(Function):
         P = dict(zip(names, params))
         dev = x.device
         dy = H.f32c(dy)
+        if meta.heads is not None:     # heads first: dy (N, HN) -> dz (N, D), head gradients into their preset views
+            hw, hb, hgw, hgb = meta.heads
+            z = S["z"]
+            HN = hw.shape[0]
+            if dy.data_ptr() % 16:
+                dy = dy.clone()
+            dz = torch.empty(N, D, device=dev)
+            lib = H.lib()
+            nz = lib.mmvae_linear_bwd_splits(N, HN, D)
+            nws = lib.mmvae_linear_bwd_ws_floats(N, HN, D)
+            ws = GradReducer.alloc(nws, dev) if nz > 1 else None
+            _call("mmvae_linear_bwd", H.ptr(dy), H.ptr(z), H.ptr(hw), None, H.ptr(dz), H.ptr(hgw), H.ptr(hgb),
+                  H.ptr(ws), N, HN, D, D, H.ACT_NONE, H.EP_NONE, H.ACC_DEFER, H.stream())
+            if nz > 1:
+                GradReducer.add(ws.data_ptr(), hgw, nz, HN * D, HN * D)
+                GradReducer.add(ws.data_ptr() + 4 * nz * HN * D, hgb, nz, HN, HN)
+            dy = dz
         w = H.TxtLayerW()
         for k in names:
             setattr(w, k, P[k].data_ptr())
@@ -1256,7 +1297,8 @@ class TxtLayer(Function):
             w.x_in_b = P["x_in_b"].data_ptr() + 4 * 2 * D
         sv = H.TxtLayerSaved()
         for k, t in S.items():
-            setattr(sv, k, t.data_ptr())
+            if k != "z":
+                setattr(sv, k, t.data_ptr())
         e = lambda *sh: torch.empty(*sh, device=dev)
         nln = 3 if dec else 2
         ln_names = [("n1_g", "n1_b"), ("n2_g", "n2_b")] + ([("n3_g", "n3_b")] if dec else [])

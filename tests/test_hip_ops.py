@@ -171,6 +171,33 @@ def test_poe_reparam_kl(ops, E, n_z, with_prior, kl_mask, B, D):
             check(tg.grad, tr.grad, 5e-5, "dtheta")
 
 
+@pytest.mark.parametrize("n_z,B,D", [(2, 128, 32), (3, 7, 9)])
+def test_poe_draws_its_own_noise(ops, n_z, B, D):
+    """rng=state: the fusion kernel generates the reparameterisation noise itself -- bit-identical z, kl and gradients
+    to drawing ops.randn((n_z, B, D), state) first, and the generator advances by exactly one draw."""
+    g = torch.Generator().manual_seed(B + D)
+    packed = [torch.cat([torch.randn(B, D, generator=g), F.softmax(torch.randn(B, D, generator=g), -1) + 1e-6], -1).to(DEV)
+              for _ in range(2)]
+    theta = (torch.randn(1, D, generator=g) * 0.3).to(DEV)
+    gz = torch.randn(n_z, B, D, generator=g).to(DEV)
+    mask = 0b111
+    res = []
+    for fused in (False, True):
+        state = torch.tensor([1234567, 5, 0], dtype=torch.int32, device=DEV)
+        pg = [p.clone().requires_grad_(True) for p in packed]
+        tg = theta.clone().requires_grad_(True)
+        if fused:
+            j, kl, z = ops.poe_reparam_kl(tg, pg, n_z, True, mask, rng=state)
+        else:
+            eps = list(ops.randn((n_z, B, D), state).unbind(0))
+            j, kl, z = ops.poe_reparam_kl(tg, pg, eps, True, mask)
+        (kl.sum() + (torch.stack(z) * gz).sum()).backward()
+        assert state.tolist() == [1234567, 6, 0]
+        res.append((kl, torch.stack(z), pg[0].grad, pg[1].grad, tg.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_bce_and_ce(ops):
     g = torch.Generator().manual_seed(3)
     B, Fd = 9, 3 * 64 * 64
@@ -204,6 +231,35 @@ def test_bce_and_ce(ops):
         out.backward(gg.to(DEV))
         check(out, ref, 1e-5, f"ce per_v={per_v}")
         check(lgg.grad, lr_.grad, 2e-5, f"ce dlogits per_v={per_v}")
+
+
+@pytest.mark.parametrize("L,N,d,HN", [(32, 128, 54, 64), (6, 5, 54, 16)])
+def test_txt_layer_with_pooled_heads(ops, L, N, d, HN):
+    """last encoder layer with the time pooling AND the packed posterior heads in its launch vs layer -> mean -> linear"""
+    from multimodal_vae_comparison_amd.models import encoders
+    torch.manual_seed(L + N + HN)
+    layer = encoders.HipTransformerEncoderLayer(d, 2, 128).to(DEV)
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(L, N, d, generator=g).to(DEV)
+    lens = torch.randint(1, L + 1, (N,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV)
+    hw = (torch.randn(HN, d, generator=g) / math.sqrt(d)).to(DEV)
+    hb = (torch.randn(HN, generator=g) * 0.1).to(DEV)
+    dh = torch.randn(N, HN, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        for p in layer.parameters():
+            p.grad = None
+        gw, gb = torch.zeros_like(hw), torch.zeros_like(hb)
+        xg = x.clone().requires_grad_(True)
+        if fused:
+            out = layer(xg, mask, None, time_mean=True, heads=(hw, hb, gw, gb))
+        else:
+            out = ops.linear(layer(xg, mask, None, time_mean=True), hw, hb, 0, gw, gb)
+        out.backward(dh)
+        res.append((out.detach(), xg.grad, gw, gb, layer.linear1.weight.grad.clone()))
+    for name, a, b in zip(("heads", "dx", "dW_heads", "db_heads", "dW_l1"), *res):
+        check(a, b, 2e-5, name)
 
 
 @pytest.mark.parametrize("B,Fd", [(9, 3 * 64 * 64), (5, 37)])
