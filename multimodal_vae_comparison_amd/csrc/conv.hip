@@ -32,6 +32,14 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
   else conv_gather_body<G, G::RWONLY>(ad, blockIdx.x - n_w, smem);
 }
 
+// 32-channel weight gradients: 8-channel chunks (4 x splits workgroups) when 16-channel chunks would leave the chip
+// half empty.  MMVAE_WGRAD_QC = 16 | 8 forces one (tuning knob).
+static inline bool wgrad_qc8(int nsplit) {
+  static const int forced = getenv("MMVAE_WGRAD_QC") ? atoi(getenv("MMVAE_WGRAD_QC")) : 0;
+  if (forced) return forced == 8;
+  return nsplit * 2 < 256;
+}
+
 static inline int dact_ep(int act) {
   return act == MMVAE_ACT_SILU ? MMVAE_EP_MUL_SILU_GRAD : act == MMVAE_ACT_RELU ? MMVAE_EP_MUL_RELU_MASK
                                                         : act == MMVAE_ACT_GELU ? MMVAE_EP_MUL_GELU_GRAD : MMVAE_EP_NONE;
@@ -69,9 +77,16 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
   scatter_visit(Hout, scatter_plan(tiles), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH <= 4) {
-      using W = WgradGeom<32, G::LGH>;
-      const int n_w = nsplit * W::NCH, n_d = (int)scatter_grid(B, Hout, G::TM);
-      hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      const int n_d = (int)scatter_grid(B, Hout, G::TM);
+      if (wgrad_qc8(nsplit)) {
+        using W = WgradGeom<32, G::LGH, 8>;
+        const int n_w = nsplit * W::NCH;
+        hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      } else {
+        using W = WgradGeom<32, G::LGH>;
+        const int n_w = nsplit * W::NCH;
+        hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      }
       launched = true;
     }
   });
@@ -104,9 +119,16 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH >= 3 && (G::CIN == 32 || G::LGH == 6)) {
-      using W = WgradGeom<G::CIN, G::LGH - 1>;       // small map = the gather's output map
-      const int n_w = nsplit * W::NCH, n_d = (int)gather_grid(B, Hin, G::TM);
-      hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      const int n_d = (int)gather_grid(B, Hin, G::TM);    // (weight gradient: small map = the gather's output map)
+      if (G::CIN == 32 && wgrad_qc8(nsplit)) {
+        using W = WgradGeom<G::CIN, G::LGH - 1, G::CIN == 32 ? 8 : WGRAD_QC_DEFAULT(G::CIN)>;
+        const int n_w = nsplit * W::NCH;
+        hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      } else {
+        using W = WgradGeom<G::CIN, G::LGH - 1>;
+        const int n_w = nsplit * W::NCH;
+        hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      }
       launched = true;
     }
   });
