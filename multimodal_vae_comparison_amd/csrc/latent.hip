@@ -2,6 +2,7 @@
 // Elementwise / small-reduction work over (experts x B x D) with D <= 256: one wavefront per sample,
 // lanes over the latent dimension, wave-shuffle reductions; no LDS, no atomics (deterministic).
 #include "common.hpp"
+#include <type_traits>
 
 #define POE_MAX_WAVES 128
 #define POE_SLOTS 4  // D <= 64 * POE_SLOTS
@@ -396,6 +397,231 @@ __global__ __launch_bounds__(256) void poe_theta_kernel(const float* __restrict_
   poe_theta_body(theta, ws, dtheta, nrows, D, accumulate, part);
 }
 
+// ---- D <= 64 fast paths -------------------------------------------------------------------------------------------
+// The generic kernels above walk POE_SLOTS column slots and MMVAE_MAX_EXPERTS experts with run-time bounds: every
+// bound is a branch, every branch a basic block the compiler cannot move loads across, so a launch was a chain of
+// four to six dependent L2 round trips (prior row, one softmax row per expert, the expert rows again, noise /
+// upstream gradients) for a few hundred flops: 8.6 / 12.5 us, on the critical path of BOTH towers.  With the expert
+// and sample counts as template arguments and one column per lane, every load of a row is issued before the first
+// use, inactive lanes load a clamped column and only their stores are predicated.  Same arithmetic, same order.
+template <int E, int NZ>
+__global__ __launch_bounds__(256) void poe_fwd_fast_kernel(mmvae_poe_fwd_args a, const float* __restrict__ theta,
+                                                           float* __restrict__ joint, float* __restrict__ kl,
+                                                           int with_prior, unsigned kl_mask, int B, int D, int ld,
+                                                           int raw, uint32_t* __restrict__ rng) {
+  MMVAE_TRACE_STAMP(22);
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const bool live = lane < D;
+  const int dc = live ? lane : D - 1;
+  const float th = theta[dc];
+  const uint32_t rkey = rng ? randn_key(rng) : 0u;
+  float sp = 1.f;
+  bool have_prior = false;
+  for (int b = wave; b < B; b += nwaves) {
+    const size_t o = (size_t)b * D + dc, oi = (size_t)b * ld + dc;
+    float mu[E], lv[E], ep[NZ > 0 ? NZ : 1];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      mu[e] = a.mu[e][oi];
+      lv[e] = a.lv[e][oi];
+    }
+    if (!rng) {
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) ep[i] = a.eps[i][o];
+    }
+    if (!have_prior) {      // prior sigma = softmax(theta) * D
+      const float mx = wave_max(live ? th : -INFINITY);
+      const float ex = live ? expf(th - mx) : 0.f;
+      const float sum = wave_sum(ex);
+      sp = (ex / sum) * (float)D;
+      have_prior = true;
+    }
+    const float lv0_raw = lv[0];
+    if (raw) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float mx = wave_max(live ? lv[e] : -INFINITY);
+        const float ex = live ? expf(lv[e] - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(ex);
+        lv[e] = expf(lv[e] - mx) * inv + 1e-6f;
+      }
+    }
+    float klacc[E + 1];
+    float P = 0.f, S = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float T = 1.0f / (expf(lv[e]) + 1e-8f);
+      P += T;
+      S += mu[e] * T;
+      klacc[e] = (live && (kl_mask & (1u << e))) ? kl_elem(mu[e], lv[e], sp) : 0.f;
+    }
+    if (with_prior == 1) P += 1.0f / (1.0f + 1e-8f);
+    float muJ = S / P, varJ = 1.0f / P;
+    if (with_prior == 2) {
+      muJ = mu[0];
+      varJ = lv0_raw;
+    }
+    klacc[E] = (live && (kl_mask & (1u << E))) ? kl_elem(muJ, varJ, sp) : 0.f;
+    if (live) {
+      joint[o] = muJ;
+      joint[(size_t)B * D + o] = varJ;
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      float ev;
+      if (rng) {
+        ev = randn_elem(rkey, (long)i * B * D + (long)o);
+        if (live) const_cast<float*>(a.eps[i])[o] = ev;
+      } else {
+        ev = ep[i];
+      }
+      if (live) a.z[i][o] = muJ + varJ * ev;
+    }
+    if (kl) {
+#pragma unroll
+      for (int j = 0; j <= E; ++j) {
+        const float v = wave_sum(klacc[j]);
+        if (lane == 0) kl[(size_t)j * B + b] = v;
+      }
+    }
+  }
+  if (rng) randn_advance(rng);
+}
+
+template <int E, int NZ>
+__global__ __launch_bounds__(256) void poe_bwd_fast_kernel(mmvae_poe_bwd_args a, const float* __restrict__ theta,
+                                                           const float* __restrict__ dkl, float* __restrict__ ws,
+                                                           int with_prior, unsigned kl_mask, int B, int D, int ld,
+                                                           int raw, float* __restrict__ dtheta,
+                                                           int* __restrict__ ticket, int accumulate) {
+  MMVAE_TRACE_STAMP(23);
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const bool live = lane < D;
+  const int dc = live ? lane : D - 1;
+  const float th = theta[dc];
+  float sp = 1.f, dsp = 0.f;
+  bool have_prior = false;
+  for (int b = wave; b < B; b += nwaves) {
+    const size_t o = (size_t)b * D + dc, oi = (size_t)b * ld + dc;
+    float gk[E + 1], mu[E], lv[E], T[E], dz[NZ > 0 ? NZ : 1], ep[NZ > 0 ? NZ : 1];
+#pragma unroll
+    for (int j = 0; j <= E; ++j) gk[j] = (dkl && (kl_mask & (1u << j))) ? dkl[(size_t)j * B + b] : 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      mu[e] = a.mu[e][oi];
+      lv[e] = a.lv[e][oi];
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      dz[i] = a.dz[i][o];
+      ep[i] = a.eps[i][o];
+    }
+    if (!have_prior) {
+      const float mx = wave_max(live ? th : -INFINITY);
+      const float ex = live ? expf(th - mx) : 0.f;
+      const float sum = wave_sum(ex);
+      sp = (ex / sum) * (float)D;
+      have_prior = true;
+    }
+    float sv[E];      // softmax(u) of the raw heads
+    if (raw) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float mx = wave_max(live ? lv[e] : -INFINITY);
+        const float ex = live ? expf(lv[e] - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(ex);
+        sv[e] = expf(lv[e] - mx) * inv;
+        lv[e] = sv[e] + 1e-6f;
+      }
+    }
+    const float isp2 = 1.0f / (sp * sp);
+    float P = 0.f, S = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      T[e] = 1.0f / (expf(lv[e]) + 1e-8f);
+      P += T[e];
+      S += mu[e] * T[e];
+    }
+    if (with_prior == 1) P += 1.0f / (1.0f + 1e-8f);
+    float muJ = S / P, varJ = 1.0f / P;
+    if (with_prior == 2) {
+      muJ = mu[0];
+      varJ = lv[0];
+    }
+    float Gmu = 0.f, Gvar = 0.f;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      Gmu += dz[i];
+      Gvar += dz[i] * ep[i];
+    }
+    float dspe = 0.f;
+    if (gk[E] != 0.f) {
+      Gmu += gk[E] * muJ * isp2;
+      Gvar += gk[E] * (varJ * isp2 - 1.0f / varJ);
+      dspe += gk[E] * (1.0f - (varJ * varJ + muJ * muJ) * isp2) / sp;
+    }
+    float dlv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float dmu = Gmu * T[e] * varJ;
+      const float dT = Gmu * (mu[e] - muJ) * varJ - Gvar * varJ * varJ;
+      dlv[e] = dT * (-expf(lv[e]) * T[e] * T[e]);
+      if (with_prior == 2) {
+        dmu = Gmu;
+        dlv[e] = Gvar;
+      }
+      if (gk[e] != 0.f) {
+        dmu += gk[e] * mu[e] * isp2;
+        dlv[e] += gk[e] * (lv[e] * isp2 - 1.0f / lv[e]);
+        dspe += gk[e] * (1.0f - (lv[e] * lv[e] + mu[e] * mu[e]) * isp2) / sp;
+      }
+      if (live) a.dmu[e][oi] = dmu;
+    }
+    if (live) dsp += dspe;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (raw) {      // through lv = softmax(u) + 1e-6:  du = s (dlv - sum(s dlv)),  s = lv - 1e-6
+        const float dot = wave_sum(live ? (lv[e] - 1e-6f) * dlv[e] : 0.f);
+        dlv[e] = sv[e] * (dlv[e] - dot);
+      }
+      if (live) a.dlv[e][oi] = dlv[e];
+    }
+  }
+  if (live) ws[(size_t)wave * D + lane] = dsp;
+  if (ticket) {
+    __shared__ float part[4][64 * POE_SLOTS];
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(ticket, 1);
+      last = t == (int)gridDim.x - 1;
+      if (last) *ticket = 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    poe_theta_body(theta, ws, dtheta, nwaves, D, accumulate, part);
+  }
+}
+
+// (E, n_z) -> instantiation; false when the generic kernels have to run
+template <typename F>
+static inline bool poe_fast_visit(int E, int n_z, int D, F&& f) {
+  static const bool off = getenv("MMVAE_POE_FAST") && atoi(getenv("MMVAE_POE_FAST")) == 0;
+  if (off || D > 64 || E < 1 || E > 3 || n_z < 0 || n_z > 3) return false;
+#define POE_CASE(EE, ZZ) if (E == EE && n_z == ZZ) { f(std::integral_constant<int, EE>{}, std::integral_constant<int, ZZ>{}); return true; }
+  POE_CASE(1, 0) POE_CASE(1, 1) POE_CASE(1, 2) POE_CASE(1, 3)
+  POE_CASE(2, 0) POE_CASE(2, 1) POE_CASE(2, 2) POE_CASE(2, 3)
+  POE_CASE(3, 0) POE_CASE(3, 1) POE_CASE(3, 2) POE_CASE(3, 3)
+#undef POE_CASE
+  return false;
+}
+
 static inline int poe_blocks(int B) {
   int waves = B < POE_MAX_WAVES ? B : POE_MAX_WAVES;
   return (waves + 3) / 4;
@@ -410,8 +636,13 @@ extern "C" int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   if (with_prior == 2 && E != 1) return MMVAE_ERR_ARG;
   if (kl_mask && !kl) return MMVAE_ERR_ARG;
-  hipLaunchKernelGGL(poe_fwd_kernel, dim3(poe_blocks(B)), dim3(256), 0, (hipStream_t)stream, *a, theta, joint, kl, E,
-                     with_prior, n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, rng_state);
+  if (!poe_fast_visit(E, n_z, D, [&](auto e, auto z) {
+        hipLaunchKernelGGL((poe_fwd_fast_kernel<decltype(e)::value, decltype(z)::value>), dim3(poe_blocks(B)), dim3(256),
+                           0, (hipStream_t)stream, *a, theta, joint, kl, with_prior, kl_mask, B, D, ld_in,
+                           raw_heads ? 1 : 0, rng_state);
+      }))
+    hipLaunchKernelGGL(poe_fwd_kernel, dim3(poe_blocks(B)), dim3(256), 0, (hipStream_t)stream, *a, theta, joint, kl, E,
+                       with_prior, n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, rng_state);
   return mmvae_launch_status();
 }
 
@@ -423,9 +654,14 @@ extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   const int nb = poe_blocks(B);
   const bool one_launch = dtheta && ticket;
-  hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
-                     n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, one_launch ? dtheta : nullptr,
-                     one_launch ? ticket : nullptr, accumulate);
+  if (!poe_fast_visit(E, n_z, D, [&](auto e, auto z) {
+        hipLaunchKernelGGL((poe_bwd_fast_kernel<decltype(e)::value, decltype(z)::value>), dim3(nb), dim3(256), 0,
+                           (hipStream_t)stream, *a, theta, dkl, ws, with_prior, kl_mask, B, D, ld_in, raw_heads ? 1 : 0,
+                           one_launch ? dtheta : nullptr, one_launch ? ticket : nullptr, accumulate);
+      }))
+    hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
+                       n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, one_launch ? dtheta : nullptr,
+                       one_launch ? ticket : nullptr, accumulate);
   if (dtheta && !one_launch)
     hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
                        accumulate);
