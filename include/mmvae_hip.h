@@ -493,6 +493,11 @@ typedef struct {
   int n;
 } mmvae_reduce_segments_t;
 int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream);
+/* ... with the ELBO assembly of mmvae_lincomb_rowptrs_fwd (out[k] = sum_n W[k][n] sum_b rows[n][b], no d_unit) riding
+ * along as one extra workgroup of the same launch: the logged loss values cost no launch in the step's serial tail */
+int mmvae_reduce_segments_lincomb(const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows,
+                                  const float* W_host, float* out, int n_rows, int B, int n_out,
+                                  mmvae_stream_t stream);
 /* partial layouts: rows x rowlen floats in ws; weight part at column 0, bias part at column bias_col */
 int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen, int* bias_col);
 /* linear weight gradient: `splits` partial (N*K) slabs followed by `splits` partial (N) bias rows; splits == 1

@@ -165,8 +165,43 @@ extern "C" int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long 
 // A block covers RS_COLS = 256 columns of one head segment: 64 lanes x float4 (16-byte loads when the whole chain is
 // 16-byte aligned and a multiple of 4 long, else four dword columns per lane) x 4 row slices, 8 loads in flight.
 #define RS_COLS 256
-__global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t) {
+// Optional rider: the ELBO assembly out_k = sum_n W[k][n] * sum_b rows_n[b] (mmvae_lincomb_rowptrs_fwd) as ONE extra
+// workgroup of the same launch.  The logged loss values only need the forward's row sums, but as a launch of their own
+// they sat in the serial tail of the step between this fold and the optimiser.
+#define RS_LC_ROWS 32
+#define RS_LC_OUT 4
+struct rs_lincomb_t {
+  const float* rows[RS_LC_ROWS];
+  float w[RS_LC_OUT * RS_LC_ROWS];
+  float* out;
+  int n_rows, B, n_out;
+};
+__device__ __forceinline__ void rs_lincomb_body(const rs_lincomb_t& lc) {
+  __shared__ float rs[RS_LC_ROWS];
+  // one wave per row (rows are short: B values), 4 rows in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = wave; n < lc.n_rows; n += 4) {
+    const float* V = lc.rows[n];
+    float a = 0.f;
+    for (int b = lane; b < lc.B; b += 64) a += V[b];
+    a = wave_sum(a);
+    if (lane == 0) rs[n] = a;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < lc.n_out) {
+    float o = 0.f;
+    for (int n = 0; n < lc.n_rows; ++n) o += lc.w[threadIdx.x * RS_LC_ROWS + n] * rs[n];
+    lc.out[threadIdx.x] = o;
+  }
+}
+
+template <bool TAIL>
+__global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t, rs_lincomb_t lc) {
   MMVAE_TRACE_STAMP(21);
+  if (TAIL && blockIdx.x == gridDim.x - 1) {
+    rs_lincomb_body(lc);
+    return;
+  }
   __shared__ float4 part[4][64];
   int sg = 0;
   while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan over head segments, n <= 64
@@ -234,7 +269,7 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segme
       if (i + c < len) dst[i + c] += s[c];
   }
 }
-extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream) {
+static int reduce_segments_impl(const mmvae_reduce_segments_t* table, const rs_lincomb_t* tail, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(table && table->n > 0 && table->n <= MMVAE_MAX_SEGMENTS);
   mmvae_reduce_segments_t t = *table;
   // chain segments that share a destination; chain heads are compacted to the front and only they get workgroups
@@ -272,8 +307,28 @@ extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae
     blocks += (o.len[k] + RS_COLS - 1) / RS_COLS;
   }
   t = o;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+  if (tail) {
+    hipLaunchKernelGGL(reduce_segments_kernel<true>, dim3(blocks + 1), dim3(256), 0, (hipStream_t)stream, t, *tail);
+  } else {
+    rs_lincomb_t none{};
+    hipLaunchKernelGGL(reduce_segments_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, none);
+  }
   return mmvae_launch_status();
+}
+extern "C" int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t stream) {
+  return reduce_segments_impl(table, nullptr, stream);
+}
+extern "C" int mmvae_reduce_segments_lincomb(const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows,
+                                             const float* W_host, float* out, int n_rows, int B, int n_out,
+                                             mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(rows && W_host && out && n_rows > 0 && B > 0 && n_out > 0);
+  if (n_rows > RS_LC_ROWS || n_out > RS_LC_OUT) return MMVAE_ERR_UNSUPPORTED;
+  rs_lincomb_t lc{};
+  for (int n = 0; n < n_rows; ++n) lc.rows[n] = rows->p[n];
+  for (int k = 0; k < n_out; ++k)
+    for (int n = 0; n < n_rows; ++n) lc.w[k * RS_LC_ROWS + n] = W_host[k * n_rows + n];
+  lc.out = out; lc.n_rows = n_rows; lc.B = B; lc.n_out = n_out;
+  return reduce_segments_impl(table, &lc, stream);
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float value) {

@@ -125,6 +125,7 @@ SIGNATURES = {
     "mmvae_reduce_rows": (c_i, [c_p, c_p, c_i, c_l, c_l, c_i, c_p]),
     "mmvae_fill": (c_i, [c_p, c_l, c_f, c_p]),
     "mmvae_reduce_segments": (c_i, [c_p, c_p]),
+    "mmvae_reduce_segments_lincomb": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "mmvae_normal_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_normal_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_expmul_fwd": (c_i, [c_p] * 3 + [c_i, c_p]),

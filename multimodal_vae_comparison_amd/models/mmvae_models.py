@@ -178,12 +178,20 @@ class MoPOE(TorchMMVAE):
                 return ops.lincomb_rows([r.detach() for r in recs] + [kl.detach()], W)
 
         out = None
+        tail = None
+        if mode == "0" and os.environ.get("MMVAE_LOSS_TAIL", "1") == "1":
+            # the logged values ride on the end-of-backward fold launch (one extra workgroup): the forward's row sums
+            # are long finished by then, and a launch of their own would sit between the fold and the optimiser
+            tail = ops.GradReducer.tail = ops.lincomb_rows_args(recs + [kl], W)
         if mode == "2" and side is not None:
             # the logged values are assembled on the fusion stream between its decoder's forward and backward: that
             # stream has slack until the fusion backward (the other decoder's backward is the longer one)
             side.wait_stream(cur)
             out = assemble(side)
         torch.autograd.backward(recs + [kl], self._seeds)
+        ops.GradReducer.tail = None
+        if tail is not None and tail["done"]:
+            out = tail["args"][2].unbind(0)
         if out is None and mode == "1" and side is not None:
             side.wait_stream(cur)
             out = assemble(side)

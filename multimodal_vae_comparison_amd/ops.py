@@ -34,6 +34,7 @@ class GradReducer:
     all segments with mmvae_reduce_segments.  Works unchanged under hipGraph capture (fixed arena offsets)."""
 
     enabled = True
+    tail = None       # lincomb_rows_args(...) of an ELBO assembly that rides on the next fold (see flush)
     _arena = {}
     _state = {}
     _side = {}        # device key -> {"wgrad": Stream, "tower": Stream}: see StreamPlan below
@@ -117,13 +118,21 @@ class GradReducer:
         st["keep"] = []
         segs, st["segs"], st["armed"] = st["segs"], [], False
         need, st["off"] = st["spilled"] + st["off"], 0
+        tail, cls.tail = cls.tail, None
         for i in range(0, len(segs), H.MAX_SEGMENTS):
             chunk = segs[i:i + H.MAX_SEGMENTS]
             t = H.ReduceSegments()
             for j, (sp, dp, r, ln, sd) in enumerate(chunk):
                 t.src[j], t.dst[j], t.rows[j], t.len[j], t.stride[j] = sp, dp, r, ln, sd
             t.n = len(chunk)
-            _call("mmvae_reduce_segments", ctypes.byref(t), H.stream())
+            if tail is not None and i + H.MAX_SEGMENTS >= len(segs):
+                # the logged loss values ride on the last fold launch as one extra workgroup
+                rp, flat, out, n, B, k = tail["args"]
+                _call("mmvae_reduce_segments_lincomb", ctypes.byref(t), ctypes.byref(rp), flat, H.ptr(out), n, B, k,
+                      H.stream())
+                tail["done"] = True
+            else:
+                _call("mmvae_reduce_segments", ctypes.byref(t), H.stream())
         if st["spill"]:        # the step did not fit one chunk: one arena of the full size from the next step on
             key = device.index if device.index is not None else torch.cuda.current_device()
             st["spill"], st["spilled"] = [], 0
@@ -986,6 +995,25 @@ class LincombRows(Function):
                 i += 1
         _call("mmvae_lincomb_rowptrs_bwd", ctypes.byref(gp), flat, ctypes.byref(dp), n, B, k, H.stream())
         return (None, *outs)
+
+
+def lincomb_rows_args(blocks, W):
+    """(row pointers, packed weights, out (k,), n, B, k) of lincomb_rows(blocks, W) without launching it (no autograd):
+    for GradReducer.tail"""
+    blocks = [H.f32c(t.detach()) for t in blocks]
+    B = blocks[0].shape[-1]
+    rows = [t.numel() // B for t in blocks]
+    n, k = sum(rows), len(W)
+    assert n <= 32 and k <= 4
+    rp = H.RowPtrs()
+    i = 0
+    for t, r in zip(blocks, rows):
+        for j in range(r):
+            rp.p[i] = t.data_ptr() + 4 * j * B
+            i += 1
+    flat = (H.c_f * (k * n))(*[float(x) for row in W for x in row])
+    out = torch.empty(k, device=blocks[0].device)
+    return {"args": (rp, flat, out, n, B, k), "keep": blocks, "done": False}
 
 
 class NormalLogRatio(Function):

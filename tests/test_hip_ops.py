@@ -496,6 +496,7 @@ def test_reduce_segments(ops, hip_lib):
     arena = torch.randn(1 << 22, generator=g).to(DEV)
     flat = torch.randn(40000, generator=g).to(DEV)
     ref = flat.clone()
+    orig = flat.clone()
     specs = [  # (src offset, dst offset, rows, len, stride)
         (0, 0, 128, 16384, 16416), (16384, 16384, 128, 32, 16416),          # conv partial: weights then bias columns
         (128 * 16416, 16416, 33, 8748, 8748 + 162), (128 * 16416 + 8748, 25164, 33, 162, 8748 + 162),
@@ -511,6 +512,17 @@ def test_reduce_segments(ops, hip_lib):
     t.n = len(specs)
     H.check(hip_lib.mmvae_reduce_segments(ctypes.byref(t), H.stream()), "mmvae_reduce_segments")
     check(flat, ref, 2e-6, "reduce_segments")
+    # the same fold once more with the ELBO assembly riding along as one extra workgroup
+    before = flat.clone()
+    blocks = [torch.randn(130, generator=g).to(DEV), torch.randn(3, 130, generator=g).to(DEV)]
+    W = [[0.5, 0.1, 0.2, 0.3], [0.0, 1.0, 1.0, 1.0]]
+    tail = ops.lincomb_rows_args(blocks, W)
+    rp, wf, out, n, B, k = tail["args"]
+    H.check(hip_lib.mmvae_reduce_segments_lincomb(ctypes.byref(t), ctypes.byref(rp), wf, H.ptr(out), n, B, k, H.stream()),
+            "mmvae_reduce_segments_lincomb")
+    rows = torch.cat([blocks[0][None], blocks[1]]).double().sum(1)
+    check(out, torch.tensor(W, dtype=torch.float64, device=DEV) @ rows, 1e-5, "lincomb rider")
+    check(flat, before.double() + (ref.double() - orig.double()), 4e-6, "reduce_segments with rider")
 
 
 @pytest.mark.parametrize("self_counting", [False, True])
