@@ -15,6 +15,13 @@ import os
 import sys
 import time
 
+# rank 0 prints ONE JSON line on stdout.  RCCL writes its debug output (the version banner of NCCL_DEBUG=VERSION, which
+# the GPU boxes export, and its warnings) to stdout as well, unbuffered and in the middle of other lines: send it to a
+# file instead
+os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug.%h.%p.log")
+if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":      # the banner ignores NCCL_DEBUG_FILE
+    del os.environ["NCCL_DEBUG"]
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,6 +41,8 @@ def parse():
     p.add_argument("--latents", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--force-collective", action="store_true",
+                   help="one GPU, but the multi-GPU step structure (graph, RCCL all-reduce over 1 rank, Adam launch)")
     return p.parse_args()
 
 
@@ -134,6 +143,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    # --force-collective (testing on one GPU): take the multi-GPU structure of the step -- graph without the optimiser,
+    # one RCCL all-reduce of the flat gradients, separate Adam launch -- with a single-rank process group
+    path_world = world
+    if a.force_collective and world == 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, device_id=dev)
+        path_world = 2
 
     from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
     from multimodal_vae_comparison_amd.synthetic import cdsprites_batch, cdsprites_config
@@ -145,7 +161,7 @@ def main():
     if world > 1:
         opt.grad_scale = 1.0 / world                       # all-reduce(sum) then average inside the Adam kernel
     batch = cdsprites_batch(a.batch, a.seq, seed=1 + rank, device=dev)
-    tr.capture(batch, world)      # world 1: the Adam step is part of the captured graph
+    tr.capture(batch, path_world)      # world 1: the Adam step is part of the captured graph
 
     def barrier():
         if world > 1:
@@ -153,11 +169,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        tr.fused_step(world)
+        tr.fused_step(path_world)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = tr.fused_step(world)
+        out = tr.fused_step(path_world)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -184,9 +200,10 @@ def main():
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(a.batch, a.seq, a.latents, a.cpu_seconds)
                 res["config"]["gpu_over_cpu"] = round(sps / res["cpu_baseline"]["value"], 1)
-        print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or path_world > 1:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
