@@ -104,6 +104,30 @@ def test_linear_fwd_bwd(ops, M, K, N, act):
     check(xg.grad, xr.grad, 5e-5, "dx")
 
 
+@pytest.mark.parametrize("M,K,N,act", [(1, 4, 1, 0), (17, 20, 33, 1), (128, 1024, 64, 0), (256, 36, 512, 2), (130, 516, 100, 1),
+                                       (64, 54, 54, 0), (3, 1028, 5, 0), (200, 8, 8, 3), (16, 512, 2048, 1)])
+def test_linear_small_batch_paths(ops, M, K, N, act):
+    """shapes around the dispatch boundaries of the register-operand GEMMs (16x16 / 32x32 tiles, float4 vs strided
+    operand loads for K % 4 != 0, reductions longer than 1024 back on the staged kernel) and the fused backward"""
+    g = torch.Generator().manual_seed(M * 7 + K * 3 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    F.linear(_act(xr, act), wr, br).backward(dy.double())
+    for preset in (False, True):      # gradients returned to autograd / accumulated into preset views
+        xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        gw = torch.ones(N, K, device=DEV) if preset else None
+        gb = torch.ones(N, device=DEV) if preset else None
+        y = ops.linear(xg, wg, bg, act, gw, gb)
+        y.backward(dy.to(DEV))
+        check(y, F.linear(_act(x.double(), act), w.double(), b.double()), 2e-5, "y")
+        check(xg.grad, xr.grad, 5e-5, "dx")
+        check(gw - 1 if preset else wg.grad, wr.grad, 5e-5, "dw")
+        check(gb - 1 if preset else bg.grad, br.grad, 5e-5, "db")
+
+
 def test_head_softmax(ops):
     g = torch.Generator().manual_seed(1)
     h = torch.randn(37, 2 * 42, generator=g)
