@@ -512,6 +512,22 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   const bool ak = sak == 1, bk_major = (sbk == 1 && sbn != 1);
   if (!ak && sam != 1) return MMVAE_ERR_UNSUPPORTED;
   if (!bk_major && sbn != 1) return MMVAE_ERR_UNSUPPORTED;
+  // split reduction over workgroups with few output tiles (the text towers' (L*N)-row weight gradients: 162 x 54
+  // outputs, 4096 rows): same kper / partial layout as the staged kernel, register-operand body
+  static const bool rsplit = !(getenv("MMVAE_RGEMM_SPLIT") && atoi(getenv("MMVAE_RGEMM_SPLIT")) == 0);
+  if (rgemm_enabled() && rsplit && nz > 1 && tiles32 <= 64 && kper <= 1024 && !ak && !bk_major) {
+    const dim3 rgrid(ntn, (M + 31) / 32, nz);
+    if (rgemm_depth(kper) == 64) hipLaunchKernelGGL((rgemm_kernel<64, false, false>), rgrid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((rgemm_kernel<16, false, false>), rgrid, dim3(512), 0, st, g);
+    int rc = mmvae_launch_status();
+    if (rc) return rc;
+    if (accumulate != MMVAE_ACC_DEFER) {
+      rc = mmvae_reduce_rows(ws, C, nz, (long)M * N, (long)M * N, accumulate, stream);
+      if (rc) return rc;
+      if (a_rowsum) rc = mmvae_reduce_rows(ws + (size_t)nz * M * N, a_rowsum, nz, M, M, accumulate, stream);
+    }
+    return rc;
+  }
   // few tiles, short reduction: register-operand kernel (no LDS staging)
   if (rgemm_enabled() && splitk == 1 && tiles32 <= 1024 && K <= 1024) {
     // k-contiguous operands that are not float4-aligned take the strided (dword) loads with a k stride of 1
