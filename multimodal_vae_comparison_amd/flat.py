@@ -27,13 +27,23 @@ class FlatParams:
             if id(p) not in seen:
                 order.append([p])
                 seen.add(id(p))
+        # encoder parameters first, everything else (decoders, prior) behind them: the second range's gradients are
+        # final when the fusion backward starts, so data parallelism can all-reduce it under the encoders' backward
+        # (trainer.capture, world_size > 1).  `split` = first element of the second range.
+        is_enc = lambda g: ".enc." in ("." + by_id[id(g[0])][0])
+        order = [g for g in order if is_enc(g)] + [g for g in order if not is_enc(g)]
         offs, total = [], 0
+        self.split = None
         for g in order:
             total = (total + 3) // 4 * 4           # 16-byte alignment of every group
+            if self.split is None and not is_enc(g):
+                self.split = total
             for p in g:
                 offs.append((p, total))
                 total += p.numel()
         total = (total + 3) // 4 * 4
+        if self.split is None:
+            self.split = total
         dev = params[0][1].device
         self.data = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)

@@ -146,6 +146,7 @@ class MoPOE(TorchMMVAE):
                     r = recon_rowsum(vae.ltype, out, mods[n])
                 recs[i] = ops.mark_tensor(r, f"dec {n} recon")   # (B,) = -lpx_z / llik_scaling
             _uses(recs[i], cur)
+        self._fusion_inputs = packed        # the towers' packed head outputs: where the backward can be cut in two
         return recs, kl, W, streams, dev
 
     def objective(self, mods):
@@ -155,7 +156,17 @@ class MoPOE(TorchMMVAE):
         out = ops.lincomb_rows(recs + [kl], W)                              # rows: M recon sums, M+1 KL rows
         return {"loss": out[0], "kld": out[1], "reconstruction_loss": recs}
 
-    def objective_backward(self, mods):
+    def backward_encoders(self):
+        """second half of objective_backward(mods, cut=True): the encoders' backward from the saved head gradients"""
+        hs, dhs, streams, dev = self._cut
+        self._cut = None
+        for st in streams:           # the towers' weight-gradient kernels run on their streams: the fold must join them
+            if st is not None:
+                ops.GradReducer.note_stream(dev, st)
+        torch.autograd.backward(hs, list(dhs))
+        self._join(streams, dev)
+
+    def objective_backward(self, mods, cut=False):
         """objective(mods)["loss"].backward() without the join in the middle: the loss is LINEAR in the per-row terms
         (recs, kl) with host-side constant weights, so every tower's backward is seeded with those constants as soon as
         its own forward is done -- no tower waits for the other one's decoder or for the loss kernel.  The loss values
@@ -188,7 +199,12 @@ class MoPOE(TorchMMVAE):
             # stream has slack until the fusion backward (the other decoder's backward is the longer one)
             side.wait_stream(cur)
             out = assemble(side)
-        torch.autograd.backward(recs + [kl], self._seeds)
+        if cut:
+            # decoders + fusion only: the gradients of the towers' head outputs come back instead of flowing on
+            self._cut = (list(self._fusion_inputs), torch.autograd.grad(recs + [kl], self._fusion_inputs, self._seeds),
+                         streams, dev)
+        else:
+            torch.autograd.backward(recs + [kl], self._seeds)
         ops.GradReducer.tail = None
         if tail is not None and tail["done"]:
             out = tail["args"][2].unbind(0)
