@@ -55,6 +55,8 @@ class FlatParams:
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
             self.index[by_id[id(p)][0]] = (o, tuple(p.shape))
         self.params = [p for p, _ in offs]
+        self.offset_of = {id(p): o for p, o in offs}
+        self.params_in_model_order = [p for _, p in params]
 
     def rebind_grads(self):
         """(re)attach the flat gradient views (after an optimizer.zero_grad(set_to_none=True))"""
@@ -94,3 +96,44 @@ class FlatAdam(torch.optim.Optimizer):
         # every step) keeps torch semantics: clear, and keep the flat views attached.
         self.flat.rebind_grads()
         self.flat.zero_grad()
+
+    # ---- torch.optim.Adam-compatible state (what a Lightning checkpoint stores under "optimizer_states") ----------
+    def state_dict(self):
+        """torch.optim.Adam(amsgrad=True).state_dict() layout over the model's parameters in `named_parameters()` order
+        (the order the reference's `Adam(filter(requires_grad, self.parameters()))` enumerates them in)"""
+        step = int(self.step_dev[0].item())
+        state = {}
+        for i, p in enumerate(self.flat.params_in_model_order):
+            o = self.flat.offset_of[id(p)]
+            sl = slice(o, o + p.numel())
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.m[sl].view(p.shape).clone(),
+                        "exp_avg_sq": self.v[sl].view(p.shape).clone(),
+                        "max_exp_avg_sq": self.vmax[sl].view(p.shape).clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": True,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        params = self.flat.params_in_model_order
+        steps = set()
+        for i, p in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            o = self.flat.offset_of[id(p)]
+            sl = slice(o, o + p.numel())
+            self.m[sl].copy_(st["exp_avg"].reshape(-1))
+            self.v[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            if "max_exp_avg_sq" in st:
+                self.vmax[sl].copy_(st["max_exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        assert len(steps) <= 1, f"per-parameter step counts differ: {steps}"
+        self.step_dev.zero_()                     # the running beta powers are rebuilt by the kernel (pow()) once
+        if steps:
+            self.step_dev[0] = steps.pop()
+        g = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = g["lr"]
+        self.param_groups[0]["betas"] = tuple(g["betas"])
+        self.param_groups[0]["eps"] = g["eps"]

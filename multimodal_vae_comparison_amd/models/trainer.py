@@ -67,6 +67,41 @@ class MultimodalVAE(nn.Module):
         self.last_losses = loss_d
         return loss_d["loss"]
 
+    # ---- checkpoints -----------------------------------------------------------
+    def save_checkpoint(self, path, epoch=0, global_step=0):
+        """Lightning-style `.ckpt` with the reference's key names (`model.vaes.mod_k.enc...`, `model._pz_params.1`;
+        main.py:46 `ModelCheckpoint`, eval/infer.py:26 `load_from_checkpoint`): `state_dict` of the wrapped mixer
+        under the `model.` prefix, `optimizer_states` in torch.optim.Adam(amsgrad) layout, `hyper_parameters`."""
+        sd = {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        ckpt = {"epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "1.9.5",
+                "state_dict": sd, "loops": {}, "callbacks": {}, "lr_schedulers": [],
+                "optimizer_states": [self.optimizer.state_dict()] if self.optimizer is not None else [],
+                "hyper_parameters": {"cfg": self.config, "feature_dims": self.feature_dims}}
+        if self.optimizer is not None:
+            for st in ckpt["optimizer_states"][0]["state"].values():
+                for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                    st[k] = st[k].cpu()
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path_or_ckpt, strict=True):
+        """Load a checkpoint written by the reference's Lightning trainer (or by save_checkpoint): parameters are copied
+        INTO the flat buffer views (the flat layout, the captured graph and the optimiser stay valid); optimiser state
+        too when present.  Buffers the reference stores but this package recomputes (`pe`) are ignored."""
+        ckpt = torch.load(path_or_ckpt, map_location="cpu", weights_only=False) if isinstance(path_or_ckpt, str) else path_or_ckpt
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
+        own = self.model.state_dict()
+        missing = [k for k, _ in self.model.named_parameters() if k not in sd]
+        if strict and missing:
+            raise KeyError(f"checkpoint lacks parameters: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own and own[k].shape == v.shape:
+                    own[k].copy_(v)                       # state_dict() tensors alias the flat views
+        if self.optimizer is not None and ckpt.get("optimizer_states"):
+            self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        return ckpt.get("epoch", 0), ckpt.get("global_step", 0)
+
     # ---- MI355X fast path ------------------------------------------------------------------------
     def capture(self, batch, world_size=1):
         """Capture objective + backward (+ the Adam step when there is no collective between them, world_size 1) for

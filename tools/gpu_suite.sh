@@ -21,4 +21,5 @@ run tests/test_parity_e2e.py -k graph_replay
 run tests/test_parity_e2e.py -k dropout
 run tests/test_parity_e2e.py -k three_modalities
 run tests/test_parity_e2e.py -k captured_step_every_mixer
+run tests/test_parity_e2e.py -k checkpoint_round_trip
 grep -E "^===|passed|failed|error|exit=" $LOG | tail -60
