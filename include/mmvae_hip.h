@@ -379,6 +379,14 @@ int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float*
                         const mmvae_txt_layer_grads_t* grads, const mmvae_txt_layer_drop_t* drop, int L, int N, int D,
                         int FF, int NH, int dec, int time_mean, mmvae_stream_t stream);
 
+/* Input expansion on the device (the step in front of the path): bit-identical to the reference's
+ * host-side `torch.tensor(uint8) / 255` (models/datasets.py:251-254) and `one_hot_encode` + `lengths_to_mask`
+ * (utils.py:414-421, :239; models/datasets.py:272-281).  tokens (B,T) int32, -1 = character outside the alphabet (zero
+ * row); lengths (B); onehot (B,T,V) fp32; mask (B,T) bytes, may be NULL. */
+int mmvae_expand_image_u8(const uint8_t* src, float* dst, long n, mmvae_stream_t stream);
+int mmvae_expand_text_tokens(const int32_t* tokens, const int32_t* lengths, float* onehot, uint8_t* mask, int B, int T,
+                             int V, mmvae_stream_t stream);
+
 /* y[t,b,:] = dropout(x[t,b,:] + pe[t,:]) -- Enc_Transformer / Dec_Transformer positional encoding
  * (models/encoders.py:721-723, models/decoders.py:607-608; PositionalEncoding try-branch nn_modules.py:430-438).
  * x may be NULL (time queries PE(zeros)).  Backward: mmvae_dropout_act_bwd with MMVAE_ACT_NONE. */

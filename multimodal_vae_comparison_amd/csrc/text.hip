@@ -656,3 +656,58 @@ extern "C" int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L,
                      N, H, hd, 1, drop_arg(drop));
   return mmvae_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Input expansion on the device (the step in front of the path).  The reference's datasets hold
+// fp32 images `torch.tensor(uint8) / 255` (models/datasets.py:251-254) and fp32 one-hot text with a mask column
+// (`one_hot_encode`, utils.py:414-421; `lengths_to_mask`, utils.py:239; models/datasets.py:272-281): 49 KB + 3.5 KB per
+// sample over PCIe.  Shipping the uint8 pixels and one token id per character (12 KB + 0.13 KB) and expanding here is
+// bit-identical and a quarter of the host traffic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n && (((uintptr_t)(src + i)) & 3) == 0 && (((uintptr_t)(dst + i)) & 15) == 0) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(src + i);
+      float4 o;      // IEEE division, as torch's true_divide of the converted value
+      o.x = __fdiv_rn((float)(w & 255u), 255.0f);
+      o.y = __fdiv_rn((float)((w >> 8) & 255u), 255.0f);
+      o.z = __fdiv_rn((float)((w >> 16) & 255u), 255.0f);
+      o.w = __fdiv_rn((float)(w >> 24), 255.0f);
+      *reinterpret_cast<float4*>(dst + i) = o;
+    } else {
+      for (long j = i; j < n && j < i + 4; ++j) dst[j] = __fdiv_rn((float)src[j], 255.0f);
+    }
+  }
+}
+extern "C" int mmvae_expand_image_u8(const uint8_t* src, float* dst, long n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(src && dst && n > 0);
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(expand_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  return mmvae_launch_status();
+}
+// tokens (B,T) int32: character index in the alphabet, -1 = not in the alphabet (an all-zero row, as one_hot_encode);
+// lengths (B): characters per sample.  onehot (B,T,V) fp32, mask (B,T) bytes (1 = data, 0 = padding).
+__global__ __launch_bounds__(256) void expand_tokens_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ len,
+                                                            float* __restrict__ onehot, uint8_t* __restrict__ mask,
+                                                            int B, int T, int V) {
+  const long n = (long)B * T * V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % V);
+    const long bt = i / V;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const bool in = t < len[b];
+    onehot[i] = (in && tok[bt] == v) ? 1.0f : 0.0f;
+    if (v == 0 && mask) mask[bt] = in ? 1 : 0;
+  }
+}
+extern "C" int mmvae_expand_text_tokens(const int32_t* tokens, const int32_t* lengths, float* onehot, uint8_t* mask,
+                                        int B, int T, int V, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(tokens && lengths && onehot && B > 0 && T > 0 && V > 0);
+  long blocks = ((long)B * T * V + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(expand_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tokens, lengths,
+                     onehot, mask, B, T, V);
+  return mmvae_launch_status();
+}

@@ -84,6 +84,8 @@ SIGNATURES = {
     "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_p]),
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_expand_image_u8": (c_i, [c_p, c_p, c_l, c_p]),
+    "mmvae_expand_text_tokens": (c_i, [c_p] * 4 + [c_i] * 3 + [c_p]),
     "mmvae_randn": (c_i, [c_p, c_l, c_p, c_p]),
     "mmvae_debug_timestamp": (c_i, [c_p, c_p]),
     "mmvae_debug_spin": (c_i, [c_p, ctypes.c_longlong, c_p]),

@@ -180,6 +180,27 @@ class MultimodalVAE(nn.Module):
                 if v[kk] is not None:
                     self._static_batch[k][kk].copy_(v[kk], non_blocking=True)
 
+    def load_batch_compact(self, compact):
+        """Like load_batch, from the compact host representation: per modality either
+        `{"u8": uint8 tensor}` (image bytes, expanded to fp32 / 255 on the device) or `{"tokens": (B,T) int32,
+        "lengths": (B,) int32}` (expanded to the one-hot tensor and the mask), a quarter of the PCIe traffic of the
+        reference's fp32 batch; anything else is treated as load_batch would."""
+        from .. import ops
+        for k, v in compact.items():
+            dst = self._static_batch[k]
+            if "u8" in v:
+                src = v["u8"].to(dst["data"].device, non_blocking=True)
+                ops.expand_image_u8(src.contiguous(), dst["data"])
+            elif "tokens" in v:
+                dev = dst["data"].device
+                tok = v["tokens"].to(dev, non_blocking=True).contiguous()
+                ln = v["lengths"].to(dev, non_blocking=True).contiguous()
+                m = dst["masks"]
+                mu8 = m.view(torch.uint8) if m is not None and m.dtype == torch.bool else m
+                ops.expand_text_tokens(tok, ln, dst["data"], mu8)
+            else:
+                self.load_batch({k: v})
+
     def fused_step(self, world_size=1):
         """one optimisation step on the static batch: graph replay -> (all-reduce) -> fused Adam"""
         self._graph.replay()

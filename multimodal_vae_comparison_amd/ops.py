@@ -1620,5 +1620,22 @@ def randn(shape, state):
     return out
 
 
+def expand_image_u8(src_u8, dst):
+    """dst (fp32, same numel) = src_u8 / 255, bit-identical to torch's true division of the converted bytes"""
+    assert src_u8.dtype == torch.uint8 and dst.dtype == torch.float32 and src_u8.numel() == dst.numel()
+    assert src_u8.is_contiguous() and dst.is_contiguous()
+    _call("mmvae_expand_image_u8", H.ptr(src_u8), H.ptr(dst), dst.numel(), H.stream())
+    return dst
+
+
+def expand_text_tokens(tokens, lengths, onehot, mask_u8=None):
+    """tokens (B,T) int32 (-1 = outside the alphabet), lengths (B) int32 -> onehot (B,T,V) fp32, mask (B,T) bytes"""
+    assert tokens.dtype == torch.int32 and lengths.dtype == torch.int32 and onehot.dtype == torch.float32
+    B, T, V = onehot.shape
+    assert tokens.shape == (B, T) and lengths.shape == (B,) and tokens.is_contiguous() and onehot.is_contiguous()
+    _call("mmvae_expand_text_tokens", H.ptr(tokens), H.ptr(lengths), H.ptr(onehot), H.ptr(mask_u8), B, T, V, H.stream())
+    return onehot
+
+
 def fill(t, value):
     _call("mmvae_fill", H.ptr(t), t.numel(), float(value), H.stream())

@@ -128,6 +128,34 @@ def test_linear_small_batch_paths(ops, M, K, N, act):
         check(gb - 1 if preset else bg.grad, br.grad, 5e-5, "db")
 
 
+def test_input_expansion_bit_exact(ops):
+    """uint8 pixels / 255 and token ids -> one-hot + mask on the device, bit-identical to the
+    reference's host preprocessing (torch.tensor(uint8) / 255; one_hot_encode + lengths_to_mask)"""
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (7, 3, 64, 64), generator=g, dtype=torch.uint8)
+    u8.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)          # every byte value
+    ref = u8 / 255
+    out = ops.expand_image_u8(u8.to(DEV), torch.empty(7, 3, 64, 64, device=DEV))
+    assert torch.equal(out.cpu(), ref)
+    odd = u8.view(-1)[1:1 + 1001].clone()                             # unaligned source, length not a multiple of 4
+    out = ops.expand_image_u8(odd.to(DEV), torch.empty(1001, device=DEV))
+    assert torch.equal(out.cpu(), odd / 255)
+    B, T, V = 9, 13, 27
+    tok = torch.randint(-1, V, (B, T), generator=g, dtype=torch.int32)
+    lens = torch.randint(0, T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    oh = torch.full((B, T, V), 7.0, device=DEV)
+    mask = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    ops.expand_text_tokens(tok.to(DEV), lens.to(DEV), oh, mask.view(torch.uint8))
+    mref = torch.arange(T)[None, :] < lens[:, None]
+    ohref = torch.zeros(B, T, V)
+    for b in range(B):
+        for t in range(int(lens[b])):
+            if tok[b, t] >= 0:
+                ohref[b, t, tok[b, t]] = 1.0
+    assert torch.equal(oh.cpu(), ohref) and torch.equal(mask.cpu(), mref)
+
+
 def test_head_softmax(ops):
     g = torch.Generator().manual_seed(1)
     h = torch.randn(37, 2 * 42, generator=g)

@@ -70,3 +70,13 @@ with torch.no_grad():
         out[f"linear fwd M={M} K={K} N={N}"] = (us, 2.0 * M * K * N / us / 1e6)
 for k, v in out.items():
     print(f"{k:48s} {v[0]:10.2f} us" + (f"   {v[1]:8.2f} TFLOP/s" if v[1] else ""))
+# input expansion on the device
+for B in batches:
+    u8 = torch.randint(0, 256, (B, 3, 64, 64), dtype=torch.uint8, device=dev)
+    img = torch.empty(B, 3, 64, 64, device=dev)
+    tok = torch.randint(0, 27, (B, 32), dtype=torch.int32, device=dev)
+    ln = torch.full((B,), 32, dtype=torch.int32, device=dev)
+    oh = torch.empty(B, 32, 27, device=dev)
+    mk = torch.empty(B, 32, dtype=torch.uint8, device=dev)
+    us = timeit(lambda: (ops.expand_image_u8(u8, img), ops.expand_text_tokens(tok, ln, oh, mk)))
+    print(f"{'input expansion (u8 image + tokens) B=' + str(B):48s} {us:10.2f} us   {(5 * u8.numel() + 4 * oh.numel()) / us / 1e3:8.2f} GB/s")
