@@ -406,19 +406,26 @@ class MOE(TorchMMVAE):
         return self.encode(mods)
 
     def forward(self, x, K=1):
-        """mmvae_models.py:80-117 (all modalities present)"""
+        """mmvae_models.py:80-117, including the cross-generation calls with missing modalities
+        (`data` None, masks kept: models/trainer.py:179-215): a missing modality takes the latent sample of the FIRST
+        present one (the reference aliases that modality's dict, :105-108) and is decoded from it under its own masks;
+        every target's cross entry is a fresh one-entry dict, so the last source in dict order wins (:109-114)."""
         missing, filled = self.get_missing_modalities(x)
         assert len(filled) > 0, "at least one modality must be present for forward call"
-        if missing:
-            raise NotImplementedError("moe.forward with missing modalities is not on the MI355X path yet")
         qz, zs, px, cross = {}, {}, {}, {}
         for m, vae in self.vaes.items():
+            if x[m]["data"] is None:
+                qz[m] = None
+                continue
             mu, lv = vae.enc(x[m])
             qz[m] = normal(mu, lv)
             eps = torch.stack([self._draw(mu.shape[0], mu.shape[1], mu.device) for _ in range(K)])
             zs[m] = {"latents": mu + lv * eps, "masks": x[m]["masks"]}
+        for m in missing:
+            zs[m] = {"latents": zs[filled[0]]["latents"], "masks": x[m]["masks"]}
+        zs = {m: zs[m] for m in self.vaes}                     # modality order, as the reference's dict
         for m, vae in self.vaes.items():
-            px[m] = normal(*vae.dec(zs[m]))
+            px[m] = normal(*vae.dec({"latents": zs[m]["latents"], "masks": x[m]["masks"]}))
         for src, z in zs.items():
             for tgt, vae in self.vaes.items():
                 if tgt != src:

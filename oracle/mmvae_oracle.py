@@ -727,6 +727,38 @@ def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
     return {"loss": loss, "kld": kld, "reconstruction_loss": lpx, "_rows": torch.stack(rows), "_z": zs, "_enc": enc}
 
 
+def moe_forward(p, mods, batch, eps, n_latents, train=False):
+    """MOE.forward (K = 1) with missing modalities, models/mmvae_models.py:80-117 -- what `save_reconstructions`
+    (models/trainer.py:179-215) calls for cross-generation.  `batch[m]["data"]` is None for a missing modality (its
+    masks stay); `eps`: one recorded draw per PRESENT modality, in modality order.
+
+    Present m: q_m = Normal(mu, lv as sigma), z_m = rsample, px_m = dec_m(z_m, masks_m).  Missing m (:105-108):
+    zs[m] IS the dict of the first present modality f -- the same object, whose masks are overwritten with masks_m --
+    and px_m = dec_m(z_f, masks_m).  Cross (:109-114): for every source s in dict order and every target t != s,
+    cross[t] = {s: dec_t(z_s, masks_t)} -- a fresh one-entry dict, so the LAST source wins.
+    Returns (q [None for missing], z [per modality], px, cross {t: (s, loc)})."""
+    M = len(mods)
+    present = [i for i in range(M) if batch[f"mod_{i + 1}"]["data"] is not None]
+    assert present, "at least one modality must be present for forward call"
+    q, z = [None] * M, [None] * M
+    for j, i in enumerate(present):
+        mu, sig = encode(p, mods, i, batch[f"mod_{i + 1}"], train)
+        q[i] = (mu, sig)
+        z[i] = mu + sig * eps[j].reshape(-1, mu.shape[0], n_latents)
+    f = present[0]
+    for i in range(M):
+        if z[i] is None:
+            z[i] = z[f]
+    masks = [batch[f"mod_{i + 1}"]["masks"] for i in range(M)]
+    px = [decode(p, mods, i, z[i], masks[i], train) for i in range(M)]
+    cross = {}
+    for s in range(M):
+        for t in range(M):
+            if t != s:
+                cross[t] = (s, decode(p, mods, t, z[s], masks[t], train))
+    return q, z, px, cross
+
+
 def dmvae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
     """DMVAE.forward + objective, models/mmvae_models.py:436-503 (all modalities present, K = 1).
 

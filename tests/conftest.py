@@ -17,7 +17,13 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """objective fixtures (make_golden.py)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("fwd_"))
+
+
+def forward_cases():
+    """inference forward() with missing modalities (make_golden_forward.py)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("fwd_"))
 
 
 def load_golden(name):

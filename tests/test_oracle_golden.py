@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import forward_cases, golden_cases, load_golden
 from oracle import golden_weights as gw
 from oracle import mmvae_oracle as orc
 
@@ -92,3 +92,30 @@ def test_chunk_bounds():
     # ... and on the singleton axis the reference actually hands it: everything goes to the last subset
     assert orc.chunk_bounds(3, 1) == [0, 0, 0, 1]
     assert orc.chunk_bounds(7, 1) == [0] * 7 + [1]
+
+
+@pytest.mark.parametrize("name", forward_cases())
+def test_forward_with_missing_modalities_matches_reference(name):
+    """MOE.forward with all / only one modality present (the cross-generation calls of
+    models/trainer.py:179-215), the oracle against the reference's own outputs"""
+    meta, g = load_golden(name)
+    shapes = orc.model_param_shapes(meta["mods"], meta["D"])
+    p = gw.make_params(shapes, meta["seed"])
+    full = _batch(g)
+    for ci, present in enumerate(meta["present"]):
+        batch = {k: dict(v, data=v["data"] if i in present else None) for i, (k, v) in enumerate(full.items())}
+        eps = [torch.from_numpy(g[f"c{ci}/eps_{i}"]) for i in range(int(g[f"c{ci}/n_eps"]))]
+        assert len(eps) == len(present)
+        with torch.no_grad():
+            q, z, px, cross = orc.moe_forward(p, meta["mods"], batch, eps, meta["D"])
+        for m in range(len(meta["mods"])):
+            assert (q[m] is not None) == bool(g[f"c{ci}/has_q_{m}"]) == (m in present)
+            if q[m] is not None:
+                _close(q[m][0], g[f"c{ci}/q_mu_{m}"], 1e-5, f"c{ci} q_mu_{m}")
+                _close(q[m][1], g[f"c{ci}/q_sigma_{m}"], 1e-5, f"c{ci} q_sigma_{m}")
+            _close(z[m], g[f"c{ci}/z_{m}"], 1e-5, f"c{ci} z_{m}")
+            assert tuple(px[m].shape) == tuple(g[f"c{ci}/px_shape_{m}"])
+            _close(gw.summarize(px[m], 256), g[f"c{ci}/px_{m}"], 1e-5, f"c{ci} px_{m}")
+        for t, (s_, loc) in cross.items():
+            _close(gw.summarize(loc, 256), g[f"c{ci}/cross_{t}_from_{s_}"], 1e-5, f"c{ci} cross_{t}_from_{s_}")
+        assert {k for k in g if k.startswith(f"c{ci}/cross_")} == {f"c{ci}/cross_{t}_from_{s_}" for t, (s_, _) in cross.items()}

@@ -23,4 +23,5 @@ run tests/test_parity_e2e.py -k three_modalities
 run tests/test_parity_e2e.py -k captured_step_every_mixer
 run tests/test_parity_e2e.py -k checkpoint_round_trip
 run tests/test_parity_e2e.py -k load_batch_compact
+run tests/test_parity_e2e.py -k forward_with_missing
 grep -E "^===|passed|failed|error|exit=" $LOG | tail -60
