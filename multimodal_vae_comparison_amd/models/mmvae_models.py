@@ -506,4 +506,44 @@ class DMVAE(TorchMMVAE):
         return self.encode(mods)
 
     def forward(self, x, K=1):
-        raise NotImplementedError("dmvae.forward (inference container) is not on the MI355X path yet; objective() is")
+        """mmvae_models.py:467-503: the container the evaluation code reads (shared / private posteriors, joint
+        posterior, own / joint / cross reconstructions), missing modalities (`data` None, masks kept) included: the
+        joint is the product of the PRESENT shared experts; a missing modality samples its shared code from the first
+        present modality's posterior and its private code from N(0, I) (:489-493); cross reconstructions from a fresh
+        shared draw of every other present modality (:499-502).  Noise in the reference's draw order."""
+        if K != 1:
+            raise NotImplementedError("dmvae.forward: K = 1 only on this path")
+        missing, filled = self.get_missing_modalities(x)
+        assert len(filled) > 0, "at least one modality must be present for forward call"
+        D = self.n_latents
+        enc_d = self.encode(x)
+        mu_j, var_j = self.product_of_experts([enc_d[n]["shared"][0] for n in filled],
+                                              [enc_d[n]["shared"][1] for n in filled])
+        B, dev = mu_j.shape[0], mu_j.device
+        draw = lambda d: self._draw(B, d, dev).unsqueeze(0)
+        joint_d = normal(mu_j, var_j)
+        z_joint = mu_j + var_j * draw(D)
+        joint_dist, qz_xs, qz_private, zss, px_zs, joint_px_zs, cross_px_zs = {}, {}, {}, {}, {}, {}, {}
+        for n, vae in self.vaes.items():
+            present = n in filled
+            joint_dist[n] = joint_d
+            qz_xs[n] = normal(*enc_d[n]["shared"]) if present else None
+            qz_private[n] = normal(*enc_d[n]["private"]) if present else None
+            s_mu, s_lv = enc_d[n if present else filled[0]]["shared"]
+            z_shared = s_mu + s_lv * draw(D)
+            if present:
+                p_mu, p_lv = enc_d[n]["private"]
+                z_private = p_mu + p_lv * draw(vae.private_latents)
+            else:
+                z_private = draw(vae.private_latents)
+            masks = x[n]["masks"]
+            dec = lambda z: normal(*vae.dec({"latents": torch.cat([z, z_private], -1), "masks": masks}))
+            zss[n] = {"latents": z_shared, "masks": masks}
+            px_zs[n] = dec(z_shared)
+            joint_px_zs[n] = dec(z_joint)
+            cross_px_zs[n] = {}
+            for m in filled:
+                if m != n:
+                    c_mu, c_lv = enc_d[m]["shared"]
+                    cross_px_zs[n][m] = dec(c_mu + c_lv * draw(D))
+        return self.make_output_dict(qz_xs, px_zs, zss, joint_dist, qz_private, None, joint_px_zs, cross_px_zs)

@@ -808,6 +808,42 @@ def dmvae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
             "_joint": (j_mu, j_var), "_inter": inter}
 
 
+def dmvae_forward(p, mods, batch, eps, n_latents, train=False):
+    """DMVAE.forward (K = 1) with missing modalities, models/mmvae_models.py:467-503 (the container the evaluation code
+    reads; `batch[m]["data"]` None = missing, masks kept).  joint = product of the PRESENT shared experts (:477-479).
+    Draw order: z_joint; then per modality z_shared -- a missing modality draws from the FIRST present modality's shared
+    posterior (:489-490) --, z_private -- a missing one from N(0, I) (:491-493) --, and one fresh shared draw of every
+    OTHER PRESENT modality for the cross reconstructions (:499-502).
+    Returns per modality: q_shared, q_private (None if missing), z_shared, px, joint_px, cross {src: loc}; and joint."""
+    M, D = len(mods), n_latents
+    present = [i for i in range(M) if batch[f"mod_{i + 1}"]["data"] is not None]
+    enc = {i: encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in present}
+    B = enc[present[0]][0].shape[0]
+    sh = {i: (enc[i][0][:, :D], enc[i][1][:, :D]) for i in present}
+    pr = {i: (enc[i][0][:, D:], enc[i][1][:, D:]) for i in present}
+    j_mu, j_var = product_of_experts(torch.stack([sh[i][0] for i in present]), torch.stack([sh[i][1] for i in present]))
+    it = iter(eps)
+    nxt = lambda d: next(it).reshape(1, B, d)
+    z_joint = j_mu + j_var * nxt(D)
+    out = []
+    for i in range(M):
+        mask = batch[f"mod_{i + 1}"]["masks"]
+        P = int(mods[i]["private"])
+        src = i if i in present else present[0]
+        z_sh = sh[src][0] + sh[src][1] * nxt(D)
+        z_pr = (pr[i][0] + pr[i][1] * nxt(P)) if i in present else nxt(P)
+        dec = lambda z: decode(p, mods, i, torch.cat([z, z_pr], -1), mask, train)
+        px, jpx = dec(z_sh), dec(z_joint)
+        cross = {}
+        for m in present:
+            if m != i:
+                cross[m] = dec(sh[m][0] + sh[m][1] * nxt(D))
+        out.append({"q_shared": sh.get(i), "q_private": pr.get(i), "z_shared": z_sh, "px": px, "joint_px": jpx,
+                    "cross": cross})
+    assert next(it, None) is None, "unused noise draws"
+    return out, (j_mu, j_var)
+
+
 OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective, "moe": moe_objective, "dmvae": dmvae_objective}
 
 
