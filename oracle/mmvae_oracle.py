@@ -382,7 +382,7 @@ def dec_mnist(p, pre, z, data_dim=(28, 28, 1)):
     d = x.reshape(*z.shape[:-1], *data_dim)
     if d.dim() == 5:
         d = d.squeeze(0)
-    return d.permute(0, 3, 1, 2)
+    return d.permute(0, 3, 1, 2) if d.dim() == 4 else d.permute(0, 1, 4, 2, 3)      # K > 1 keeps (K,B,...)
 
 
 def enc_svhn(p, pre, x):
@@ -404,7 +404,10 @@ def dec_svhn(p, pre, z):
     h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv2.weight"], p[f"{pre}.dec.conv2.bias"], stride=2, padding=1))
     h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv3.weight"], p[f"{pre}.dec.conv3.bias"], stride=2, padding=1))
     h = F.conv_transpose2d(h, p[f"{pre}.dec.conv4.weight"], p[f"{pre}.dec.conv4.bias"], stride=2, padding=1)
-    return torch.sigmoid(h).permute(0, 2, 3, 1)
+    d = torch.sigmoid(h).permute(0, 2, 3, 1)
+    if z.dim() == 3 and z.shape[0] > 1:                 # K > 1: (K,B,32,32,3), decoders.py:119,145-146
+        d = d.reshape(z.shape[0], z.shape[1], *d.shape[1:])
+    return d
 
 
 def enc_transformer(p, pre, data, mask, train=False):
@@ -692,7 +695,85 @@ def normal_log_prob(z, mu, sigma):
     return -((z - mu) ** 2) / (2 * sigma ** 2) - sigma.log() - math.log(math.sqrt(2 * math.pi))
 
 
-def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+def laplace_log_prob(z, mu, scale):
+    """torch.distributions.Laplace.log_prob"""
+    return -torch.log(2 * scale) - torch.abs(z - mu) / scale
+
+
+def kl_laplace_normal(mu_q, scale_q, mu_p, sig_p):
+    """torch.distributions.kl._kl_laplace_normal: KL(Laplace(mu_q, scale_q) || Normal(mu_p, sig_p)), reached through
+    utils.kl_divergence (utils.py:399-402) when the config says `prior: laplace` -- the POSTERIOR is then a Laplace
+    (models/trainer.py:104) while MOE.objective still builds its prior with the model-level `self.pz` = Normal
+    (models/mmvae_base.py:31, models/mmvae_models.py:45)"""
+    var_n = sig_p ** 2
+    ratio = scale_q ** 2 / var_n
+    t1 = 0.5 * torch.log(2 * ratio / math.pi)
+    return -t1 + ratio + (0.5 * mu_q ** 2 - mu_q * mu_p + 0.5 * mu_p ** 2) / var_n - 1
+
+
+def resolve_llik_scaling(mods):
+    """TorchMMVAE.set_likelihood_scales, models/mmvae_base.py:41-47: "auto" -> min_m prod(data_dim) / prod(data_dim_m)"""
+    dims = [float(torch.tensor(m["data_dim"]).prod()) for m in mods]
+    return [min(dims) / d if m.get("llik_scaling", 1.0) == "auto" else float(m.get("llik_scaling", 1.0))
+            for m, d in zip(mods, dims)]
+
+
+def recon_lprob_k(loc, target, K, laplace=False):
+    """recon_loss_fn + reshape_for_loss + ReconLoss.lprob for a K-sample decoder output (objectives.py:30-52,103-125,
+    409-424): the target is repeated K times and reshaped like loc (K,B,...) -- or (B,...) when the decoder squeezed
+    K = 1 away --, bs = loc.shape[0]; returns the positive fp64 loss of shape (loc.shape[0], -1)."""
+    t = target.float().repeat(K, *([1] * (target.dim() - 1))).reshape(loc.shape).detach()
+    sc = torch.full_like(loc, PX_SCALE)
+    lp = laplace_log_prob(t, loc, sc) if laplace else normal_log_prob(t, loc, sc)
+    out = lp.reshape(loc.shape[0], -1).double()
+    return -torch.where(torch.isnan(out), torch.zeros_like(out), out)
+
+
+def moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior="normal", train=False):
+    """MOE.forward + objective with obj "dreg" (the shipped configs/config_mnistsvhn.yml: K = 30, prior laplace,
+    llik_scaling auto), models/mmvae_models.py:32-117 + MultimodalObjective.dreg / _m_dreg_looser
+    (models/objectives.py:361-387).  Two modalities, towers that keep the K axis (MNIST / SVHN), `lprob`.
+
+      q_m = Normal | Laplace(mu_m, scale = lv_m) per the config's `prior`; z_m = q_m.rsample([K]) (K,B,D).
+      own reconstruction: Normal(dec_m(z_m), 0.75) (dist.Normal, :101-103); cross reconstruction of modality t from
+      the other modality's z: `vae.px_z` = the config's `prior` class again (:115).
+      lpx (K,) = sum over batch AND features of log p(x) * llik_scaling (the decoders keep K, so recon_loss_fn's
+      bs is K and `.view(batch_shape[:1], -1).sum(-1)` sums the batch away, :47-48,64-70).
+      lw_r (K,) = sum_b log N(z_r; 0, softmax(theta) D) + lpx_own_r + lpx_cross_r
+                  - sum_b log-mean-exp_m log q_m(z_r)                               (objectives.py:366-373)
+      grad_wt = softmax_K(lw) detached; the hook of objectives.py:382-383 sits on a fresh torch.stack(zss) that
+      nothing consumes, so it never fires.  loss = -(grad_wt * lw).mean(0).sum();  kld = tensor(0);
+      reconstruction_loss = (M, 2, K) [own, cross]."""
+    M = len(mods)
+    assert M == 2, "MOE dreg: the reference's cross-term indexing (mmvae_models.py:64-70) is only meaningful for M = 2"
+    lap = prior == "laplace"
+    logq = laplace_log_prob if lap else normal_log_prob
+    enc = [encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in range(M)]
+    B = enc[0][0].shape[0]
+    zs = [enc[i][0] + enc[i][1] * eps[i].reshape(K, B, n_latents) for i in range(M)]            # (K,B,D)
+    lam = resolve_llik_scaling(mods)
+    sig_p = prior_sigma(p["_pz_params.1"])
+    lws, recs = [], []
+    for r in range(M):
+        o = 1 - r
+        tgt = batch[f"mod_{r + 1}"]["data"]
+        own = decode(p, mods, r, zs[r], None, train)
+        cross = decode(p, mods, r, zs[o], None, train)
+        lpx_own = (-recon_lprob_k(own, tgt, K, False) * lam[r]).sum(-1)
+        lpx_cross = (-recon_lprob_k(cross, tgt, K, lap) * lam[r]).sum(-1)
+        lpz = normal_log_prob(zs[r], 0.0, sig_p).sum(-1)                                       # (K,B)
+        lq = torch.stack([logq(zs[r], enc[m][0], enc[m][1]).sum(-1) for m in range(M)])        # (M,K,B)
+        lqz = torch.logsumexp(lq, 0) - math.log(M)
+        lws.append(lpz.sum(-1) + (lpx_own + lpx_cross) - lqz.sum(-1))
+        recs.append(torch.stack([lpx_own, lpx_cross]))
+    lw = torch.stack(lws)                                                                      # (M,K) fp64
+    with torch.no_grad():
+        grad_wt = (lw - torch.logsumexp(lw, 1, keepdim=True)).exp()
+    return {"loss": -(grad_wt * lw).mean(0).sum(), "kld": torch.tensor(0), "reconstruction_loss": torch.stack(recs),
+            "_lw": lw, "_z": zs, "_enc": enc}
+
+
+def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, obj="elbo", K=1, prior="normal"):
     """MOE.forward + objective (obj "elbo", K = 1), models/mmvae_models.py:32-117.
 
     q_m = Normal(mu_m, lv_m as sigma), z_m = rsample; own decode; cross decode of every target from the LAST other
@@ -700,23 +781,33 @@ def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
     (`vae._pz_params`, models/vae.py:159-162; :45); importance weight exp(log q_r(z_o) - log q_o(z_o).detach()) on
     the cross terms with z_o detached (:56-62); rows [own_1, w_1 cross_1, own_2, ...]; loss = elbo / M (:73-77).
     """
+    if obj == "dreg":
+        return moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior, train)
+    assert obj == "elbo" and K == 1
     M = len(mods)
+    lap = prior == "laplace"      # posterior Laplace(mu, scale = lv), cross likelihood Laplace, KL(Laplace || N(0,1))
     enc = [encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in range(M)]
     B = enc[0][0].shape[0]
     zs = [enc[i][0] + enc[i][1] * eps[i].reshape(-1, B, n_latents) for i in range(M)]     # (1,B,D)
-    lam = [float(m.get("llik_scaling", 1.0)) for m in mods]
+    lam = resolve_llik_scaling(mods)
     rows, klds = [], []
     own = [decode(p, mods, i, zs[i], batch[f"mod_{i + 1}"]["masks"], train) for i in range(M)]
     cross_src = [[s for s in range(M) if s != t][-1] for t in range(M)]
     cross = [decode(p, mods, t, zs[cross_src[t]], batch[f"mod_{t + 1}"]["masks"], train) for t in range(M)]
     for r in range(M):
         mu, sig = enc[r]
-        klds.append(kl_normal(mu, sig, 0.0, torch.ones(1, n_latents)).sum(-1))
+        one = torch.ones(1, n_latents)
+        klds.append((kl_laplace_normal(mu, sig, 0.0 * one, one) if lap else kl_normal(mu, sig, 0.0, one)).sum(-1))
         lpx_own = (-recon_loss(mods[r]["ltype"], own[r], batch[f"mod_{r + 1}"]) * lam[r]).sum(-1)
-        lpx_cross = (-recon_loss(mods[r]["ltype"], cross[r], batch[f"mod_{r + 1}"]) * lam[r]).sum(-1)
+        if lap:      # the cross reconstruction's likelihood is `vae.px_z` = Laplace (mmvae_models.py:115); lprob only
+            assert mods[r]["ltype"] == "lprob" and batch[f"mod_{r + 1}"]["masks"] is None
+            lpx_cross = (-recon_lprob(cross[r], batch[f"mod_{r + 1}"]["data"], None, True) * lam[r]).sum(-1)
+        else:
+            lpx_cross = (-recon_loss(mods[r]["ltype"], cross[r], batch[f"mod_{r + 1}"]) * lam[r]).sum(-1)
         o = cross_src[r]
         z_o = zs[o].detach()
-        lwt = (normal_log_prob(z_o, mu, sig) - normal_log_prob(z_o, enc[o][0], enc[o][1]).detach()).sum(-1).reshape(-1)
+        logq = laplace_log_prob if lap else normal_log_prob
+        lwt = (logq(z_o, mu, sig) - logq(z_o, enc[o][0], enc[o][1]).detach()).sum(-1).reshape(-1)
         rows.append(lpx_own)
         rows.append(lwt.exp() * lpx_cross)
     # `lp.sum() != 0` filter (:73): rows whose importance weight underflowed to exactly 0 are DROPPED, which also

@@ -71,12 +71,33 @@ CASES += [
 ]
 
 
-def build_reference(mixing, D, beta, private=None, mods=None):
+# the shipped configs/config_mnistsvhn.yml path: MoE with obj dreg, K > 1, prior laplace, llik_scaling auto
+# (`prior` also selects the posterior and the cross-reconstruction likelihood, models/trainer.py:104)
+MS_AUTO = [dict(m, llik_scaling="auto") for m in MS]
+CASE_OPTS = {
+    "moe_ms_b5_d8_dreg_k3_laplace": {"obj": "dreg", "K": 3, "prior": "laplace"},
+    "moe_ms_b4_d20_dreg_k30_laplace": {"obj": "dreg", "K": 30, "prior": "laplace"},
+    "moe_ms_b5_d8_dreg_k2_normal": {"obj": "dreg", "K": 2, "prior": "normal"},
+    "moe_ms_b6_d8_elbo_laplace": {"obj": "elbo", "K": 1, "prior": "laplace"},
+}
+for _n in CASE_OPTS:
+    CASE_MODS[_n] = MS_AUTO
+CASES += [
+    ("moe_ms_b5_d8_dreg_k3_laplace", "moe", 5, 0, 8, None, "eval", 1.0),
+    ("moe_ms_b4_d20_dreg_k30_laplace", "moe", 4, 0, 20, None, "eval", 1.0),
+    ("moe_ms_b5_d8_dreg_k2_normal", "moe", 5, 0, 8, None, "eval", 1.0),
+    ("moe_ms_b6_d8_elbo_laplace", "moe", 6, 0, 8, None, "eval", 2.0),
+]
+
+
+def build_reference(mixing, D, beta, private=None, mods=None, obj="elbo", K=1, prior="normal"):
     vaes = {}
     for i, m in enumerate(mods or MODS):
-        vaes[f"mod_{i + 1}"] = VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], private, obj_fn="elbo", beta=beta,
-                                   id_name=f"mod_{i + 1}", llik_scaling=m["llik_scaling"])
-    return getattr(models, mixing)(nn.ModuleDict(vaes), D, {"obj": "elbo", "beta": beta, "K": 1}, {})
+        # prior / posterior / likelihood all follow the config's `prior` key (models/trainer.py:100-105)
+        vaes[f"mod_{i + 1}"] = VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], private, obj_fn=obj, beta=beta,
+                                   id_name=f"mod_{i + 1}", llik_scaling=m["llik_scaling"], prior_dist=prior,
+                                   post_dist=prior, likelihood_dist=prior)
+    return getattr(models, mixing)(nn.ModuleDict(vaes), D, {"obj": obj, "beta": beta, "K": K}, {})
 
 
 def make_batch(B, T, lengths, seed):
@@ -93,7 +114,8 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     private = PRIVATE.get(name)
     base = CASE_MODS.get(name, MODS)
     mods = [dict(m, private=private) for m in base] if private else base
-    model = build_reference(mixing, D, beta, private, mods)
+    opts = CASE_OPTS.get(name, {})
+    model = build_reference(mixing, D, beta, private, mods, **opts)
     shapes = orc.model_param_shapes(mods, D)
     ref_sd = model.state_dict()
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
@@ -135,6 +157,9 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
         out["act"], out["amask"] = act.numpy(), amask.numpy()
     meta = {"name": name, "mixing": mixing, "B": B, "T": T, "D": D, "beta": beta, "seed": seed, "mode": mode,
             "mods": mods, "lr": 1e-4}
+    meta.update(opts)
+    if opts:
+        meta["llik"] = [float(v.llik_scaling) for v in model.vaes.values()]     # "auto" resolved by the reference
 
     order = None
     if mixing == "poe":                     # record the hash-seed dependent subset order (utils.py:98)
@@ -154,7 +179,7 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     out["kld"] = res["kld"].detach().numpy()
     for i, r in enumerate(res["reconstruction_loss"]):
         out[f"rec_{i}"] = r.detach().numpy()
-    if mixing == "moe":      # MoE leaves the trainable model prior untouched: the reference has no gradient for it
+    if mixing == "moe" and opts.get("obj", "elbo") == "elbo":      # MoE leaves the trainable model prior untouched: the reference has no gradient for it
         for k, q in model.named_parameters():
             if q.requires_grad and q.grad is None:
                 q.grad = torch.zeros_like(q)

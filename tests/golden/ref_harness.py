@@ -10,7 +10,9 @@ imports it.  Recipe = SURVEY.md Appendix C:
   * `.cuda()` / `.to("cuda")` -> identity so the reference's hard-coded device moves
     (models/mmvae_models.py:45,51,173,...; models/objectives.py:165,...,406) run on the CPU;
   * recording / replaying of the standard-normal draws behind `Normal.rsample`
-    (torch/distributions/normal.py -> torch.distributions.utils._standard_normal).
+    (torch/distributions/normal.py -> torch.distributions.utils._standard_normal) and of the draws behind
+    `Laplace.rsample` (recorded as the standard-Laplace variate e = -sign(u) log1p(-|u|) of torch's uniform u, so that
+    z = loc + scale * e exactly as for the Normal case).
 """
 import importlib.machinery
 import os
@@ -121,9 +123,38 @@ class EpsTape:
 
         du._standard_normal = rec
         dn._standard_normal = rec
+
+        # Laplace.rsample draws u ~ U(eps - 1, 1) with Tensor.uniform_ and returns loc - scale * sign(u) * log1p(-|u|)
+        # (torch/distributions/laplace.py).  Record: run the original, then redraw the same u from the saved
+        # generator state; replay: loc + scale * e (bit-identical, sign(u) is +-1).
+        import torch.distributions.laplace as dl
+        self._dl = dl
+        self._orig_lap = dl.Laplace.rsample
+        tape = self
+
+        def lap_rsample(d, sample_shape=torch.Size()):
+            shape = d._extended_shape(sample_shape)
+            if tape.replay is not None:
+                e = tape.replay.pop(0)
+                assert tuple(e.shape) == tuple(shape), (e.shape, shape)
+                tape.draws.append(e.detach().clone())
+                return d.loc + d.scale * e.to(d.loc.dtype)
+            st = torch.get_rng_state()
+            out = tape._orig_lap(d, sample_shape)
+            end = torch.get_rng_state()
+            torch.set_rng_state(st)
+            u = d.loc.new(shape).uniform_(torch.finfo(d.loc.dtype).eps - 1, 1)
+            torch.set_rng_state(end)
+            e = -(u.sign() * torch.log1p(-u.abs()))
+            assert torch.equal(d.loc + d.scale * e, out)
+            tape.draws.append(e.detach().clone())
+            return out
+
+        dl.Laplace.rsample = lap_rsample
         return self
 
     def __exit__(self, *exc):
         self._du._standard_normal = self._orig
         self._dn._standard_normal = self._orig
+        self._dl.Laplace.rsample = self._orig_lap
         return False

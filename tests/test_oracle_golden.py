@@ -26,6 +26,9 @@ def _run(meta, g):
     p = gw.make_params(shapes, meta["seed"], requires_grad=True)
     eps = [torch.from_numpy(g[f"eps_{i}"]) for i in range(meta["n_eps"])]
     kw = {"order": meta["order"]} if meta["mixing"] == "poe" else {}
+    if "obj" in meta:       # MoE dreg / K > 1 / prior laplace / llik_scaling auto (configs/config_mnistsvhn.yml)
+        kw.update(obj=meta["obj"], K=meta["K"], prior=meta["prior"])
+        assert orc.resolve_llik_scaling(meta["mods"]) == pytest.approx(meta["llik"], rel=1e-12)
     out = orc.OBJECTIVES[meta["mixing"]](p, meta["mods"], _batch(g), eps, meta["D"], beta=meta["beta"], **kw)
     return p, out
 
