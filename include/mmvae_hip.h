@@ -264,11 +264,16 @@ int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float
 /* ReconLoss.lprob (models/objectives.py:409-424): row[b] = sum_f -log p(target[b,f]) under Normal (laplace = 0) or
  * Laplace(loc[b,f], scale); elements in fp32, the row sum in fp64 (the reference sums the elements as doubles), NaN
  * elements count 0 and get zero gradient.  scale <= 0: scale := loc (BaseObjective.recon_loss_fn, objectives.py:43-45,
- * when the modality has masks). */
-int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F, float scale,
-                           int laplace, mmvae_stream_t stream);
+ * when the modality has masks).  target_rows: the target has that many rows and row b of loc is compared with target
+ * row b % target_rows -- the K-sample case, where the reference repeats the target K times
+ * (BaseObjective.reshape_for_loss, objectives.py:118-120); target_rows == B otherwise.  lap_block_rows > 0: `laplace`
+ * is a bit mask over consecutive blocks of that many rows (bit j: rows [j, j+1) * lap_block_rows are Laplace) -- one
+ * launch for a decoder pass whose own / cross reconstructions carry different likelihood families (MoE,
+ * models/mmvae_models.py:101-103 vs :115); 0: `laplace` is the flag for every row. */
+int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F, int target_rows,
+                           float scale, int laplace, int lap_block_rows, mmvae_stream_t stream);
 int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, const float* g_row, float* dloc, int B, int F,
-                           float scale, int laplace, mmvae_stream_t stream);
+                           int target_rows, float scale, int laplace, int lap_block_rows, mmvae_stream_t stream);
 /* ReconLoss.optimal_sigma (models/objectives.py:503-509) + utils.softclip (utils.py:66-69): one log sigma per call
  * from the mean squared error over all B*F elements; row[b] = sum_f ((t-x)/sigma)^2 + F (log sigma + log sqrt(2 pi)).
  * stats (3 floats, written by fwd, read by bwd) = {mean square, log sigma, unclipped log sigma}.  Gradient flows only
@@ -311,6 +316,71 @@ int mmvae_moe_elbo_fwd(const float* rows, const float* W_host, const float* kld,
                        float beta, mmvae_stream_t stream);
 int mmvae_moe_elbo_bwd(const float* g, const float* out, const float* W_host, float* drows, float* dkld, int n_rows,
                        int M, int B, float beta, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MoE with K samples per posterior + the DReG objective: the shipped configs/config_mnistsvhn.yml (mixing moe,
+ * obj dreg, K 30, prior laplace).  Replaces MOE.forward's `q_m.rsample([K])` (models/mmvae_models.py:96-100),
+ * the non-elbo branch of MOE.objective (:63-78) and MultimodalObjective.dreg / _m_dreg_looser
+ * (models/objectives.py:361-387).
+ *   packed[m] (B, 2D) = [mu_m | scale_m] head outputs (softmax + 1e-6 already applied); laplace[m] != 0: q_m is a
+ *   Laplace (the config's `prior` key also selects the posterior family, models/trainer.py:104), else a Normal.
+ *   eps[m] (K,B,D): standard Normal / Laplace variates (mmvae_randn / mmvae_rand_laplace);  z[m] (K,B,D) out.
+ *   lat (M,K,B)   = sum_d log N(z_r[k,b]; 0, softmax(theta) D) - log-mean-exp_m sum_d log q_m(z_r[k,b])
+ *   pi  (M,K,B,M) = softmax_m of those row sums (saved for the backward pass).
+ * bwd: dlat (M,K,B), dz[m] (K,B,D) or NULL -> dpacked[m] (B,2D) [written], dtheta_rows (B,D) [row b = sample b's
+ *   contribution to d theta; the caller folds the rows; NULL = not wanted].  D <= 256, 2 <= M <= 4.
+ * ---------------------------------------------------------------------------------------------- */
+#define MMVAE_MOE_MAX_MODS 4
+typedef struct {
+  const float* packed[MMVAE_MOE_MAX_MODS];
+  const float* eps[MMVAE_MOE_MAX_MODS];
+  float* z[MMVAE_MOE_MAX_MODS];
+  int laplace[MMVAE_MOE_MAX_MODS];
+} mmvae_moe_k_args;
+typedef struct {
+  const float* packed[MMVAE_MOE_MAX_MODS];
+  const float* eps[MMVAE_MOE_MAX_MODS];
+  const float* z[MMVAE_MOE_MAX_MODS];
+  const float* dz[MMVAE_MOE_MAX_MODS];
+  float* dpacked[MMVAE_MOE_MAX_MODS];
+  int laplace[MMVAE_MOE_MAX_MODS];
+} mmvae_moe_k_bwd_args;
+int mmvae_moe_ksample_fwd(const mmvae_moe_k_args* a, const float* theta, float* lat, float* pi, int M, int K, int B,
+                          int D, mmvae_stream_t stream);
+int mmvae_moe_ksample_bwd(const mmvae_moe_k_bwd_args* a, const float* theta, const float* dlat, const float* pi,
+                          float* dtheta_rows, int M, int K, int B, int D, mmvae_stream_t stream);
+/* DReG loss (objectives.py:375-387).  own[r] / cross[r] (K*B): POSITIVE per-sample reconstruction sums of modality r
+ * decoded from its own / the other modality's samples (mmvae_lprob_rowsum_fwd); lam[r] = llik_scaling.
+ *   lw[r,k] = sum_b lat[r,k,b] - lam_r sum_b (own_r + cross_r)[k,b]   (fp64 sums);  w = softmax_k lw, detached;
+ *   out (doubles, 1 + 2 M K + 2 M K): [0] loss = -(1/M) sum_rk w lw | lw (M,K) | w (M,K) | lpx (M,2,K) [own, cross]
+ * bwd: g = d loss (device double) -> dlat (M,K,B) = -g w / M, d own = d cross = g w lam / M. */
+typedef struct {
+  const float* own[MMVAE_MOE_MAX_MODS];
+  const float* cross[MMVAE_MOE_MAX_MODS];
+  float lam[MMVAE_MOE_MAX_MODS];
+} mmvae_dreg_rows;
+typedef struct {
+  float* own[MMVAE_MOE_MAX_MODS];
+  float* cross[MMVAE_MOE_MAX_MODS];
+  float lam[MMVAE_MOE_MAX_MODS];
+} mmvae_dreg_rows_grad;
+int mmvae_dreg_loss_fwd(const float* lat, const mmvae_dreg_rows* rows, double* out, int M, int K, int B,
+                        mmvae_stream_t stream);
+int mmvae_dreg_loss_bwd(const double* out, const double* g, const mmvae_dreg_rows_grad* rows, float* dlat, int M, int K,
+                        int B, mmvae_stream_t stream);
+/* `prior: laplace` with the elbo objective: KL(Laplace(mu, s) || N(0,1)) row sums (torch's _kl_laplace_normal reached
+ * through utils.kl_divergence, utils.py:399-402; models/mmvae_models.py:45) and the importance ratio of :56-62 under
+ * Laplace posteriors (gradient into packed_r only, as mmvae_normal_logratio_*). */
+int mmvae_kl_laplace_normal_fwd(const float* packed, float* kl, int B, int D, mmvae_stream_t stream);
+int mmvae_kl_laplace_normal_bwd(const float* packed, const float* g, float* dpacked, int B, int D,
+                                mmvae_stream_t stream);
+int mmvae_laplace_logratio_fwd(const float* packed_r, const float* packed_o, const float* z, float* lw, int B, int D,
+                               mmvae_stream_t stream);
+int mmvae_laplace_logratio_bwd(const float* packed_r, const float* z, const float* g, float* dpacked_r, int B, int D,
+                               mmvae_stream_t stream);
+/* standard-Laplace variates e = -sign(u) log1p(-|u|), u ~ U(-1,1) (torch.distributions.Laplace.rsample: z = loc +
+ * scale e); generator state as mmvae_randn */
+int mmvae_rand_laplace(float* out, long n, uint32_t* state, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Text towers (Enc_TxtTransformer / Dec_TxtTransformer, models/encoders.py:790-837, decoders.py:668-723)

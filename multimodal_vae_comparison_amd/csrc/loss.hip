@@ -174,13 +174,16 @@ __device__ __forceinline__ float lprob_logp(float x, float t, float s, int lapla
   return -(d * d) / (2.0f * (s * s)) - logf(s) - HALF_LOG_2PI;
 }
 __global__ __launch_bounds__(256) void lprob_rowsum_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
-                                                           float* __restrict__ row, int F, float scale, int laplace) {
+                                                           float* __restrict__ row, int F, int trows, float scale,
+                                                           int laplace, int lap_rows) {
   __shared__ double red[4];
+  if (lap_rows > 0) laplace = (laplace >> (blockIdx.x / lap_rows)) & 1;
   const size_t base = (size_t)blockIdx.x * F;
+  const size_t tbase = (size_t)(blockIdx.x % trows) * F;
   double acc = 0.0;
   for (int i = threadIdx.x; i < F; i += 256) {
     const float x = loc[base + i];
-    const float lp = lprob_logp(x, tg[base + i], scale > 0.f ? scale : x, laplace);
+    const float lp = lprob_logp(x, tg[tbase + i], scale > 0.f ? scale : x, laplace);
     if (lp == lp) acc -= (double)lp;
   }
 #pragma unroll
@@ -191,12 +194,14 @@ __global__ __launch_bounds__(256) void lprob_rowsum_kernel(const float* __restri
 }
 __global__ __launch_bounds__(256) void lprob_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
                                                         const float* __restrict__ grow, float* __restrict__ dl, int F,
-                                                        float scale, int laplace) {
+                                                        int trows, float scale, int laplace, int lap_rows) {
+  if (lap_rows > 0) laplace = (laplace >> (blockIdx.y / lap_rows)) & 1;
   const size_t base = (size_t)blockIdx.y * F;
+  const size_t tbase = (size_t)(blockIdx.y % trows) * F;
   const float g = grow[blockIdx.y];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F) return;
-  const float x = loc[base + i], t = tg[base + i], d = t - x;
+  const float x = loc[base + i], t = tg[tbase + i], d = t - x;
   const bool own = !(scale > 0.f);
   const float s = own ? x : scale;
   const float lp = lprob_logp(x, t, s, laplace);
@@ -211,18 +216,20 @@ __global__ __launch_bounds__(256) void lprob_bwd_kernel(const float* __restrict_
   }
   dl[base + i] = (lp == lp && v == v) ? g * v : 0.f;
 }
-extern "C" int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F, float scale,
-                                      int laplace, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(loc && target && row_loss && B > 0 && F > 0);
-  hipLaunchKernelGGL(lprob_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, target, row_loss, F, scale,
-                     laplace);
+extern "C" int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F,
+                                      int target_rows, float scale, int laplace, int lap_block_rows,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && row_loss && B > 0 && F > 0 && target_rows > 0 && lap_block_rows >= 0);
+  hipLaunchKernelGGL(lprob_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, target, row_loss, F,
+                     target_rows, scale, laplace, lap_block_rows);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, const float* g_row, float* dloc, int B,
-                                      int F, float scale, int laplace, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(loc && target && g_row && dloc && B > 0 && F > 0);
+                                      int F, int target_rows, float scale, int laplace, int lap_block_rows,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && g_row && dloc && B > 0 && F > 0 && target_rows > 0 && lap_block_rows >= 0);
   hipLaunchKernelGGL(lprob_bwd_kernel, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, loc, target, g_row,
-                     dloc, F, scale, laplace);
+                     dloc, F, target_rows, scale, laplace, lap_block_rows);
   return mmvae_launch_status();
 }
 

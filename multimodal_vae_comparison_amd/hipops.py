@@ -42,6 +42,23 @@ class Dropout(ctypes.Structure):
     _fields_ = [("state", c_p), ("slot", c_u), ("site", c_u), ("p", c_f)]
 
 
+MOE_MAX_MODS = 4
+
+
+class MoeKArgs(ctypes.Structure):
+    _fields_ = [("packed", c_p * MOE_MAX_MODS), ("eps", c_p * MOE_MAX_MODS), ("z", c_p * MOE_MAX_MODS),
+                ("laplace", c_i * MOE_MAX_MODS)]
+
+
+class MoeKBwdArgs(ctypes.Structure):
+    _fields_ = [("packed", c_p * MOE_MAX_MODS), ("eps", c_p * MOE_MAX_MODS), ("z", c_p * MOE_MAX_MODS),
+                ("dz", c_p * MOE_MAX_MODS), ("dpacked", c_p * MOE_MAX_MODS), ("laplace", c_i * MOE_MAX_MODS)]
+
+
+class DregRows(ctypes.Structure):      # also mmvae_dreg_rows_grad (same layout, non-const pointers)
+    _fields_ = [("own", c_p * MOE_MAX_MODS), ("cross", c_p * MOE_MAX_MODS), ("lam", c_f * MOE_MAX_MODS)]
+
+
 c_dp = ctypes.POINTER(Dropout)
 DROPOUT_SLOTS = 16
 
@@ -97,8 +114,8 @@ SIGNATURES = {
     "mmvae_convT2d_generic_wgrad": (c_i, [c_p] * 4 + [c_i] * 10 + [c_p]),
     "mmvae_sigmoid_fwd": (c_i, [c_p, c_p, c_l, c_p]),
     "mmvae_sigmoid_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
-    "mmvae_lprob_rowsum_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
-    "mmvae_lprob_rowsum_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
+    "mmvae_lprob_rowsum_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "mmvae_lprob_rowsum_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "mmvae_optimal_sigma_ws_floats": (c_sz, [c_i, c_i]),
     "mmvae_optimal_sigma_fwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
     "mmvae_optimal_sigma_bwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
@@ -134,6 +151,15 @@ SIGNATURES = {
     "mmvae_expmul_bwd": (c_i, [c_p] * 5 + [c_i, c_p]),
     "mmvae_moe_elbo_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_moe_elbo_bwd": (c_i, [c_p, c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "mmvae_moe_ksample_fwd": (c_i, [ctypes.POINTER(MoeKArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mmvae_moe_ksample_bwd": (c_i, [ctypes.POINTER(MoeKBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mmvae_dreg_loss_fwd": (c_i, [c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_dreg_loss_bwd": (c_i, [c_p, c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_kl_laplace_normal_fwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "mmvae_kl_laplace_normal_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    "mmvae_laplace_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
+    "mmvae_laplace_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
+    "mmvae_rand_laplace": (c_i, [c_p, c_l, c_p, c_p]),
     "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),
     "mmvae_dropout_mask": (c_i, [c_dp, c_p, c_l, c_p]),
     "mmvae_dropout_act_fwd": (c_i, [c_p, c_p, c_l, c_i, c_dp, c_p]),

@@ -62,6 +62,15 @@ class TorchMMVAE(nn.Module):
             else:
                 vae.llik_scaling = float(vae.llik_scaling)
 
+    def _require_normal_priors(self):
+        """`prior: laplace` makes the reference build Laplace posteriors / likelihoods (models/trainer.py:104); only the
+        MoE mixer carries that arithmetic on this path (the shipped configs use it there only) -- anything else must
+        not silently compute Normal terms"""
+        for name, vae in self.vaes.items():
+            if vae.prior_str not in ("normal", "gaussian"):
+                raise NotImplementedError(f"{self.modelName}: prior '{vae.prior_str}' ({name}) is only wired for "
+                                          f"mixing: moe on the MI355X path")
+
     @property
     def latent_factorization(self):
         return any(v.private_latents is not None for v in self.vaes.values())

@@ -37,6 +37,7 @@ class MoPOE(TorchMMVAE):
         super().__init__(vaes, n_latents, **obj_config)
         self.model_config = model_config
         self.modelName = "mopoe"
+        self._require_normal_priors()
         self.subsets = self.set_subsets()
         self.weights = None
 
@@ -352,30 +353,51 @@ class POE(TorchMMVAE):
 
 
 class MOE(TorchMMVAE):
-    """MMVAE, mixture of experts (mmvae_models.py:10-131), objective "elbo" with K = 1 (`iwae`
-    crashes in the reference and `dreg` / K > 1 fail with the text decoder).
+    """MMVAE, mixture of experts (mmvae_models.py:10-131): objective "elbo" with K = 1 and "dreg"
+    with any K on towers that keep the K axis (the shipped configs/config_mnistsvhn.yml: MNIST / SVHN towers, K = 30,
+    `prior: laplace`).  `iwae` crashes in the reference; elbo with K > 1 fails there too.
 
-    q_m = Normal(mu_m, sigma = lv_m), one z per modality; every modality is decoded from its own z and from the z
-    of the LAST other modality (the reference's dict overwrite, :112-116); KL against the per-VAE fixed N(0,1)
-    prior; cross terms weighted by exp(log q_r(z_o) - log q_o(z_o).detach()) with z_o detached; rows whose weighted
-    sum is exactly 0 are dropped and beta*kld.sum() is subtracted once per surviving row (:73, objectives.py:67);
-    loss / M."""
+    q_m = Normal | Laplace(mu_m, scale = lv_m) -- the config's `prior` key also names the posterior and the likelihood
+    family (models/trainer.py:104) --, K samples z_m per modality; every modality is decoded from its own z
+    (likelihood Normal, :101-103) and from the z of the LAST other modality (likelihood `vae.px_z`, the dict overwrite
+    of :112-116).
+    elbo: KL against the per-VAE fixed N(0,1) prior through the model-level `self.pz` = Normal (:45); cross terms
+      weighted by exp(log q_r(z_o) - log q_o(z_o).detach()) with z_o detached; rows whose weighted sum is exactly 0
+      are dropped and beta*kld.sum() is subtracted once per surviving row (:73, objectives.py:67); loss / M.
+    dreg: objectives.py:361-387 with the TRAINABLE model prior N(0, softmax(theta) D) (:76, pz_params)."""
 
     def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
         super().__init__(vaes, n_latents, **obj_config)
         self.model_config = model_config
         self.modelName = "moe"
-        if self.obj_fn.obj_name != "elbo" or self.K != 1:
-            raise NotImplementedError("moe: only obj 'elbo' with K = 1 is defined on this path "
-                                      "(reference: iwae crashes, dreg/K>1 fail with the text decoder)")
+        obj = self.obj_fn.obj_name
+        if obj == "iwae":
+            self.obj_fn.iwae(None)                                # raises: the reference's iwae crashes
+        if obj == "elbo" and self.K != 1:
+            raise NotImplementedError("moe: obj elbo with K > 1 fails in the reference (mmvae_models.py:62); use dreg")
+        if obj == "dreg" and len(self.vaes) != 2:
+            raise NotImplementedError("moe dreg: the reference's cross-term indexing (mmvae_models.py:64-70) is only "
+                                      "meaningful for two modalities")
+        for vae in self.vaes.values():
+            if vae.prior_str not in ("normal", "gaussian", "laplace"):
+                raise NotImplementedError(f"prior: {vae.prior_str} is not on the MI355X path (normal, laplace are)")
+        self._laplace = [v.prior_str == "laplace" for v in self.vaes.values()]
         self.register_buffer("_theta0", torch.zeros(1, n_latents), persistent=False)   # softmax(0)*D = 1: N(0,1)
 
     @property
     def pz_params(self):
         return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
 
+    def _draw_k(self, m, K, B, D, dev):
+        """(K,B,D) standard variates of q_m's family: one recorded draw (`eps_override`) or the device generator"""
+        if self.eps_override is not None:
+            return self.eps_override.pop(0).reshape(K, B, D).to(device=dev, dtype=torch.float32).contiguous()
+        return (ops.rand_laplace if self._laplace[m] else ops.randn)((K, B, D), self._rng_state)
+
     def objective(self, data):
         """mmvae_models.py:32-78"""
+        if self.obj_fn.obj_name == "dreg":
+            return self._objective_dreg(data)
         self._begin_step()
         names = list(self.vaes.keys())
         M = len(names)
@@ -384,23 +406,61 @@ class MOE(TorchMMVAE):
         B, D = packed[0].shape[0], self.n_latents
         zs, kls = [], []
         for i in range(M):
-            _, kl, z = ops.poe_reparam_kl(self._theta0, [packed[i]], [self._draw(B, D, dev)], 2, 0b10)
+            eps = self._draw_k(i, 1, B, D, dev).reshape(B, D)
+            if self._laplace[i]:      # z = mu + scale * e all the same; KL(Laplace || N(0,1)) has its own closed form
+                _, _, z = ops.poe_reparam_kl(self._theta0, [packed[i]], [eps], 2, 0)
+                kls.append(ops.kl_laplace_normal(packed[i]))
+            else:
+                _, kl, z = ops.poe_reparam_kl(self._theta0, [packed[i]], [eps], 2, 0b10)
+                kls.append(kl[1])
             zs.append(z[0])
-            kls.append(kl[1])
         rows, W = [], []
         for r, n in enumerate(names):
             vae = self.vaes[n]
             own, _ = vae.dec({"latents": zs[r].unsqueeze(0), "masks": data[n]["masks"]})
             o = [s for s in range(M) if s != r][-1]
             cross, _ = vae.dec({"latents": zs[o].unsqueeze(0), "masks": data[n]["masks"]})
-            lw = ops.normal_logratio(packed[r], packed[o].detach(), zs[o].detach())
-            rows += [recon_rowsum(vae.ltype, own, data[n]), ops.expmul(lw, recon_rowsum(vae.ltype, cross, data[n]))]
+            ratio = ops.laplace_logratio if self._laplace[r] else ops.normal_logratio
+            lw = ratio(packed[r], packed[o].detach(), zs[o].detach())
+            # own: dist.Normal(*px_z) (:101-103); cross: vae.px_z = the config's `prior` family (:115)
+            rows += [recon_rowsum(vae.ltype, own, data[n]),
+                     ops.expmul(lw, recon_rowsum(vae.ltype, cross, data[n], laplace=self._laplace[r]))]
             W += [float(vae.llik_scaling)] * 2
         kld = torch.stack(kls)                                              # (M, B), also the logged "kld"
         loss = ops.moe_elbo(rows, W, kld, self.obj_fn.beta, M)
         with torch.no_grad():                                               # logged only: lpx rows, reference sign
             lpx = [-w * r for w, r in zip(W, rows)]
         return {"loss": loss, "reconstruction_loss": lpx, "kld": kld}
+
+    def _objective_dreg(self, data):
+        """MOE.objective's non-elbo branch + MultimodalObjective.dreg (mmvae_models.py:63-78, objectives.py:361-387).
+        Every decoder decodes ALL M*K*B latent samples in one pass (rows [r*K*B, (r+1)*K*B) are z_r): its own block is
+        the own reconstruction, the other block the cross reconstruction."""
+        self._begin_step()
+        names = list(self.vaes.keys())
+        M, K, D = len(names), int(self.K), self.n_latents
+        dev = next(v["data"] for v in data.values() if v["data"] is not None).device
+        packed = [packed_head(*self.vaes[n].enc(data[n])) for n in names]
+        B = packed[0].shape[0]
+        eps = [self._draw_k(m, K, B, D, dev) for m in range(M)]
+        theta = self._pz_params[1]
+        lat, z = ops.moe_ksample(theta, packed, eps, self._laplace, theta.grad)          # z: (M,K,B,D)
+        KB = K * B
+        rows, lam = [], []
+        for r, n in enumerate(names):
+            vae = self.vaes[n]
+            if vae.ltype != "lprob" or data[n]["masks"] is not None:
+                raise NotImplementedError("moe dreg: recon_loss lprob on unmasked modalities (the MNIST / SVHN towers) "
+                                          "is what keeps the K axis in the reference")
+            self.obj_fn.set_ltype(vae.ltype)
+            o = 1 - r
+            out, _ = vae.dec({"latents": z.view(M * K, B, D), "masks": None})          # (M*K, B, ...)
+            # own block r: dist.Normal (:101-103); cross block o: vae.px_z = the config's `prior` family (:115)
+            lap_mask = (1 << o) if self._laplace[r] else 0
+            rs = recon_rowsum("lprob", out, data[n], laplace=(lap_mask, KB))            # (M*K*B,)
+            rows += [rs[r * KB:(r + 1) * KB], rs[o * KB:(o + 1) * KB]]
+            lam.append(float(vae.llik_scaling))
+        return self.obj_fn.calculate_loss({"lat": lat, "rows": rows, "lam": lam})
 
     def modality_mixing(self, mods):
         return self.encode(mods)
@@ -445,6 +505,7 @@ class DMVAE(TorchMMVAE):
         super().__init__(vaes, n_latents, **obj_config)
         self.model_config = model_config
         self.modelName = "dmvae"
+        self._require_normal_priors()
         assert self.latent_factorization, "DMVAE requires private_latents in the config"
         if self.K != 1:
             raise NotImplementedError("dmvae: K = 1 only on this path")

@@ -47,7 +47,10 @@ def recon_rowsum(ltype, out, target, laplace=False):
         out = out[:, : target["masks"].shape[1]]
     data = target["data"]
     if ltype == "lprob":
-        return ops.lprob_rowsum(out, data.float().reshape(out.shape), None if masked else PX_SCALE, laplace)
+        # a K-sample decoder output (K,B,...) is compared with the target repeated K times (reshape_for_loss,
+        # objectives.py:118-120): the kernel indexes the target row as (output row) % B instead of materialising it
+        tgt = data.float().reshape(out.shape) if out.numel() == data.numel() else data.float().reshape(data.shape[0], -1)
+        return ops.lprob_rowsum(out, tgt, None if masked else PX_SCALE, laplace)
     if ltype == "optimal_sigma":
         return ops.optimal_sigma_rowsum(out, data.float().reshape(out.shape))
     if ltype == "bce":
@@ -95,8 +98,8 @@ class BaseObjective:
 
 
 class MultimodalObjective(BaseObjective):
-    """models/objectives.py:305-340 (elbo).  `iwae` crashes in the reference (objectives.py:353) and `dreg` needs
-    K-preserving towers; both are outside the pinned hot path."""
+    """models/objectives.py:305-387: `elbo` and `dreg`.  `iwae` crashes in the reference (objectives.py:353: `.cuda()`
+    on a tuple), so there is nothing to be faithful to: selecting it raises."""
 
     def __init__(self, obj: str, beta=1):
         super().__init__()
@@ -114,3 +117,15 @@ class MultimodalObjective(BaseObjective):
     def elbo(self, data):
         loss = BaseObjective.elbo(self, data["lpx_z"], data["kld"], self.beta)
         return {"loss": loss, "reconstruction_loss": data["lpx_z"], "kld": data["kld"]}
+
+    def dreg(self, data):
+        """objectives.py:375-387 on the fused kernels (csrc/moe.hip).  data: {"lat": (M,K,B) latent part of the
+        importance weights (ops.moe_ksample), "rows": [own_0, cross_0, own_1, ...] positive per-sample reconstruction
+        sums (K*B), "lam": llik_scaling per modality}.  The z hook of :382-383 never fires in the reference (it is
+        registered on a fresh torch.stack nothing consumes), so gradients flow through lw unweighted."""
+        loss, rec = ops.dreg_loss(data["lat"], data["lam"], data["rows"])
+        return {"loss": loss, "kld": torch.zeros((), dtype=torch.int64), "reconstruction_loss": rec}
+
+    def iwae(self, data):
+        raise NotImplementedError("obj: iwae crashes in the reference itself (models/objectives.py:353 calls .cuda() "
+                                  "on a tuple): there is no behaviour to reproduce; use dreg or elbo")

@@ -17,7 +17,8 @@ from .vae import VAE
 # feature_dims of the reference's dataset classes (models/datasets.py:207-209): the only part of the input
 # pipeline the towers depend on
 FEATURE_DIMS = {
-    "cdspritesplus": {"image": [64, 64, 3], "text": [45, 27, 1]},
+    "cdspritesplus": {"image": [64, 64, 3], "text": [45, 27, 1]},                     # datasets.py:207-209
+    "mnist_svhn": {"mnist": [28, 28, 1], "svhn": [32, 32, 3]},                        # datasets.py:418-420
 }
 
 

@@ -815,23 +815,28 @@ class LprobRowsum(Function):
 
     @staticmethod
     def forward(ctx, loc, target, scale, laplace):
+        """laplace: bool, or (bit mask, block rows): rows [j, j+1) * block rows are Laplace where bit j is set"""
         loc, target = H.f32c(loc), H.f32c(target)
-        B = loc.shape[0]
-        F_ = loc.numel() // B
+        lap, lap_rows = (int(laplace[0]), int(laplace[1])) if isinstance(laplace, tuple) else (int(laplace), 0)
+        trows = target.shape[0]
+        F_ = target.numel() // trows
+        B = loc.numel() // F_            # rows of loc; > trows: K-sample output, target row = row % trows
+        assert B * F_ == loc.numel() and B % trows == 0
         row = torch.empty(B, device=loc.device)
         sc = -1.0 if scale is None else float(scale)
-        _call("mmvae_lprob_rowsum_fwd", H.ptr(loc), H.ptr(target), H.ptr(row), B, F_, sc, int(laplace), H.stream())
+        _call("mmvae_lprob_rowsum_fwd", H.ptr(loc), H.ptr(target), H.ptr(row), B, F_, trows, sc, lap, lap_rows,
+              H.stream())
         ctx.save_for_backward(loc, target)
-        ctx.cfg = (sc, int(laplace))
+        ctx.cfg = (sc, lap, lap_rows, B, F_, trows)
         return row
 
     @staticmethod
     def backward(ctx, g):
         loc, target = ctx.saved_tensors
-        B = loc.shape[0]
+        sc, lap, lap_rows, B, F_, trows = ctx.cfg
         d = torch.empty_like(loc)
-        _call("mmvae_lprob_rowsum_bwd", H.ptr(loc), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(d), B, loc.numel() // B,
-              ctx.cfg[0], ctx.cfg[1], H.stream())
+        _call("mmvae_lprob_rowsum_bwd", H.ptr(loc), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(d), B, F_, trows, sc, lap,
+              lap_rows, H.stream())
         return d, None, None, None
 
 
@@ -1086,8 +1091,164 @@ class MoeElbo(Function):
         return (dkld, None, None, None, *[drows[i] for i in range(n)])
 
 
+class LaplaceLogRatio(Function):
+    """NormalLogRatio under Laplace posteriors (`prior: laplace`, models/mmvae_models.py:56-62)"""
+
+    @staticmethod
+    def forward(ctx, packed_r, packed_o, z):
+        packed_r, packed_o, z = H.f32c(packed_r), H.f32c(packed_o), H.f32c(z)
+        B, D2 = packed_r.shape
+        lw = torch.empty(B, device=z.device)
+        _call("mmvae_laplace_logratio_fwd", H.ptr(packed_r), H.ptr(packed_o), H.ptr(z), H.ptr(lw), B, D2 // 2,
+              H.stream())
+        ctx.save_for_backward(packed_r, z)
+        return lw
+
+    @staticmethod
+    def backward(ctx, g):
+        packed_r, z = ctx.saved_tensors
+        B, D2 = packed_r.shape
+        d = torch.empty_like(packed_r)
+        _call("mmvae_laplace_logratio_bwd", H.ptr(packed_r), H.ptr(z), H.ptr(H.f32c(g)), H.ptr(d), B, D2 // 2,
+              H.stream())
+        return d, None, None
+
+
+class KlLaplaceNormal(Function):
+    """kl[b] = sum_d KL(Laplace(mu, s) || N(0, 1)) for packed (B, 2D) = [mu | s]"""
+
+    @staticmethod
+    def forward(ctx, packed):
+        packed = H.f32c(packed)
+        B, D2 = packed.shape
+        kl = torch.empty(B, device=packed.device)
+        _call("mmvae_kl_laplace_normal_fwd", H.ptr(packed), H.ptr(kl), B, D2 // 2, H.stream())
+        ctx.save_for_backward(packed)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        (packed,) = ctx.saved_tensors
+        B, D2 = packed.shape
+        d = torch.empty_like(packed)
+        _call("mmvae_kl_laplace_normal_bwd", H.ptr(packed), H.ptr(H.f32c(g)), H.ptr(d), B, D2 // 2, H.stream())
+        return d
+
+
+class MoeKSample(Function):
+    """K reparameterised samples per modality posterior + the latent part of the DReG importance weights
+    (csrc/moe.hip; MOE.forward :96-100, _m_dreg_looser objectives.py:366-373).
+
+    packed[m] (B,2D) = [mu | scale]; eps[m] (K,B,D) standard variates of q_m's family.  Returns lat (M,K,B) =
+    sum_d log p(z) - log-mean-exp_m sum_d log q_m(z) and z (M,K,B,D) (one tensor: the decoders take all of it)."""
+
+    @staticmethod
+    def forward(ctx, theta, gtheta, laplace, M, *tensors):
+        packed = [H.f32c(t) for t in tensors[:M]]
+        eps = [H.f32c(t) for t in tensors[M:2 * M]]
+        K, B, D = eps[0].shape
+        dev = packed[0].device
+        z = torch.empty(M, K, B, D, device=dev)
+        zs = z.unbind(0)
+        lat = torch.empty(M, K, B, device=dev)
+        pi = torch.empty(M, K, B, M, device=dev)
+        a = H.MoeKArgs()
+        for m in range(M):
+            a.packed[m], a.eps[m], a.z[m], a.laplace[m] = packed[m].data_ptr(), eps[m].data_ptr(), zs[m].data_ptr(), \
+                int(laplace[m])
+        _call("mmvae_moe_ksample_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(lat), H.ptr(pi), M, K, B, D, H.stream())
+        ctx.save_for_backward(theta, pi, z, *packed, *eps)
+        ctx.cfg = (gtheta, tuple(int(x) for x in laplace), M, K, B, D)
+        ctx.set_materialize_grads(False)
+        return lat, z
+
+    @staticmethod
+    def backward(ctx, dlat, dz):
+        gtheta, laplace, M, K, B, D = ctx.cfg
+        theta, pi, z = ctx.saved_tensors[:3]
+        packed = ctx.saved_tensors[3:3 + M]
+        eps = ctx.saved_tensors[3 + M:3 + 2 * M]
+        zs = z.unbind(0)
+        dev = theta.device
+        dlat = H.f32c(dlat) if dlat is not None else torch.zeros(M, K, B, device=dev)
+        dzs = list(H.f32c(dz).unbind(0)) if dz is not None else [None] * M
+        dpacked = [torch.empty_like(p) for p in packed]
+        a = H.MoeKBwdArgs()
+        for m in range(M):
+            a.packed[m], a.eps[m], a.z[m] = packed[m].data_ptr(), eps[m].data_ptr(), zs[m].data_ptr()
+            a.dz[m] = dzs[m].data_ptr() if dzs[m] is not None else None
+            a.dpacked[m], a.laplace[m] = dpacked[m].data_ptr(), laplace[m]
+        ret = None
+        rows = None
+        if ctx.needs_input_grad[0] or gtheta is not None:
+            rows = GradReducer.alloc(B * D, dev) if _defer(gtheta) else torch.empty(B, D, device=dev)
+        _call("mmvae_moe_ksample_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dlat), H.ptr(pi), H.ptr(rows), M, K, B, D,
+              H.stream())
+        if rows is not None:
+            if _defer(gtheta):
+                GradReducer.add(rows.data_ptr(), gtheta, B, D, D)
+            elif gtheta is not None:
+                gtheta += rows.sum(0).view_as(gtheta)
+            else:
+                ret = rows.sum(0).view_as(theta)
+        return (ret, None, None, None, *dpacked, *([None] * M))
+
+
+def moe_ksample(theta, packed, eps, laplace, gtheta=None):
+    """-> lat (M,K,B), z (M,K,B,D)"""
+    return MoeKSample.apply(theta, gtheta, laplace, len(packed), *packed, *eps)
+
+
+class DregLoss(Function):
+    """MultimodalObjective.dreg (objectives.py:375-387) from the latent terms `lat` (M,K,B) and the positive
+    per-sample reconstruction sums own_r / cross_r (K*B): returns (loss fp64 scalar, lpx (M,2,K) fp64 [logged])."""
+
+    @staticmethod
+    def forward(ctx, lat, lam, M, *rows):
+        lat = H.f32c(lat)
+        rows = [H.f32c(r).reshape(-1) for r in rows]
+        _, K, B = lat.shape
+        assert len(rows) == 2 * M and all(r.numel() == K * B for r in rows)
+        out = torch.empty(1 + 4 * M * K, dtype=torch.float64, device=lat.device)
+        t = H.DregRows()
+        for r in range(M):
+            t.own[r], t.cross[r], t.lam[r] = rows[2 * r].data_ptr(), rows[2 * r + 1].data_ptr(), float(lam[r])
+        _call("mmvae_dreg_loss_fwd", H.ptr(lat), ctypes.byref(t), H.ptr(out), M, K, B, H.stream())
+        ctx.save_for_backward(out)
+        ctx.cfg = (tuple(float(x) for x in lam), M, K, B, [tuple(r.shape) for r in rows])
+        rec = out[1 + 2 * M * K:].view(M, 2, K)
+        ctx.mark_non_differentiable(rec)
+        return out[0], rec
+
+    @staticmethod
+    def backward(ctx, g, _grec):
+        (out,) = ctx.saved_tensors
+        lam, M, K, B, shapes = ctx.cfg
+        dev = out.device
+        g = g.to(torch.float64).reshape(1).contiguous()
+        dlat = torch.empty(M, K, B, device=dev)
+        drows = [torch.empty(K * B, device=dev) for _ in range(2 * M)]
+        t = H.DregRows()
+        for r in range(M):
+            t.own[r], t.cross[r], t.lam[r] = drows[2 * r].data_ptr(), drows[2 * r + 1].data_ptr(), lam[r]
+        _call("mmvae_dreg_loss_bwd", H.ptr(out), H.ptr(g), ctypes.byref(t), H.ptr(dlat), M, K, B, H.stream())
+        return (dlat, None, None, *drows)
+
+
+def dreg_loss(lat, lam, rows):
+    return DregLoss.apply(lat, lam, len(lam), *rows)
+
+
 def normal_logratio(packed_r, packed_o, z):
     return NormalLogRatio.apply(packed_r, packed_o, z)
+
+
+def laplace_logratio(packed_r, packed_o, z):
+    return LaplaceLogRatio.apply(packed_r, packed_o, z)
+
+
+def kl_laplace_normal(packed):
+    return KlLaplaceNormal.apply(packed)
 
 
 def expmul(lw, r):
@@ -1617,6 +1778,13 @@ def randn(shape, state):
     """standard-normal tensor from the counter-based device generator (`state`: int32[3] = seed, counter, ticket)"""
     out = torch.empty(shape, device=state.device)
     _call("mmvae_randn", H.ptr(out), out.numel(), H.ptr(state), H.stream())
+    return out
+
+
+def rand_laplace(shape, state):
+    """standard-Laplace variates (Laplace.rsample: z = loc + scale * e) from the counter-based device generator"""
+    out = torch.empty(shape, device=state.device)
+    _call("mmvae_rand_laplace", H.ptr(out), out.numel(), H.ptr(state), H.stream())
     return out
 
 

@@ -27,15 +27,15 @@ def cdsprites_config(mixing="mopoe", n_latents=32, batch_size=128, beta=1, lr=1e
                            "recon_loss": "category_ce", "prior": "normal", "private_latents": private}}
 
 
-def config_from_mods(mixing, mods, n_latents, batch_size=128, beta=1, lr=1e-4):
+def config_from_mods(mixing, mods, n_latents, batch_size=128, beta=1, lr=1e-4, obj="elbo", K=1, prior="normal"):
     """(config dict, feature_dims) for an arbitrary modality list [{"enc", "dec", "data_dim", "ltype", "private"?,
     "llik_scaling"?}] in the reference's YAML schema; the parity tests build their models from fixture metadata"""
     cfg = {"batch_size": batch_size, "beta": beta, "dataset_name": "synthetic", "lr": lr, "mixing": mixing,
-           "n_latents": n_latents, "obj": "elbo", "optimizer": "adam", "K": 1}
+           "n_latents": n_latents, "obj": obj, "optimizer": "adam", "K": K}
     dims = {}
     for i, m in enumerate(mods):
         cfg[f"modality_{i + 1}"] = {"decoder": m["dec"], "encoder": m["enc"], "mod_type": f"m{i + 1}",
-                                    "recon_loss": m["ltype"], "prior": "normal",
+                                    "recon_loss": m["ltype"], "prior": m.get("prior", prior),
                                     "private_latents": m.get("private"), "llik_scaling": m.get("llik_scaling", 1)}
         dims[f"m{i + 1}"] = list(m["data_dim"])
     return cfg, dims
