@@ -9,10 +9,20 @@ from .decoders import VaeDecoder
 from .encoders import VaeEncoder
 
 
+# towers of the reference's registry that are outside SURVEY section 8's hot-path scope: selecting one fails loudly,
+# by name, instead of with the reference's generic "Did not find encoder" assert
+OUT_OF_SCOPE_TOWERS = ("FNN", "PolyMNIST", "VideoGPT", "VIT", "TransformerIMG", "TxtRNN", "Audio", "AudioConv",
+                       "CNN_CUB", "Fashion_CNN", "Sprites")
+
+
 class DencoderFactory(object):
     @classmethod
     def get_nework_classes(cls, enc_name, dec_name, n_latents, private_latents, data_dim: tuple, enc_mu_logvar: bool):
         """vae.py:15-30: `Enc_<name>` / `Dec_<name>` looked up by string"""
+        for name in (enc_name, dec_name):
+            if name in OUT_OF_SCOPE_TOWERS:
+                raise NotImplementedError(f"tower '{name}' is outside the MI355X hot-path scope (SURVEY.md section 8: "
+                                          f"CNN2/CNN, TxtTransformer, Transformer, MNIST, SVHN are built)")
         assert hasattr(encoders, "Enc_{}".format(enc_name)), "Did not find encoder {}".format(enc_name)
         enc_obj = getattr(encoders, "Enc_{}".format(enc_name))(n_latents, data_dim, private_latents, enc_mu_logvar)
         assert hasattr(decoders, "Dec_{}".format(dec_name)), "Did not find decoder {}".format(dec_name)
