@@ -1,13 +1,13 @@
-"""bench.py -- training samples/sec of the MoPoE CdSprites+ level-2 step (BASELINE.json configs[1]) on N MI355X.
+"""bench.py -- training samples/sec of the multimodal-VAE step on N MI355X (default: BASELINE.json configs[1]).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 200 --warmup 20 [--config cfg1|cfg2|cfg3|cfg4|cfg5|mnistsvhn]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = forward + backward + Adam(amsgrad) of MoPoE (CNN2 image tower + TxtTransformer text tower,
-n_latents 32) on one synthetic batch of 128 samples per GPU (64x64x3 image + 32-token text), inputs resident in
-HBM.  N > 1: one process per GPU, weak scaling (128 samples per GPU), ONE RCCL all-reduce of the flat 3.95 MB
-gradient buffer per step.  Prints ONE JSON line (rank 0).
+One step = forward + backward + Adam(amsgrad) of the mixer on one synthetic batch per GPU, inputs resident in HBM.
+Default workload cfg2 = MoPoE (CNN2 image tower + TxtTransformer text tower, n_latents 32), 128 samples per GPU
+(64x64x3 image + 32-token text).  N > 1: one process per GPU, weak scaling, ONE RCCL all-reduce of the flat gradient
+buffer per step (multimodal_vae_comparison_amd/parallel.py).  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -27,8 +27,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_SAMPLE = 98.9e6        # 16 477 056 MAC fwd x 2 x 3 (fwd + dgrad + wgrad)
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
+METRIC = {"cfg2": "training samples/sec, MoPoE CdSprites+ L2 (fwd+bwd+Adam)"}
 
 
 def parse():
@@ -36,75 +36,174 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--batch", type=int, default=128, help="samples per GPU (BASELINE configs[1]: 128)")
-    p.add_argument("--seq", type=int, default=32)
-    p.add_argument("--latents", type=int, default=32)
+    p.add_argument("--config", default="cfg2", help="BASELINE workload: cfg1..cfg5 | mnistsvhn (default cfg2, the one "
+                                                    "the metric is quoted on)")
+    p.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--no-extras", action="store_true", help="skip the non-headline figures (input pipeline, large batch)")
     p.add_argument("--force-collective", action="store_true",
                    help="one GPU, but the multi-GPU step structure (graph, RCCL all-reduce over 1 rank, Adam launch)")
     return p.parse_args()
 
 
-def cpu_baseline(B, T, D, budget_s):
-    """The CPU restatement of the same step (oracle, kind "port"): objective + backward + Adam(amsgrad), train mode
-    (dropout on, as the reference trains), all host cores, on a bounded number of steps."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (kind "port") timed on this box's host cores, SURVEY 8(d)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo, limited to the CPUs this process may run on"""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        n = len(seen) or allowed
+    except OSError:
+        n = allowed
+    return max(1, min(n, allowed))
+
+
+def _oracle_step_fn(meta, batch):
+    """one optimisation step of the oracle for this workload: objective + backward + Adam(amsgrad), train mode (dropout
+    on, as the reference trains)"""
     from oracle import golden_weights as gw
     from oracle import mmvae_oracle as orc
-    from multimodal_vae_comparison_amd.synthetic import cdsprites_batch
-    mods = [{"enc": "CNN2", "dec": "CNN", "data_dim": [64, 64, 3], "ltype": "bce"},
-            {"enc": "TxtTransformer", "dec": "TxtTransformer", "data_dim": [45, 27, 1], "ltype": "category_ce"}]
+    mods, D, B, mixing = meta["mods"], meta["D"], meta["B"], meta["mixing"]
+    K = meta.get("K", 1)
     params = gw.make_params(orc.model_param_shapes(mods, D), 0, requires_grad=True)
     state = {k: (torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)) for k, p in params.items()}
-    batch = cdsprites_batch(B, T, seed=1)
+    M = len(mods)
+    if mixing == "dmvae":
+        P = [m.get("private") for m in mods]
+        shapes = [D] + [d for i in range(M) for d in [D, P[i]] + [D] * (M - 1)]
+    elif mixing == "poe":
+        shapes = [D] * (2 ** M - 1)
+    else:
+        shapes = [D] * M
+    kw = {k: meta[k] for k in ("obj", "K", "prior") if k in meta}
 
     def step(i):
-        eps = [torch.randn(1, B, D) for _ in range(2)]
-        out = orc.mopoe_objective(params, mods, batch, eps, D, train=True)
+        eps = [torch.randn(K, B, d) for d in shapes]
+        out = orc.OBJECTIVES[mixing](params, mods, batch, eps, D, train=True, **kw)
         out["loss"].backward()
         with torch.no_grad():
-            orc.adam_amsgrad_step(params, {k: p.grad for k, p in params.items()}, state, 1e-4, i)
+            grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+            orc.adam_amsgrad_step(params, grads, state, 1e-4, i)
             for p in params.values():
                 p.grad = None
+    return step
 
-    # torch's intra-op pool does not scale to hundreds of threads on ops this small: calibrate the thread count
-    # (a few steps each) and time the baseline at the fastest setting.
-    ncpu = os.cpu_count() or 1
-    best = (float("inf"), 1)
-    it = 0
-    for nt in sorted({t for t in (4, 8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
-        torch.set_num_threads(nt)
+
+def _time_steps(step, warm, timed, budget_s, it0):
+    it = it0
+    t0 = time.perf_counter()
+    for w in range(warm):
+        if w >= 1 and time.perf_counter() - t0 > budget_s / 3:      # slow workloads: the warm-up is time-bounded too
+            break
         it += 1
         step(it)
-        t0 = time.perf_counter()
-        for _ in range(2):
-            it += 1
-            step(it)
-        dt = (time.perf_counter() - t0) / 2
-        if dt < best[0]:
-            best = (dt, nt)
-    cores = best[1]
-    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     n = 0
-    while time.perf_counter() - t0 < budget_s and n < 400:
+    while n < timed and (n < 3 or time.perf_counter() - t0 < budget_s):
         n += 1
-        step(it + n)
-    dt = time.perf_counter() - t0
-    return {"value": round(n * B / dt, 1), "unit": "samples/s", "cores": cores, "host_cpus": ncpu, "kind": "port",
-            "sample": f"{n} steps of the oracle (oracle/mmvae_oracle.py, train mode) at B={B}, T={T}, D={D}, "
-                      f"{1e3 * dt / n:.1f} ms/step"}
+        it += 1
+        step(it)
+    return (time.perf_counter() - t0) / n, n, it
 
 
-# HBM bytes per launch of the conv2 forward kernel at B=128 from the PMC passes of tools/gpu_pmc.sh
-# (2 * FETCH_SIZE 10059.9 KB + WRITE_SIZE 4096.0 KB); bench.py cannot collect counters itself.
-CONV2_FWD_HBM_BYTES_B128 = int((2 * 10059.9 + 4096.0) * 1024)
+def cpu_baseline(meta, batch_cpu):
+    """the CPU restatement of the same step at (1) all physical cores, (2) the thread count torch's
+    intra-op pool is fastest at on this box (ops this small stop scaling long before 128 threads: measured, all 128
+    physical cores of the GPU box run this step 5x SLOWER than one thread), (3) one thread; 10 warm-up + 50 timed
+    steps where the time bound allows (each leg is cut at ~12 s, >= 3 timed steps).  `value` / `cores` = the fastest
+    of the three (the baseline a CPU user would run); all three legs are reported."""
+    B = meta["B"]
+    step = _oracle_step_fn(meta, batch_cpu)
+    phys = _physical_cores()
+    legs = {}
+    it = 0
+    torch.set_num_threads(phys)
+    dt, n, it = _time_steps(step, 10, 50, 12.0, it)
+    legs["all_physical_cores"] = (dt, n, phys)
+    best = None
+    for nt in sorted({t for t in (8, 16, 32) if t < phys}):
+        torch.set_num_threads(nt)
+        dtc, _, it = _time_steps(step, 1, 3, 2.0, it)
+        if best is None or dtc < best[0]:
+            best = (dtc, nt)
+    if best is not None and best[0] < legs["all_physical_cores"][0]:
+        torch.set_num_threads(best[1])
+        dt, n, it = _time_steps(step, 3, 50, 10.0, it)
+        legs["tuned"] = (dt, n, best[1])
+    torch.set_num_threads(1)
+    dt, n, it = _time_steps(step, 1, 10, 8.0, it)
+    legs["single_thread"] = (dt, n, 1)
+    torch.set_num_threads(phys)
+    fmt = lambda leg: {"value": round(B / leg[0], 1), "cores": leg[2], "ms_per_step": round(1e3 * leg[0], 1),
+                       "timed_steps": leg[1]}
+    name, main = min(legs.items(), key=lambda kv: kv[1][0])
+    out = {"value": round(B / main[0], 1), "unit": "samples/s", "cores": main[2], "kind": "port",
+           "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "physical_cores": phys,
+           "sample": f"{main[1]} timed steps of the oracle (oracle/mmvae_oracle.py, train mode, {meta['mixing']}) at "
+                     f"B={B}, {1e3 * main[0]:.1f} ms/step on {main[2]} threads (fastest leg: {name})",
+           "all_physical_cores": fmt(legs["all_physical_cores"]), "single_thread": fmt(legs["single_thread"])}
+    if "tuned" in legs:
+        out["tuned"] = fmt(legs["tuned"])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# ---------------------------------------------------------------------------------------------------------------------
+def _pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a conv kernel at B=128 from the newest committed PMC summary (tools/gpu_pmc.sh ->
+    profiles/r*_pmc_conv_b128.txt): 2 x FETCH_SIZE (the gfx950 16-B/lane correction) + WRITE_SIZE, in KB there."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_b128.txt")))
+    if not files:
+        return None, None
+    path = files[-1]
+    fetch = write = None
+    for line in open(path):
+        if kernel_prefix not in line:
+            continue
+        m = re.search(r"'FETCH_SIZE': ([0-9.]+)", line)
+        if m and line.startswith("fetch"):
+            fetch = float(m.group(1))
+        m = re.search(r"'WRITE_SIZE': ([0-9.]+)", line)
+        if m and line.startswith("write"):
+            write = float(m.group(1))
+    if fetch is None or write is None:
+        return None, os.path.relpath(path, ROOT)
+    return int((2 * fetch + write) * 1024), os.path.relpath(path, ROOT)
 
 
 def dominant_kernel_roofline(B, device):
-    """Average duration of the dominant kernel at this workload's shape, measured live with HIP events on the
-    launch stream: the 32->32 channel 4x4/s2 gather conv at 32x32 -> 16x16 (encoder conv2; the decoder's
-    convT2 backward-data is the same kernel and shape).  Algorithmic FLOPs per launch = 2 * B*16*16*32 * 512."""
+    """Average duration of the dominant kernel of the CdSprites+ step at this batch, measured live with HIP events on
+    the launch stream: the 32->32 channel 4x4/s2 gather conv at 32x32 -> 16x16 (encoder conv2; the decoder's convT2
+    backward-data is the same kernel and shape).  Algorithmic FLOPs per launch = 2 * B*16*16*32 * 512."""
     from multimodal_vae_comparison_amd import ops
     from multimodal_vae_comparison_amd import hipops as H
     x = torch.randn(B, 32, 32, 32, device=device)
@@ -124,25 +223,55 @@ def dominant_kernel_roofline(B, device):
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 2.0 * B * 16 * 16 * 32 * 512
     ach = flops / (us * 1e-6) / 1e12
+    traffic, src = _pmc_traffic("conv_gather_kernel<GatherGeom<32, 5")
     return {"bound": "mfma", "kernel": "conv_gather_kernel<32,*> (conv2 fwd shape)", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "avg_us": round(us, 2), "traffic": CONV2_FWD_HBM_BYTES_B128 if B == 128 else None,
-            "traffic_unit": "bytes/launch",
-            "traffic_source": "profiles/r01_e_pmc_conv_b128.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                              "FETCH doubled per the gfx950 16-B/lane correction); algorithmic 21.0e6"}
+            "avg_us": round(us, 2), "traffic": traffic if B == 128 else None, "traffic_unit": "bytes/launch",
+            "traffic_source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
+                              f"16-B/lane correction); algorithmic 21.0e6 at B=128"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _timed(tr, steps, warmup, path_world, barrier, pre=None):
+    for _ in range(warmup):
+        if pre:
+            pre()
+        tr.fused_step(path_world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if pre:
+            pre()
+        out = tr.fused_step(path_world)
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+def _build(name, batch, dev, rank, world, path_world):
+    from multimodal_vae_comparison_amd import parallel
+    from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
+    from multimodal_vae_comparison_amd.synthetic import workload
+    desc, cfg, dims, data, meta = workload(name, batch, device=dev, seed=1 + rank)
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    tr = MultimodalVAE(cfg, feature_dims=dims, device=dev)
+    tr.model.train()
+    tr.configure_optimizers()
+    if path_world > 1:
+        # broadcast of the flat parameters, 1/world folded into Adam, per-rank noise / dropout streams
+        parallel.setup_replica(tr, rank, world)
+    tr.capture(data, path_world)       # world 1: the Adam step is part of the captured graph
+    return tr, desc, meta
 
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", 0))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    from multimodal_vae_comparison_amd import parallel
+    from multimodal_vae_comparison_amd.synthetic import step_flops_per_sample, workload
+    # torchrun: the process group comes up before anything touches the GPU
+    rank, local, world = parallel.init_from_env("nccl")
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
     # --force-collective (testing on one GPU): take the multi-GPU structure of the step -- graph without the optimiser,
     # one RCCL all-reduce of the flat gradients, separate Adam launch -- with a single-rank process group
     path_world = world
@@ -151,59 +280,86 @@ def main():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, device_id=dev)
         path_world = 2
 
-    from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
-    from multimodal_vae_comparison_amd.synthetic import cdsprites_batch, cdsprites_config
-
-    torch.manual_seed(0)                                   # identical replicas on every rank
-    tr = MultimodalVAE(cdsprites_config("mopoe", a.latents, batch_size=a.batch), device=dev)
-    tr.model.train()
-    opt = tr.configure_optimizers()
-    if world > 1:
-        opt.grad_scale = 1.0 / world                       # all-reduce(sum) then average inside the Adam kernel
-    batch = cdsprites_batch(a.batch, a.seq, seed=1 + rank, device=dev)
-    tr.capture(batch, path_world)      # world 1: the Adam step is part of the captured graph
-
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        tr.fused_step(path_world)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = tr.fused_step(path_world)
-    barrier()
-    dt = time.perf_counter() - t0
+    tr, desc, meta = _build(a.config, a.batch, dev, rank, world, path_world)
+    B = meta["B"]
+    dt, out = _timed(tr, a.steps, a.warmup, path_world, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["loss"].item())
 
+    res = None
     if rank == 0:
-        sps = a.steps * a.batch * world / dt
-        res = {"metric": "training samples/sec, MoPoE CdSprites+ L2 (fwd+bwd+Adam)", "value": round(sps, 1),
+        flops = step_flops_per_sample(meta)
+        sps = a.steps * B * world / dt
+        res = {"metric": METRIC.get(a.config, f"training samples/sec, {a.config} (fwd+bwd+Adam)"), "value": round(sps, 1),
                "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[1]: MoPoE, CdSprites+ L2 shapes, CNN2 image tower + TxtTransformer "
-                                      f"text tower, n_latents={a.latents}, batch={a.batch}/GPU, T={a.seq}, "
-                                      "Adam(amsgrad) lr 1e-4, beta 1",
-                          "global_batch": a.batch * world, "parallelism": f"dp{world}",
+               "config": {"workload": f"{desc}; Adam(amsgrad) lr 1e-4, beta 1, train mode (dropout on)",
+                          "global_batch": B * world, "parallelism": f"dp{world}",
+                          "step_mflop_per_sample": round(flops / 1e6, 1),
                           "step_flops_fraction_of_f32_mfma_peak": round(
-                              sps / world * FLOP_PER_SAMPLE / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
+                              sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
                "final_loss": round(loss, 3)}
-        if world == 1:
-            res["roofline"] = dominant_kernel_roofline(a.batch, dev)
-            if not a.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(a.batch, a.seq, a.latents, a.cpu_seconds)
-                res["config"]["gpu_over_cpu"] = round(sps / res["cpu_baseline"]["value"], 1)
-    if world > 1 or path_world > 1:
+    if world == 1 and rank == 0:
+        res["roofline"] = dominant_kernel_roofline(B if meta["mods"][0]["enc"] == "CNN2" else 128, dev)
+        if not a.no_extras and path_world == 1 and a.config == "cfg2":
+            res["extras"] = extras(tr, a, dev, barrier)
+        if not a.no_cpu_baseline:
+            _, _, _, batch_cpu, _ = workload(a.config, a.batch, device="cpu", seed=1)
+            res["cpu_baseline"] = cpu_baseline(meta, batch_cpu)
+            res["config"]["gpu_over_cpu"] = round(sps / res["cpu_baseline"]["value"], 1)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+def extras(tr, a, dev, barrier):
+    """non-headline figures (never `value`): (1) the same step with the input step in the loop -- a fresh batch in the
+    compact host format (uint8 pixels, int32 token ids) copied H2D from pinned memory and expanded on the device
+    (MultimodalVAE.load_batch_compact) before every replay; (2) large per-GPU batches (512 and 1000 = the reference's
+    positional-table cap, nn_modules.py:419)"""
+    from multimodal_vae_comparison_amd.synthetic import step_flops_per_sample
+    out = {}
+    B, T, V = 128, 32, 27
+    g = torch.Generator().manual_seed(3)
+    host = []
+    for _ in range(4):          # a small ring of pinned host batches
+        u8 = torch.randint(0, 256, (B, 3, 64, 64), generator=g, dtype=torch.uint8).pin_memory()
+        tok = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32).pin_memory()
+        lens = torch.randint(3, T + 1, (B,), generator=g, dtype=torch.int32)
+        lens[0] = T
+        host.append({"mod_1": {"u8": u8}, "mod_2": {"tokens": tok, "lengths": lens.pin_memory()}})
+    it = {"i": 0}
+
+    def feed():
+        tr.load_batch_compact(host[it["i"] & 3])
+        it["i"] += 1
+    steps = max(20, a.steps // 2)
+    dt, _ = _timed(tr, steps, 5, 1, barrier, pre=feed)
+    out["with_input_pipeline"] = {"value": round(steps * B / dt, 1), "unit": "samples/s",
+                                  "ms_per_step": round(1e3 * dt / steps, 4),
+                                  "what": "pinned uint8 image + int32 token batch (1.6 MB) H2D + device expansion + the "
+                                          "captured step, every step"}
+    lb = {}
+    for Bl in (512, 1000):
+        t2, _, meta = _build("cfg2", Bl, dev, 0, 1, 1)
+        dt, _ = _timed(t2, 30, 5, 1, barrier)
+        sps = 30 * Bl / dt
+        lb[str(Bl)] = {"value": round(sps, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt / 30, 4),
+                       "step_flops_fraction_of_f32_mfma_peak": round(
+                           sps * step_flops_per_sample(meta) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)}
+        del t2
+    out["large_batch"] = lb
+    return out
 
 
 if __name__ == "__main__":

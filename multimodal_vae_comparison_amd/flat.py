@@ -81,10 +81,27 @@ class FlatAdam(torch.optim.Optimizer):
         self.vmax = torch.zeros_like(flat.data)
         self.step_dev = torch.zeros(6, dtype=torch.int32, device=flat.data.device)   # {count, ticket, b1^count, b2^count}
         self.grad_scale = grad_scale
+        self._steps_since_check = 0
+
+    def check_grad_views(self):
+        """every parameter's .grad must still be its slice of the flat gradient buffer (a zero_grad(set_to_none=True),
+        a model.to() or .half() detaches them: autograd would then fill fresh tensors while this optimiser keeps
+        reading an all-zero flat buffer and silently updates nothing)"""
+        base = self.flat.grad.data_ptr()
+        for p in self.flat.params:
+            g = p.grad
+            o = self.flat.offset_of[id(p)]
+            if g is None or g.data_ptr() != base + 4 * o or p.data_ptr() != self.flat.data.data_ptr() + 4 * o:
+                raise RuntimeError("FlatAdam: a parameter (or its .grad) is no longer a view of the flat buffers; use "
+                                   "FlatAdam.zero_grad() / MultimodalVAE.zero_grad() (not set_to_none) and do not move "
+                                   "or cast the model after construction")
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        if self._steps_since_check == 0:          # first step and every 256th (180 pointer reads: not per step)
+            self.check_grad_views()
+        self._steps_since_check = (self._steps_since_check + 1) & 255
         g = self.param_groups[0]
         # step = -1: the kernel takes step_dev[0] + 1 and stores it itself (one launch per step)
         ops.adam_amsgrad_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]),
@@ -118,10 +135,16 @@ class FlatAdam(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         params = self.flat.params_in_model_order
         steps = set()
+        if sd["state"] and len(sd["state"]) != len(params):
+            raise RuntimeError(f"optimizer state has {len(sd['state'])} entries, the model has {len(params)} trainable "
+                               f"parameters")
         for i, p in enumerate(params):
             st = sd["state"].get(i)
             if st is None:
                 continue
+            if st["exp_avg"].numel() != p.numel():
+                raise RuntimeError(f"optimizer state {i}: exp_avg has {st['exp_avg'].numel()} elements, parameter "
+                                   f"{tuple(p.shape)} has {p.numel()}")
             o = self.flat.offset_of[id(p)]
             sl = slice(o, o + p.numel())
             self.m[sl].copy_(st["exp_avg"].reshape(-1))

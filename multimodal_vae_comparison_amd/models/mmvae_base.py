@@ -77,6 +77,7 @@ class TorchMMVAE(nn.Module):
 
     def _begin_step(self):
         """start of an objective() call: per-step dropout call counters back to 0"""
+        ops.GradReducer.begin_step(self._rng_state.device)
         for vae in self.vaes.values():
             for part in (vae.enc, vae.dec):
                 st = getattr(part, "drop_state", None)

@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .. import flat as flatmod
 from .. import hipops as H
+from .. import parallel
 from . import mmvae_models  # noqa: F401
 from .mmvae_base import TorchMMVAE
 from .vae import VAE
@@ -35,6 +36,8 @@ class MultimodalVAE(nn.Module):
         self.to(device)
         self.flat = flatmod.FlatParams(self.model)
         self._graph = None
+        self.dp_world = 1           # ranks the flat gradients are summed over (parallel.setup_replica sets it)
+        self.dp_force_collective = False
 
     def get_model(self):
         """models/trainer.py:91-115"""
@@ -95,6 +98,13 @@ class MultimodalVAE(nn.Module):
         missing = [k for k, _ in self.model.named_parameters() if k not in sd]
         if strict and missing:
             raise KeyError(f"checkpoint lacks parameters: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        # torch's load_state_dict semantics: a shape mismatch is an error (another n_latents / tower config must not
+        # load silently and leave those parameters at their random initialisation)
+        bad = [f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}"
+               for k, v in sd.items() if k in own and own[k].shape != v.shape]
+        bad += [f"unexpected key {k}" for k in sd if k not in own]
+        if bad and strict:
+            raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(bad))
         with torch.no_grad():
             for k, v in sd.items():
                 if k in own and own[k].shape == v.shape:
@@ -102,6 +112,15 @@ class MultimodalVAE(nn.Module):
         if self.optimizer is not None and ckpt.get("optimizer_states"):
             self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
         return ckpt.get("epoch", 0), ckpt.get("global_step", 0)
+
+    def zero_grad(self, set_to_none=False):
+        """nn.Module.zero_grad defaults to set_to_none=True, which would detach every parameter from its flat gradient
+        view (the weight-gradient kernels accumulate straight into those views): clear the flat buffer instead"""
+        if self.optimizer is not None:
+            self.optimizer.zero_grad()
+        elif self.flat is not None:
+            self.flat.rebind_grads()
+            self.flat.zero_grad()
 
     # ---- MI355X fast path ------------------------------------------------------------------------
     def capture(self, batch, world_size=1):
@@ -112,7 +131,14 @@ class MultimodalVAE(nn.Module):
         self._static_batch = batch
         self._one = torch.ones((), device=self.flat.data.device)     # loss.backward() seed: no fill kernel per step
         from .. import ops
-        ops.LincombRows.unit_seed_ptr = self._one.data_ptr()         # ... and the ELBO assembly's backward is free
+        import weakref
+        ptr = self._one.data_ptr()
+        ops.LincombRows.unit_seed_ptr = ptr                          # ... and the ELBO assembly's backward is free
+
+        def _clear(ptr=ptr):        # the address may be recycled once this trainer is gone
+            if ops.LincombRows.unit_seed_ptr == ptr:
+                ops.LincombRows.unit_seed_ptr = None
+        weakref.finalize(self, _clear)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -217,7 +243,8 @@ class MultimodalVAE(nn.Module):
             for w in (w_dec, w_enc):
                 if w is not None:
                     w.wait()                                   # stream-level wait, the host does not block
-        elif world_size > 1:
-            torch.distributed.all_reduce(self.flat.grad)       # ONE RCCL collective over the 3.95 MB flat buffer
-        self.optimizer.step()
+            self.optimizer.step()
+            return self._static_out
+        # ONE RCCL collective over the flat gradient buffer, then the Adam kernel with the 1/world mean folded in
+        parallel.reduce_gradients_and_step(self.flat.grad, self.optimizer, self.dp_world, None, self.dp_force_collective)
         return self._static_out

@@ -50,6 +50,18 @@ class GradReducer:
         return key, st
 
     @classmethod
+    def begin_step(cls, device):
+        """start of an objective(): the previous backward pass must have folded and cleared everything.  If it raised
+        (autograd skips the final callbacks then) the state is stale -- `armed` would stay set, no later backward
+        would queue a fold and the deferred weight gradients would never reach the flat buffer: reset it."""
+        if device.type != "cuda":
+            return
+        _, st = cls._st(device)
+        if st["armed"] or st["segs"] or st["pending"]:
+            st.update(off=0, segs=[], armed=False, keep=[], used=set(), pending=[], spill=[], spilled=0)
+            cls.tail = None
+
+    @classmethod
     def alloc(cls, n_floats, device):
         """a private slice of the step arena.  The arena never moves or gets folded in the middle of a backward pass
         (kernels on several streams are writing into it): when it is full a further chunk is chained for the rest of

@@ -17,6 +17,10 @@ torch.distributions.Normal + kl_divergence.  The reference pins "PyTorch 1.12.1"
 
 All file:line citations are relative to /root/reference/multimodal_compare/.
 
+Precision: every cast in this file goes to torch.get_default_dtype(), so the whole restatement runs in fp64 under
+`torch.set_default_dtype(torch.float64)` with fp64 parameters / inputs / noise (tests use that to measure how
+ill-conditioned a quantity is: |oracle32 - oracle64| bounds what ANY fp32 implementation can be held to).
+
 Conventions
 -----------
 * `params`: dict {reference state_dict key: tensor}.  Key names are the reference's, including the
@@ -217,7 +221,7 @@ def process_output(h, w_mu, b_mu, w_lv, b_lv):
 
 def enc_cnn2(p, pre, x):
     """Enc_CNN2.forward, models/encoders.py:202-223: 4x [Conv2d(k4,s2,p1)+SiLU], flatten, Linear, heads."""
-    o = x.float()
+    o = x.to(torch.get_default_dtype())
     for i in (1, 2, 3, 4):
         o = F.silu(F.conv2d(o, p[f"{pre}.enc.conv{i}.weight"], p[f"{pre}.enc.conv{i}.bias"], stride=2, padding=1))
     o = o.reshape(o.shape[0], -1)
@@ -244,11 +248,12 @@ def dec_cnn(p, pre, z, data_dim=(64, 64, 3)):
     return d.reshape(-1, *data_dim)
 
 
-def positional_table(d_model, n, dtype=torch.float32):
+def positional_table(d_model, n, dtype=None):
     """PositionalEncoding buffer rows [0, n): models/nn_modules.py:422-428.  Returns (n, d_model)."""
+    dtype = dtype or torch.get_default_dtype()
     pe = torch.zeros(n, d_model, dtype=dtype)
-    position = torch.arange(0, n, dtype=torch.float).unsqueeze(1)
-    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    position = torch.arange(0, n, dtype=dtype).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).to(torch.get_default_dtype()) * (-math.log(10000.0) / d_model))
     pe[:, 0::2] = torch.sin(position * div_term)
     pe[:, 1::2] = torch.cos(position * div_term)[:, : d_model // 2]
     return pe
@@ -361,12 +366,12 @@ def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
     tq = _dropout(tq, train, nm("pe"))
     out = transformer_decoder_layer(tq, z, p, f"{pre}.dec.seqTransDecoder.layers.0", 2, ~mask, train, nm)
     out = F.linear(out, p[f"{pre}.dec.finallayer.module.weight"], p[f"{pre}.dec.finallayer.module.bias"])
-    return out.permute(1, 0, 2) * mask.unsqueeze(-1).float()    # (B,T,V), zero at padding
+    return out.permute(1, 0, 2) * mask.unsqueeze(-1).to(torch.get_default_dtype())    # (B,T,V), zero at padding
 
 
 def enc_mnist(p, pre, x):
     """Enc_MNIST.forward, models/encoders.py:252-265"""
-    h = x.reshape(x.shape[0], -1).float()
+    h = x.reshape(x.shape[0], -1).to(torch.get_default_dtype())
     h = F.relu(F.linear(h, p[f"{pre}.enc.enc.0.0.weight"], p[f"{pre}.enc.enc.0.0.bias"]))
     h = F.relu(F.linear(h, p[f"{pre}.enc.enc.1.0.weight"], p[f"{pre}.enc.enc.1.0.bias"]))
     return process_output(h, p[f"{pre}.enc.hidden_mu.weight"], p[f"{pre}.enc.hidden_mu.bias"],
@@ -387,7 +392,7 @@ def dec_mnist(p, pre, z, data_dim=(28, 28, 1)):
 
 def enc_svhn(p, pre, x):
     """Enc_SVHN.forward, models/encoders.py:458-478"""
-    h = x.float()
+    h = x.to(torch.get_default_dtype())
     for i, pad in enumerate((1, 1, 1, 0)):
         h = F.relu(F.conv2d(h, p[f"{pre}.enc.conv{i + 1}.weight"], p[f"{pre}.enc.conv{i + 1}.bias"], stride=2, padding=pad))
     h = h.reshape(h.shape[0], -1)
@@ -420,7 +425,7 @@ def enc_transformer(p, pre, data, mask, train=False):
     B, T = x.shape[0], x.shape[1]
     if mask is None:
         mask = torch.ones(B, T, dtype=torch.bool)
-    x = x.permute(1, 0, 2, 3).reshape(T, B, -1).float()
+    x = x.permute(1, 0, 2, 3).reshape(T, B, -1).to(torch.get_default_dtype())
     x = F.linear(x, p[f"{pre}.enc.skel_Embedding.module.weight"], p[f"{pre}.enc.skel_Embedding.module.bias"])
     d = x.shape[-1]
     x = x + positional_table(d, T).reshape(T, 1, d)
@@ -529,14 +534,14 @@ def recon_bce(x_hat, target):
     """ReconLoss.bce, models/objectives.py:392-406; target reshaped to the output's (viewed) shape
     (`:120`).  Returns (B, F) positive loss."""
     B = target.shape[0]
-    return F.binary_cross_entropy(x_hat, target.float().reshape(x_hat.shape).detach(), reduction="none").reshape(B, -1)
+    return F.binary_cross_entropy(x_hat, target.to(torch.get_default_dtype()).reshape(x_hat.shape).detach(), reduction="none").reshape(B, -1)
 
 
 def recon_category_ce(logits, target):
     """ReconLoss.category_ce, models/objectives.py:486-500: CrossEntropyLoss over dim 1 (= time) with
     probability targets.  logits/target (B,T,V) -> (B,V)."""
     lsm = F.log_softmax(logits, dim=1)
-    return -(target.float().detach() * lsm).sum(dim=1)
+    return -(target.to(torch.get_default_dtype()).detach() * lsm).sum(dim=1)
 
 
 PX_SCALE = 0.75     # the decoders' second return value: Normal(loc, 0.75), models/decoders.py:98,616,723
@@ -547,7 +552,7 @@ def recon_lprob(loc, target, scale=None, laplace=False):
     fp32 by torch.distributions, THEN cast to float64, NaN -> 0 (an in-place masked write: those elements carry no
     gradient).  scale = 0.75, or `loc` itself when the modality has masks (`output.scale = output.loc`, :43-45)."""
     B = target.shape[0]
-    t = target.float().reshape(loc.shape).detach()
+    t = target.to(torch.get_default_dtype()).reshape(loc.shape).detach()
     sc = torch.full_like(loc, PX_SCALE) if scale is None else scale
     if laplace:
         lp = -torch.log(2 * sc) - torch.abs(t - loc) / sc                     # torch.distributions.Laplace.log_prob
@@ -560,7 +565,7 @@ def recon_lprob(loc, target, scale=None, laplace=False):
 
 def softclip(t, lo):
     """utils.softclip, utils.py:66-69"""
-    return lo + F.softplus((t - lo).float())
+    return lo + F.softplus((t - lo).to(torch.get_default_dtype()))
 
 
 def recon_optimal_sigma(loc, target):
@@ -568,7 +573,7 @@ def recon_optimal_sigma(loc, target):
     every element of (t - x)^2), -6) per call; the squared term is `.clone().detach()`-ed, so the only gradient path
     into the decoder is through log sigma."""
     B = target.shape[0]
-    t = target.float().reshape(loc.shape).detach()
+    t = target.to(torch.get_default_dtype()).reshape(loc.shape).detach()
     log_sigma = softclip(((t - loc) ** 2).mean().sqrt().log(), -6.0)
     sq = (((t - loc) / log_sigma.exp()) ** 2).detach()
     return (sq + log_sigma + 0.5 * math.log(2 * math.pi)).reshape(B, -1)
@@ -722,7 +727,7 @@ def recon_lprob_k(loc, target, K, laplace=False):
     """recon_loss_fn + reshape_for_loss + ReconLoss.lprob for a K-sample decoder output (objectives.py:30-52,103-125,
     409-424): the target is repeated K times and reshaped like loc (K,B,...) -- or (B,...) when the decoder squeezed
     K = 1 away --, bs = loc.shape[0]; returns the positive fp64 loss of shape (loc.shape[0], -1)."""
-    t = target.float().repeat(K, *([1] * (target.dim() - 1))).reshape(loc.shape).detach()
+    t = target.to(torch.get_default_dtype()).repeat(K, *([1] * (target.dim() - 1))).reshape(loc.shape).detach()
     sc = torch.full_like(loc, PX_SCALE)
     lp = laplace_log_prob(t, loc, sc) if laplace else normal_log_prob(t, loc, sc)
     out = lp.reshape(loc.shape[0], -1).double()
