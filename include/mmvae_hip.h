@@ -142,6 +142,12 @@ int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias, const flo
                    long ldc, int a_act, int b_act, int ep_mode, int accumulate, int splitk,
                    mmvae_stream_t stream);
 size_t mmvae_gemm_ws_floats(int M, int N, int splitk);
+/* number of partial results (rows of M*N [+ M] floats in ws) mmvae_gemm_f32 writes for a requested splitk */
+int mmvae_gemm_splits(int M, int N, int K, int splitk);
+/* grouped bias of a layer whose N outputs are C channels x G positions (nn.ConvTranspose2d on a 1x1 input run as a
+ * GEMM, models/decoders.py:116,129-131):  y[r, c*G + g] += bias[c];   db[c] (+)= sum_r sum_g dy[r, c*G + g] */
+int mmvae_bias_group_add(float* y, const float* bias, int rows, int C, int G, mmvae_stream_t stream);
+int mmvae_bias_group_grad(const float* dy, float* db, int rows, int C, int G, int accumulate, mmvae_stream_t stream);
 
 /* y = ep(x W^T + b): x (M,K) ld ldx, W (N,K), y (M,N).  F.linear */
 int mmvae_linear_fwd(const float* x, const float* w, const float* b, float* aux, float* y, int M, int N, int K,

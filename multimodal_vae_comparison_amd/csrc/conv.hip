@@ -48,7 +48,7 @@ static int conv_bwd_reduce(float* ws, float* dw, float* db, int B, int Q, int Hs
                            mmvae_stream_t stream) {
   if (accumulate == MMVAE_ACC_DEFER) return MMVAE_OK;
   int rows, rowlen, bias_col;
-  conv_wgrad_layout(B, Q, Hs, &rows, &rowlen, &bias_col);
+  conv_wgrad_layout(B, 32, Q, Hs, &rows, &rowlen, &bias_col);
   int rc = mmvae_reduce_rows(ws, dw, rows, bias_col, rowlen, accumulate, stream);
   if (rc) return rc;
   if (db) rc = mmvae_reduce_rows(ws + bias_col, db, rows, nbias, rowlen, accumulate, stream);
@@ -67,10 +67,10 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
     return conv_scatter_dispatch(dy, w, nullptr, x, dx, B, Cout, Cin, Hout, MMVAE_ACT_NONE, dact_ep(x_act), st);
   }
   const int ep = dact_ep(x_act);
-  ConvScatterArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep};
+  ConvScatterArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep, CONV_CO};
   const long tiles = ((long)B * Hout * Hout + 31) / 32;
   const int n_macro = wgrad_n_macro(B, Hout), nsplit = wgrad_splits(n_macro, 32);
-  ConvWgradArgs aw{dy, x, ws, B, MMVAE_ACT_NONE, x_act, db ? 1 : 0, n_macro};
+  ConvWgradArgs aw{dy, x, ws, B, MMVAE_ACT_NONE, x_act, db ? 1 : 0, n_macro, 32, (long)32 * 32 * 16 + 32};
   // one instantiation per layer shape: the scatter plan is a function of the map size at a given batch, but both
   // template arguments must be compile-time, so the (few) combinations are enumerated by the two visitors
   bool launched = false;
@@ -111,10 +111,10 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
     return conv_gather_dispatch(dy, w, nullptr, x, dx, B, Cout, Cin, 2 * Hin, MMVAE_ACT_NONE, ep, st);
   }
   // input gradient = gather conv over dy (2Hin x 2Hin, Cout channels) -> (Hin x Hin, 32 channels)
-  ConvGatherArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep};
+  ConvGatherArgs ad{dy, w, nullptr, x, dx, B, MMVAE_ACT_NONE, ep, CONV_CO};
   const long tiles = ((long)B * Hin * Hin + 31) / 32;
   const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
-  ConvWgradArgs aw{x, dy, ws, B, x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro};
+  ConvWgradArgs aw{x, dy, ws, B, x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro, 32, (long)32 * Cout * 16 + 32};
   bool launched = false;
   gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles), [&](auto g) {
     using G = decltype(g);
@@ -179,14 +179,12 @@ extern "C" int mmvae_convT2d_k4s2_wgrad(const float* x, const float* dy, float* 
                              (hipStream_t)stream);
 }
 extern "C" size_t mmvae_conv_wgrad_ws_floats(int B, int Csmall, int Clarge, int Hsmall) {
-  (void)Csmall;
-  return conv_wgrad_ws_floats(B, Clarge, Hsmall);
+  return conv_wgrad_ws_floats(B, Csmall, Clarge, Hsmall);
 }
 extern "C" int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen,
                                        int* bias_col) {
-  (void)Csmall;
   MMVAE_CHECK_ARG(rows && rowlen && bias_col);
-  conv_wgrad_layout(B, Clarge, Hsmall, rows, rowlen, bias_col);
+  conv_wgrad_layout(B, Csmall, Clarge, Hsmall, rows, rowlen, bias_col);
   return MMVAE_OK;
 }
 

@@ -257,3 +257,48 @@ extern "C" int mmvae_sigmoid_bwd(const float* dy, const float* y, float* dx, lon
   hipLaunchKernelGGL(sigmoid_kernel, dim3(gconv_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, 1);
   return mmvae_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// grouped bias (a ConvTranspose2d on a 1x1 input is the GEMM (B, Cin) x (Cin, Cout*K*K); its bias repeats over the
+// K*K positions of a channel)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_group_add_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                             long n4, int N4, int G4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float bv = bias[(int)(i % N4) / G4];
+    float4 v = reinterpret_cast<float4*>(y)[i];
+    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+// one workgroup per channel: rows x G elements, column block [c*G, c*G + G)
+__global__ __launch_bounds__(256) void bias_group_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                              int rows, int C, int G, int accumulate) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const long N = (long)C * G;
+  float acc = 0.f;
+  for (long e = threadIdx.x; e < (long)rows * G; e += 256) {
+    const long r = e / G, g = e - r * G;
+    acc += dy[r * N + (long)c * G + g];
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + acc : acc;
+}
+extern "C" int mmvae_bias_group_add(float* y, const float* bias, int rows, int C, int G, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(y && bias && rows > 0 && C > 0 && G > 0);
+  if (G % 4) return MMVAE_ERR_UNSUPPORTED;
+  const long n4 = (long)rows * C * G / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bias_group_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, n4,
+                     C * G / 4, G / 4);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_bias_group_grad(const float* dy, float* db, int rows, int C, int G, int accumulate,
+                                     mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && db && rows > 0 && C > 0 && G > 0);
+  hipLaunchKernelGGL(bias_group_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, rows, C, G,
+                     accumulate ? 1 : 0);
+  return mmvae_launch_status();
+}

@@ -474,6 +474,23 @@ static bool rgemm_enabled() {
   return v != 0;
 }
 
+// tiling variant, reduction length per split and number of splits actually used for (M, N, K, requested splitk)
+static int gemm_split_plan(int M, int N, int K, int splitk, int* variant_out, int* kper_out) {
+  if (splitk < 1) splitk = 1;
+  const int ntn = (N + 31) / 32;
+  const long tiles128 = (long)((M + 127) / 128) * ntn, tiles32 = (long)((M + 31) / 32) * ntn;
+  int variant = 4;
+  if (tiles128 >= 256) variant = 1;   // measured: below that the single-stage 32x32 tiles are faster
+  else if (K >= 384 && tiles32 <= 512 && splitk == 1) variant = 8;
+  const int bk = variant == 1 ? GEMM_BK1 : 32 * variant;
+  int kper = (K + splitk - 1) / splitk;
+  kper = (kper + bk - 1) / bk * bk;
+  if (variant_out) *variant_out = variant;
+  if (kper_out) *kper_out = kper;
+  return (K + kper - 1) / kper;
+}
+extern "C" int mmvae_gemm_splits(int M, int N, int K, int splitk) { return gemm_split_plan(M, N, K, splitk, nullptr, nullptr); }
+
 extern "C" size_t mmvae_gemm_ws_floats(int M, int N, int splitk) {
   return splitk > 1 ? (size_t)splitk * ((size_t)M * N + M) : 0;
 }
@@ -497,13 +514,8 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   //   K >= 384, few tiles    : 32x32 tile, 8 waves x 256-deep stages (half the serial stages)  (KSPLIT 8)
   //   otherwise              : 32x32 tile, 4 waves x 128-deep stages                       (KSPLIT 4)
   const long tiles128 = (long)((M + 127) / 128) * ntn, tiles32 = (long)((M + 31) / 32) * ntn;
-  int variant = 4;
-  if (tiles128 >= 256) variant = 1;   // measured: below that the single-stage 32x32 tiles are faster
-  else if (K >= 384 && tiles32 <= 512 && splitk == 1) variant = 8;
-  const int bk = variant == 1 ? GEMM_BK1 : 32 * variant;
-  int kper = (K + splitk - 1) / splitk;
-  kper = (kper + bk - 1) / bk * bk;
-  const int nz = (K + kper - 1) / kper;
+  int variant, kper;
+  const int nz = gemm_split_plan(M, N, K, splitk, &variant, &kper);
   g.kper = kper;
   if (nz > 1 && !ws) return MMVAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

@@ -77,6 +77,9 @@ SIGNATURES = {
     "mmvae_convT2d_k4s2_bwd": (c_i, [c_p] * 7 + [c_i] * 6 + [c_p]),
     "mmvae_gemm_f32": (c_i, [c_p] * 7 + [c_i] * 3 + [c_l] * 5 + [c_i] * 5 + [c_p]),
     "mmvae_gemm_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_gemm_splits": (c_i, [c_i] * 4),
+    "mmvae_bias_group_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_bias_group_grad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "mmvae_linear_fwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_linear_bwd_data": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
     "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),

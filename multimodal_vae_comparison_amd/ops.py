@@ -529,23 +529,48 @@ def _pow2(v, lo, hi):
     return lo <= v <= hi and (v & (v - 1)) == 0
 
 
+def _mfma_conv_shape(c_gather_red, c_out32, h_big):
+    """shapes the MFMA 4x4 / stride-2 / pad-1 kernels are instantiated for, in the gather orientation (big map h_big
+    with `c_gather_red` channels <-> small map h_big / 2 with `c_out32` channels, a multiple of 32): the CdSprites+
+    towers' 3 / 32-channel layers and the SVHN towers' 64-channel layers"""
+    if c_out32 % 32 or c_out32 > 128:
+        return False
+    if c_gather_red == 3:
+        return c_out32 == 32 and _pow2(h_big, 8, 64)
+    if c_gather_red == 32:
+        return _pow2(h_big, 8, 32)
+    if c_gather_red == 64:
+        return _pow2(h_big, 8, 16)
+    return False
+
+
 def conv2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, gw=None, gb=None):
-    """nn.Conv2d on act(x): the MFMA kernels for the k4-s2-p1 3/32 -> 32 channel layers, the generic kernel otherwise"""
+    """nn.Conv2d on act(x): the MFMA kernels for the k4-s2-p1 layers (3 / 32 / 64 -> 32 / 64 channels), a plain GEMM
+    when the kernel covers the whole map (SVHN conv4: k4 s2 p0 on 4x4 -> 1x1), the generic kernel otherwise"""
     Cout, Cin, K, _ = w.shape
     Hin = x.shape[-1]
-    if (K == 4 and stride == 2 and pad == 1 and Cout == 32 and x.shape[-2] == Hin and
-            ((Cin == 32 and _pow2(Hin, 8, 32)) or (Cin == 3 and _pow2(Hin, 8, 64)))):
+    if K == 4 and stride == 2 and pad == 1 and x.shape[-2] == Hin and _mfma_conv_shape(Cin, Cout, Hin):
         return Conv2dK4S2.apply(x, w, b, in_act, gw, gb)
+    if pad == 0 and x.shape[-2] == K and Hin == K:      # one output position: y[b, o] = <act(x[b]), w[o]> + bias[o]
+        B = x.shape[0]
+        y = Linear.apply(x.reshape(B, Cin * K * K), w.view(Cout, Cin * K * K), b, in_act,
+                         gw.view(Cout, Cin * K * K) if gw is not None else None, gb)
+        return y.view(B, Cout, 1, 1)
     return ConvGeneric.apply(x, w, b, False, stride, pad, in_act, H.EP_NONE, gw, gb)
 
 
 def convT2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None):
-    """nn.ConvTranspose2d on act(x), optional sigmoid epilogue"""
+    """nn.ConvTranspose2d on act(x), optional sigmoid epilogue: MFMA kernels for the k4-s2-p1 layers, a plain GEMM for a
+    1x1 input (SVHN decoder conv1: k4 s1 p0, 1x1 -> 4x4), the generic kernel otherwise"""
     Cin, Cout, K, _ = w.shape
     Hin = x.shape[-1]
-    if (K == 4 and stride == 2 and pad == 1 and Cin == 32 and x.shape[-2] == Hin and
-            ((Cout == 32 and _pow2(Hin, 4, 16) and out_ep == H.EP_NONE) or (Cout == 3 and Hin in (16, 32)))):
-        return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+    if K == 4 and stride == 2 and pad == 1 and x.shape[-2] == Hin:
+        if Cout == 3 and Cin == 32 and Hin in (16, 32):
+            return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+        if out_ep == H.EP_NONE and Cin in (32, 64) and _mfma_conv_shape(Cout, Cin, 2 * Hin) and Hin >= 4:
+            return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+    if Hin == 1 and x.shape[-2] == 1 and pad == 0 and out_ep == H.EP_NONE:
+        return LinearKN.apply(x.reshape(x.shape[0], Cin), w, b, in_act, gw, gb).view(x.shape[0], Cout, K, K)
     return ConvGeneric.apply(x, w, b, True, stride, pad, in_act, out_ep, gw, gb)
 
 
@@ -640,6 +665,67 @@ class Linear(Function):
 
 def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
     return Linear.apply(x, w, b, in_act, gw, gb)
+
+
+class LinearKN(Function):
+    """y[m, (c, g)] = sum_k act(x)[m, k] w[k, c, g] + b[c]  with the weight stored (K, C, kh, kw): nn.ConvTranspose2d
+    (kernel = output size, stride 1, pad 0) on a 1x1 input -- the first layer of Dec_SVHN (models/decoders.py:116) --
+    as plain strided GEMMs (forward, data gradient, weight gradient) + a grouped bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, in_act, gw, gb):
+        x = H.f32c(x)
+        M, K = x.shape
+        C = w.shape[1]
+        G = w.shape[2] * w.shape[3]
+        N = C * G
+        y = torch.empty(M, N, device=x.device)
+        _call("mmvae_gemm_f32", H.ptr(x), H.ptr(w), None, None, H.ptr(y), None, None, M, N, K, K, 1, N, 1, N, in_act,
+              H.ACT_NONE, H.EP_NONE, 0, 1, H.stream())
+        if b is not None:
+            _call("mmvae_bias_group_add", H.ptr(y), H.ptr(b), M, C, G, H.stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (in_act, gw, gb, b is not None, C, G)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        in_act, gw, gb, has_b, C, G = ctx.cfg
+        dy = H.f32c(dy)
+        M, K = x.shape
+        N = C * G
+        lib = H.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:       # dx[m, k] = ep( sum_n dy[m, n] w[k, n] )
+            dx = torch.empty_like(x)
+            ep = _DACT[in_act]
+            _call("mmvae_gemm_f32", H.ptr(dy), H.ptr(w), None, H.ptr(x) if ep else None, H.ptr(dx), None, None, M, K, N,
+                  N, 1, 1, N, K, H.ACT_NONE, H.ACT_NONE, ep, 0, 1, H.stream())
+        # dw[k, n] (+)= sum_m act(x)[m, k] dy[m, n]: rows K, columns N, reduction over the M samples (split)
+        dw, acc_w, ret_w = _new_like_param(w, gw)
+        tiles = ((K + 31) // 32) * ((N + 31) // 32)
+        want = max(1, min(64, 512 // max(tiles, 1), (M + 127) // 128))
+        nz = lib.mmvae_gemm_splits(K, N, M, want)
+        if nz <= 1:
+            want, nz = 1, 1
+        defer = _defer(gw) and nz > 1
+        ws = None
+        if nz > 1:
+            nws = lib.mmvae_gemm_ws_floats(K, N, nz)
+            ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
+        _call("mmvae_gemm_f32", H.ptr(x), H.ptr(dy), None, None, H.ptr(dw), None, H.ptr(ws), K, N, M, 1, K, N, 1, N,
+              in_act, H.ACT_NONE, H.EP_NONE, H.ACC_DEFER if defer else acc_w, want, H.stream())
+        if defer:
+            GradReducer.add(ws.data_ptr(), dw, nz, K * N, K * N)
+        ret_b = None
+        if has_b:
+            if gb is not None:
+                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(gb), M, C, G, 1, H.stream())
+            else:
+                ret_b = torch.empty(C, device=x.device)
+                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(ret_b), M, C, G, 0, H.stream())
+        return dx, ret_w, ret_b, None, None, None
 
 
 class HeadSoftmax(Function):

@@ -350,7 +350,13 @@ def test_seeded_losses_write_their_own_backward(ops, B, Fd):
 @pytest.mark.parametrize("transposed,B,Cin,Cout,Hin,S,P,act,ep", [
     (False, 5, 32, 64, 16, 2, 1, 2, 0), (False, 3, 64, 64, 8, 2, 1, 2, 0), (False, 4, 64, 128, 4, 2, 0, 2, 0),
     (False, 2, 3, 32, 32, 2, 1, 0, 0), (True, 4, 128, 64, 1, 1, 0, 2, 0), (True, 3, 64, 64, 4, 2, 1, 2, 0),
-    (True, 3, 64, 32, 8, 2, 1, 2, 0), (True, 2, 32, 3, 16, 2, 1, 2, 7), (True, 2, 16, 5, 6, 2, 1, 1, 7)])
+    (True, 3, 64, 32, 8, 2, 1, 2, 0), (True, 2, 32, 3, 16, 2, 1, 2, 7), (True, 2, 16, 5, 6, 2, 1, 1, 7),
+    # the 64-channel MFMA instantiations at sizes with several workgroups / ragged last tiles, every plan
+    (False, 130, 32, 64, 16, 2, 1, 2, 0), (False, 70, 64, 64, 8, 2, 1, 2, 0), (False, 600, 64, 64, 8, 2, 1, 1, 0),
+    (False, 3, 32, 64, 32, 2, 1, 0, 0), (False, 6, 64, 32, 16, 2, 1, 2, 0), (False, 40, 64, 128, 4, 2, 0, 2, 0),
+    (True, 260, 64, 64, 4, 2, 1, 2, 0), (True, 65, 64, 32, 8, 2, 1, 2, 0), (True, 900, 64, 32, 8, 2, 1, 2, 0),
+    (True, 5, 32, 64, 8, 2, 1, 0, 0), (True, 3, 64, 32, 16, 2, 1, 1, 0), (True, 33, 128, 64, 1, 1, 0, 2, 0),
+    (True, 1100, 128, 64, 1, 1, 0, 2, 0)])
 def test_conv_generic(ops, transposed, B, Cin, Cout, Hin, S, P, act, ep):
     """ops.conv2d / ops.convT2d (generic kernels, or the MFMA kernels when the shape is theirs) vs torch fp64: the
     SVHN tower layers (channels 64 / 128, k4 s2 p0, k4 s1 p0) and the plain-sigmoid epilogue"""
@@ -377,6 +383,38 @@ def test_conv_generic(ops, transposed, B, Cin, Cout, Hin, S, P, act, ep):
     check(xg.grad, gx, 5e-5, "conv dx")
     check(wg.grad, wr.grad, 5e-5, "conv dw")
     check(bg.grad, br.grad, 5e-5, "conv db")
+
+
+@pytest.mark.parametrize("transposed,B,Cin,Cout,Hin,S,P", [(False, 9, 32, 64, 16, 2, 1), (False, 9, 64, 64, 8, 2, 1),
+                                                          (False, 9, 64, 128, 4, 2, 0), (True, 9, 128, 64, 1, 1, 0),
+                                                          (True, 9, 64, 64, 4, 2, 1), (True, 300, 64, 32, 8, 2, 1)])
+def test_wide_conv_accumulates_into_preset_gradients(ops, transposed, B, Cin, Cout, Hin, S, P):
+    """the SVHN layers with their parameters' preset (flat-buffer) gradient views: split partials go through the
+    deferred end-of-backward fold, and the generic (non-MFMA) kernels are never reached"""
+    g = torch.Generator().manual_seed(Cin + Cout + Hin)
+    x = torch.randn(B, Cin, Hin, Hin, generator=g)
+    w = torch.randn(*((Cin, Cout) if transposed else (Cout, Cin)), 4, 4, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    f = F.conv_transpose2d if transposed else F.conv2d
+    ref = f(torch.relu(xr), wr, br, stride=S, padding=P)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV), b.to(DEV)
+    gw, gb = torch.ones_like(wd), torch.ones_like(bd)
+    generic = ops.ConvGeneric.apply
+    ops.ConvGeneric.apply = staticmethod(lambda *a, **k: (_ for _ in ()).throw(AssertionError("generic conv reached")))
+    try:
+        out = (ops.convT2d(xg, wd, bd, S, P, 2, 0, gw, gb) if transposed else ops.conv2d(xg, wd, bd, S, P, 2, gw, gb))
+        out.backward(dy.to(DEV))
+    finally:
+        ops.ConvGeneric.apply = generic
+    torch.cuda.synchronize()
+    check(out, ref, 2e-5, "out")
+    check(xg.grad, xr.grad, 5e-5, "dx")
+    check(gw - 1, wr.grad, 5e-5, "dw (accumulated)")
+    check(gb - 1, br.grad, 5e-5, "db (accumulated)")
 
 
 @pytest.mark.parametrize("B,F_,own,laplace", [(7, 33, False, False), (128, 12288, False, False), (5, 24, True, False),
