@@ -147,7 +147,12 @@ int mmvae_gemm_splits(int M, int N, int K, int splitk);
 /* grouped bias of a layer whose N outputs are C channels x G positions (nn.ConvTranspose2d on a 1x1 input run as a
  * GEMM, models/decoders.py:116,129-131):  y[r, c*G + g] += bias[c];   db[c] (+)= sum_r sum_g dy[r, c*G + g] */
 int mmvae_bias_group_add(float* y, const float* bias, int rows, int C, int G, mmvae_stream_t stream);
-int mmvae_bias_group_grad(const float* dy, float* db, int rows, int C, int G, int accumulate, mmvae_stream_t stream);
+size_t mmvae_bias_group_ws_floats(int rows, int C);   /* = parts * C; parts = mmvae_bias_group_parts(rows) */
+int mmvae_bias_group_parts(int rows);
+/* ws: mmvae_bias_group_ws_floats floats of row-block partials (parts, C); accumulate = MMVAE_ACC_DEFER leaves them
+ * there for the caller's fold */
+int mmvae_bias_group_grad(const float* dy, float* db, float* ws, int rows, int C, int G, int accumulate,
+                          mmvae_stream_t stream);
 
 /* y = ep(x W^T + b): x (M,K) ld ldx, W (N,K), y (M,N).  F.linear */
 int mmvae_linear_fwd(const float* x, const float* w, const float* b, float* aux, float* y, int M, int N, int K,
@@ -275,11 +280,18 @@ int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float
  * (BaseObjective.reshape_for_loss, objectives.py:118-120); target_rows == B otherwise.  lap_block_rows > 0: `laplace`
  * is a bit mask over consecutive blocks of that many rows (bit j: rows [j, j+1) * lap_block_rows are Laplace) -- one
  * launch for a decoder pass whose own / cross reconstructions carry different likelihood families (MoE,
- * models/mmvae_models.py:101-103 vs :115); 0: `laplace` is the flag for every row. */
+ * models/mmvae_models.py:101-103 vs :115); 0: `laplace` is the flag for every row.
+ * perm_c > 0: loc (and dloc) are stored (B, perm_c, F / perm_c) -- the NCHW output of a conv decoder -- while element j
+ * of a target row pairs with loc[b, j % perm_c, j / perm_c]: Dec_SVHN returns its output permuted to (B,H,W,C) and
+ * the loss reshapes (does not permute) the NCHW target to that shape (decoders.py:144, objectives.py:120); the kernel
+ * indexes instead of materialising the permuted copy.
+ * logit_grad != 0: loc holds y = sigmoid(logits) written by the producing layer's epilogue, and bwd emits the
+ * gradient with respect to the LOGITS, dloc = g * d(-log p)/dy * y (1 - y) (no separate sigmoid backward pass). */
 int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F, int target_rows,
-                           float scale, int laplace, int lap_block_rows, mmvae_stream_t stream);
+                           float scale, int laplace, int lap_block_rows, int perm_c, mmvae_stream_t stream);
 int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, const float* g_row, float* dloc, int B, int F,
-                           int target_rows, float scale, int laplace, int lap_block_rows, mmvae_stream_t stream);
+                           int target_rows, float scale, int laplace, int lap_block_rows, int perm_c, int logit_grad,
+                           mmvae_stream_t stream);
 /* ReconLoss.optimal_sigma (models/objectives.py:503-509) + utils.softclip (utils.py:66-69): one log sigma per call
  * from the mean squared error over all B*F elements; row[b] = sum_f ((t-x)/sigma)^2 + F (log sigma + log sqrt(2 pi)).
  * stats (3 floats, written by fwd, read by bwd) = {mean square, log sigma, unclipped log sigma}.  Gradient flows only

@@ -50,6 +50,7 @@ __device__ __forceinline__ float apply_epilogue(float v, float aux_v, int ep) {
     case MMVAE_EP_GELU: return dev_gelu(v);
     case MMVAE_EP_MUL_GELU_GRAD: return v * dev_gelu_grad(aux_v);
     case MMVAE_EP_SIGMOID_CLAMP: return fminf(fmaxf(dev_sigmoid(v), 1e-6f), 1.0f - 1e-6f);
+    case MMVAE_EP_SIGMOID: return dev_sigmoid(v);
     default: return v;
   }
 }

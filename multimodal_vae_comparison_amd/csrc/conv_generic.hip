@@ -271,20 +271,26 @@ __global__ __launch_bounds__(256) void bias_group_add_kernel(float* __restrict__
     reinterpret_cast<float4*>(y)[i] = v;
   }
 }
-// one workgroup per channel: rows x G elements, column block [c*G, c*G + G)
-__global__ __launch_bounds__(256) void bias_group_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
-                                                              int rows, int C, int G, int accumulate) {
+// stage 1: workgroup (c, part) sums its block of rows of channel c's G columns -> ws[part * C + c]
+__global__ __launch_bounds__(256) void bias_group_grad_kernel(const float* __restrict__ dy, float* __restrict__ ws,
+                                                              int rows, int C, int G, int rows_per) {
   __shared__ float red[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, part = blockIdx.y;
   const long N = (long)C * G;
+  const int r0 = part * rows_per, r1 = min(rows, r0 + rows_per);
   float acc = 0.f;
-  for (long e = threadIdx.x; e < (long)rows * G; e += 256) {
+  for (long e = threadIdx.x; e < (long)(r1 - r0) * G; e += 256) {
     const long r = e / G, g = e - r * G;
-    acc += dy[r * N + (long)c * G + g];
+    acc += dy[(r0 + r) * N + (long)c * G + g];
   }
   acc = block_sum_256(acc, red);
-  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + acc : acc;
+  if (threadIdx.x == 0) ws[(size_t)part * C + c] = acc;
 }
+extern "C" int mmvae_bias_group_parts(int rows) {
+  int parts = (rows + 127) / 128;
+  return parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+}
+extern "C" size_t mmvae_bias_group_ws_floats(int rows, int C) { return (size_t)mmvae_bias_group_parts(rows) * C; }
 extern "C" int mmvae_bias_group_add(float* y, const float* bias, int rows, int C, int G, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(y && bias && rows > 0 && C > 0 && G > 0);
   if (G % 4) return MMVAE_ERR_UNSUPPORTED;
@@ -295,10 +301,14 @@ extern "C" int mmvae_bias_group_add(float* y, const float* bias, int rows, int C
                      C * G / 4, G / 4);
   return mmvae_launch_status();
 }
-extern "C" int mmvae_bias_group_grad(const float* dy, float* db, int rows, int C, int G, int accumulate,
+extern "C" int mmvae_bias_group_grad(const float* dy, float* db, float* ws, int rows, int C, int G, int accumulate,
                                      mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(dy && db && rows > 0 && C > 0 && G > 0);
-  hipLaunchKernelGGL(bias_group_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, rows, C, G,
-                     accumulate ? 1 : 0);
-  return mmvae_launch_status();
+  MMVAE_CHECK_ARG(dy && db && ws && rows > 0 && C > 0 && G > 0);
+  const int parts = mmvae_bias_group_parts(rows);
+  const int rows_per = (rows + parts - 1) / parts;
+  hipLaunchKernelGGL(bias_group_grad_kernel, dim3(C, parts), dim3(256), 0, (hipStream_t)stream, dy, ws, rows, C, G,
+                     rows_per);
+  int rc = mmvae_launch_status();
+  if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
+  return mmvae_reduce_rows(ws, db, parts, C, C, accumulate, stream);
 }

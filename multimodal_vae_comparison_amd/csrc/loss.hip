@@ -175,14 +175,15 @@ __device__ __forceinline__ float lprob_logp(float x, float t, float s, int lapla
 }
 __global__ __launch_bounds__(256) void lprob_rowsum_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
                                                            float* __restrict__ row, int F, int trows, float scale,
-                                                           int laplace, int lap_rows) {
+                                                           int laplace, int lap_rows, int perm_c) {
   __shared__ double red[4];
   if (lap_rows > 0) laplace = (laplace >> (blockIdx.x / lap_rows)) & 1;
   const size_t base = (size_t)blockIdx.x * F;
   const size_t tbase = (size_t)(blockIdx.x % trows) * F;
+  const int hw = perm_c > 0 ? F / perm_c : 0;
   double acc = 0.0;
   for (int i = threadIdx.x; i < F; i += 256) {
-    const float x = loc[base + i];
+    const float x = loc[base + (perm_c > 0 ? (i % perm_c) * hw + i / perm_c : i)];
     const float lp = lprob_logp(x, tg[tbase + i], scale > 0.f ? scale : x, laplace);
     if (lp == lp) acc -= (double)lp;
   }
@@ -194,14 +195,17 @@ __global__ __launch_bounds__(256) void lprob_rowsum_kernel(const float* __restri
 }
 __global__ __launch_bounds__(256) void lprob_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
                                                         const float* __restrict__ grow, float* __restrict__ dl, int F,
-                                                        int trows, float scale, int laplace, int lap_rows) {
+                                                        int trows, float scale, int laplace, int lap_rows, int perm_c,
+                                                        int logit_grad) {
   if (lap_rows > 0) laplace = (laplace >> (blockIdx.y / lap_rows)) & 1;
   const size_t base = (size_t)blockIdx.y * F;
   const size_t tbase = (size_t)(blockIdx.y % trows) * F;
   const float g = grow[blockIdx.y];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;     // index into loc's memory: coalesced loads / stores there
   if (i >= F) return;
-  const float x = loc[base + i], t = tg[tbase + i], d = t - x;
+  // the target element paired with loc element i = (c, p) of a (perm_c, F / perm_c) plane set is j = p * perm_c + c
+  const int j = perm_c > 0 ? (i % (F / perm_c)) * perm_c + i / (F / perm_c) : i;
+  const float x = loc[base + i], t = tg[tbase + j], d = t - x;
   const bool own = !(scale > 0.f);
   const float s = own ? x : scale;
   const float lp = lprob_logp(x, t, s, laplace);
@@ -214,22 +218,25 @@ __global__ __launch_bounds__(256) void lprob_bwd_kernel(const float* __restrict_
     v = -d / (s * s);
     if (own) v += 1.0f / s - (d * d) / (s * s * s);
   }
+  if (logit_grad) v *= x * (1.0f - x);
   dl[base + i] = (lp == lp && v == v) ? g * v : 0.f;
 }
 extern "C" int mmvae_lprob_rowsum_fwd(const float* loc, const float* target, float* row_loss, int B, int F,
-                                      int target_rows, float scale, int laplace, int lap_block_rows,
+                                      int target_rows, float scale, int laplace, int lap_block_rows, int perm_c,
                                       mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(loc && target && row_loss && B > 0 && F > 0 && target_rows > 0 && lap_block_rows >= 0);
+  MMVAE_CHECK_ARG(perm_c >= 0 && (perm_c == 0 || F % perm_c == 0));
   hipLaunchKernelGGL(lprob_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, target, row_loss, F,
-                     target_rows, scale, laplace, lap_block_rows);
+                     target_rows, scale, laplace, lap_block_rows, perm_c);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, const float* g_row, float* dloc, int B,
-                                      int F, int target_rows, float scale, int laplace, int lap_block_rows,
-                                      mmvae_stream_t stream) {
+                                      int F, int target_rows, float scale, int laplace, int lap_block_rows, int perm_c,
+                                      int logit_grad, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(loc && target && g_row && dloc && B > 0 && F > 0 && target_rows > 0 && lap_block_rows >= 0);
+  MMVAE_CHECK_ARG(perm_c >= 0 && (perm_c == 0 || F % perm_c == 0));
   hipLaunchKernelGGL(lprob_bwd_kernel, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, loc, target, g_row,
-                     dloc, F, target_rows, scale, laplace, lap_block_rows);
+                     dloc, F, target_rows, scale, laplace, lap_block_rows, perm_c, logit_grad);
   return mmvae_launch_status();
 }
 

@@ -79,7 +79,9 @@ SIGNATURES = {
     "mmvae_gemm_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_gemm_splits": (c_i, [c_i] * 4),
     "mmvae_bias_group_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
-    "mmvae_bias_group_grad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mmvae_bias_group_grad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mmvae_bias_group_ws_floats": (c_sz, [c_i, c_i]),
+    "mmvae_bias_group_parts": (c_i, [c_i]),
     "mmvae_linear_fwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_linear_bwd_data": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
     "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
@@ -117,8 +119,8 @@ SIGNATURES = {
     "mmvae_convT2d_generic_wgrad": (c_i, [c_p] * 4 + [c_i] * 10 + [c_p]),
     "mmvae_sigmoid_fwd": (c_i, [c_p, c_p, c_l, c_p]),
     "mmvae_sigmoid_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
-    "mmvae_lprob_rowsum_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
-    "mmvae_lprob_rowsum_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "mmvae_lprob_rowsum_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p]),
+    "mmvae_lprob_rowsum_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p]),
     "mmvae_optimal_sigma_ws_floats": (c_sz, [c_i, c_i]),
     "mmvae_optimal_sigma_fwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
     "mmvae_optimal_sigma_bwd": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),

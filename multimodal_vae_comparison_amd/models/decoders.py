@@ -258,12 +258,16 @@ class Dec_MNIST(VaeDecoder):
     def forward(self, z):
         z = z["latents"]
         lead = z.shape[:-1]
-        h = self.fc3(self.dec[1][0](self.dec[0][0](z.reshape(-1, z.shape[-1]))))
-        x_hat = ops.sigmoid(h)
+        # sigmoid in the last GEMM's epilogue; `raw` holds the same values but takes the LOGITS' gradient (a lprob loss
+        # feeds it directly through `_lprob_src`, anything else goes through SigmoidOut)
+        raw = self.fc3(self.dec[1][0](self.dec[0][0](z.reshape(-1, z.shape[-1]))), out_ep=H.EP_SIGMOID)
+        x_hat = ops.sigmoid_out(raw)
         d = x_hat.reshape(*lead, *self.data_dim)
         if d.dim() == 5:
             d = d.squeeze(0)
         d = d.permute(0, 3, 1, 2) if d.dim() == 4 else d.permute(0, 1, 4, 2, 3)
+        if self.data_dim[-1] == 1:        # a size-1 channel axis: the permute does not reorder memory
+            d._lprob_src = (raw, 0)
         return d, self._scale
 
 
@@ -288,7 +292,11 @@ class Dec_SVHN(VaeDecoder):
         bs = zs.shape[:2] if (zs.dim() == 3 and zs.shape[0] > 1) else None
         zs = zs.reshape(-1, zs.shape[-1])
         h = self.linear(zs).reshape(-1, 128, 1, 1)
-        d = self.conv4(self.conv3(self.conv2(self.conv1(h)))).permute(0, 2, 3, 1)
+        # sigmoid in conv4's epilogue; `raw` (NCHW) takes the logits' gradient.  The reference returns the output
+        # permuted to (B,32,32,3); a lprob loss reads `raw` with that pairing instead of the materialised permutation
+        raw = self.conv4(self.conv3(self.conv2(self.conv1(h))), ep_bwd=False)
+        d = ops.sigmoid_out(raw).permute(0, 2, 3, 1)
         if bs:
             d = d.reshape(*bs, *d.shape[1:])
+        d._lprob_src = (raw, raw.shape[1])
         return d, self._scale

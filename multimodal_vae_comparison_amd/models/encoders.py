@@ -151,10 +151,11 @@ class HipConv(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x):
+    def forward(self, x, ep_bwd=True):
         stride, pad, in_act, transposed, out_ep = self.cfg
         if transposed:
-            return ops.convT2d(x, self.weight, self.bias, stride, pad, in_act, out_ep, self.weight.grad, self.bias.grad)
+            return ops.convT2d(x, self.weight, self.bias, stride, pad, in_act, out_ep, self.weight.grad, self.bias.grad,
+                               ep_bwd)
         return ops.conv2d(x, self.weight, self.bias, stride, pad, in_act, self.weight.grad, self.bias.grad)
 
 

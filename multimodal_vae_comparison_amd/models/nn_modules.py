@@ -85,9 +85,9 @@ class HipLinear(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x, in_act=None):
+    def forward(self, x, in_act=None, out_ep=H.EP_NONE):
         return ops.linear(x, self.weight, self.bias, self.in_act if in_act is None else in_act, self.weight.grad,
-                          self.bias.grad)
+                          self.bias.grad, out_ep)
 
 
 class HipLayerNorm(nn.Module):

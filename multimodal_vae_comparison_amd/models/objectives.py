@@ -50,6 +50,10 @@ def recon_rowsum(ltype, out, target, laplace=False):
         # a K-sample decoder output (K,B,...) is compared with the target repeated K times (reshape_for_loss,
         # objectives.py:118-120): the kernel indexes the target row as (output row) % B instead of materialising it
         tgt = data.float().reshape(out.shape) if out.numel() == data.numel() else data.float().reshape(data.shape[0], -1)
+        src = getattr(out, "_lprob_src", None)      # Dec_MNIST / Dec_SVHN: sigmoid-epilogue output, logits' gradient
+        if src is not None and not masked and src[0].numel() == out.numel():
+            return ops.lprob_rowsum(src[0], tgt.reshape(tgt.shape[0], -1), PX_SCALE, laplace, perm_c=src[1],
+                                    logit_grad=True)
         return ops.lprob_rowsum(out, tgt, None if masked else PX_SCALE, laplace)
     if ltype == "optimal_sigma":
         return ops.optimal_sigma_rowsum(out, data.float().reshape(out.shape))

@@ -559,19 +559,22 @@ def conv2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, gw=None, gb=None):
     return ConvGeneric.apply(x, w, b, False, stride, pad, in_act, H.EP_NONE, gw, gb)
 
 
-def convT2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None):
+def convT2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=None, gb=None, ep_bwd=True):
     """nn.ConvTranspose2d on act(x), optional sigmoid epilogue: MFMA kernels for the k4-s2-p1 layers, a plain GEMM for a
     1x1 input (SVHN decoder conv1: k4 s1 p0, 1x1 -> 4x4), the generic kernel otherwise"""
     Cin, Cout, K, _ = w.shape
     Hin = x.shape[-1]
     if K == 4 and stride == 2 and pad == 1 and x.shape[-2] == Hin:
         if Cout == 3 and Cin == 32 and Hin in (16, 32):
-            return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
+            return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb, ep_bwd)
         if out_ep == H.EP_NONE and Cin in (32, 64) and _mfma_conv_shape(Cout, Cin, 2 * Hin) and Hin >= 4:
             return ConvT2dK4S2.apply(x, w, b, in_act, out_ep, gw, gb)
     if Hin == 1 and x.shape[-2] == 1 and pad == 0 and out_ep == H.EP_NONE:
         return LinearKN.apply(x.reshape(x.shape[0], Cin), w, b, in_act, gw, gb).view(x.shape[0], Cout, K, K)
-    return ConvGeneric.apply(x, w, b, True, stride, pad, in_act, out_ep, gw, gb)
+    y = ConvGeneric.apply(x, w, b, True, stride, pad, in_act, out_ep, gw, gb)
+    # (the generic kernel applies its epilogue's backward itself: undo that when the caller feeds logit gradients)
+    assert ep_bwd or out_ep == H.EP_NONE, "ep_bwd=False needs an MFMA-kernel shape"
+    return y
 
 
 def _conv_segments(ws, dw, db, B, c_small, c_large, h_small, n_bias):
@@ -606,14 +609,15 @@ class Linear(Function):
     """y = act(x) W^T + b over the last dim   [nn.Linear / MHA projections / FFN]"""
 
     @staticmethod
-    def forward(ctx, x, w, b, in_act, gw, gb):
+    def forward(ctx, x, w, b, in_act, gw, gb, out_ep=H.EP_NONE):
+        """out_ep: EP_NONE, or EP_SIGMOID -- y = sigmoid(.) in the GEMM's epilogue; the incoming gradient is then
+        taken as the gradient of the LOGITS (wrap the output in ops.sigmoid_out, see SigmoidOut)"""
         x = H.f32c(x)
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-        _call("mmvae_linear_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), M, N, K, K, in_act, H.EP_NONE,
-              H.stream())
+        _call("mmvae_linear_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), M, N, K, K, in_act, out_ep, H.stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (in_act, gw, gb, b is not None)
         return y
@@ -660,11 +664,35 @@ class Linear(Function):
             GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
             if db is not None:
                 GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
-        return dx, ret_w, ret_b, None, None, None
+        return dx, ret_w, ret_b, None, None, None, None
 
 
-def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
-    return Linear.apply(x, w, b, in_act, gw, gb)
+def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None, out_ep=H.EP_NONE):
+    return Linear.apply(x, w, b, in_act, gw, gb, out_ep)
+
+
+class SigmoidOut(Function):
+    """Identity on the forward values of a layer whose kernel already applied sigmoid(.) in its epilogue (and whose
+    backward takes the LOGITS' gradient); in backward it turns the gradient of that output into the gradient of the
+    logits.  A loss that knows the logits' gradient in closed form (LprobRowsum, logit_grad) feeds the layer directly
+    through the raw tensor (decoders set `out._lprob_src`)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = H.f32c(dy)
+        dl = torch.empty_like(dy)
+        _call("mmvae_sigmoid_bwd", H.ptr(dy), H.ptr(y), H.ptr(dl), dy.numel(), H.stream())
+        return dl
+
+
+def sigmoid_out(y_raw):
+    return SigmoidOut.apply(y_raw)
 
 
 class LinearKN(Function):
@@ -720,11 +748,18 @@ class LinearKN(Function):
             GradReducer.add(ws.data_ptr(), dw, nz, K * N, K * N)
         ret_b = None
         if has_b:
-            if gb is not None:
-                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(gb), M, C, G, 1, H.stream())
+            nbw = lib.mmvae_bias_group_ws_floats(M, C)
+            if _defer(gb):
+                bws = GradReducer.alloc(nbw, x.device)
+                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(gb), H.ptr(bws), M, C, G, H.ACC_DEFER, H.stream())
+                GradReducer.add(bws.data_ptr(), gb, lib.mmvae_bias_group_parts(M), C, C)
+            elif gb is not None:
+                bws = torch.empty(nbw, device=x.device)
+                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(gb), H.ptr(bws), M, C, G, 1, H.stream())
             else:
                 ret_b = torch.empty(C, device=x.device)
-                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(ret_b), M, C, G, 0, H.stream())
+                bws = torch.empty(nbw, device=x.device)
+                _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(ret_b), H.ptr(bws), M, C, G, 0, H.stream())
         return dx, ret_w, ret_b, None, None, None
 
 
@@ -912,8 +947,11 @@ class LprobRowsum(Function):
     modalities).  ReconLoss.lprob summed per sample (models/objectives.py:409-424)."""
 
     @staticmethod
-    def forward(ctx, loc, target, scale, laplace):
-        """laplace: bool, or (bit mask, block rows): rows [j, j+1) * block rows are Laplace where bit j is set"""
+    def forward(ctx, loc, target, scale, laplace, perm_c=0, logit_grad=False):
+        """laplace: bool, or (bit mask, block rows): rows [j, j+1) * block rows are Laplace where bit j is set.
+        perm_c: loc is the (rows, perm_c, F / perm_c) NCHW output of a conv decoder paired with the target as if it
+        had been permuted to (rows, F / perm_c, perm_c) (Dec_SVHN).  logit_grad: loc = sigmoid(logits) from the
+        producing layer's epilogue; backward returns the gradient with respect to the logits."""
         loc, target = H.f32c(loc), H.f32c(target)
         lap, lap_rows = (int(laplace[0]), int(laplace[1])) if isinstance(laplace, tuple) else (int(laplace), 0)
         trows = target.shape[0]
@@ -923,19 +961,19 @@ class LprobRowsum(Function):
         row = torch.empty(B, device=loc.device)
         sc = -1.0 if scale is None else float(scale)
         _call("mmvae_lprob_rowsum_fwd", H.ptr(loc), H.ptr(target), H.ptr(row), B, F_, trows, sc, lap, lap_rows,
-              H.stream())
+              int(perm_c), H.stream())
         ctx.save_for_backward(loc, target)
-        ctx.cfg = (sc, lap, lap_rows, B, F_, trows)
+        ctx.cfg = (sc, lap, lap_rows, B, F_, trows, int(perm_c), int(bool(logit_grad)))
         return row
 
     @staticmethod
     def backward(ctx, g):
         loc, target = ctx.saved_tensors
-        sc, lap, lap_rows, B, F_, trows = ctx.cfg
+        sc, lap, lap_rows, B, F_, trows, perm_c, logit_grad = ctx.cfg
         d = torch.empty_like(loc)
         _call("mmvae_lprob_rowsum_bwd", H.ptr(loc), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(d), B, F_, trows, sc, lap,
-              lap_rows, H.stream())
-        return d, None, None, None
+              lap_rows, perm_c, logit_grad, H.stream())
+        return d, None, None, None, None, None
 
 
 class OptimalSigmaRowsum(Function):
@@ -964,8 +1002,8 @@ class OptimalSigmaRowsum(Function):
         return d, None
 
 
-def lprob_rowsum(loc, target, scale=0.75, laplace=False):
-    return LprobRowsum.apply(loc, target, scale, laplace)
+def lprob_rowsum(loc, target, scale=0.75, laplace=False, perm_c=0, logit_grad=False):
+    return LprobRowsum.apply(loc, target, scale, laplace, perm_c, logit_grad)
 
 
 def optimal_sigma_rowsum(loc, target):

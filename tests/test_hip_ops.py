@@ -385,6 +385,27 @@ def test_conv_generic(ops, transposed, B, Cin, Cout, Hin, S, P, act, ep):
     check(bg.grad, br.grad, 5e-5, "conv db")
 
 
+@pytest.mark.parametrize("rows,trows,C,HW,laplace", [(6, 6, 3, 64, False), (12, 4, 3, 16, True), (10, 5, 1, 49, False)])
+def test_lprob_rowsum_nchw_source_with_logit_gradient(ops, rows, trows, C, HW, laplace):
+    """the conv decoders' path: loc = sigmoid(logits) stored NCHW, paired with the target as if permuted to NHWC
+    (decoders.py:144 + objectives.py:120), K-sample rows against repeated targets, gradient taken w.r.t. the logits"""
+    g = torch.Generator().manual_seed(rows + C + HW)
+    logits = torch.randn(rows, C, HW, generator=g)
+    tgt = torch.rand(trows, C * HW, generator=g)
+    gr = torch.randn(rows, generator=g)
+    lr_ = logits.clone().requires_grad_(True)
+    y = torch.sigmoid(lr_).permute(0, 2, 1).reshape(rows, HW * C)          # what the reference's decoder returns
+    t = tgt.repeat(rows // trows, 1)
+    dist = torch.distributions.Laplace if laplace else torch.distributions.Normal
+    ref = -(dist(y, torch.tensor(0.75)).log_prob(t)).double().sum(-1)
+    ref.backward(gr.double())
+    raw = torch.sigmoid(logits).to(DEV).requires_grad_(True)               # the layer's epilogue output
+    out = ops.lprob_rowsum(raw, tgt.to(DEV), 0.75, laplace, perm_c=C if C > 1 else 0, logit_grad=True)
+    out.backward(gr.to(DEV))
+    check(out, ref, 1e-5, "rows")
+    check(raw.grad, lr_.grad, 1e-4, "d logits")
+
+
 @pytest.mark.parametrize("transposed,B,Cin,Cout,Hin,S,P", [(False, 9, 32, 64, 16, 2, 1), (False, 9, 64, 64, 8, 2, 1),
                                                           (False, 9, 64, 128, 4, 2, 0), (True, 9, 128, 64, 1, 1, 0),
                                                           (True, 9, 64, 64, 4, 2, 1), (True, 300, 64, 32, 8, 2, 1)])
