@@ -200,35 +200,55 @@ def _pmc_traffic(kernel_prefix):
     return int((2 * fetch + write) * 1024), os.path.relpath(path, ROOT)
 
 
-def dominant_kernel_roofline(B, device):
-    """Average duration of the dominant kernel of the CdSprites+ step at this batch, measured live with HIP events on
-    the launch stream: the 32->32 channel 4x4/s2 gather conv at 32x32 -> 16x16 (encoder conv2; the decoder's convT2
-    backward-data is the same kernel and shape).  Algorithmic FLOPs per launch = 2 * B*16*16*32 * 512."""
-    from multimodal_vae_comparison_amd import ops
-    from multimodal_vae_comparison_amd import hipops as H
-    x = torch.randn(B, 32, 32, 32, device=device)
-    w = torch.randn(32, 32, 4, 4, device=device) * 0.05
-    b = torch.zeros(32, device=device)
+def _event_time_us(fn, reps=50):
     with torch.no_grad():
         for _ in range(5):
-            ops.conv2d_k4s2(x, w, b, H.ACT_SILU)
+            fn()
         torch.cuda.synchronize()
-        reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.conv2d_k4s2(x, w, b, H.ACT_SILU)
+            fn()
         e1.record()
         torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    flops = 2.0 * B * 16 * 16 * 32 * 512
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def dominant_kernel_roofline(meta, device):
+    """Average duration of the workload's dominant kernel at the shape it runs at, measured live with HIP events on the
+    launch stream (torch's current stream is the stream the C-ABI launches on).
+      CdSprites+ towers: the 32->32 channel 4x4/s2 gather conv at 32x32 -> 16x16 (encoder conv2; the decoder's convT2
+        backward-data is the same kernel and shape): 2 * B*16*16*32 * 512 FLOP per launch;
+      MNIST / SVHN towers: Dec_SVHN's ConvTranspose2d 64->32 at 8x8 -> 16x16 (scatter form), N = the decoder's batch
+        (B for DMVAE / MoPoE, M*K*B latent samples for MoE dreg): 2 * N*8*8*64 * 32*16 FLOP per launch."""
+    from multimodal_vae_comparison_amd import ops
+    from multimodal_vae_comparison_amd import hipops as H
+    B = meta["B"]
+    if meta["mods"][0]["enc"] == "MNIST":
+        N = B * len(meta["mods"]) * meta.get("K", 1) if meta.get("obj") == "dreg" else B
+        x = torch.randn(N, 64, 8, 8, device=device)
+        w = torch.randn(64, 32, 4, 4, device=device) * 0.05
+        b = torch.zeros(32, device=device)
+        us = _event_time_us(lambda: ops.convT2d(x, w, b, 2, 1, H.ACT_RELU))
+        flops = 2.0 * N * 64 * 64 * 32 * 16
+        kernel = f"conv_scatter_kernel<ScatterGeom<3,*,*,64>> (Dec_SVHN conv3 fwd, N={N})"
+        traffic, src = None, None
+    else:
+        x = torch.randn(B, 32, 32, 32, device=device)
+        w = torch.randn(32, 32, 4, 4, device=device) * 0.05
+        b = torch.zeros(32, device=device)
+        us = _event_time_us(lambda: ops.conv2d_k4s2(x, w, b, H.ACT_SILU))
+        flops = 2.0 * B * 16 * 16 * 32 * 512
+        kernel = "conv_gather_kernel<32,*> (conv2 fwd shape)"
+        traffic, src = _pmc_traffic("conv_gather_kernel<GatherGeom<32, 5")
+        if B != 128:
+            traffic = None
     ach = flops / (us * 1e-6) / 1e12
-    traffic, src = _pmc_traffic("conv_gather_kernel<GatherGeom<32, 5")
-    return {"bound": "mfma", "kernel": "conv_gather_kernel<32,*> (conv2 fwd shape)", "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "avg_us": round(us, 2), "traffic": traffic if B == 128 else None, "traffic_unit": "bytes/launch",
-            "traffic_source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
-                              f"16-B/lane correction); algorithmic 21.0e6 at B=128"}
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_us": round(us, 2),
+            "traffic": traffic, "traffic_unit": "bytes/launch",
+            "traffic_source": (f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
+                               f"16-B/lane correction); algorithmic 21.0e6 at B=128") if src else None}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -309,7 +329,7 @@ def main():
                               sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
                "final_loss": round(loss, 3)}
     if world == 1 and rank == 0:
-        res["roofline"] = dominant_kernel_roofline(B if meta["mods"][0]["enc"] == "CNN2" else 128, dev)
+        res["roofline"] = dominant_kernel_roofline(meta, dev)
         if not a.no_extras and path_world == 1 and a.config == "cfg2":
             res["extras"] = extras(tr, a, dev, barrier)
         if not a.no_cpu_baseline:
