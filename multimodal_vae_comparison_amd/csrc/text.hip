@@ -86,26 +86,27 @@ extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* d
 }
 
 // ---------------------------------------------------------------------------------------------
-// Attention core of nn.MultiheadAttention for L, S <= 64, head_dim <= 32.  One wavefront per (sample n, head h).
-// Rows of K / V / Q / dO live in LDS with pitch 36 floats and are consumed as broadcast ds_read_b128 (all lanes
-// read the same row => conflict free); the L x S score / probability tiles live in LDS with pitch 65 (lane =
-// row or lane = column are both conflict free).  Every dot product is computed exactly once.
+// Attention core of nn.MultiheadAttention for L, S <= 128, head_dim <= 32.  One workgroup of AM threads (AM = 64 or
+// 128: one or two wavefronts) per (sample n, head h); thread = query row or key column.  Rows of K / V / Q / dO live
+// in LDS with pitch 36 floats and are consumed as broadcast ds_read_b128 (all lanes read the same row => conflict
+// free); the L x S score / probability tile lives in LDS with pitch AM + 1 (thread = row or thread = column are both
+// conflict free).  The 128 form serves the action towers' Ta = 100 sequences (models/datasets.py:887).
 // ---------------------------------------------------------------------------------------------
-#define ATT_MAX 64
+#define ATT_MAX 128
 #define ATT_HD 32  // head_dim <= 32 (27 encoder, D/2 decoder); padded columns are zero
 #define ATT_HP 36  // row pitch (16-byte aligned rows)
-#define ATT_SP 65
 
-// rows x 32 floats -> LDS, 8 independent loads in flight per lane (a load -> store loop waits one memory
+// rows x 32 floats -> LDS, 8 independent loads in flight per thread (a load -> store loop waits one memory
 // latency per iteration)
+template <int NT>
 __device__ __forceinline__ void att_stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int N,
-                                               int n, long ld, int col0, int hd, int lane) {
+                                               int n, long ld, int col0, int hd, int tid) {
   const int total = rows * ATT_HD;
-  for (int e0 = 0; e0 < total; e0 += 64 * 8) {
+  for (int e0 = 0; e0 < total; e0 += NT * 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 64 + lane;
+      const int e = e0 + u * NT + tid;
       const int r = e >> 5, d = e & 31;
       const bool ok = e < total && d < hd;
       v[u] = src[ok ? ((size_t)r * N + n) * ld + col0 + d : (size_t)n * ld + col0];
@@ -113,29 +114,30 @@ __device__ __forceinline__ void att_stage_rows(float* __restrict__ dst, const fl
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 64 + lane;
+      const int e = e0 + u * NT + tid;
       if (e < total) dst[(e >> 5) * ATT_HP + (e & 31)] = v[u];
     }
   }
 }
-// L x S probability tile -> LDS (pitch ATT_SP), same batching
+// L x S probability tile -> LDS (pitch SP), same batching
+template <int NT, int SP>
 __device__ __forceinline__ void att_stage_tile(float* __restrict__ dst, const float* __restrict__ src, int L, int S,
-                                               int lane) {
+                                               int tid) {
   const int total = L * S;
   const float invS = 1.0f / (float)S;
-  for (int e0 = 0; e0 < total; e0 += 64 * 8) {
+  for (int e0 = 0; e0 < total; e0 += NT * 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 64 + lane;
+      const int e = e0 + u * NT + tid;
       v[u] = src[e < total ? e : 0];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 64 + lane;
+      const int e = e0 + u * NT + tid;
       if (e < total) {
         const int l = (int)(((float)e + 0.5f) * invS);
-        dst[l * ATT_SP + (e - l * S)] = v[u];
+        dst[l * SP + (e - l * S)] = v[u];
       }
     }
   }
@@ -163,19 +165,21 @@ __device__ __forceinline__ void att_axpy(float (&acc)[ATT_HD], float p, const fl
   }
 }
 
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+template <int AM>
+__global__ __launch_bounds__(AM) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const uint8_t* __restrict__ kpm,
                                                       float* __restrict__ out, float* __restrict__ probs, int L, int S,
                                                       int N, int H, int hd, long ldq, long ldk, long ldv,
                                                       int mask_is_valid, mmvae_dropout_t drop) {
-  __shared__ __attribute__((aligned(16))) float sk[ATT_MAX * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sv[ATT_MAX * ATT_HP];
-  __shared__ float sp[ATT_MAX * ATT_SP];
-  __shared__ float smask[ATT_MAX];
-  __shared__ float sinv[ATT_MAX];
+  constexpr int SP = AM + 1;
+  __shared__ __attribute__((aligned(16))) float sk[AM * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sv[AM * ATT_HP];
+  __shared__ float sp[AM * SP];
+  __shared__ float smask[AM];
+  __shared__ float sinv[AM];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  att_stage_rows(sk, k, S, N, n, ldk, h * hd, hd, lane);
-  att_stage_rows(sv, v, S, N, n, ldv, h * hd, hd, lane);
+  att_stage_rows<AM>(sk, k, S, N, n, ldk, h * hd, hd, lane);
+  att_stage_rows<AM>(sv, v, S, N, n, ldv, h * hd, hd, lane);
   // kpm bytes: 1 = ignore this key (key_padding_mask) or, with mask_is_valid, the batch's own validity mask
   // (1 = real token) read in place -- no conversion kernel
   if (lane < S) smask[lane] = (kpm && ((kpm[(size_t)n * S + lane] != 0) != (mask_is_valid != 0))) ? 1.f : 0.f;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     for (int s = 0; s < S; ++s) {
       float sc = att_dot(sk + s * ATT_HP, qr);
       if (smask[s] != 0.f) sc = -INFINITY;
-      sp[lane * ATT_SP + s] = sc;
+      sp[lane * SP + s] = sc;
       mx = fmaxf(mx, sc);
     }
     float o[ATT_HD];
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     const DropKey dk = drop_key(drop);   // dropout on the attention weights (after the softmax, before P V)
     const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + lane) * S);
     for (int s = 0; s < S; ++s) {
-      const float p = expf(sp[lane * ATT_SP + s] - mx);
-      sp[lane * ATT_SP + s] = p;
+      const float p = expf(sp[lane * SP + s] - mx);
+      sp[lane * SP + s] = p;
       sum += p;
       att_axpy(o, p * drop_mul(dk, drow + s), sv + s * ATT_HP);
     }
@@ -215,51 +219,68 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   // normalised probabilities, written row by row with lane = key index (coalesced)
   float* P = probs + ((size_t)n * H + h) * L * S;
   if (lane < S)
-    for (int l = 0; l < L; ++l) P[(size_t)l * S + lane] = sp[l * ATT_SP + lane] * sinv[l];
+    for (int l = 0; l < L; ++l) P[(size_t)l * S + lane] = sp[l * SP + lane] * sinv[l];
 }
 
 // dV[s] = sum_l P[l,s] dO[l];  dP[l,s] = dO[l].V[s];  dS = P (dP - sum_s P dP);
 // dQ[l] = scale * sum_s dS[l,s] K[s];  dK[s] = scale * sum_l dS[l,s] Q[l]
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+// ONE L x S tile in LDS: column pass for dV on P, row pass that overwrites P with dS (the dP dot products are computed
+// twice instead of being parked in a second tile: 2 x 66 KB would not fit beside the four row arrays at AM = 128),
+// column pass for dK on dS.
+template <int AM>
+__global__ __launch_bounds__(AM) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const float* __restrict__ probs,
                                                       const float* __restrict__ dout, float* __restrict__ dq,
                                                       float* __restrict__ dk, float* __restrict__ dv, int L, int S,
                                                       int N, int H, int hd, long ldq, long ldk, long ldv,
                                                       mmvae_dropout_t drop) {
-  __shared__ __attribute__((aligned(16))) float sq[ATT_MAX * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sk[ATT_MAX * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sv[ATT_MAX * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sdo[ATT_MAX * ATT_HP];
-  __shared__ float sp[ATT_MAX * ATT_SP];
-  __shared__ float sds[ATT_MAX * ATT_SP];
+  constexpr int SP = AM + 1;
+  __shared__ __attribute__((aligned(16))) float sq[AM * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sk[AM * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sv[AM * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sdo[AM * ATT_HP];
+  __shared__ float sp[AM * SP];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const long E = (long)H * hd;
-  att_stage_rows(sk, k, S, N, n, ldk, h * hd, hd, lane);
-  att_stage_rows(sv, v, S, N, n, ldv, h * hd, hd, lane);
-  att_stage_rows(sq, q, L, N, n, ldq, h * hd, hd, lane);
-  att_stage_rows(sdo, dout, L, N, n, E, h * hd, hd, lane);
-  att_stage_tile(sp, probs + ((size_t)n * H + h) * L * S, L, S, lane);
+  att_stage_rows<AM>(sk, k, S, N, n, ldk, h * hd, hd, lane);
+  att_stage_rows<AM>(sv, v, S, N, n, ldv, h * hd, hd, lane);
+  att_stage_rows<AM>(sq, q, L, N, n, ldq, h * hd, hd, lane);
+  att_stage_rows<AM>(sdo, dout, L, N, n, E, h * hd, hd, lane);
+  att_stage_tile<AM, SP>(sp, probs + ((size_t)n * H + h) * L * S, L, S, lane);
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)hd);
+  const DropKey dkey = drop_key(drop);
+  if (lane < S) {     // dV sees the dropped weights
+    const int s = lane;
+    float dvr[ATT_HD];
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) dvr[d] = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const uint32_t di = (uint32_t)((((size_t)n * H + h) * L + l) * S + s);
+      att_axpy(dvr, sp[l * SP + s] * drop_mul(dkey, di), sdo + l * ATT_HP);
+    }
+    float* dvrow = dv + ((size_t)s * N + n) * ldv + h * hd;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d)
+      if (d < hd) dvrow[d] = dvr[d];
+  }
+  __syncthreads();
   if (lane < L) {
     const int l = lane;
     float dor[ATT_HD];
 #pragma unroll
     for (int d = 0; d < ATT_HD; ++d) dor[d] = sdo[l * ATT_HP + d];
     float delta = 0.f;
-    const DropKey dkey = drop_key(drop);
     const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + l) * S);
-    for (int s = 0; s < S; ++s) {
-      const float dp = att_dot(sv + s * ATT_HP, dor) * drop_mul(dkey, drow + s);   // through the weight dropout
-      sds[l * ATT_SP + s] = dp;
-      delta += sp[l * ATT_SP + s] * dp;
-    }
+    for (int s = 0; s < S; ++s)
+      delta += sp[l * SP + s] * att_dot(sv + s * ATT_HP, dor) * drop_mul(dkey, drow + s);   // through the weight dropout
     float dqr[ATT_HD];
 #pragma unroll
     for (int d = 0; d < ATT_HD; ++d) dqr[d] = 0.f;
     for (int s = 0; s < S; ++s) {
-      const float ds = sp[l * ATT_SP + s] * (sds[l * ATT_SP + s] - delta);
-      sds[l * ATT_SP + s] = ds;
+      const float dp = att_dot(sv + s * ATT_HP, dor) * drop_mul(dkey, drow + s);
+      const float ds = sp[l * SP + s] * (dp - delta);
+      sp[l * SP + s] = ds;
       att_axpy(dqr, ds, sk + s * ATT_HP);
     }
     float* dqrow = dq + ((size_t)l * N + n) * ldq + h * hd;
@@ -270,23 +291,14 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   __syncthreads();
   if (lane < S) {
     const int s = lane;
-    float dvr[ATT_HD], dkr[ATT_HD];
+    float dkr[ATT_HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) dvr[d] = dkr[d] = 0.f;
-    const DropKey dkey = drop_key(drop);
-    for (int l = 0; l < L; ++l) {
-      const uint32_t di = (uint32_t)((((size_t)n * H + h) * L + l) * S + s);
-      att_axpy(dvr, sp[l * ATT_SP + s] * drop_mul(dkey, di), sdo + l * ATT_HP);   // dV sees the dropped weights
-      att_axpy(dkr, sds[l * ATT_SP + s], sq + l * ATT_HP);
-    }
-    float* dvrow = dv + ((size_t)s * N + n) * ldv + h * hd;
+    for (int d = 0; d < ATT_HD; ++d) dkr[d] = 0.f;
+    for (int l = 0; l < L; ++l) att_axpy(dkr, sp[l * SP + s], sq + l * ATT_HP);
     float* dkrow = dk + ((size_t)s * N + n) * ldk + h * hd;
 #pragma unroll
     for (int d = 0; d < ATT_HD; ++d)
-      if (d < hd) {
-        dvrow[d] = dvr[d];
-        dkrow[d] = dkr[d] * scale;
-      }
+      if (d < hd) dkrow[d] = dkr[d] * scale;
   }
 }
 
@@ -295,8 +307,12 @@ extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, co
                               int mask_is_valid, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L, S, N,
-                     H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
+  if (L <= 64 && S <= 64)
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L,
+                       S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<128>), dim3(N, H), dim3(128), 0, (hipStream_t)stream, q, k, v, kpm, out, probs,
+                       L, S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
   return mmvae_launch_status();
 }
 extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
@@ -304,8 +320,12 @@ extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, co
                               long ldv, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk, dv,
-                     L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
+  if (L <= 64 && S <= 64)
+    hipLaunchKernelGGL((attn_bwd_kernel<64>), dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk,
+                       dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
+  else
+    hipLaunchKernelGGL((attn_bwd_kernel<128>), dim3(N, H), dim3(128), 0, (hipStream_t)stream, q, k, v, probs, dout, dq,
+                       dk, dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
   return mmvae_launch_status();
 }
 

@@ -1,5 +1,6 @@
 """TorchMMVAE: base class of the multimodal mixers (reference: models/mmvae_base.py)."""
 import abc
+import os
 
 import numpy as np
 import torch
@@ -105,12 +106,17 @@ class TorchMMVAE(nn.Module):
         names = list(self.vaes.keys())
         if not (ops.StreamPlan.enabled and device.type == "cuda") or len(names) < 2:
             return [None] * len(names)
-        out = []
+        # ONE side stream however many towers there are: a captured step with three parallel branches (image, text,
+        # actions on their own streams) crashes ROCm 7.2's hipGraphInstantiate (segmentation fault inside capture_end;
+        # two branches and the eager three-stream path are fine) -- the towers beyond the first two share a stream
+        max_side = int(os.environ.get("MMVAE_MAX_SIDE_STREAMS", "1"))
+        out, side = [], 0
         for i in range(len(names)):
             if i == main % len(names):
                 out.append(None)
                 continue
-            s = ops.StreamPlan.get(f"tower{i}", device)
+            side = min(side + 1, max_side)
+            s = ops.StreamPlan.get(f"tower{side}", device)
             ops.GradReducer.note_stream(device, s)
             out.append(s)
         return out

@@ -527,7 +527,8 @@ def test_embed_pe(ops, B, T):
     check(eg.grad, er.grad, 2e-5, "demb")
 
 
-@pytest.mark.parametrize("L,N,E,H_", [(5, 6, 54, 2), (32, 128, 54, 2), (9, 7, 32, 2), (64, 3, 16, 2)])
+@pytest.mark.parametrize("L,N,E,H_", [(5, 6, 54, 2), (32, 128, 54, 2), (9, 7, 32, 2), (64, 3, 16, 2),
+                                      (100, 5, 32, 2), (128, 3, 64, 2), (65, 130, 32, 2)])
 def test_attention(ops, L, N, E, H_):
     g = torch.Generator().manual_seed(L * N)
     qkv = torch.randn(L, N, 3 * E, generator=g)

@@ -75,6 +75,26 @@ def test_mnistsvhn_config_details(tmp_path):
     assert all(isinstance(v.post_dist, type) and v.post_dist is torch.distributions.Laplace for v in m.vaes.values())
 
 
+def test_vilanro_config_with_the_plain_conv_encoder(tmp_path):
+    """configs/config_vilanro.yml (PoE over language [4,9,1] + actions [100,4,1] + image, optimal_sigma everywhere)
+    with `encoder: CNN` -> `CNN2` (the plain conv tower; CNN = ResNet-50 is SURVEY 8(f) rank 1): the 8 / 4-layer
+    action Transformer towers at the reference's Ta = 100"""
+    import copy
+    from multimodal_vae_comparison_amd.models.config_cls import Config
+    from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
+    rec = copy.deepcopy(SHIPPED["config_vilanro.yml"])
+    rec["config"]["modality_3"]["encoder"] = "CNN2"
+    path = tmp_path / "config_vilanro_cnn2.yml"
+    with open(path, "w") as f:
+        yaml.safe_dump(rec["config"], f)
+    tr = MultimodalVAE(Config(str(path)), feature_dims=rec["feature_dims"], device="cpu")
+    m = tr.model
+    assert type(m).__name__ == "POE" and len(m.vaes) == 3
+    assert [type(v.enc).__name__ for v in m.vaes.values()] == ["Enc_TxtTransformer", "Enc_Transformer", "Enc_CNN2"]
+    assert m.vaes["mod_2"].enc.data_dim == [100, 4, 1] and len(m.vaes["mod_2"].enc.seqTransEncoder.layers) == 8
+    assert all(v.ltype == "optimal_sigma" for v in m.vaes.values())
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/multimodal_compare/configs"), reason="reference tree absent")
 def test_fixture_matches_the_reference_files():
     """in the build container: the JSON fixture is exactly what the reference's files parse to"""
