@@ -228,6 +228,38 @@ class MultimodalVAE(nn.Module):
             else:
                 self.load_batch({k: v})
 
+    def prefetch_compact(self, compact):
+        """Start the host -> device copy of the NEXT batch (compact host format, pinned tensors) on a copy stream into
+        staging buffers; it runs under the current step.  `commit_prefetched()` then expands the staged bytes into the
+        captured step's static inputs (two HBM-bound launches, ~5 us at batch 128) right before the next replay."""
+        dev = self.flat.data.device
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+            self._staging, self._staged_evt = {}, torch.cuda.Event()
+        cs = self._copy_stream
+        cs.wait_stream(torch.cuda.current_stream(dev))     # the previous commit has finished reading the staging buffers
+        with torch.cuda.stream(cs):
+            for k, v in compact.items():
+                slot = self._staging.setdefault(k, {})
+                for name, t in v.items():
+                    if name not in slot or slot[name].shape != t.shape or slot[name].dtype != t.dtype:
+                        slot[name] = torch.empty(t.shape, dtype=t.dtype, device=dev)
+                    slot[name].copy_(t, non_blocking=True)
+            self._staged_evt.record(cs)
+
+    def commit_prefetched(self):
+        """expand the staged compact batch into the static input buffers (on the current stream, after the copy)"""
+        from .. import ops
+        torch.cuda.current_stream(self.flat.data.device).wait_event(self._staged_evt)
+        for k, slot in self._staging.items():
+            dst = self._static_batch[k]
+            if "u8" in slot:
+                ops.expand_image_u8(slot["u8"], dst["data"])
+            elif "tokens" in slot:
+                m = dst["masks"]
+                mu8 = m.view(torch.uint8) if m is not None and m.dtype == torch.bool else m
+                ops.expand_text_tokens(slot["tokens"], slot["lengths"], dst["data"], mu8)
+
     def fused_step(self, world_size=1):
         """one optimisation step on the static batch: graph replay -> (all-reduce) -> fused Adam"""
         self._graph.replay()
