@@ -1,0 +1,383 @@
+// Helper kernels of the ResNet-50 image tower (`encoder: CNN`, reference models/encoders.py:86-127 = torchvision's
+// resnet50 -> SiLU -> heads).  Inside the tower activations are NHWC = (rows = B*H*W, C) matrices:
+// every 1x1 convolution is then a plain GEMM on the MFMA kernels of gemm.hip (mmvae_linear_*), every k x k convolution
+// an im2col pass + the same GEMMs (columns ordered (c, kh, kw) = the native (Cout, Cin, k, k) weight layout, so the
+// weight tensor is used as it is stored), BatchNorm / pooling are HBM-bound column-statistics and elementwise kernels.
+// Layers emit PRE-activations (package convention): the ReLU after a BatchNorm is applied by the consumer while it
+// stages its input (GEMM x_act, im2col in_act, pool in_act) and by the data-gradient epilogues.
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// im2col / col2im, square kernel K, stride S, padding P.
+//   x: (B,H,W,C) [nchw = 0] or (B,C,H,W) [nchw = 1, the stem's image input]
+//   cols[(b,oh,ow), c*K*K + kh*K + kw] = act(x[b, oh*S-P+kh, ow*S-P+kw, c])   (0 outside)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int H,
+                                                     int W, int C, int K, int S, int P, int Ho, int Wo, int act,
+                                                     int nchw) {
+  const int KK = K * K, N = C * KK;
+  const long total = (long)B * Ho * Wo * N;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int j = (int)(e % N);
+    const long r = e / N;
+    const int ow = (int)(r % Wo), oh = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
+    const int c = j / KK, t = j - c * KK, kh = t / K, kw = t - kh * K;
+    const int ih = oh * S - P + kh, iw = ow * S - P + kw;
+    float v = 0.f;
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+      v = nchw ? x[(((size_t)b * C + c) * H + ih) * W + iw] : x[(((size_t)b * H + ih) * W + iw) * C + c];
+      v = apply_in_act(v, act);
+    }
+    cols[e] = v;
+  }
+}
+// dx[b,h,w,c] = act'(x[b,h,w,c]) * sum over the taps that read this pixel of dcols[...]   (NHWC only)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, const float* __restrict__ x,
+                                                     float* __restrict__ dx, int B, int H, int W, int C, int K, int S,
+                                                     int P, int Ho, int Wo, int act) {
+  const int KK = K * K, N = C * KK;
+  const long total = (long)B * H * W * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long r = e / C;
+    const int w = (int)(r % W), h = (int)((r / W) % H), b = (int)(r / ((long)W * H));
+    float acc = 0.f;
+    for (int kh = 0; kh < K; ++kh) {
+      const int th = h + P - kh;
+      if (th < 0 || th % S) continue;
+      const int oh = th / S;
+      if (oh >= Ho) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int tw = w + P - kw;
+        if (tw < 0 || tw % S) continue;
+        const int ow = tw / S;
+        if (ow >= Wo) continue;
+        acc += dcols[(((size_t)b * Ho + oh) * Wo + ow) * N + c * KK + kh * K + kw];
+      }
+    }
+    if (act == MMVAE_ACT_RELU) acc = x[e] > 0.f ? acc : 0.f;
+    dx[e] = acc;
+  }
+}
+static inline unsigned ew_blocks(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+extern "C" int mmvae_im2col(const float* x, float* cols, int B, int H, int W, int C, int K, int S, int P, int in_act,
+                            int nchw, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && cols && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && S > 0 && P >= 0);
+  const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+  MMVAE_CHECK_ARG(Ho > 0 && Wo > 0);
+  hipLaunchKernelGGL(im2col_kernel, dim3(ew_blocks((long)B * Ho * Wo * C * K * K)), dim3(256), 0, (hipStream_t)stream, x,
+                     cols, B, H, W, C, K, S, P, Ho, Wo, in_act, nchw);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_col2im(const float* dcols, const float* x, float* dx, int B, int H, int W, int C, int K, int S, int P,
+                            int in_act, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dcols && dx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && S > 0 && P >= 0);
+  if (in_act != MMVAE_ACT_NONE && in_act != MMVAE_ACT_RELU) return MMVAE_ERR_UNSUPPORTED;
+  MMVAE_CHECK_ARG(in_act == MMVAE_ACT_NONE || x);
+  const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+  hipLaunchKernelGGL(col2im_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dcols, x,
+                     dx, B, H, W, C, K, S, P, Ho, Wo, in_act);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d in training mode over an (M, C) NHWC matrix (torch.nn.BatchNorm2d: biased variance for the
+// normalisation, unbiased for running_var, momentum 0.1, eps 1e-5; per-rank statistics under data parallelism).
+//   stats:  workgroup (column tile of 64, row block) -> partial (mean, M2) of its rows, two sweeps (no cancellation)
+//   apply:  every thread merges its column's partials (Chan), y = (x - mean) rstd gamma + beta [+ relu?(res)],
+//           workgroup row 0 stores mean / rstd and updates the running statistics.
+// ---------------------------------------------------------------------------------------------
+#define BN_ROWS_PER_BLOCK 256
+static inline int bn_row_blocks(int M) {
+  int nb = (M + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+  return nb > 128 ? 128 : (nb < 1 ? 1 : nb);
+}
+extern "C" int mmvae_bn_row_blocks(int M) { return bn_row_blocks(M); }
+extern "C" size_t mmvae_bn_ws_floats(int M, int C) { return (size_t)bn_row_blocks(M) * C * 2; }
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int M,
+                                                       int C, int rows_per) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, blk = blockIdx.y;
+  const int r0 = blk * rows_per, r1 = min(M, r0 + rows_per);
+  const int n = max(r1 - r0, 0);
+  float s = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(size_t)r * C + c];
+  red[rl][lane] = s;
+  __syncthreads();
+  const float mean = n > 0 ? (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)n : 0.f;
+  __syncthreads();
+  float q = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float d = x[(size_t)r * C + c] - mean;
+      q += d * d;
+    }
+  red[rl][lane] = q;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    part[((size_t)blk * C + c) * 2] = mean;
+    part[((size_t)blk * C + c) * 2 + 1] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  }
+}
+// merge of the row blocks' (count, mean, M2) for one column, in double
+__device__ __forceinline__ void bn_merge(const float* __restrict__ part, int c, int C, int nblk, int M, int rows_per,
+                                         double* mean_out, double* m2_out) {
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    const int r0 = b * rows_per;
+    const double nb = (double)max(min(M, r0 + rows_per) - r0, 0);
+    if (nb <= 0.0) continue;
+    const double mb = (double)part[((size_t)b * C + c) * 2], qb = (double)part[((size_t)b * C + c) * 2 + 1];
+    const double d = mb - mean, tot = n + nb;
+    mean += d * nb / tot;
+    m2 += qb + d * d * n * nb / tot;
+    n = tot;
+  }
+  *mean_out = mean;
+  *m2_out = m2;
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, float* __restrict__ y,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       int M, int C, int nblk, int rows_per, float eps, float momentum,
+                                                       int res_relu, int eval_mode) {
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (c >= C) return;
+  double mean = 0.0, m2 = 0.0;
+  float mu, rstd;
+  if (eval_mode) {      // model.eval(): the running statistics (torch.nn.BatchNorm2d with self.training == False)
+    mu = run_mean[c];
+    rstd = 1.0f / sqrtf(run_var[c] + eps);
+  } else {
+    bn_merge(part, c, C, nblk, M, rows_per, &mean, &m2);
+    mu = (float)mean;
+    rstd = (float)(1.0 / sqrt(m2 / (double)M + (double)eps));
+  }
+  if (blockIdx.y == 0 && rl == 0) {
+    save_mean[c] = mu;
+    save_rstd[c] = rstd;
+    if (run_mean && !eval_mode) {
+      run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mu;
+      const float unbiased = (float)(m2 / (double)(M > 1 ? M - 1 : 1));
+      run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unbiased;
+    }
+  }
+  const float g = gamma[c] * rstd, bt = beta[c] - mu * gamma[c] * rstd;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  for (int r = r0 + rl; r < r1; r += 4) {
+    float v = x[(size_t)r * C + c] * g + bt;
+    if (res) {
+      const float rv = res[(size_t)r * C + c];
+      v += res_relu ? fmaxf(rv, 0.f) : rv;
+    }
+    y[(size_t)r * C + c] = v;
+  }
+}
+extern "C" int mmvae_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y,
+                                  float* save_mean, float* save_rstd, float* run_mean, float* run_var, float* ws, int M,
+                                  int C, float eps, float momentum, int res_relu, int eval_mode,
+                                  mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && ws && M > 0 && C > 0);
+  MMVAE_CHECK_ARG(!eval_mode || (run_mean && run_var));
+  const int nblk = bn_row_blocks(M), rows_per = (M + nblk - 1) / nblk;
+  const dim3 grid((C + 63) / 64, nblk);
+  if (!eval_mode) hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, M, C, rows_per);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, gamma, beta, res, y, save_mean,
+                     save_rstd, run_mean, run_var, M, C, nblk, rows_per, eps, momentum, res_relu, eval_mode);
+  return mmvae_launch_status();
+}
+// backward.  xhat = (x - mean) rstd;  dgamma = sum dy xhat, dbeta = sum dy;
+//   dx = gamma rstd (dy - dbeta / M - xhat dgamma / M);   dres = dy [* (res > 0) when the residual went through a ReLU]
+// stage 1: row-block partials of (sum dy, sum dy xhat) -> part (nblk, C, 2); stage 2: every thread sums its column's
+// partials, writes dx (and dres); row block 0 writes dgamma / dbeta partial-free (or leaves the partials for the
+// caller's fold: accumulate = MMVAE_ACC_DEFER).
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, float* __restrict__ part,
+                                                           int M, int C, int rows_per) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, blk = blockIdx.y;
+  const int r0 = blk * rows_per, r1 = min(M, r0 + rows_per);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float mu = save_mean[c], rs = save_rstd[c];
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float g = dy[(size_t)r * C + c];
+      s0 += g;
+      s1 += g * ((x[(size_t)r * C + c] - mu) * rs);
+    }
+  }
+  red[0][rl][lane] = s0;
+  red[1][rl][lane] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    part[(size_t)blk * 2 * C + c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    part[(size_t)blk * 2 * C + C + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd,
+                                                           const float* __restrict__ part, const float* __restrict__ res,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                           int C, int nblk, int rows_per, int res_relu, int accumulate,
+                                                           int eval_mode) {
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (c >= C) return;
+  float sdy = 0.f, sdyx = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    sdy += part[(size_t)b * 2 * C + c];
+    sdyx += part[(size_t)b * 2 * C + C + c];
+  }
+  if (blockIdx.y == 0 && rl == 0 && accumulate != MMVAE_ACC_DEFER) {
+    dgamma[c] = accumulate ? dgamma[c] + sdyx : sdyx;
+    dbeta[c] = accumulate ? dbeta[c] + sdy : sdy;
+  }
+  const float mu = save_mean[c], rs = save_rstd[c], gr = gamma[c] * rs, invM = 1.0f / (float)M;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  for (int r = r0 + rl; r < r1; r += 4) {
+    const size_t i = (size_t)r * C + c;
+    const float g = dy[i];
+    const float xh = (x[i] - mu) * rs;
+    dx[i] = eval_mode ? gr * g : gr * (g - sdy * invM - xh * sdyx * invM);   // eval: the statistics are constants
+    if (dres) dres[i] = (res_relu && !(res[i] > 0.f)) ? 0.f : g;
+  }
+}
+extern "C" int mmvae_bn_train_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                  const float* save_rstd, const float* res, float* dx, float* dres, float* dgamma,
+                                  float* dbeta, float* ws, int M, int C, int res_relu, int accumulate, int eval_mode,
+                                  mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && ws && M > 0 && C > 0);
+  MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || (dgamma && dbeta));
+  MMVAE_CHECK_ARG(!dres || !res_relu || res);
+  const int nblk = bn_row_blocks(M), rows_per = (M + nblk - 1) / nblk;
+  const dim3 grid((C + 63) / 64, nblk);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd, ws, M, C,
+                     rows_per);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean, save_rstd, ws,
+                     res, dx, dres, dgamma, dbeta, M, C, nblk, rows_per, res_relu, accumulate, eval_mode);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride 2, padding 1) on relu(x), NHWC; idx = flat input position (h*W + w) of the FIRST maximum in
+// window scan order (torch.nn.functional.max_pool2d: strict '>' comparison), kept for the backward pass.
+// backward (gather form, deterministic): dx[b,h,w,c] = (x > 0) * sum over the <= 4 windows containing (h,w) whose
+// recorded maximum is this pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int* __restrict__ idx, int B, int H, int W, int C, int Ho,
+                                                          int Wo, int act) {
+  const long total = (long)B * Ho * Wo * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long r = e / C;
+    const int ow = (int)(r % Wo), oh = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
+    float best = -INFINITY;
+    int bi = -1;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = 2 * oh - 1 + kh;
+      if (ih < 0 || ih >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = 2 * ow - 1 + kw;
+        if (iw < 0 || iw >= W) continue;
+        const float v = apply_in_act(x[(((size_t)b * H + ih) * W + iw) * C + c], act);
+        if (v > best || bi < 0) {
+          best = v;
+          bi = ih * W + iw;
+        }
+      }
+    }
+    y[e] = best;
+    idx[e] = bi;
+  }
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                          const float* __restrict__ x, float* __restrict__ dx, int B,
+                                                          int H, int W, int C, int Ho, int Wo, int act) {
+  const long total = (long)B * H * W * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long r = e / C;
+    const int w = (int)(r % W), h = (int)((r / W) % H), b = (int)(r / ((long)W * H));
+    float acc = 0.f;
+    const int me = h * W + w;
+    for (int oh = (h + 1 - 2 + 1) / 2; oh <= (h + 1) / 2; ++oh) {      // windows with 2 oh - 1 <= h <= 2 oh + 1
+      if (oh < 0 || oh >= Ho) continue;
+      for (int ow = (w) / 2; ow <= (w + 1) / 2; ++ow) {
+        if (ow < 0 || ow >= Wo) continue;
+        const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + c;
+        if (idx[o] == me) acc += dy[o];
+      }
+    }
+    if (act == MMVAE_ACT_RELU && !(x[e] > 0.f)) acc = 0.f;
+    dx[e] = acc;
+  }
+}
+extern "C" int mmvae_maxpool3x3s2_fwd(const float* x, float* y, int* idx, int B, int H, int W, int C, int in_act,
+                                      mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && y && idx && B > 0 && H > 1 && W > 1 && C > 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     idx, B, H, W, C, Ho, Wo, in_act);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_maxpool3x3s2_bwd(const float* dy, const int* idx, const float* x, float* dx, int B, int H, int W,
+                                      int C, int in_act, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && idx && x && dx && B > 0 && H > 1 && W > 1 && C > 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, idx,
+                     x, dx, B, H, W, C, Ho, Wo, in_act);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdaptiveAvgPool2d(1) on relu(x): (B, HW, C) -> (B, C), and its backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                          int HW, int C, int act) {
+  const long total = (long)B * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C), b = (int)(e / C);
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += apply_in_act(x[((size_t)b * HW + p) * C + c], act);
+    y[e] = s / (float)HW;
+  }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dx, int B, int HW, int C, int act) {
+  const long total = (long)B * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C), b = (int)(e / ((long)HW * C));
+    float g = dy[(size_t)b * C + c] * inv;
+    if (act == MMVAE_ACT_RELU && !(x[e] > 0.f)) g = 0.f;
+    dx[e] = g;
+  }
+}
+extern "C" int mmvae_avgpool_fwd(const float* x, float* y, int B, int HW, int C, int in_act, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && y && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_blocks((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, HW, C,
+                     in_act);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW, int C, int in_act,
+                                 mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && dx && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx,
+                     B, HW, C, in_act);
+  return mmvae_launch_status();
+}

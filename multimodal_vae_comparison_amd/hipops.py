@@ -165,6 +165,16 @@ SIGNATURES = {
     "mmvae_laplace_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_laplace_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_rand_laplace": (c_i, [c_p, c_l, c_p, c_p]),
+    "mmvae_im2col": (c_i, [c_p, c_p] + [c_i] * 9 + [c_p]),
+    "mmvae_col2im": (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    "mmvae_bn_ws_floats": (c_sz, [c_i, c_i]),
+    "mmvae_bn_row_blocks": (c_i, [c_i]),
+    "mmvae_bn_train_fwd": (c_i, [c_p] * 10 + [c_i, c_i, c_f, c_f, c_i, c_i, c_p]),
+    "mmvae_bn_train_bwd": (c_i, [c_p] * 11 + [c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mmvae_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 5 + [c_p]),
+    "mmvae_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p]),
+    "mmvae_avgpool_fwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_p]),
+    "mmvae_avgpool_bwd": (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),
     "mmvae_dropout_mask": (c_i, [c_dp, c_p, c_l, c_p]),
     "mmvae_dropout_act_fwd": (c_i, [c_p, c_p, c_l, c_i, c_dp, c_p]),

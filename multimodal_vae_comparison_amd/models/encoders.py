@@ -205,13 +205,24 @@ class Enc_SVHN(_HiddenHeads, VaeEncoder):
 
 
 class Enc_CNN(VaeEncoder):
-    """`encoder: CNN` in the reference is a torchvision ResNet-50 with downloaded ImageNet weights
-    (models/encoders.py:86-127); it is outside this build's hot-path scope and cannot be
-    constructed offline.  Use `encoder: CNN2` for the conv tower."""
+    """models/encoders.py:86-127: `encoder: CNN` = ResNet-50 -> SiLU -> heads on the 1000 logits.  The tower itself is
+    models/resnet.py (NHWC GEMM formulation on the MFMA kernels); ImageNet weights come from a user file
+    (MMVAE_RESNET50_WEIGHTS), else torchvision's random initialisation -- the reference downloads them."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("Enc_CNN (ResNet-50 + ImageNet weights) is not part of the MI355X hot path; "
-                                  "use encoder: CNN2 (see DESIGN.md, out of scope)")
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar):
+        from .resnet import ResNet50, maybe_load_pretrained
+        data_dim = (3, 64, 64)
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.CNN)
+        self.hidden_dim = 1000
+        self.reshape = (32, 4, 4)
+        self.resnet = ResNet50()
+        self.pretrained = maybe_load_pretrained(self.resnet)
+        self.init_final_layers(self.hidden_dim)
+
+    def forward(self, x):
+        if isinstance(x, dict):
+            x = x["data"]
+        return self.process_output(self.resnet(x), H.ACT_SILU)
 
 
 FUSED_TXT_LAYERS = os.environ.get("MMVAE_FUSED_TXT", "1") != "0"

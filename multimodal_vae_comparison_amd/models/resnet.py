@@ -1,0 +1,152 @@
+"""ResNet-50 image tower: what `encoder: CNN` selects in the reference (models/encoders.py:86-127 -- torchvision's
+`resnet50(weights=IMAGENET1K_V1)` -> SiLU -> Linear(1000 -> D) heads).
+
+torchvision is not a dependency: the published ResNet-50 v1.5 topology (He et al. 2016; stride on the 3x3 convolution
+of a bottleneck) is laid out here from scratch with torchvision's parameter / buffer names, so a torchvision state_dict
+(the ImageNet weights the reference downloads at construction, models/encoders.py:108) loads into it:
+    MMVAE_RESNET50_WEIGHTS=/path/to/resnet50.pth   (a `resnet50().state_dict()` file; keys `conv1.weight`, `bn1.*`,
+                                                   `layer1.0.conv1.weight`, ..., `fc.bias`)
+Without it the tower starts from torchvision's own random initialisation (kaiming-normal fan-out convolutions,
+BatchNorm weight 1 / bias 0, default Linear) -- there is no network here to fetch the ImageNet file from.
+
+MI355X mapping: activations are NHWC (rows, C) matrices inside the tower, so that all 53 convolutions run on the fp32
+MFMA GEMM kernels (1x1: one GEMM; 3x3 / 7x7: im2col + GEMM with the weight in its stored layout); BatchNorm (training:
+per-rank batch statistics, running statistics updated in the same launch), max / average pooling are HBM-bound
+kernels of csrc/resnet.hip.  Layers emit pre-activations; the consumers apply the ReLUs while staging.
+Parity: pinned against an oracle restatement of the same published topology with synthetic weights
+(oracle/mmvae_oracle.py: enc_cnn_resnet50); UNPINNED against torchvision itself, which is absent in this image."""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import hipops as H
+from .. import ops
+from .nn_modules import HipLinear
+
+LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))      # (planes, blocks, stride of the first block)
+EXPANSION = 4
+
+
+class ConvW(nn.Module):
+    """nn.Conv2d(bias=False) parameters, torchvision's initialisation (kaiming_normal_, fan_out, relu)"""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+        self.weight = nn.Parameter(w)
+        self.k, self.stride, self.pad = k, stride, pad
+
+    def forward(self, x, B, Hh, W, in_act, nchw=False):
+        y = ops.conv_nhwc(x, B, Hh, W, self.weight, self.stride, self.pad, in_act, self.weight.grad, nchw)
+        Ho = (Hh + 2 * self.pad - self.k) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.k) // self.stride + 1
+        return y, Ho, Wo
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d parameters / buffers (weight, bias, running_mean, running_var, num_batches_tracked)"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.momentum, self.eps = 0.1, 1e-5
+
+    def flat_groups(self):
+        return [[self.weight, self.bias]]
+
+    def forward(self, x, res=None, res_relu=False):
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, res,
+                              res_relu, self.momentum, self.eps)
+
+
+class Bottleneck(nn.Module):
+    """conv1 1x1 -> bn1 -> relu -> conv2 3x3 (stride) -> bn2 -> relu -> conv3 1x1 -> bn3 (+ identity) -> relu.
+    Input and output are PRE-activations `s` (the block's consumers apply relu)."""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = ConvW(inplanes, planes, 1, 1, 0)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = ConvW(planes, planes, 3, stride, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = ConvW(planes, planes * EXPANSION, 1, 1, 0)
+        self.bn3 = BatchNorm2d(planes * EXPANSION)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.ModuleList([ConvW(inplanes, planes * EXPANSION, 1, stride, 0),
+                                             BatchNorm2d(planes * EXPANSION)])
+
+    def forward(self, s, B, Hh, W, in_act=H.ACT_RELU):
+        """s: (B*H*W, inplanes), consumed through `in_act` (RELU; NONE for the max-pooled stem output)"""
+        h, _, _ = self.conv1(s, B, Hh, W, in_act)
+        h = self.bn1(h)
+        h, Ho, Wo = self.conv2(h, B, Hh, W, H.ACT_RELU)
+        h = self.bn2(h)
+        h, _, _ = self.conv3(h, B, Ho, Wo, H.ACT_RELU)
+        if self.downsample is not None:
+            idn, _, _ = self.downsample[0](s, B, Hh, W, in_act)
+            idn = self.downsample[1](idn)
+            out = self.bn3(h, res=idn, res_relu=False)
+        else:
+            out = self.bn3(h, res=s, res_relu=(in_act == H.ACT_RELU))
+        return out, Ho, Wo
+
+
+class ResNet50(nn.Module):
+    """torchvision.models.resnet50 topology and state_dict names"""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        self.conv1 = ConvW(3, 64, 7, 2, 3)
+        self.bn1 = BatchNorm2d(64)
+        inplanes = 64
+        for li, (planes, blocks, stride) in enumerate(LAYERS):
+            layer = []
+            for b in range(blocks):
+                st = stride if b == 0 else 1
+                layer.append(Bottleneck(inplanes, planes, st, downsample=(b == 0)))
+                inplanes = planes * EXPANSION
+            setattr(self, f"layer{li + 1}", nn.ModuleList(layer))
+        self.fc = HipLinear(512 * EXPANSION, num_classes)
+
+    def forward(self, x):
+        """x (B,3,H,W) NCHW image batch -> (B, 1000) logits"""
+        B, _, Hh, W = x.shape
+        if self.training:       # nn.BatchNorm2d counts its training-mode forward passes (one multi-tensor launch)
+            torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, BatchNorm2d)], 1)
+        h, Hh, W = self.conv1(x.float().contiguous(), B, Hh, W, H.ACT_NONE, nchw=True)
+        h = self.bn1(h)
+        h = ops.MaxPool3x3S2.apply(h, B, Hh, W, H.ACT_RELU)              # relu then maxpool
+        Hh, W = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+        act = H.ACT_NONE                                                  # the pooled values are already rectified
+        for li in range(4):
+            for blk in getattr(self, f"layer{li + 1}"):
+                h, Hh, W = blk(h, B, Hh, W, act)
+                act = H.ACT_RELU
+        h = ops.AvgPoolGlobal.apply(h, B, Hh * W, H.ACT_RELU)
+        return self.fc(h)
+
+
+def load_torchvision_weights(resnet, path):
+    """load a torchvision `resnet50().state_dict()` file (the ImageNet weights the reference fetches itself)"""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    sd = sd.get("state_dict", sd)
+    missing, unexpected = resnet.load_state_dict(sd, strict=False)
+    if missing or unexpected:
+        raise RuntimeError(f"{path}: not a torchvision resnet50 state_dict (missing {missing[:3]}, unexpected "
+                           f"{unexpected[:3]})")
+
+
+def maybe_load_pretrained(resnet):
+    path = os.environ.get("MMVAE_RESNET50_WEIGHTS")
+    if path:
+        load_torchvision_weights(resnet, path)
+        return True
+    return False

@@ -17,8 +17,8 @@ def make_tensor(key, shape, seed=0):
     u = rng.random(n, dtype=np.float64) * 2.0 - 1.0
     if key.endswith("_pz_params.1"):
         v = 0.5 * u                                     # non-trivial trainable prior
-    elif "norm" in key and key.endswith("weight"):
-        v = 1.0 + 0.1 * u
+    elif ("norm" in key or ".bn" in key or "downsample.1" in key) and key.endswith("weight"):
+        v = 1.0 + 0.1 * u                               # LayerNorm / BatchNorm scales
     elif "embedding" in key:
         v = u
     elif key.endswith("bias"):

@@ -57,7 +57,12 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
     """
     Dp = n_latents + (private or 0)
     s = {}
-    if enc == "CNN2":
+    if enc == "CNN":
+        s.update({f"{prefix}.enc.resnet.{k}": v for k, v in resnet50_param_shapes().items()})
+        for h in ("mu_layer", "logvar_layer"):
+            s[f"{prefix}.enc.{h}.weight"] = (Dp, 1000)
+            s[f"{prefix}.enc.{h}.bias"] = (Dp,)
+    elif enc == "CNN2":
         s[f"{prefix}.enc.conv1.weight"] = (32, 3, 4, 4)
         s[f"{prefix}.enc.conv1.bias"] = (32,)
         for i in (2, 3, 4):
@@ -200,6 +205,30 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
     return s
 
 
+RESNET50_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))     # (planes, blocks, first stride); expansion 4
+
+
+def resnet50_param_shapes():
+    """learnable tensors of the published ResNet-50 (He et al. 2016, v1.5: the stride sits on the 3x3 convolution)
+    under torchvision's state_dict names -- what `Enc_CNN.resnet` holds in the reference (models/encoders.py:108)"""
+    s = {"conv1.weight": (64, 3, 7, 7), "bn1.weight": (64,), "bn1.bias": (64,)}
+    inplanes = 64
+    for li, (planes, blocks, _) in enumerate(RESNET50_LAYERS):
+        for b in range(blocks):
+            pre = f"layer{li + 1}.{b}"
+            s[f"{pre}.conv1.weight"] = (planes, inplanes, 1, 1)
+            s[f"{pre}.conv2.weight"] = (planes, planes, 3, 3)
+            s[f"{pre}.conv3.weight"] = (4 * planes, planes, 1, 1)
+            for j, c in ((1, planes), (2, planes), (3, 4 * planes)):
+                s[f"{pre}.bn{j}.weight"], s[f"{pre}.bn{j}.bias"] = (c,), (c,)
+            if b == 0:
+                s[f"{pre}.downsample.0.weight"] = (4 * planes, inplanes, 1, 1)
+                s[f"{pre}.downsample.1.weight"], s[f"{pre}.downsample.1.bias"] = (4 * planes,), (4 * planes,)
+            inplanes = 4 * planes
+    s["fc.weight"], s["fc.bias"] = (1000, 2048), (1000,)
+    return s
+
+
 def model_param_shapes(mods, n_latents):
     """All trainable tensors of a multimodal model.  `mods` = list of dicts with keys
     enc, dec, data_dim, (private).  Trainable prior theta = `_pz_params.1` (models/mmvae_base.py:35-38)."""
@@ -227,6 +256,44 @@ def enc_cnn2(p, pre, x):
     o = o.reshape(o.shape[0], -1)
     o = F.linear(o, p[f"{pre}.enc.lin1.weight"], p[f"{pre}.enc.lin1.bias"])
     return process_output(o, p[f"{pre}.enc.mu_layer.weight"], p[f"{pre}.enc.mu_layer.bias"],
+                          p[f"{pre}.enc.logvar_layer.weight"], p[f"{pre}.enc.logvar_layer.bias"])
+
+
+def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
+    """Enc_CNN.forward, models/encoders.py:116-127: silu(resnet50(x)) -> heads.  resnet50 is NOT vendored by the
+    reference (torchvision, absent in this image; parity with torchvision itself is UNPINNED): the published topology is
+    restated here -- conv 7x7/2 (no bias), BatchNorm, ReLU, maxpool 3x3/2, [3, 4, 6, 3] bottlenecks (1x1, 3x3 with the
+    stride, 1x1 x4; 1x1 projection shortcut on the first block of a stage), global average pool, Linear(2048, 1000).
+    BatchNorm: batch statistics when `train` (a reference model in .train()), else the running statistics `stats`
+    ({key.running_mean / key.running_var}; default 0 / 1 = a freshly constructed module in .eval())."""
+    r = f"{pre}.enc.resnet"
+
+    def bn(h, key):
+        c = h.shape[1]
+        rm = stats[f"{key}.running_mean"] if stats else torch.zeros(c, dtype=h.dtype)
+        rv = stats[f"{key}.running_var"] if stats else torch.ones(c, dtype=h.dtype)
+        return F.batch_norm(h, None if train else rm, None if train else rv, p[f"{key}.weight"], p[f"{key}.bias"],
+                            training=bool(train), momentum=0.1, eps=1e-5)
+
+    h = F.conv2d(x.to(torch.get_default_dtype()), p[f"{r}.conv1.weight"], None, stride=2, padding=3)
+    h = F.max_pool2d(F.relu(bn(h, f"{r}.bn1")), 3, 2, 1)
+    for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+        for b in range(blocks):
+            k = f"{r}.layer{li + 1}.{b}"
+            st = stride if b == 0 else 1
+            o = F.relu(bn(F.conv2d(h, p[f"{k}.conv1.weight"]), f"{k}.bn1"))
+            o = F.relu(bn(F.conv2d(o, p[f"{k}.conv2.weight"], None, stride=st, padding=1), f"{k}.bn2"))
+            o = bn(F.conv2d(o, p[f"{k}.conv3.weight"]), f"{k}.bn3")
+            idn = h
+            if b == 0:
+                idn = bn(F.conv2d(h, p[f"{k}.downsample.0.weight"], None, stride=st), f"{k}.downsample.1")
+            h = F.relu(o + idn)
+            if taps is not None:        # (tests) the stage outputs, to localise a mismatch
+                h.retain_grad()
+                taps.append((k, h))
+    h = F.adaptive_avg_pool2d(h, 1).flatten(1)
+    h = F.silu(F.linear(h, p[f"{r}.fc.weight"], p[f"{r}.fc.bias"]))
+    return process_output(h, p[f"{pre}.enc.mu_layer.weight"], p[f"{pre}.enc.mu_layer.bias"],
                           p[f"{pre}.enc.logvar_layer.weight"], p[f"{pre}.enc.logvar_layer.bias"])
 
 
@@ -462,6 +529,7 @@ def dec_transformer(p, pre, z, mask, data_dim, train=False):
 
 
 _ENC = {"CNN2": lambda p, pre, d, train: enc_cnn2(p, pre, d["data"]),
+        "CNN": lambda p, pre, d, train: enc_cnn_resnet50(p, pre, d["data"], train),
         "TxtTransformer": lambda p, pre, d, train: enc_txt_transformer(p, pre, d["data"], d["masks"], train),
         "Transformer": lambda p, pre, d, train: enc_transformer(p, pre, d["data"], d["masks"], train),
         "MNIST": lambda p, pre, d, train: enc_mnist(p, pre, d["data"]),

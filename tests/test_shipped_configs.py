@@ -21,11 +21,11 @@ with open(os.path.join(GOLDEN_DIR, "shipped_configs.json")) as f:
 # file -> what construction must do.  ("ok", mixer class, checks) or ("error", substring of the message)
 EXPECT = {
     "config_mnistsvhn.yml": ("ok", "MOE"),
-    # `encoder: CNN` = the ResNet-50 tower: documented error until it is built
-    "config_cdspritesplus.yml": ("error", "Enc_CNN"),
-    "config_cub.yml": ("error", "Enc_CNN"),
-    "config_vilanro.yml": ("error", "Enc_CNN"),
-    "config_celeba.yml": ("error", "Enc_CNN|tower 'FNN'"),
+    # `encoder: CNN` = the ResNet-50 tower (models/resnet.py)
+    "config_cdspritesplus.yml": ("ok", "MOE"),
+    "config_cub.yml": ("ok", "MOE"),
+    "config_vilanro.yml": ("ok", "POE"),
+    "config_celeba.yml": ("error", "tower 'FNN'"),
     "config_fashionmnist.yml": ("error", "tower 'FNN'"),
     "config_polymnist.yml": ("error", "tower 'PolyMNIST'"),
     "config_sprites.yml": ("error", "tower 'VideoGPT'"),
