@@ -81,6 +81,9 @@ WORKLOADS = {
              "optimal_sigma on the actions, n_latents=32, batch=128",
              "mopoe", CD_MODS + [{"enc": "Transformer", "dec": "Transformer", "data_dim": [100, 4, 1],
                                   "ltype": "optimal_sigma"}], 32, 128, 32, {}),
+    "cdsprites_shipped": ("the shipped configs/config_cdspritesplus.yml: MoE elbo, `encoder: CNN` = ResNet-50 image "
+                          "tower + Dec_CNN, TxtTransformer text towers, n_latents=24, batch=24, T=32",
+                          "moe", [dict(CD_MODS[0], enc="CNN"), CD_MODS[1]], 24, 24, 32, {}),
     "mnistsvhn": ("the shipped configs/config_mnistsvhn.yml: MoE, obj dreg, K=30, prior laplace, llik_scaling auto, "
                   "n_latents=20, batch=128", "moe", [dict(m, llik_scaling="auto") for m in MS_MODS], 20, 128, 0,
                   {"obj": "dreg", "K": 30, "prior": "laplace"}),
@@ -105,7 +108,8 @@ def workload(name, batch=None, device="cpu", seed=1):
 # counted the same way: conv = out positions x Cout x Cin x 16, linear = in x out)
 def tower_macs(m, D, T=32):
     Dp = D + (m.get("private") or 0)
-    enc = {"CNN2": 7372800 - 32768 + 512 * 2 * Dp, "TxtTransformer": 929664 * T // 32, "MNIST": 784 * 400 + 400 * 400 + 400 * 2 * Dp,
+    enc = {"CNN": 335_000_000 + 1000 * 2 * Dp,            # ResNet-50 at 64x64 (~335 MMAC) + heads
+           "CNN2": 7372800 - 32768 + 512 * 2 * Dp, "TxtTransformer": 929664 * T // 32, "MNIST": 784 * 400 + 400 * 400 + 400 * 2 * Dp,
            "SVHN": 393216 + 2097152 + 1048576 + 131072 + 128 * 2 * Dp}
     dec = {"CNN": 7618560 - 32 * 512 + Dp * 512, "TxtTransformer": 556032 * T // 32, "MNIST": Dp * 400 + 400 * 400 + 400 * 784,
            "SVHN": Dp * 128 + 131072 + 1048576 + 2097152 + 393216}
