@@ -55,7 +55,7 @@ class MultimodalVAE(nn.Module):
             self.model = getattr(models, c.mixing.lower())(nn.ModuleDict(vaes), c.n_latents, obj_cfg, c.model_cfg)
             assert isinstance(self.model, TorchMMVAE)
         else:
-            raise NotImplementedError("unimodal VAE objective is outside the multimodal hot path")
+            self.model = vaes["mod_1"]          # unimodal VAE scenario (models/trainer.py:112-113)
         return self.model
 
     def configure_optimizers(self):

@@ -4,6 +4,7 @@ import torch.distributions as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from . import decoders, encoders
 from .decoders import VaeDecoder
 from .encoders import VaeEncoder
@@ -78,6 +79,16 @@ class VAE(BaseVae):
         self.modelName = id_name
         self.ltype = ltype
         self.obj_name = obj_fn
+        self.beta = beta
+        # unimodal use (models/trainer.py:112-113): noise generator state and the N(0, 1) prior of UnimodalObjective.elbo
+        self.eps_override = None
+        self.register_buffer("_rng_state", torch.tensor([torch.initial_seed() & 0x7FFFFFFF, 0, 0], dtype=torch.int32),
+                             persistent=False)
+        self.register_buffer("_theta0", torch.zeros(1, self.total_latents), persistent=False)
+        for part in ("enc", "dec"):
+            st = getattr(getattr(self, part), "drop_state", None)
+            if st is not None and not st.prefix:
+                st.prefix = part
 
     @property
     def pz_params(self):
@@ -87,3 +98,34 @@ class VAE(BaseVae):
     def pz_params_private(self):
         return self._pz_params_private[0], \
             F.softmax(self._pz_params_private[1], dim=1) * self._pz_params_private[1].size(-1)
+
+    # ---- the unimodal case: `self.model = vaes["mod_1"]` (models/trainer.py:112-113) ------------------------------
+    def objective(self, data):
+        """VAE.forward + objective with UnimodalObjective.elbo (models/vae.py:92-119,268-282, models/objectives.py:233-247):
+        q = Normal(mu, lv as sigma), one rsample, recon = dec(z), KL(q || N(0, 1)) against the raw `_pz_params`;
+        loss = -(lpx_z.sum(-1) - beta * kld.sum()).sum() = sum_b recon_b + B * beta * sum_b kld_b (kld.sum() is the batch
+        total and is subtracted from every row).  Returns per-sample sums for "kld" (B,) and "reconstruction_loss"
+        (B,) -- the reference returns the (B, D) / (B, F) element tensors; the logged `.sum()`s are the same."""
+        from .mmvae_base import packed_head
+        from .objectives import recon_rowsum
+        if self.obj_name != "elbo":
+            raise NotImplementedError(f"unimodal objective '{self.obj_name}': elbo is on the MI355X path")
+        if self.prior_str not in ("normal", "gaussian"):
+            raise NotImplementedError(f"unimodal VAE with prior '{self.prior_str}'")
+        x = data["mod_1"]
+        ops.GradReducer.begin_step(self._rng_state.device)
+        for part in (self.enc, self.dec):
+            st = getattr(part, "drop_state", None)
+            if st is not None:
+                st.reset_calls()
+        packed = packed_head(*self.enc(x))
+        B, D = packed.shape[0], self.total_latents
+        if self.eps_override is not None:
+            eps = self.eps_override.pop(0).reshape(B, D).to(device=packed.device, dtype=torch.float32).contiguous()
+        else:
+            eps = ops.randn((B, D), self._rng_state)
+        _, kl, z = ops.poe_reparam_kl(self._theta0, [packed], [eps], 2, 0b10)
+        out, _ = self.dec({"latents": z[0].unsqueeze(0), "masks": x["masks"]})
+        rec = recon_rowsum(self.ltype, out, x)
+        loss = ops.lincomb_rows([rec, kl[1]], [[1.0, float(B) * float(self.beta)]])
+        return {"loss": loss[0], "kld": kl[1], "reconstruction_loss": -rec}

@@ -31,7 +31,7 @@ def config_from_mods(mixing, mods, n_latents, batch_size=128, beta=1, lr=1e-4, o
     """(config dict, feature_dims) for an arbitrary modality list [{"enc", "dec", "data_dim", "ltype", "private"?,
     "llik_scaling"?}] in the reference's YAML schema; the parity tests build their models from fixture metadata"""
     cfg = {"batch_size": batch_size, "beta": beta, "dataset_name": "synthetic", "lr": lr, "mixing": mixing,
-           "n_latents": n_latents, "obj": obj, "optimizer": "adam", "K": K}
+           "n_latents": n_latents, "obj": obj, "optimizer": "adam", "K": K}     # one modality: the unimodal VAE
     dims = {}
     for i, m in enumerate(mods):
         cfg[f"modality_{i + 1}"] = {"decoder": m["dec"], "encoder": m["enc"], "mod_type": f"m{i + 1}",

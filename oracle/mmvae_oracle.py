@@ -1008,7 +1008,31 @@ def dmvae_forward(p, mods, batch, eps, n_latents, train=False):
     return out, (j_mu, j_var)
 
 
-OBJECTIVES = {"mopoe": mopoe_objective, "poe": poe_objective, "moe": moe_objective, "dmvae": dmvae_objective}
+def vae_param_shapes(mod, n_latents):
+    """trainable tensors of a unimodal VAE (models/trainer.py:112-113: `self.model = vaes["mod_1"]`): the tower keys
+    without the `vaes.mod_1.` prefix (its `_pz_params` are not trainable, models/vae.py:159-162)"""
+    full = tower_param_shapes("vaes.mod_1", mod["enc"], mod["dec"], mod["data_dim"], n_latents, mod.get("private"))
+    return {k[len("vaes.mod_1."):]: v for k, v in full.items()}
+
+
+def vae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+    """VAE.forward + objective, the unimodal case (models/vae.py:92-119,268-282) with UnimodalObjective.elbo
+    (models/objectives.py:233-247): q = Normal(mu, lv as sigma), ONE rsample, recon = dec(z);
+    lpx_z = -ReconLoss (B, F);  kld = KL(q || N(0, 1)) (B, D) against the RAW `_pz_params` (zeros, ones);
+    loss = -(lpx_z.sum(-1) - beta * kld.sum()).sum()  -- kld.sum() is the batch TOTAL, subtracted from every row."""
+    mod = mods[0]
+    pp = {"vaes.mod_1." + k: v for k, v in p.items()}
+    mu, sig = encode(pp, [mod], 0, batch["mod_1"], train)
+    B = mu.shape[0]
+    z = mu + sig * eps[0].reshape(1, B, n_latents)
+    out = decode(pp, [mod], 0, z, batch["mod_1"]["masks"], train)
+    lpx_z = -recon_loss(mod["ltype"], out, batch["mod_1"])
+    kld = kl_normal(mu, sig, 0.0, torch.ones(1, n_latents))
+    loss = -(lpx_z.sum(-1) - beta * kld.sum()).sum()
+    return {"loss": loss, "kld": kld, "reconstruction_loss": lpx_z}
+
+
+OBJECTIVES = {"vae": vae_objective, "mopoe": mopoe_objective, "poe": poe_objective, "moe": moe_objective, "dmvae": dmvae_objective}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -90,7 +90,22 @@ CASES += [
 ]
 
 
+# the unimodal case (models/trainer.py:112-113): one VAE trained with UnimodalObjective.elbo
+CASE_MODS["vae_cnn2_b5_d8"] = [MODS[0]]
+CASE_MODS["vae_txt_b5_t6_d8"] = [MODS[1]]
+CASE_MODS["vae_mnist_b6_d8_lprob"] = [MS[0]]
+CASES += [
+    ("vae_cnn2_b5_d8", "vae", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.5),
+    ("vae_txt_b5_t6_d8", "vae", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.0),
+    ("vae_mnist_b6_d8_lprob", "vae", 6, 0, 8, None, "eval", 0.5),
+]
+
+
 def build_reference(mixing, D, beta, private=None, mods=None, obj="elbo", K=1, prior="normal"):
+    if mixing == "vae":
+        m = mods[0]
+        return VAE(m["enc"], m["dec"], m["data_dim"], D, m["ltype"], None, obj_fn="elbo", beta=beta, id_name="mod_1",
+                   llik_scaling=m["llik_scaling"])
     vaes = {}
     for i, m in enumerate(mods or MODS):
         # prior / posterior / likelihood all follow the config's `prior` key (models/trainer.py:100-105)
@@ -116,7 +131,7 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     mods = [dict(m, private=private) for m in base] if private else base
     opts = CASE_OPTS.get(name, {})
     model = build_reference(mixing, D, beta, private, mods, **opts)
-    shapes = orc.model_param_shapes(mods, D)
+    shapes = orc.vae_param_shapes(mods[0], D) if mixing == "vae" else orc.model_param_shapes(mods, D)
     ref_sd = model.state_dict()
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
     assert trainable == set(shapes), (trainable ^ set(shapes))
@@ -134,7 +149,21 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
                 mod.p = 0.0
             if isinstance(mod, nn.MultiheadAttention):
                 mod.dropout = 0.0
-    if mods[0]["enc"] == "MNIST":       # image pair (B,1,28,28) / (B,3,32,32) in [0,1], no masks
+    if mixing == "vae":                 # ONE modality, keyed mod_1 as the reference's objective expects
+        gm = torch.Generator().manual_seed(seed + 1)
+        if mods[0]["enc"] == "MNIST":
+            x = torch.rand(B, 1, 28, 28, generator=gm)
+            batch = {"mod_1": {"data": x, "masks": None, "categorical": False}}
+            out = {"mnist": x.numpy()}
+        else:
+            img, onehot, mask = make_batch(B, T, lengths, seed + 1)
+            if mods[0]["enc"] == "CNN2":
+                batch = {"mod_1": {"data": img, "masks": None, "categorical": False}}
+                out = {"img": img.numpy()}
+            else:
+                batch = {"mod_1": {"data": onehot, "masks": mask, "categorical": True}}
+                out = {"onehot": onehot.numpy(), "mask": mask.numpy()}
+    elif mods[0]["enc"] == "MNIST":       # image pair (B,1,28,28) / (B,3,32,32) in [0,1], no masks
         gm = torch.Generator().manual_seed(seed + 1)
         mn, sv = torch.rand(B, 1, 28, 28, generator=gm), torch.rand(B, 3, 32, 32, generator=gm)
         batch = {"mod_1": {"data": mn, "masks": None, "categorical": False},
@@ -177,8 +206,12 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     meta["n_eps"] = len(tape.draws)
     out["loss"] = res["loss"].detach().numpy()
     out["kld"] = res["kld"].detach().numpy()
-    for i, r in enumerate(res["reconstruction_loss"]):
-        out[f"rec_{i}"] = r.detach().numpy()
+    if mixing == "vae":      # (B, F) / (B, D) element tensors: keep the per-sample sums
+        out["rec_0"] = res["reconstruction_loss"].detach().double().sum(-1).numpy()
+        out["kld"] = res["kld"].detach().sum(-1).numpy()
+    else:
+        for i, r in enumerate(res["reconstruction_loss"]):
+            out[f"rec_{i}"] = r.detach().numpy()
     if mixing == "moe" and opts.get("obj", "elbo") == "elbo":      # MoE leaves the trainable model prior untouched: the reference has no gradient for it
         for k, q in model.named_parameters():
             if q.requires_grad and q.grad is None:
@@ -200,6 +233,9 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
                 o = fw.mods[f"mod_{i + 1}"]
                 out[f"z_{i}"] = o.latent_samples["latents"].numpy()
                 out[f"recon_{i}"] = gw.summarize(o.decoder_dist.loc, 256)
+        elif mixing == "vae":
+            mu, lv = model.enc(batch["mod_1"])
+            out["enc_mu_0"], out["enc_lv_0"] = mu.numpy(), lv.numpy()
         else:
             for i in range(len(mods)):
                 mu, lv = model.vaes[f"mod_{i + 1}"].enc(batch[f"mod_{i + 1}"])

@@ -10,7 +10,13 @@ from oracle import golden_weights as gw
 from oracle import mmvae_oracle as orc
 
 
-def _batch(g):
+def _batch(g, unimodal=False):
+    if unimodal:         # exactly one of mnist / img / onehot
+        if "mnist" in g:
+            return {"mod_1": {"data": torch.from_numpy(g["mnist"]), "masks": None, "categorical": False}}
+        if "img" in g:
+            return {"mod_1": {"data": torch.from_numpy(g["img"]), "masks": None, "categorical": False}}
+        return {"mod_1": {"data": torch.from_numpy(g["onehot"]), "masks": torch.from_numpy(g["mask"]), "categorical": True}}
     if "mnist" in g:     # MNIST / SVHN image pair
         return {"mod_1": {"data": torch.from_numpy(g["mnist"]), "masks": None, "categorical": False},
                 "mod_2": {"data": torch.from_numpy(g["svhn"]), "masks": None, "categorical": False}}
@@ -22,14 +28,16 @@ def _batch(g):
 
 
 def _run(meta, g):
-    shapes = orc.model_param_shapes(meta["mods"], meta["D"])
+    shapes = (orc.vae_param_shapes(meta["mods"][0], meta["D"]) if meta["mixing"] == "vae"
+              else orc.model_param_shapes(meta["mods"], meta["D"]))
     p = gw.make_params(shapes, meta["seed"], requires_grad=True)
     eps = [torch.from_numpy(g[f"eps_{i}"]) for i in range(meta["n_eps"])]
     kw = {"order": meta["order"]} if meta["mixing"] == "poe" else {}
     if "obj" in meta:       # MoE dreg / K > 1 / prior laplace / llik_scaling auto (configs/config_mnistsvhn.yml)
         kw.update(obj=meta["obj"], K=meta["K"], prior=meta["prior"])
         assert orc.resolve_llik_scaling(meta["mods"]) == pytest.approx(meta["llik"], rel=1e-12)
-    out = orc.OBJECTIVES[meta["mixing"]](p, meta["mods"], _batch(g), eps, meta["D"], beta=meta["beta"], **kw)
+    out = orc.OBJECTIVES[meta["mixing"]](p, meta["mods"], _batch(g, meta["mixing"] == "vae"), eps, meta["D"],
+                                         beta=meta["beta"], **kw)
     return p, out
 
 
@@ -46,6 +54,10 @@ def test_objective_matches_reference(name):
     meta, g = load_golden(name)
     p, out = _run(meta, g)
     _close(out["loss"].item(), g["loss"], 2e-5, "loss")
+    if meta["mixing"] == "vae":      # the fixture keeps the per-sample sums of the (B, D) / (B, F) element tensors
+        _close(out["kld"].detach().sum(-1).numpy(), g["kld"], 2e-5, "kld")
+        _close(out["reconstruction_loss"].detach().double().sum(-1).numpy(), g["rec_0"], 2e-5, "rec_0")
+        return
     _close(out["kld"].detach().numpy(), g["kld"], 2e-5, "kld")
     for i, r in enumerate(out["reconstruction_loss"]):
         _close(r.detach().numpy(), g[f"rec_{i}"], 2e-5, f"rec_{i}")
