@@ -313,6 +313,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["loss"].item())
+    in_sync = None
+    if world > 1:       # replicas must still hold identical parameters: compare a checksum across the ranks
+        cs = tr.flat.data.double().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        in_sync = bool(lo.item() == hi.item())
 
     res = None
     if rank == 0:
@@ -328,6 +335,12 @@ def main():
                           "step_flops_fraction_of_f32_mfma_peak": round(
                               sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
                "final_loss": round(loss, 3)}
+        if world > 1 or path_world > 1:
+            res["config"]["collective"] = ("one all-reduce of the flat gradient buffer per step, captured into the step's "
+                                           "hipGraph with the Adam launch" if getattr(tr, "_collective_in_graph", False)
+                                           else "one all-reduce of the flat gradient buffer per step after the graph")
+            if in_sync is not None:
+                res["config"]["replicas_in_sync"] = in_sync
     if world == 1 and rank == 0:
         res["roofline"] = dominant_kernel_roofline(meta, dev)
         if not a.no_extras and path_world == 1 and a.config == "cfg2":
