@@ -474,6 +474,239 @@ static bool rgemm_enabled() {
   return v != 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Large GEMMs (round 2: the MNIST MLP towers at M = K*B = 7680 rows, the ResNet-50 tower's NHWC convolutions, the
+// text towers' weight gradients at large batches): 128 x BN output tile per workgroup (BN = 128 | 64), 4 waves as 2 x 2,
+// each wave a 64 x BN/2 block = 2 x (BN/64) accumulators of v_mfma_f32_32x32x2_f32; K staged 16 deep, double
+// buffered in LDS as [k][m] / [k][n] (pitch +4: the transposing dword stores of a k-contiguous operand and the
+// b128 stores of a row-contiguous one are both conflict free, fragment reads are consecutive lanes = consecutive
+// banks); operands come in as float4 (all of a stage's loads in flight, next stage's loads issued before this
+// stage's MFMAs).  Same GemmArgs / split-K partial layout / epilogue semantics as gemm_kernel.
+// Requires 16-byte aligned operands along their contiguous axis (the dispatcher checks; else the staged kernel runs).
+// ------------------------------------------------------------------------------------------------
+#define GB_BM 128
+#define GB_BK 16
+template <int BN, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
+  constexpr int BM = GB_BM, BK = GB_BK;
+  constexpr int AP = BM + 4, BP = BN + 4;
+  constexpr int TN = BN / 64;                 // 32-column MFMA tiles per wave along N
+  constexpr int NB4 = BN * BK / 4 / 256;      // float4 of the B tile per thread (2 | 1)
+  __shared__ __attribute__((aligned(16))) float As[2][BK * AP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int nz = gridDim.z, bz = blockIdx.z;
+  const int kbeg = bz * g.kper, kend = min(g.K, kbeg + g.kper);
+
+  // ---- staging slots.  k-contiguous operand: float4 = 4 k of one row (row = slot % R, k4 = slot / R);
+  //      row-contiguous operand: float4 = 4 rows of one k (r4 = slot % (R/4), k = slot / (R/4))
+  long a_off[2];
+  int a_lds[2], a_k[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 256 * i;
+    if (A_KMAJOR) {
+      const int m = q % BM, k4 = q / BM;
+      a_k[i] = 4 * k4;
+      a_ok[i] = m0 + m < g.M;
+      a_off[i] = (long)(m0 + (a_ok[i] ? m : 0)) * g.sam + 4 * k4;
+      a_lds[i] = 4 * k4 * AP + m;
+    } else {
+      const int m4 = q % (BM / 4), k = q / (BM / 4);
+      a_k[i] = k;
+      a_ok[i] = m0 + 4 * m4 < g.M;            // M % 4 == 0 (dispatcher): a float4 is all in or all out
+      a_off[i] = (long)k * g.sak + m0 + (a_ok[i] ? 4 * m4 : 0);
+      a_lds[i] = k * AP + 4 * m4;
+    }
+  }
+  long b_off[NB4];
+  int b_lds[NB4], b_k[NB4];
+  bool b_ok[NB4];
+#pragma unroll
+  for (int i = 0; i < NB4; ++i) {
+    const int q = tid + 256 * i;
+    if (B_KMAJOR) {
+      const int n = q % BN, k4 = q / BN;
+      b_k[i] = 4 * k4;
+      b_ok[i] = n0 + n < g.N;
+      b_off[i] = (long)(n0 + (b_ok[i] ? n : 0)) * g.sbn + 4 * k4;
+      b_lds[i] = 4 * k4 * BP + n;
+    } else {
+      const int n4 = q % (BN / 4), k = q / (BN / 4);
+      b_k[i] = k;
+      b_ok[i] = n0 + 4 * n4 < g.N;
+      b_off[i] = (long)k * g.sbk + n0 + (b_ok[i] ? 4 * n4 : 0);
+      b_lds[i] = k * BP + 4 * n4;
+    }
+  }
+  float4 ra[2], rb[NB4];
+  unsigned oka = 0, okb = 0;
+  auto load_stage = [&](int k0) {
+    oka = okb = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // k-contiguous: the float4 covers k0+a_k .. +3 (K % 4 == 0: all in or all out); row-contiguous: one k
+      const bool ok = a_ok[i] && (k0 + a_k[i] < kend);
+      oka |= (ok ? 1u : 0u) << i;
+      const long o = ok ? (A_KMAJOR ? a_off[i] + k0 : a_off[i] + (long)k0 * g.sak) : 0;
+      ra[i] = *reinterpret_cast<const float4*>(g.A + o);
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const bool ok = b_ok[i] && (k0 + b_k[i] < kend);
+      okb |= (ok ? 1u : 0u) << i;
+      const long o = ok ? (B_KMAJOR ? b_off[i] + k0 : b_off[i] + (long)k0 * g.sbk) : 0;
+      rb[i] = *reinterpret_cast<const float4*>(g.B + o);
+    }
+  };
+  auto act4 = [&](float4& v, int act) {
+    float t[4] = {v.x, v.y, v.z, v.w};
+    act_inplace(t, act);
+    v = make_float4(t[0], t[1], t[2], t[3]);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = (oka >> i & 1u) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.a_act != MMVAE_ACT_NONE) act4(v, g.a_act);
+      float* d = As[buf] + a_lds[i];
+      if (A_KMAJOR) { d[0] = v.x; d[AP] = v.y; d[2 * AP] = v.z; d[3 * AP] = v.w; }
+      else *reinterpret_cast<float4*>(d) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      float4 v = (okb >> i & 1u) ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.b_act != MMVAE_ACT_NONE) act4(v, g.b_act);
+      float* d = Bs[buf] + b_lds[i];
+      if (B_KMAJOR) { d[0] = v.x; d[BP] = v.y; d[2 * BP] = v.z; d[3 * BP] = v.w; }
+      else *reinterpret_cast<float4*>(d) = v;
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float asum = 0.f;                                   // row sums of act(A) (the bias gradient when A = dy^T)
+  const bool want_rs = g.a_rowsum != nullptr && blockIdx.x == 0;
+
+  int buf = 0;
+  if (kbeg < kend) {
+    load_stage(kbeg);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) load_stage(k0 + BK);
+    const float* __restrict__ a_s = As[buf] + lh * AP + wm * 64 + li;
+    const float* __restrict__ b_s = Bs[buf] + lh * BP + wn * (BN / 2) + li;
+    // operands of k pair kp+1 are read from LDS while the MFMAs of pair kp issue (hipcc otherwise sinks every ds_read
+    // next to its consumer, see conv_gather.inc)
+    float av[2][2], bv[2][TN];
+    auto load_ops = [&](int kp, int ob) {
+      av[ob][0] = a_s[2 * kp * AP];
+      av[ob][1] = a_s[2 * kp * AP + 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[ob][j] = b_s[2 * kp * BP + 32 * j];
+    };
+    load_ops(0, 0);
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      if (kp + 1 < BK / 2) load_ops(kp + 1, (kp + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][0], bv[kp & 1][j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][1], bv[kp & 1][j], acc[1][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (want_rs && tid < BM) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) asum += As[buf][k * AP + tid];
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- output: bias / epilogue / accumulate, or the raw partial of this K split ----
+  const bool partial = nz > 1;
+  float* Cout = partial ? g.ws + (size_t)bz * g.M * g.N : g.C;
+  const long ldc = partial ? g.N : g.ldc;
+  const int ep = partial ? MMVAE_EP_NONE : g.ep;
+  const bool acc_out = !partial && g.accumulate;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + 32 * j + li;
+    const float bias_v = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][r] + bias_v;
+          const long o = (long)row * ldc + col;
+          if (ep != MMVAE_EP_NONE || acc_out) {
+            float av = 0.f;
+            if (ep_reads_aux(ep)) av = g.aux[o];
+            if (ep == MMVAE_EP_GELU && g.aux) g.aux[o] = v;
+            v = apply_epilogue(v, av, ep);
+            if (acc_out) v += Cout[o];
+          }
+          Cout[o] = v;
+        }
+      }
+    }
+  }
+  if (want_rs && tid < BM && m0 + tid < g.M) {
+    float* rs_out = partial ? g.ws + (size_t)nz * g.M * g.N + (size_t)bz * g.M : g.a_rowsum;
+    rs_out[m0 + tid] = acc_out ? rs_out[m0 + tid] + asum : asum;
+  }
+}
+
+// shapes the large-tile kernel takes: big enough to fill the chip with 128-row tiles, float4-loadable operands
+// shapes the large-tile kernel takes: enough 128-row tiles to put >= 2 workgroups on every CU, float4-loadable
+// operands.  Returns the N tile (128 | 64) or 0.
+static inline int gemm_big_bn(const GemmArgs& g, int nz, bool ak, bool bk_major) {
+  static const int on = [] { const char* e = getenv("MMVAE_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  if (!on) return 0;
+  if (g.K < 16 || g.N < 32 || g.M < 128) return 0;
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  if (!al16(g.A) || !al16(g.B)) return 0;
+  if (ak) { if ((g.sam & 3) || (g.K & 3) || (g.kper & 3)) return 0; }
+  else { if ((g.sak & 3) || (g.M & 3)) return 0; }
+  if (bk_major) { if ((g.sbn & 3) || (g.K & 3) || (g.kper & 3)) return 0; }
+  else { if ((g.sbk & 3) || (g.N & 3)) return 0; }
+  const long rows = (g.M + 127) / 128;
+  if (rows * ((g.N + 127) / 128) * nz >= 512 && g.N > 64) return 128;
+  if (rows * ((g.N + 63) / 64) * nz >= 384) return 64;
+  return 0;
+}
+static void gemm_big_launch(const GemmArgs& g, int bn, int nz, bool ak, bool bk_major, hipStream_t st) {
+  const dim3 grid((g.N + bn - 1) / bn, (g.M + 127) / 128, nz);
+#define GB_LAUNCH(BN)                                                                                   \
+  do {                                                                                                  \
+    if (ak && bk_major) hipLaunchKernelGGL((gemm_big_kernel<BN, true, true>), grid, dim3(256), 0, st, g);   \
+    else if (ak) hipLaunchKernelGGL((gemm_big_kernel<BN, true, false>), grid, dim3(256), 0, st, g);         \
+    else if (!bk_major) hipLaunchKernelGGL((gemm_big_kernel<BN, false, false>), grid, dim3(256), 0, st, g); \
+    else hipLaunchKernelGGL((gemm_big_kernel<BN, false, true>), grid, dim3(256), 0, st, g);                 \
+  } while (0)
+  if (bn == 128) GB_LAUNCH(128);
+  else GB_LAUNCH(64);
+#undef GB_LAUNCH
+}
+
 // tiling variant, reduction length per split and number of splits actually used for (M, N, K, requested splitk)
 static int gemm_split_plan(int M, int N, int K, int splitk, int* variant_out, int* kper_out) {
   if (splitk < 1) splitk = 1;
@@ -524,6 +757,18 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   const bool ak = sak == 1, bk_major = (sbk == 1 && sbn != 1);
   if (!ak && sam != 1) return MMVAE_ERR_UNSUPPORTED;
   if (!bk_major && sbn != 1) return MMVAE_ERR_UNSUPPORTED;
+  // large problems: 128 x 128 | 64 tiles, float4 staging (same kper / partial layout)
+  if (const int big_bn = gemm_big_bn(g, nz, ak, bk_major)) {
+    gemm_big_launch(g, big_bn, nz, ak, bk_major, st);
+    int rc = mmvae_launch_status();
+    if (rc) return rc;
+    if (nz > 1 && accumulate != MMVAE_ACC_DEFER) {
+      rc = mmvae_reduce_rows(ws, C, nz, (long)M * N, (long)M * N, accumulate, stream);
+      if (rc) return rc;
+      if (a_rowsum) rc = mmvae_reduce_rows(ws + (size_t)nz * M * N, a_rowsum, nz, M, M, accumulate, stream);
+    }
+    return rc;
+  }
   // split reduction over workgroups with few output tiles (the text towers' (L*N)-row weight gradients: 162 x 54
   // outputs, 4096 rows): same kper / partial layout as the staged kernel, register-operand body
   static const bool rsplit = !(getenv("MMVAE_RGEMM_SPLIT") && atoi(getenv("MMVAE_RGEMM_SPLIT")) == 0);
@@ -609,6 +854,15 @@ extern "C" int mmvae_linear_bwd_data(const float* dy, const float* w, const floa
 }
 static int wgrad_splitk(int M, int N, int K) {
   // reduction length is M (rows); output N x K.  Split so that tiles * splits ~ 512 workgroups.
+  if (M >= 2048 && N >= 128 && K >= 32 && !(N & 3) && !(K & 3)) {
+    // long reductions into a sizeable output run on the large-tile kernel (128 x 64 tiles): splits for ITS grid
+    const long big = (long)((N + 127) / 128) * ((K + 63) / 64);
+    int s = (int)((512 + big - 1) / big);
+    const int maxs = M / 256;
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    if (s >= 1) return s;
+  }
   const long tiles = (long)((N + 31) / 32) * ((K + 31) / 32);
   int s = (int)(512 / (tiles > 0 ? tiles : 1));
   const int maxs = (M + 127) / 128;

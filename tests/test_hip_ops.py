@@ -85,7 +85,11 @@ def test_convT2d_fwd_bwd(ops, B, Cout, Hin, act, ep):
 
 
 @pytest.mark.parametrize("M,K,N,act", [(128, 512, 512, 1), (6, 8, 512, 0), (7, 512, 64, 2), (4096, 54, 162, 0),
-                                       (160, 128, 54, 3), (33000, 54, 128, 0), (5, 54, 16, 0), (300, 32, 27, 0)])
+                                       (160, 128, 54, 3), (33000, 54, 128, 0), (5, 54, 16, 0), (300, 32, 27, 0),
+                                       # the large-tile kernel (gemm_big_kernel): MNIST towers at K*B rows, ResNet shapes,
+                                       # ragged edges in M / N / K, every orientation through fwd / dgrad / wgrad
+                                       (7680, 400, 400, 2), (7680, 400, 784, 2), (7680, 20, 400, 0), (6144, 576, 64, 2),
+                                       (1000, 2048, 512, 2), (32000, 56, 160, 0), (520, 1024, 256, 3), (3844, 36, 132, 1)])
 def test_linear_fwd_bwd(ops, M, K, N, act):
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g)
