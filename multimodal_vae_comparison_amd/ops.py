@@ -212,9 +212,9 @@ class StreamPlan:
     batch_wgrad = _mode == "batch"                            # queue conv wgrads, launch them in batches
     wgrad_enabled = _mode in ("conv", "1")                    # fork per wgrad launch
     wgrad_linear = _mode == "1"
-    # MMVAE_SPLIT_CONV_BWD=1: a conv layer's backward as a data-gradient launch on the tower's stream (the dependency
-    # chain) and a weight-gradient launch on the `wgrad` side stream, which only the end-of-backward fold waits for
-    split_conv_bwd = os.environ.get("MMVAE_SPLIT_CONV_BWD", "0") == "1"
+    # (measured and removed in round 2, DESIGN.md 5b: a conv layer's backward as a data-gradient launch on the tower's
+    # stream + a weight-gradient launch on a third stream -- 0.634 ms/step, the graph serialises; and the small-map
+    # layers' fused backward as two launches on the same stream -- 0.450 / 0.457 / 0.489 ms for maps <= 4 / 8 / 16)
     _streams = {}
 
     @classmethod
@@ -328,18 +328,7 @@ class Conv2dK4S2(Function):
         ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
         acc = H.ACC_DEFER if defer else acc_w
         dx = None
-        if ctx.needs_input_grad[0] and defer and StreamPlan.enabled and StreamPlan.split_conv_bwd:
-            dx = torch.empty_like(x)
-            ep = _DACT[in_act]
-            _call("mmvae_conv2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout, Hout,
-                  ep, H.stream())
-            side = StreamPlan.fork(os.environ.get("MMVAE_WGRAD_STREAM", "wgrad"), x.device)
-            GradReducer.note_stream(x.device, side)
-            GradReducer.keep(x.device, dy, x)
-            with torch.cuda.stream(side):
-                _call("mmvae_conv2d_k4s2_wgrad", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout,
-                      Hout, in_act, acc, H.stream())
-        elif ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
+        if ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
             dx = torch.empty_like(x)
             _call("mmvae_conv2d_k4s2_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
                   B, Cin, Cout, Hout, in_act, acc, H.stream())
@@ -403,18 +392,7 @@ class ConvT2dK4S2(Function):
         ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
         acc = H.ACC_DEFER if defer else acc_w
         dx = None
-        if ctx.needs_input_grad[0] and defer and StreamPlan.enabled and StreamPlan.split_conv_bwd:
-            dx = torch.empty_like(x)
-            ep = _DACT[in_act]
-            _call("mmvae_convT2d_k4s2_dgrad", H.ptr(dy), H.ptr(w), H.ptr(x) if ep else None, H.ptr(dx), B, Cin, Cout, Hin,
-                  ep, H.stream())
-            side = StreamPlan.fork(os.environ.get("MMVAE_WGRAD_STREAM", "wgrad"), x.device)
-            GradReducer.note_stream(x.device, side)
-            GradReducer.keep(x.device, dy, x)
-            with torch.cuda.stream(side):
-                _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hin,
-                      in_act, acc, H.stream())
-        elif ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
+        if ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
             dx = torch.empty_like(x)
             _call("mmvae_convT2d_k4s2_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
                   B, Cin, Cout, Hin, in_act, acc, H.stream())
