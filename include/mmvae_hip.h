@@ -631,6 +631,16 @@ int mmvae_reduce_segments(const mmvae_reduce_segments_t* table, mmvae_stream_t s
 int mmvae_reduce_segments_lincomb(const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows,
                                   const float* W_host, float* out, int n_rows, int B, int n_out,
                                   mmvae_stream_t stream);
+/* The fold and the optimiser step of a one-GPU training step as ONE launch: the gradient of element i is
+ * g[i] + (sum of the registered partials that target it); every destination must lie inside [g, g + n), destination
+ * ranges must not overlap (equal ranges are chained).  Same arithmetic, in the same order, as mmvae_reduce_segments
+ * followed by mmvae_adam_amsgrad_flat(step = -1): bit-identical parameters and optimiser state.  step_dev as above
+ * (the kernel advances it); rows == NULL: no ELBO assembly rider.  Replaces torch.optim.Adam.step()
+ * (reference models/trainer.py:79-81) behind the backward pass's split weight gradients. */
+int mmvae_adam_fold_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
+                         float beta2, float eps, int* step_dev, float grad_scale, int zero_grad,
+                         const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows, const float* W_host,
+                         float* out, int n_rows, int B, int n_out, mmvae_stream_t stream);
 /* partial layouts: rows x rowlen floats in ws; weight part at column 0, bias part at column bias_col */
 int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen, int* bias_col);
 /* linear weight gradient: `splits` partial (N*K) slabs followed by `splits` partial (N) bias rows; splits == 1

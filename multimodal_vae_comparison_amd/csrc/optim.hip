@@ -5,6 +5,22 @@
 // torch.optim.Adam(amsgrad=True) (reference: models/trainer.py:79-81), torch's single-tensor formula:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; vmax = max(vmax, v)
 //   p -= (lr / bc1) * m / (sqrt(vmax) / sqrt(bc2) + eps)
+// ONE spelling of the update for every kernel that applies it (adam_amsgrad_kernel, adam_fold_kernel): explicit fused
+// multiply-adds and no compiler contraction, so that the same inputs give the same bits wherever the update is inlined
+// (left to -ffp-contract=fast the quotient's denominator was fused in one kernel and not in the other: 1-ulp differences
+// in a handful of parameters per step).
+__device__ __forceinline__ void adam_update1(float& P, const float G, float& M, float& V, float& X, const float b1,
+                                             const float b2, const float eps, const float gscale, const float lr_bc1,
+                                             const float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+  const float gr = G * gscale;
+  M = fmaf(b1, M, (1.0f - b1) * gr);
+  V = fmaf(b2, V, ((1.0f - b2) * gr) * gr);
+  X = fmaxf(X, V);
+  const float den = fmaf(sqrtf(X), inv_sqrt_bc2, eps);
+  P = P - (lr_bc1 * M) / den;
+}
+
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ vmax, long n, float lr,
@@ -46,13 +62,7 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
     float* vv = &Vv.x;
     float* xx = &X.x;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gr = gg[k] * gscale;
-      mm[k] = b1 * mm[k] + (1.0f - b1) * gr;
-      vv[k] = b2 * vv[k] + (1.0f - b2) * gr * gr;
-      xx[k] = fmaxf(xx[k], vv[k]);
-      pp[k] -= lr_bc1 * mm[k] / (sqrtf(xx[k]) * inv_sqrt_bc2 + eps);
-    }
+    for (int k = 0; k < 4; ++k) adam_update1(pp[k], gg[k], mm[k], vv[k], xx[k], b1, b2, eps, gscale, lr_bc1, inv_sqrt_bc2);
   };
   float4* p4 = reinterpret_cast<float4*>(p);
   float4* g4 = reinterpret_cast<float4*>(g);
@@ -80,11 +90,9 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
   }
   // tail
   for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const float gr = g[i] * gscale;
-    float mi = b1 * m[i] + (1.0f - b1) * gr;
-    float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
-    float xi = fmaxf(vmax[i], vi);
-    p[i] -= lr_bc1 * mi / (sqrtf(xi) * inv_sqrt_bc2 + eps);
+    float pi = p[i], mi = m[i], vi = v[i], xi = vmax[i];
+    adam_update1(pi, g[i], mi, vi, xi, b1, b2, eps, gscale, lr_bc1, inv_sqrt_bc2);
+    p[i] = pi;
     m[i] = mi;
     v[i] = vi;
     vmax[i] = xi;
@@ -329,6 +337,265 @@ extern "C" int mmvae_reduce_segments_lincomb(const mmvae_reduce_segments_t* tabl
     for (int n = 0; n < n_rows; ++n) lc.w[k * RS_LC_ROWS + n] = W_host[k * n_rows + n];
   lc.out = out; lc.n_rows = n_rows; lc.B = B; lc.n_out = n_out;
   return reduce_segments_impl(table, &lc, stream);
+}
+
+
+// ---- fold + Adam in ONE launch (the serial tail of a one-GPU step: fold 16-18 us + gap + Adam 13 us before) ----------
+// The flat gradient of a step = what the backward kernels wrote straight into `g` PLUS the split partials registered as
+// segments.  Workgroups [0, fold_blocks) each own 256 columns of one destination range: they sum the partials exactly as
+// reduce_segments_kernel does (same order, same float4 lanes), add the direct contribution, and apply the Adam update to
+// those 256 elements themselves -- the folded gradient never travels through memory.  Workgroups behind them run the
+// plain Adam body over the gaps between the destination ranges (2048 elements each); the optional last workgroup is the
+// ELBO assembly.  Bit-identical to mmvae_reduce_segments followed by mmvae_adam_amsgrad_flat.
+#define AF_PLAIN 2048
+struct af_seg_t {
+  const float* src;
+  int dst_off, len, stride;   // destination = g + dst_off
+  short rows, next;
+  int blk0;
+};
+struct af_table_t {
+  af_seg_t seg[MMVAE_MAX_SEGMENTS];      // heads first, sorted by dst_off; chained members behind
+  int pblk0[MMVAE_MAX_SEGMENTS + 2];     // first workgroup of plain range k = [end of head k-1, start of head k)
+  int n_heads, fold_blocks, plain_blocks;
+};
+struct af_adam_t {
+  float *p, *g, *m, *v, *vmax;
+  long n;
+  int* step_dev;
+  float lr, b1, b2, eps, gscale;
+  int zero_grad;
+};
+
+template <bool TAIL>
+__global__ __launch_bounds__(256) void adam_fold_kernel(af_adam_t A, af_table_t t, rs_lincomb_t lc) {
+  MMVAE_TRACE_STAMP(20);
+  const int bid = blockIdx.x;
+  const int work_blocks = t.fold_blocks + t.plain_blocks;
+  if (TAIL && bid == work_blocks) {       // does not take a ticket: the step counter waits for work_blocks tickets
+    rs_lincomb_body(lc);
+    return;
+  }
+  __shared__ float bc[2];
+  __shared__ double pw[2];
+  __shared__ float4 part[4][64];
+  if (threadIdx.x == 0) {      // this launch IS step (*step_dev + 1), see adam_amsgrad_kernel
+    const int st = A.step_dev[0] + 1;
+    const double* run = reinterpret_cast<const double*>(A.step_dev + 2);
+    const double r1 = run[0], r2 = run[1];
+    const double p1 = st == 1 ? (double)A.b1 : (r1 > 0.0 ? r1 * (double)A.b1 : pow((double)A.b1, (double)st));
+    const double p2 = st == 1 ? (double)A.b2 : (r2 > 0.0 ? r2 * (double)A.b2 : pow((double)A.b2, (double)st));
+    pw[0] = p1;
+    pw[1] = p2;
+    bc[0] = (float)((double)A.lr / (1.0 - p1));
+    bc[1] = (float)(1.0 / sqrt(1.0 - p2));
+  }
+  const float b1 = A.b1, b2 = A.b2, eps = A.eps, gscale = A.gscale;
+  auto update1 = [&](float& P, float G, float& M, float& V, float& X, float lr_bc1, float inv_sqrt_bc2) {
+    adam_update1(P, G, M, V, X, b1, b2, eps, gscale, lr_bc1, inv_sqrt_bc2);
+  };
+  if (bid < t.fold_blocks) {
+    int sg = 0;
+    while (sg + 1 < t.n_heads && bid >= t.seg[sg + 1].blk0) ++sg;      // uniform scan over the heads
+    const long len = t.seg[sg].len;
+    const long off = t.seg[sg].dst_off;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const long i = ((long)bid - t.seg[sg].blk0) * RS_COLS + 4 * cx;
+    bool vec = (len & 3) == 0;
+    for (int cur = sg; cur >= 0; cur = t.seg[cur].next)
+      vec = vec && (((uintptr_t)t.seg[cur].src) & 15) == 0 && (t.seg[cur].stride & 3) == 0;
+    // this thread's own column (tid) of the 256: issued before the partial sums, consumed after them
+    const long e = ((long)bid - t.seg[sg].blk0) * RS_COLS + threadIdx.x;
+    const bool mine = e < len;
+    const long fe = off + e;
+    float P = 0.f, G = 0.f, M = 0.f, V = 0.f, X = 0.f;
+    if (mine) { P = A.p[fe]; G = A.g[fe]; M = A.m[fe]; V = A.v[fe]; X = A.vmax[fe]; }
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cur = sg; cur >= 0; cur = t.seg[cur].next) {
+      const float* __restrict__ src = t.seg[cur].src;
+      const int n_rows = t.seg[cur].rows;
+      const long stride = t.seg[cur].stride;
+      if (vec) {
+        if (i < len) {
+          int r = ry;
+          for (; r + 28 < n_rows; r += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + 4 * u) * stride + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+          }
+          for (; r < n_rows; r += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * stride + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+          }
+        }
+      } else if (i < len) {
+        float* ap = &a.x;
+        int r = ry;
+        for (; r + 28 < n_rows; r += 32) {
+          float v[8][4];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u][c] = src[(size_t)(r + 4 * u) * stride + (i + c < len ? i + c : i)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ap[c] += v[u][c];
+        }
+        for (; r < n_rows; r += 4) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = src[(size_t)r * stride + (i + c < len ? i + c : i)];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ap[c] += v[c];
+        }
+      }
+    }
+    part[ry][cx] = a;
+    __syncthreads();
+    if (mine) {
+      const float* pf = reinterpret_cast<const float*>(&part[0][0]);
+      const int c = threadIdx.x;                 // column c = lane (c >> 2), component (c & 3)
+      const float s = pf[c] + pf[256 + c] + pf[512 + c] + pf[768 + c];
+      G += s;
+      update1(P, G, M, V, X, bc[0], bc[1]);
+      A.p[fe] = P; A.m[fe] = M; A.v[fe] = V; A.vmax[fe] = X;
+      A.g[fe] = A.zero_grad ? 0.f : G;
+    }
+  } else {
+    __syncthreads();
+    const float lr_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
+    const int pb = bid - t.fold_blocks;
+    int k = 0;
+    while (k < t.n_heads && pb >= t.pblk0[k + 1]) ++k;                  // uniform scan over the plain ranges
+    const long rs = k == 0 ? 0 : (long)t.seg[k - 1].dst_off + t.seg[k - 1].len;
+    const long re = k == t.n_heads ? A.n : (long)t.seg[k].dst_off;
+    const long cs = rs + (long)(pb - t.pblk0[k]) * AF_PLAIN;
+    const long ce = cs + AF_PLAIN < re ? cs + AF_PLAIN : re;
+    const long a0 = (cs + 3) & ~3L, a1 = ce & ~3L;                      // float4 body [a0, a1), dword edges
+    if (a0 < a1) {
+      float4* p4 = reinterpret_cast<float4*>(A.p);
+      float4* g4 = reinterpret_cast<float4*>(A.g);
+      float4* m4 = reinterpret_cast<float4*>(A.m);
+      float4* v4 = reinterpret_cast<float4*>(A.v);
+      float4* x4 = reinterpret_cast<float4*>(A.vmax);
+      const long q0 = (a0 >> 2) + threadIdx.x, q1 = q0 + 256, qe = a1 >> 2;
+      const bool h0 = q0 < qe, h1 = q1 < qe;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 P0 = z, G0 = z, M0 = z, V0 = z, X0 = z, P1 = z, G1 = z, M1 = z, V1 = z, X1 = z;
+      if (h0) { P0 = p4[q0]; G0 = g4[q0]; M0 = m4[q0]; V0 = v4[q0]; X0 = x4[q0]; }
+      if (h1) { P1 = p4[q1]; G1 = g4[q1]; M1 = m4[q1]; V1 = v4[q1]; X1 = x4[q1]; }
+      if (h0) {
+        update1(P0.x, G0.x, M0.x, V0.x, X0.x, lr_bc1, inv_sqrt_bc2);
+        update1(P0.y, G0.y, M0.y, V0.y, X0.y, lr_bc1, inv_sqrt_bc2);
+        update1(P0.z, G0.z, M0.z, V0.z, X0.z, lr_bc1, inv_sqrt_bc2);
+        update1(P0.w, G0.w, M0.w, V0.w, X0.w, lr_bc1, inv_sqrt_bc2);
+        p4[q0] = P0; m4[q0] = M0; v4[q0] = V0; x4[q0] = X0;
+        if (A.zero_grad) g4[q0] = z;
+      }
+      if (h1) {
+        update1(P1.x, G1.x, M1.x, V1.x, X1.x, lr_bc1, inv_sqrt_bc2);
+        update1(P1.y, G1.y, M1.y, V1.y, X1.y, lr_bc1, inv_sqrt_bc2);
+        update1(P1.z, G1.z, M1.z, V1.z, X1.z, lr_bc1, inv_sqrt_bc2);
+        update1(P1.w, G1.w, M1.w, V1.w, X1.w, lr_bc1, inv_sqrt_bc2);
+        p4[q1] = P1; m4[q1] = M1; v4[q1] = V1; x4[q1] = X1;
+        if (A.zero_grad) g4[q1] = z;
+      }
+    }
+    // dword edges: [cs, min(a0, ce)) and [max(a1, a0), ce): at most 3 + 3 elements
+    {
+      const long lo_end = a0 < ce ? a0 : ce;
+      const long hi_beg = a1 > lo_end ? a1 : lo_end;
+      long e = -1;
+      if ((long)threadIdx.x < lo_end - cs) e = cs + threadIdx.x;
+      else if (threadIdx.x >= 64 && (long)(threadIdx.x - 64) < ce - hi_beg) e = hi_beg + (threadIdx.x - 64);
+      if (e >= 0) {
+        float P = A.p[e], G = A.g[e], M = A.m[e], V = A.v[e], X = A.vmax[e];
+        update1(P, G, M, V, X, lr_bc1, inv_sqrt_bc2);
+        A.p[e] = P; A.m[e] = M; A.v[e] = V; A.vmax[e] = X;
+        if (A.zero_grad) A.g[e] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(A.step_dev + 1, 1);
+    if (ticket == work_blocks - 1) {
+      A.step_dev[1] = 0;
+      A.step_dev[0] += 1;
+      double* run = reinterpret_cast<double*>(A.step_dev + 2);
+      run[0] = pw[0];
+      run[1] = pw[1];
+    }
+  }
+}
+
+extern "C" int mmvae_adam_fold_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
+                                    float beta2, float eps, int* step_dev, float grad_scale, int zero_grad,
+                                    const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows,
+                                    const float* W_host, float* out, int n_rows, int B, int n_out,
+                                    mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(p && g && m && v && vmax && n > 0 && n < (1L << 31) && step_dev && table);
+  MMVAE_CHECK_ARG(table->n > 0 && table->n <= MMVAE_MAX_SEGMENTS);
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) != 0) return MMVAE_ERR_ARG;
+  if ((((uintptr_t)step_dev) & 7) != 0) return MMVAE_ERR_ARG;
+  const mmvae_reduce_segments_t& t = *table;
+  // heads = distinct destination ranges, sorted by offset; members with the same (dst, len) chained behind their head
+  int head[MMVAE_MAX_SEGMENTS], n_heads = 0;
+  for (int s = 0; s < t.n; ++s) {
+    if (!t.src[s] || !t.dst[s] || t.rows[s] <= 0 || t.rows[s] > 32767 || t.len[s] <= 0) return MMVAE_ERR_ARG;
+    if (t.dst[s] < g || t.dst[s] + t.len[s] > g + n || t.stride[s] < 0 || t.stride[s] >= (1L << 31)) return MMVAE_ERR_ARG;
+    bool seen = false;
+    for (int k = 0; k < n_heads; ++k)
+      if (t.dst[head[k]] == t.dst[s] && t.len[head[k]] == t.len[s]) { seen = true; break; }
+    if (!seen) head[n_heads++] = s;
+  }
+  for (int a = 1; a < n_heads; ++a)         // insertion sort by destination
+    for (int b = a; b > 0 && t.dst[head[b]] < t.dst[head[b - 1]]; --b) { const int x = head[b]; head[b] = head[b - 1]; head[b - 1] = x; }
+  for (int k = 1; k < n_heads; ++k)         // overlapping destination ranges would race
+    if (t.dst[head[k - 1]] + t.len[head[k - 1]] > t.dst[head[k]]) return MMVAE_ERR_ARG;
+  af_table_t o{};
+  int pos = n_heads, blocks = 0;
+  for (int k = 0; k < n_heads; ++k) {
+    const int hs = head[k];
+    o.seg[k] = af_seg_t{t.src[hs], (int)(t.dst[hs] - g), (int)t.len[hs], (int)t.stride[hs], (short)t.rows[hs], (short)-1, blocks};
+    blocks += (int)((t.len[hs] + RS_COLS - 1) / RS_COLS);
+    int last = k;
+    for (int s = 0; s < t.n; ++s) {
+      if (s == hs || t.dst[s] != t.dst[hs] || t.len[s] != t.len[hs]) continue;
+      o.seg[pos] = af_seg_t{t.src[s], (int)(t.dst[s] - g), (int)t.len[s], (int)t.stride[s], (short)t.rows[s], (short)-1, 0x7fffffff};
+      o.seg[last].next = (short)pos;
+      last = pos++;
+    }
+  }
+  o.n_heads = n_heads;
+  o.fold_blocks = blocks;
+  int pblocks = 0;
+  for (int k = 0; k <= n_heads; ++k) {
+    const long rs = k == 0 ? 0 : (long)o.seg[k - 1].dst_off + o.seg[k - 1].len;
+    const long re = k == n_heads ? n : (long)o.seg[k].dst_off;
+    o.pblk0[k] = pblocks;
+    pblocks += (int)((re - rs + AF_PLAIN - 1) / AF_PLAIN);
+  }
+  o.pblk0[n_heads + 1] = pblocks;
+  o.plain_blocks = pblocks;
+  af_adam_t A{p, g, m, v, vmax, n, step_dev, lr, beta1, beta2, eps, grad_scale, zero_grad};
+  if (rows) {
+    MMVAE_CHECK_ARG(W_host && out && n_rows > 0 && B > 0 && n_out > 0);
+    if (n_rows > RS_LC_ROWS || n_out > RS_LC_OUT) return MMVAE_ERR_UNSUPPORTED;
+    rs_lincomb_t lc{};
+    for (int i = 0; i < n_rows; ++i) lc.rows[i] = rows->p[i];
+    for (int k = 0; k < n_out; ++k)
+      for (int i = 0; i < n_rows; ++i) lc.w[k * RS_LC_ROWS + i] = W_host[k * n_rows + i];
+    lc.out = out; lc.n_rows = n_rows; lc.B = B; lc.n_out = n_out;
+    hipLaunchKernelGGL(adam_fold_kernel<true>, dim3(blocks + pblocks + 1), dim3(256), 0, (hipStream_t)stream, A, o, lc);
+  } else {
+    rs_lincomb_t none{};
+    hipLaunchKernelGGL(adam_fold_kernel<false>, dim3(blocks + pblocks), dim3(256), 0, (hipStream_t)stream, A, o, none);
+  }
+  return mmvae_launch_status();
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float value) {

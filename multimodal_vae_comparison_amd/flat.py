@@ -103,6 +103,12 @@ class FlatAdam(torch.optim.Optimizer):
             self.check_grad_views()
         self._steps_since_check = (self._steps_since_check + 1) & 255
         g = self.param_groups[0]
+        d, ops.GradReducer.deferred = ops.GradReducer.deferred, None
+        if d is not None:
+            # the backward pass left its split partials unfolded for us (GradReducer.defer_next): fold + update at once
+            ops.adam_fold_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]), g["betas"][0],
+                               g["betas"][1], g["eps"], self.step_dev, self.grad_scale, True, d)
+            return loss
         # step = -1: the kernel takes step_dev[0] + 1 and stores it itself (one launch per step)
         ops.adam_amsgrad_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]),
                               g["betas"][0], g["betas"][1], g["eps"], -1, self.step_dev, self.grad_scale, True)

@@ -186,7 +186,10 @@ class MultimodalVAE(nn.Module):
                 kw = {"capture_error_mode": "thread_local"} if with_collective else {}
                 with torch.cuda.graph(self._graph, **kw):
                     ops.Marks.mark("step start")
+                    # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
+                    ops.GradReducer.defer_next = self._adam_in_graph and os.environ.get("MMVAE_ADAM_FOLD", "1") == "1"
                     res = self._fwd_bwd(batch)
+                    ops.GradReducer.defer_next = False
                     ops.Marks.mark("backward done")
                     if self._adam_in_graph:
                         self.optimizer.step()

@@ -35,6 +35,11 @@ class GradReducer:
 
     enabled = True
     tail = None       # lincomb_rows_args(...) of an ELBO assembly that rides on the next fold (see flush)
+    # defer_next: the caller promises that an optimiser step over the flat buffers follows the backward pass at once
+    # (trainer.capture with the optimiser inside the graph).  flush() then only joins the streams and parks the segment
+    # table in `deferred`; FlatAdam.step() takes it and folds + updates in ONE launch (mmvae_adam_fold_flat).
+    defer_next = False
+    deferred = None
     _arena = {}
     _state = {}
     _side = {}        # device key -> {"wgrad": Stream, "tower": Stream}: see StreamPlan below
@@ -57,6 +62,10 @@ class GradReducer:
         if device.type != "cuda":
             return
         _, st = cls._st(device)
+        if cls.deferred is not None:
+            cls.deferred = None
+            raise RuntimeError("GradReducer: a deferred fold was never taken by an optimiser step: the split weight "
+                               "gradients of the previous backward pass were lost")
         if st["armed"] or st["segs"] or st["pending"]:
             st.update(off=0, segs=[], armed=False, keep=[], used=set(), pending=[], spill=[], spilled=0)
             cls.tail = None
@@ -131,6 +140,16 @@ class GradReducer:
         segs, st["segs"], st["armed"] = st["segs"], [], False
         need, st["off"] = st["spilled"] + st["off"], 0
         tail, cls.tail = cls.tail, None
+        defer, cls.defer_next = cls.defer_next, False
+        if defer and 0 < len(segs) <= H.MAX_SEGMENTS and not st["spill"]:
+            t = H.ReduceSegments()
+            for j, (sp, dp, r, ln, sd) in enumerate(segs):
+                t.src[j], t.dst[j], t.rows[j], t.len[j], t.stride[j] = sp, dp, r, ln, sd
+            t.n = len(segs)
+            cls.deferred = {"table": t, "tail": tail, "device": device}
+            if tail is not None:
+                tail["done"] = True          # filled by the optimiser's launch
+            return
         for i in range(0, len(segs), H.MAX_SEGMENTS):
             chunk = segs[i:i + H.MAX_SEGMENTS]
             t = H.ReduceSegments()
@@ -2030,6 +2049,18 @@ def permute_mask(x, mask_u8):
 def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=None, grad_scale=1.0, zero_grad=True):
     _call("mmvae_adam_amsgrad_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), lr, beta1, beta2,
           eps, int(step), H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())
+
+
+def adam_fold_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step_dev, grad_scale, zero_grad, deferred):
+    """GradReducer.deferred + Adam(amsgrad) in one launch (mmvae_adam_fold_flat)"""
+    tail = deferred["tail"]
+    if tail is not None:
+        rp, flat, out, n, B, k = tail["args"]
+        extra = (ctypes.byref(rp), flat, H.ptr(out), n, B, k)
+    else:
+        extra = (None, None, None, 0, 0, 0)
+    _call("mmvae_adam_fold_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), lr, beta1, beta2, eps,
+          H.ptr(step_dev), grad_scale, int(zero_grad), ctypes.byref(deferred["table"]), *extra, H.stream())
 
 
 def step_inc(step_dev):

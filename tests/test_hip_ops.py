@@ -641,6 +641,74 @@ def test_reduce_segments(ops, hip_lib):
     check(flat, before.double() + (ref.double() - orig.double()), 4e-6, "reduce_segments with rider")
 
 
+@pytest.mark.parametrize("rider", [False, True])
+def test_adam_fold_flat_is_fold_then_adam(ops, hip_lib, rider):
+    """mmvae_adam_fold_flat == mmvae_reduce_segments[_lincomb] followed by mmvae_adam_amsgrad_flat(step=-1), BIT for bit
+    (parameters, both moments, the running maximum, the cleared gradient buffer, the device step block), over three
+    steps; aligned / unaligned / chained segments, gaps of every alignment between them, a segment at the very end"""
+    import ctypes
+    from multimodal_vae_comparison_amd import hipops as H
+    g = torch.Generator().manual_seed(5)
+    n = 40000
+    arena = torch.randn(1 << 22, generator=g).to(DEV)
+    specs = [  # (src offset, dst offset, rows, len, stride), unsorted on purpose
+        (128 * 16416, 16416, 33, 8748, 8748 + 162), (0, 0, 128, 16384, 16416), (16384, 16384, 128, 32, 16416),
+        (128 * 16416 + 8748, 25164, 33, 162, 8748 + 162), (3000001, 30001, 7, 1001, 1003),
+        (3100000, 0, 5, 16384, 16384), (3300000, 33000, 1, 64, 64), (3400000, n - 13, 9, 13, 16)]
+    state = {}
+    for name in ("a", "b"):
+        gg = torch.Generator().manual_seed(6)
+        state[name] = {"p": torch.randn(n, generator=gg).to(DEV), "m": torch.zeros(n, device=DEV),
+                       "v": torch.zeros(n, device=DEV), "x": torch.zeros(n, device=DEV), "g": torch.zeros(n, device=DEV),
+                       "step": torch.zeros(6, dtype=torch.int32, device=DEV)}
+    blocks = [torch.randn(130, generator=g).to(DEV), torch.randn(3, 130, generator=g).to(DEV)]
+    W = [[0.5, 0.1, 0.2, 0.3], [0.0, 1.0, 1.0, 1.0]]
+    for it in range(3):
+        direct = (torch.randn(n, generator=g) * (torch.rand(n, generator=g) < 0.5)).to(DEV)   # what kernels wrote straight to g
+        arena.mul_(0.9).add_(0.01 * it)
+        outs = {}
+        for name, st in state.items():
+            st["g"].copy_(direct)
+            t = H.ReduceSegments()
+            for j, (so, do, r, ln, sd) in enumerate(specs):
+                t.src[j], t.dst[j] = arena.data_ptr() + 4 * so, st["g"].data_ptr() + 4 * do
+                t.rows[j], t.len[j], t.stride[j] = r, ln, sd
+            t.n = len(specs)
+            tail = ops.lincomb_rows_args(blocks, W) if rider else None
+            if name == "a":
+                if rider:
+                    rp, wf, out, nr, B, k = tail["args"]
+                    H.check(hip_lib.mmvae_reduce_segments_lincomb(ctypes.byref(t), ctypes.byref(rp), wf, H.ptr(out), nr, B,
+                                                                  k, H.stream()), "fold")
+                else:
+                    H.check(hip_lib.mmvae_reduce_segments(ctypes.byref(t), H.stream()), "fold")
+                ops.adam_amsgrad_flat(st["p"], st["g"], st["m"], st["v"], st["x"], 1e-3, 0.9, 0.999, 1e-8, -1, st["step"],
+                                      0.5, True)
+            else:
+                ops.adam_fold_flat(st["p"], st["g"], st["m"], st["v"], st["x"], 1e-3, 0.9, 0.999, 1e-8, st["step"], 0.5,
+                                   True, {"table": t, "tail": tail})
+            outs[name] = tail["args"][2].clone() if rider else None
+        torch.cuda.synchronize()
+        for k in ("p", "m", "v", "x", "g", "step"):
+            da, db = state["a"][k], state["b"][k]
+            if not torch.equal(da, db):
+                bad = (da != db).nonzero().flatten()
+                raise AssertionError(f"step {it}: {k} differs at {bad.numel()} elements, first {bad[:8].tolist()}, last "
+                                     f"{bad[-4:].tolist()}, max |d| {float((da.double() - db.double()).abs().max()):.3e}")
+        if rider:
+            assert torch.equal(outs["a"], outs["b"])
+    assert int(state["b"]["step"][0]) == 3 and float(state["b"]["g"].abs().max()) == 0.0
+    # destinations outside the flat buffer / overlapping ranges are refused
+    t = H.ReduceSegments()
+    t.src[0], t.dst[0], t.rows[0], t.len[0], t.stride[0] = arena.data_ptr(), state["b"]["g"].data_ptr() + 4 * (n - 8), 2, 16, 16
+    t.n = 1
+    st = state["b"]
+    rc = hip_lib.mmvae_adam_fold_flat(H.ptr(st["p"]), H.ptr(st["g"]), H.ptr(st["m"]), H.ptr(st["v"]), H.ptr(st["x"]), n,
+                                      1e-3, 0.9, 0.999, 1e-8, H.ptr(st["step"]), 1.0, 1, ctypes.byref(t), None, None, None,
+                                      0, 0, 0, H.stream())
+    assert rc == 1      # MMVAE_ERR_ARG
+
+
 @pytest.mark.parametrize("self_counting", [False, True])
 def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
     """self_counting: step = -1, the kernel bumps the device step counter itself (what FlatAdam uses)"""
