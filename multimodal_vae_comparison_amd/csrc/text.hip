@@ -93,21 +93,52 @@ extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* d
 // conflict free).  The 128 form serves the action towers' Ta = 100 sequences (models/datasets.py:887).
 // ---------------------------------------------------------------------------------------------
 #define ATT_MAX 128
-#define ATT_HD 32  // head_dim <= 32 (27 encoder, D/2 decoder); padded columns are zero
-#define ATT_HP 36  // row pitch (16-byte aligned rows)
+// head_dim <= HD (template: 32 for the text towers' 27, 16 for the action towers' D/2 = 16 -- half the LDS reads and
+// FMAs of the padded form); padded columns are zero; row pitch HD + 4 floats (16-byte aligned rows)
+#define ATT_HD_MAX 32
 
 // rows x 32 floats -> LDS, 8 independent loads in flight per thread (a load -> store loop waits one memory
 // latency per iteration)
-template <int NT>
+template <int NT, int HD>
 __device__ __forceinline__ void att_stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int N,
                                                int n, long ld, int col0, int hd, int tid) {
-  const int total = rows * ATT_HD;
+  const int total = rows * HD;
+  if ((hd & 3) == 0 && (col0 & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+    // 16-byte form (the action towers: head_dim 16, T = 100): one round of loads instead of four -- with 128 threads
+    // per workgroup the staging's memory round trips, not the arithmetic, were most of the kernel
+    const int q4 = hd >> 2, tot4 = rows * q4;
+    for (int e0 = 0; e0 < tot4; e0 += NT * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * NT + tid;
+        const int r = e / q4, c = e - r * q4;
+        v[u] = *reinterpret_cast<const float4*>(src + (e < tot4 ? ((size_t)r * N + n) * ld + col0 + 4 * c
+                                                                 : (size_t)n * ld + col0));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * NT + tid;
+        if (e < tot4) {
+          const int r = e / q4, c = e - r * q4;
+          *reinterpret_cast<float4*>(dst + r * (HD + 4) + 4 * c) = v[u];
+        }
+      }
+    }
+    // zero padding columns hd .. 31
+    const int padq = (HD - hd) >> 2;
+    for (int e = tid; e < rows * padq; e += NT) {
+      const int r = e / padq, c = e - r * padq;
+      *reinterpret_cast<float4*>(dst + r * (HD + 4) + hd + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   for (int e0 = 0; e0 < total; e0 += NT * 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * NT + tid;
-      const int r = e >> 5, d = e & 31;
+      const int r = e / HD, d = e - r * HD;
       const bool ok = e < total && d < hd;
       v[u] = src[ok ? ((size_t)r * N + n) * ld + col0 + d : (size_t)n * ld + col0];
       v[u] = ok ? v[u] : 0.f;
@@ -115,7 +146,7 @@ __device__ __forceinline__ void att_stage_rows(float* __restrict__ dst, const fl
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * NT + tid;
-      if (e < total) dst[(e >> 5) * ATT_HP + (e & 31)] = v[u];
+      if (e < total) dst[(e / HD) * (HD + 4) + (e % HD)] = v[u];
     }
   }
 }
@@ -125,6 +156,27 @@ __device__ __forceinline__ void att_stage_tile(float* __restrict__ dst, const fl
                                                int tid) {
   const int total = L * S;
   const float invS = 1.0f / (float)S;
+  if ((S & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+    const int tot4 = total >> 2, s4 = S >> 2;
+    for (int e0 = 0; e0 < tot4; e0 += NT * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * NT + tid;
+        v[u] = reinterpret_cast<const float4*>(src)[e < tot4 ? e : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * NT + tid;
+        if (e < tot4) {
+          const int l = e / s4, c = e - l * s4;
+          float* d = dst + l * SP + 4 * c;
+          d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+      }
+    }
+    return;
+  }
   for (int e0 = 0; e0 < total; e0 += NT * 8) {
     float v[8];
 #pragma unroll
@@ -142,10 +194,11 @@ __device__ __forceinline__ void att_stage_tile(float* __restrict__ dst, const fl
     }
   }
 }
-__device__ __forceinline__ float att_dot(const float* __restrict__ row, const float (&x)[ATT_HD]) {
+template <int HD>
+__device__ __forceinline__ float att_dot(const float* __restrict__ row, const float (&x)[HD]) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-  for (int d = 0; d < ATT_HD; d += 4) {
+  for (int d = 0; d < HD; d += 4) {
     const float4 k4 = *reinterpret_cast<const float4*>(row + d);
     a0 += x[d] * k4.x;
     a1 += x[d + 1] * k4.y;
@@ -154,9 +207,10 @@ __device__ __forceinline__ float att_dot(const float* __restrict__ row, const fl
   }
   return (a0 + a1) + (a2 + a3);
 }
-__device__ __forceinline__ void att_axpy(float (&acc)[ATT_HD], float p, const float* __restrict__ row) {
+template <int HD>
+__device__ __forceinline__ void att_axpy(float (&acc)[HD], float p, const float* __restrict__ row) {
 #pragma unroll
-  for (int d = 0; d < ATT_HD; d += 4) {
+  for (int d = 0; d < HD; d += 4) {
     const float4 v4 = *reinterpret_cast<const float4*>(row + d);
     acc[d] += p * v4.x;
     acc[d + 1] += p * v4.y;
@@ -165,40 +219,40 @@ __device__ __forceinline__ void att_axpy(float (&acc)[ATT_HD], float p, const fl
   }
 }
 
-template <int AM>
+template <int AM, int HD>
 __global__ __launch_bounds__(AM) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const uint8_t* __restrict__ kpm,
                                                       float* __restrict__ out, float* __restrict__ probs, int L, int S,
                                                       int N, int H, int hd, long ldq, long ldk, long ldv,
                                                       int mask_is_valid, mmvae_dropout_t drop) {
   constexpr int SP = AM + 1;
-  __shared__ __attribute__((aligned(16))) float sk[AM * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sv[AM * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sk[AM * (HD + 4)];
+  __shared__ __attribute__((aligned(16))) float sv[AM * (HD + 4)];
   __shared__ float sp[AM * SP];
   __shared__ float smask[AM];
   __shared__ float sinv[AM];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  att_stage_rows<AM>(sk, k, S, N, n, ldk, h * hd, hd, lane);
-  att_stage_rows<AM>(sv, v, S, N, n, ldv, h * hd, hd, lane);
+  att_stage_rows<AM, HD>(sk, k, S, N, n, ldk, h * hd, hd, lane);
+  att_stage_rows<AM, HD>(sv, v, S, N, n, ldv, h * hd, hd, lane);
   // kpm bytes: 1 = ignore this key (key_padding_mask) or, with mask_is_valid, the batch's own validity mask
   // (1 = real token) read in place -- no conversion kernel
   if (lane < S) smask[lane] = (kpm && ((kpm[(size_t)n * S + lane] != 0) != (mask_is_valid != 0))) ? 1.f : 0.f;
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)hd);
   if (lane < L) {
-    float qr[ATT_HD];
+    float qr[HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) qr[d] = d < hd ? q[((size_t)lane * N + n) * ldq + h * hd + d] * scale : 0.f;
+    for (int d = 0; d < HD; ++d) qr[d] = d < hd ? q[((size_t)lane * N + n) * ldq + h * hd + d] * scale : 0.f;
     float mx = -INFINITY;
     for (int s = 0; s < S; ++s) {
-      float sc = att_dot(sk + s * ATT_HP, qr);
+      float sc = att_dot<HD>(sk + s * (HD + 4), qr);
       if (smask[s] != 0.f) sc = -INFINITY;
       sp[lane * SP + s] = sc;
       mx = fmaxf(mx, sc);
     }
-    float o[ATT_HD];
+    float o[HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) o[d] = 0.f;
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
     float sum = 0.f;
     const DropKey dk = drop_key(drop);   // dropout on the attention weights (after the softmax, before P V)
     const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + lane) * S);
@@ -206,13 +260,13 @@ __global__ __launch_bounds__(AM) void attn_fwd_kernel(const float* __restrict__ 
       const float p = expf(sp[lane * SP + s] - mx);
       sp[lane * SP + s] = p;
       sum += p;
-      att_axpy(o, p * drop_mul(dk, drow + s), sv + s * ATT_HP);
+      att_axpy<HD>(o, p * drop_mul(dk, drow + s), sv + s * (HD + 4));
     }
     const float inv = 1.0f / sum;
     sinv[lane] = inv;
     float* orow = out + ((size_t)lane * N + n) * ((size_t)H * hd) + h * hd;
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d)
+    for (int d = 0; d < HD; ++d)
       if (d < hd) orow[d] = o[d] * inv;
   }
   __syncthreads();
@@ -227,7 +281,7 @@ __global__ __launch_bounds__(AM) void attn_fwd_kernel(const float* __restrict__ 
 // ONE L x S tile in LDS: column pass for dV on P, row pass that overwrites P with dS (the dP dot products are computed
 // twice instead of being parked in a second tile: 2 x 66 KB would not fit beside the four row arrays at AM = 128),
 // column pass for dK on dS.
-template <int AM>
+template <int AM, int HD>
 __global__ __launch_bounds__(AM) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const float* __restrict__ probs,
                                                       const float* __restrict__ dout, float* __restrict__ dq,
@@ -235,69 +289,69 @@ __global__ __launch_bounds__(AM) void attn_bwd_kernel(const float* __restrict__ 
                                                       int N, int H, int hd, long ldq, long ldk, long ldv,
                                                       mmvae_dropout_t drop) {
   constexpr int SP = AM + 1;
-  __shared__ __attribute__((aligned(16))) float sq[AM * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sk[AM * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sv[AM * ATT_HP];
-  __shared__ __attribute__((aligned(16))) float sdo[AM * ATT_HP];
+  __shared__ __attribute__((aligned(16))) float sq[AM * (HD + 4)];
+  __shared__ __attribute__((aligned(16))) float sk[AM * (HD + 4)];
+  __shared__ __attribute__((aligned(16))) float sv[AM * (HD + 4)];
+  __shared__ __attribute__((aligned(16))) float sdo[AM * (HD + 4)];
   __shared__ float sp[AM * SP];
   const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const long E = (long)H * hd;
-  att_stage_rows<AM>(sk, k, S, N, n, ldk, h * hd, hd, lane);
-  att_stage_rows<AM>(sv, v, S, N, n, ldv, h * hd, hd, lane);
-  att_stage_rows<AM>(sq, q, L, N, n, ldq, h * hd, hd, lane);
-  att_stage_rows<AM>(sdo, dout, L, N, n, E, h * hd, hd, lane);
+  att_stage_rows<AM, HD>(sk, k, S, N, n, ldk, h * hd, hd, lane);
+  att_stage_rows<AM, HD>(sv, v, S, N, n, ldv, h * hd, hd, lane);
+  att_stage_rows<AM, HD>(sq, q, L, N, n, ldq, h * hd, hd, lane);
+  att_stage_rows<AM, HD>(sdo, dout, L, N, n, E, h * hd, hd, lane);
   att_stage_tile<AM, SP>(sp, probs + ((size_t)n * H + h) * L * S, L, S, lane);
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)hd);
   const DropKey dkey = drop_key(drop);
   if (lane < S) {     // dV sees the dropped weights
     const int s = lane;
-    float dvr[ATT_HD];
+    float dvr[HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) dvr[d] = 0.f;
+    for (int d = 0; d < HD; ++d) dvr[d] = 0.f;
     for (int l = 0; l < L; ++l) {
       const uint32_t di = (uint32_t)((((size_t)n * H + h) * L + l) * S + s);
-      att_axpy(dvr, sp[l * SP + s] * drop_mul(dkey, di), sdo + l * ATT_HP);
+      att_axpy<HD>(dvr, sp[l * SP + s] * drop_mul(dkey, di), sdo + l * (HD + 4));
     }
     float* dvrow = dv + ((size_t)s * N + n) * ldv + h * hd;
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d)
+    for (int d = 0; d < HD; ++d)
       if (d < hd) dvrow[d] = dvr[d];
   }
   __syncthreads();
   if (lane < L) {
     const int l = lane;
-    float dor[ATT_HD];
+    float dor[HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) dor[d] = sdo[l * ATT_HP + d];
+    for (int d = 0; d < HD; ++d) dor[d] = sdo[l * (HD + 4) + d];
     float delta = 0.f;
     const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + l) * S);
     for (int s = 0; s < S; ++s)
-      delta += sp[l * SP + s] * att_dot(sv + s * ATT_HP, dor) * drop_mul(dkey, drow + s);   // through the weight dropout
-    float dqr[ATT_HD];
+      delta += sp[l * SP + s] * att_dot<HD>(sv + s * (HD + 4), dor) * drop_mul(dkey, drow + s);   // through the weight dropout
+    float dqr[HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) dqr[d] = 0.f;
+    for (int d = 0; d < HD; ++d) dqr[d] = 0.f;
     for (int s = 0; s < S; ++s) {
-      const float dp = att_dot(sv + s * ATT_HP, dor) * drop_mul(dkey, drow + s);
+      const float dp = att_dot<HD>(sv + s * (HD + 4), dor) * drop_mul(dkey, drow + s);
       const float ds = sp[l * SP + s] * (dp - delta);
       sp[l * SP + s] = ds;
-      att_axpy(dqr, ds, sk + s * ATT_HP);
+      att_axpy<HD>(dqr, ds, sk + s * (HD + 4));
     }
     float* dqrow = dq + ((size_t)l * N + n) * ldq + h * hd;
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d)
+    for (int d = 0; d < HD; ++d)
       if (d < hd) dqrow[d] = dqr[d] * scale;
   }
   __syncthreads();
   if (lane < S) {
     const int s = lane;
-    float dkr[ATT_HD];
+    float dkr[HD];
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d) dkr[d] = 0.f;
-    for (int l = 0; l < L; ++l) att_axpy(dkr, sp[l * SP + s], sq + l * ATT_HP);
+    for (int d = 0; d < HD; ++d) dkr[d] = 0.f;
+    for (int l = 0; l < L; ++l) att_axpy<HD>(dkr, sp[l * SP + s], sq + l * (HD + 4));
     float* dkrow = dk + ((size_t)s * N + n) * ldk + h * hd;
 #pragma unroll
-    for (int d = 0; d < ATT_HD; ++d)
+    for (int d = 0; d < HD; ++d)
       if (d < hd) dkrow[d] = dkr[d] * scale;
   }
 }
@@ -306,26 +360,26 @@ extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, co
                               float* probs, int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv,
                               int mask_is_valid, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
-  if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
-  if (L <= 64 && S <= 64)
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L,
-                       S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<128>), dim3(N, H), dim3(128), 0, (hipStream_t)stream, q, k, v, kpm, out, probs,
-                       L, S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
+  if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
+#define ATT_FWD(AM, HD)                                                                                              \
+  hipLaunchKernelGGL((attn_fwd_kernel<AM, HD>), dim3(N, H), dim3(AM), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, \
+                     L, S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop))
+  if (L <= 64 && S <= 64) { if (hd <= 16) ATT_FWD(64, 16); else ATT_FWD(64, 32); }
+  else { if (hd <= 16) ATT_FWD(128, 16); else ATT_FWD(128, 32); }
+#undef ATT_FWD
   return mmvae_launch_status();
 }
 extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                               float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
                               long ldv, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
-  if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD) return MMVAE_ERR_UNSUPPORTED;
-  if (L <= 64 && S <= 64)
-    hipLaunchKernelGGL((attn_bwd_kernel<64>), dim3(N, H), dim3(64), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk,
-                       dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
-  else
-    hipLaunchKernelGGL((attn_bwd_kernel<128>), dim3(N, H), dim3(128), 0, (hipStream_t)stream, q, k, v, probs, dout, dq,
-                       dk, dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
+  if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
+#define ATT_BWD(AM, HD)                                                                                              \
+  hipLaunchKernelGGL((attn_bwd_kernel<AM, HD>), dim3(N, H), dim3(AM), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, \
+                     dk, dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop))
+  if (L <= 64 && S <= 64) { if (hd <= 16) ATT_BWD(64, 16); else ATT_BWD(64, 32); }
+  else { if (hd <= 16) ATT_BWD(128, 16); else ATT_BWD(128, 32); }
+#undef ATT_BWD
   return mmvae_launch_status();
 }
 
@@ -438,8 +492,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 static inline int ln_blocks(int rows, int* rpb) {
-  int nb = (rows + 31) / 32;
-  if (nb > 128) nb = 128;
+  // a wave walks its rows one after the other (one dependent load round per row): at most ~4 rows per wave, i.e. 16 per
+  // workgroup, up to 1024 workgroups (the action towers' 12 800-row LayerNorms: 26.5 -> 6 us; 128 workgroups of 100 rows
+  // before).  The per-workgroup [dgamma | dbeta] partials grow with it: 1024 x 2d floats, folded with the others.
+  int nb = (rows + 15) / 16;
+  if (nb > 1024) nb = 1024;
   *rpb = (rows + nb - 1) / nb;
   return (rows + *rpb - 1) / *rpb;
 }
