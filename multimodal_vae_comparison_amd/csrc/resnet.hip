@@ -90,10 +90,20 @@ extern "C" int mmvae_col2im(const float* dcols, const float* x, float* dx, int B
 //   apply:  every thread merges its column's partials (Chan), y = (x - mean) rstd gamma + beta [+ relu?(res)],
 //           workgroup row 0 stores mean / rstd and updates the running statistics.
 // ---------------------------------------------------------------------------------------------
-#define BN_ROWS_PER_BLOCK 256
+// Row blocks: 64 rows each (4 rows per thread of the 16-slice kernels below, register resident), at most 256 blocks.
+// (First version: 256 rows per block walked one scalar load at a time by 4 row slices -- 64 dependent memory round
+// trips per sweep; at the shipped CdSprites+ batch of 24 every BatchNorm kernel took 20 us for < 6 MB and the four of
+// them were 52 % of the step.)
+#define BN_ROWS_PER_BLOCK 64
+#define BN_MAX_BLOCKS 256
+#define BN_RT 8                      // rows a thread may keep in registers (float4 each)
 static inline int bn_row_blocks(int M) {
   int nb = (M + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
-  return nb > 128 ? 128 : (nb < 1 ? 1 : nb);
+  return nb > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : (nb < 1 ? 1 : nb);
+}
+static inline int bn_rows_per(int M, int nblk) {
+  const int rp = (M + nblk - 1) / nblk;
+  return (rp + 15) / 16 * 16;        // a multiple of the 16 row slices
 }
 extern "C" int mmvae_bn_row_blocks(int M) { return bn_row_blocks(M); }
 extern "C" size_t mmvae_bn_ws_floats(int M, int C) { return (size_t)bn_row_blocks(M) * C * 2; }
@@ -182,14 +192,356 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     y[(size_t)r * C + c] = v;
   }
 }
+// ---- 16-byte forms (C % 4 == 0): workgroup = 16 channel quads (64 channels) x 16 row slices ------------------------
+// every load is a float4 over 4 channels; a thread's rows are independent loads issued back to back; when a row block
+// has <= 16 * BN_RT rows the first sweep's values stay in registers for the second one.
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// sum over the 16 row slices of a float4 per channel quad; red: [16][16] float4
+__device__ __forceinline__ float4 bn_slice_sum(float4 v, float4* red, int cq, int rs) {
+  __syncthreads();
+  red[rs * 16 + cq] = v;
+  __syncthreads();
+  float4 t = red[cq];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) t = f4add(t, red[i * 16 + cq]);
+  return t;
+}
+__global__ __launch_bounds__(256) void bn_stats4_kernel(const float* __restrict__ x, float* __restrict__ part, int M,
+                                                        int C, int rows_per) {
+  __shared__ float4 red[256];
+  const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq, blk = blockIdx.y;
+  const bool cok = c < C;
+  const int r0 = blk * rows_per, r1 = min(M, r0 + rows_per);
+  const int n = max(r1 - r0, 0);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
+  if (rows_per <= 16 * BN_RT) {
+    float4 v[BN_RT];
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) {
+      const int r = r0 + rs + 16 * i;
+      v[i] = (cok && r < r1) ? *reinterpret_cast<const float4*>(x + (size_t)r * C + c) : z;
+    }
+    float4 s = z;
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) s = f4add(s, v[i]);
+    s = bn_slice_sum(s, red, cq, rs);
+    const float4 mean = make_float4(s.x * inv_n, s.y * inv_n, s.z * inv_n, s.w * inv_n);
+    float4 q = z;
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) {
+      if (r0 + rs + 16 * i < r1) {
+        const float dx = v[i].x - mean.x, dy = v[i].y - mean.y, dz = v[i].z - mean.z, dw = v[i].w - mean.w;
+        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+      }
+    }
+    q = bn_slice_sum(q, red, cq, rs);
+    if (rs == 0 && cok) {
+      float* o = part + ((size_t)blk * C + c) * 2;
+      *reinterpret_cast<float4*>(o) = make_float4(mean.x, q.x, mean.y, q.y);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(mean.z, q.z, mean.w, q.w);
+    }
+    return;
+  }
+  float4 s = z;
+  if (cok) {
+    int r = r0 + rs;
+    for (; r + 48 < r1; r += 64) {
+      const float4 a = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+      const float4 b = *reinterpret_cast<const float4*>(x + (size_t)(r + 16) * C + c);
+      const float4 d = *reinterpret_cast<const float4*>(x + (size_t)(r + 32) * C + c);
+      const float4 e = *reinterpret_cast<const float4*>(x + (size_t)(r + 48) * C + c);
+      s = f4add(s, f4add(f4add(a, b), f4add(d, e)));
+    }
+    for (; r < r1; r += 16) s = f4add(s, *reinterpret_cast<const float4*>(x + (size_t)r * C + c));
+  }
+  s = bn_slice_sum(s, red, cq, rs);
+  const float4 mean = make_float4(s.x * inv_n, s.y * inv_n, s.z * inv_n, s.w * inv_n);
+  float4 q = z;
+  if (cok) {
+    auto sq = [&](const float4& v) {
+      const float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+      q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    };
+    int r = r0 + rs;
+    for (; r + 48 < r1; r += 64) {
+      const float4 a = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+      const float4 b = *reinterpret_cast<const float4*>(x + (size_t)(r + 16) * C + c);
+      const float4 d = *reinterpret_cast<const float4*>(x + (size_t)(r + 32) * C + c);
+      const float4 e = *reinterpret_cast<const float4*>(x + (size_t)(r + 48) * C + c);
+      sq(a); sq(b); sq(d); sq(e);
+    }
+    for (; r < r1; r += 16) sq(*reinterpret_cast<const float4*>(x + (size_t)r * C + c));
+  }
+  q = bn_slice_sum(q, red, cq, rs);
+  if (rs == 0 && cok) {
+    float* o = part + ((size_t)blk * C + c) * 2;
+    *reinterpret_cast<float4*>(o) = make_float4(mean.x, q.x, mean.y, q.y);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(mean.z, q.z, mean.w, q.w);
+  }
+}
+// Chan merge of (count, mean, M2) pairs in double
+__device__ __forceinline__ void bn_chan(double& n, double& mean, double& m2, double nb, double mb, double qb) {
+  if (nb <= 0.0) return;
+  const double d = mb - mean, tot = n + nb;
+  mean += d * nb / tot;
+  m2 += qb + d * d * n * nb / tot;
+  n = tot;
+}
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ res, float* __restrict__ y,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                        int M, int C, int nblk, int rows_per, float eps, float momentum,
+                                                        int res_relu, int eval_mode) {
+  __shared__ double sm[16][64][3];      // per row slice and channel: (n, mean, M2) of its share of the row blocks
+  const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq;
+  const bool cok = c < C;
+  // this thread's rows: issued first, they fly under the merge of the statistics
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const bool regs = rows_per <= 16 * BN_RT;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[BN_RT], rv[BN_RT];
+  if (regs) {
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) {
+      const int r = r0 + rs + 16 * i;
+      const bool ok = cok && r < r1;
+      v[i] = ok ? *reinterpret_cast<const float4*>(x + (size_t)r * C + c) : z;
+      rv[i] = (ok && res) ? *reinterpret_cast<const float4*>(res + (size_t)r * C + c) : z;
+    }
+  }
+  float mu[4], rstd[4];
+  if (eval_mode) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mu[k] = cok ? run_mean[c + k] : 0.f;
+      rstd[k] = cok ? 1.0f / sqrtf(run_var[c + k] + eps) : 0.f;
+    }
+  } else {
+    // slice rs merges row blocks rs, rs + 16, ... of its 4 channels; the 16 slice results are merged in slice order
+    double n[4] = {0, 0, 0, 0}, mean[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+    if (cok) {
+      for (int b = rs; b < nblk; b += 16) {
+        const int br0 = b * rows_per;
+        const double nb = (double)max(min(M, br0 + rows_per) - br0, 0);
+        const float* pp = part + ((size_t)b * C + c) * 2;
+        const float4 p0 = *reinterpret_cast<const float4*>(pp), p1 = *reinterpret_cast<const float4*>(pp + 4);
+        bn_chan(n[0], mean[0], m2[0], nb, (double)p0.x, (double)p0.y);
+        bn_chan(n[1], mean[1], m2[1], nb, (double)p0.z, (double)p0.w);
+        bn_chan(n[2], mean[2], m2[2], nb, (double)p1.x, (double)p1.y);
+        bn_chan(n[3], mean[3], m2[3], nb, (double)p1.z, (double)p1.w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sm[rs][4 * cq + k][0] = n[k];
+      sm[rs][4 * cq + k][1] = mean[k];
+      sm[rs][4 * cq + k][2] = m2[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double tn = 0.0, tm = 0.0, tq = 0.0;
+      for (int i = 0; i < 16; ++i) bn_chan(tn, tm, tq, sm[i][4 * cq + k][0], sm[i][4 * cq + k][1], sm[i][4 * cq + k][2]);
+      mu[k] = (float)tm;
+      rstd[k] = (float)(1.0 / sqrt(tq / (double)M + (double)eps));
+      if (blockIdx.y == 0 && rs == 0 && cok && run_mean) {
+        run_mean[c + k] = (1.0f - momentum) * run_mean[c + k] + momentum * mu[k];
+        const float unbiased = (float)(tq / (double)(M > 1 ? M - 1 : 1));
+        run_var[c + k] = (1.0f - momentum) * run_var[c + k] + momentum * unbiased;
+      }
+    }
+  }
+  if (!cok) return;
+  if (blockIdx.y == 0 && rs == 0) {
+    *reinterpret_cast<float4*>(save_mean + c) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+    *reinterpret_cast<float4*>(save_rstd + c) = make_float4(rstd[0], rstd[1], rstd[2], rstd[3]);
+  }
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+  const float g[4] = {gm.x * rstd[0], gm.y * rstd[1], gm.z * rstd[2], gm.w * rstd[3]};
+  const float bt[4] = {be.x - mu[0] * g[0], be.y - mu[1] * g[1], be.z - mu[2] * g[2], be.w - mu[3] * g[3]};
+  auto out = [&](int r, const float4& xv, const float4& resv) {
+    float4 o = make_float4(xv.x * g[0] + bt[0], xv.y * g[1] + bt[1], xv.z * g[2] + bt[2], xv.w * g[3] + bt[3]);
+    if (res) {
+      o.x += res_relu ? fmaxf(resv.x, 0.f) : resv.x;
+      o.y += res_relu ? fmaxf(resv.y, 0.f) : resv.y;
+      o.z += res_relu ? fmaxf(resv.z, 0.f) : resv.z;
+      o.w += res_relu ? fmaxf(resv.w, 0.f) : resv.w;
+    }
+    *reinterpret_cast<float4*>(y + (size_t)r * C + c) = o;
+  };
+  if (regs) {
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) {
+      const int r = r0 + rs + 16 * i;
+      if (r < r1) out(r, v[i], rv[i]);
+    }
+  } else {
+    for (int r = r0 + rs; r < r1; r += 64) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 16 * u;
+        a[u] = rr < r1 ? *reinterpret_cast<const float4*>(x + (size_t)rr * C + c) : z;
+        b[u] = (rr < r1 && res) ? *reinterpret_cast<const float4*>(res + (size_t)rr * C + c) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 16 * u < r1) out(r + 16 * u, a[u], b[u]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_rstd, float* __restrict__ part,
+                                                            int M, int C, int rows_per) {
+  __shared__ float4 red[256];
+  const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq, blk = blockIdx.y;
+  const bool cok = c < C;
+  const int r0 = blk * rows_per, r1 = min(M, r0 + rows_per);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s0 = z, s1 = z;
+  if (cok) {
+    const float4 mu = *reinterpret_cast<const float4*>(save_mean + c), rsd = *reinterpret_cast<const float4*>(save_rstd + c);
+    auto acc = [&](const float4& g, const float4& xv) {
+      s0 = f4add(s0, g);
+      s1.x += g.x * ((xv.x - mu.x) * rsd.x); s1.y += g.y * ((xv.y - mu.y) * rsd.y);
+      s1.z += g.z * ((xv.z - mu.z) * rsd.z); s1.w += g.w * ((xv.w - mu.w) * rsd.w);
+    };
+    for (int r = r0 + rs; r < r1; r += 64) {
+      float4 g[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 16 * u;
+        g[u] = rr < r1 ? *reinterpret_cast<const float4*>(dy + (size_t)rr * C + c) : z;
+        xv[u] = rr < r1 ? *reinterpret_cast<const float4*>(x + (size_t)rr * C + c) : mu;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc(g[u], xv[u]);
+    }
+  }
+  s0 = bn_slice_sum(s0, red, cq, rs);
+  s1 = bn_slice_sum(s1, red, cq, rs);
+  if (rs == 0 && cok) {
+    *reinterpret_cast<float4*>(part + (size_t)blk * 2 * C + c) = s0;
+    *reinterpret_cast<float4*>(part + (size_t)blk * 2 * C + C + c) = s1;
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_rstd,
+                                                            const float* __restrict__ part, const float* __restrict__ res,
+                                                            float* __restrict__ dx, float* __restrict__ dres,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                            int C, int nblk, int rows_per, int res_relu, int accumulate,
+                                                            int eval_mode) {
+  __shared__ float4 red[256];
+  const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq;
+  const bool cok = c < C;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const bool regs = rows_per <= 16 * BN_RT;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gv[BN_RT], xv[BN_RT];
+  if (regs) {
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) {
+      const int r = r0 + rs + 16 * i;
+      const bool ok = cok && r < r1;
+      gv[i] = ok ? *reinterpret_cast<const float4*>(dy + (size_t)r * C + c) : z;
+      xv[i] = ok ? *reinterpret_cast<const float4*>(x + (size_t)r * C + c) : z;
+    }
+  }
+  // column sums of the row blocks' partials: slice rs adds blocks rs, rs + 16, ...; then the 16 slices in order
+  float4 a = z, b = z;
+  if (cok)
+    for (int k = rs; k < nblk; k += 16) {
+      a = f4add(a, *reinterpret_cast<const float4*>(part + (size_t)k * 2 * C + c));
+      b = f4add(b, *reinterpret_cast<const float4*>(part + (size_t)k * 2 * C + C + c));
+    }
+  const float4 sdy = bn_slice_sum(a, red, cq, rs);
+  const float4 sdyx = bn_slice_sum(b, red, cq, rs);
+  if (!cok) return;
+  if (blockIdx.y == 0 && rs == 0 && accumulate != MMVAE_ACC_DEFER) {
+    float4 og = sdyx, ob = sdy;
+    if (accumulate) {
+      og = f4add(og, *reinterpret_cast<const float4*>(dgamma + c));
+      ob = f4add(ob, *reinterpret_cast<const float4*>(dbeta + c));
+    }
+    *reinterpret_cast<float4*>(dgamma + c) = og;
+    *reinterpret_cast<float4*>(dbeta + c) = ob;
+  }
+  const float4 mu = *reinterpret_cast<const float4*>(save_mean + c), rsd = *reinterpret_cast<const float4*>(save_rstd + c);
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+  const float invM = 1.0f / (float)M;
+  const float gr[4] = {gm.x * rsd.x, gm.y * rsd.y, gm.z * rsd.z, gm.w * rsd.w};
+  auto out = [&](int r, const float4& g, const float4& xx) {
+    const size_t i = (size_t)r * C + c;
+    float4 o;
+    if (eval_mode) {
+      o = make_float4(gr[0] * g.x, gr[1] * g.y, gr[2] * g.z, gr[3] * g.w);
+    } else {
+      o.x = gr[0] * (g.x - sdy.x * invM - ((xx.x - mu.x) * rsd.x) * sdyx.x * invM);
+      o.y = gr[1] * (g.y - sdy.y * invM - ((xx.y - mu.y) * rsd.y) * sdyx.y * invM);
+      o.z = gr[2] * (g.z - sdy.z * invM - ((xx.z - mu.z) * rsd.z) * sdyx.z * invM);
+      o.w = gr[3] * (g.w - sdy.w * invM - ((xx.w - mu.w) * rsd.w) * sdyx.w * invM);
+    }
+    *reinterpret_cast<float4*>(dx + i) = o;
+    if (dres) {
+      float4 d = g;
+      if (res_relu) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + i);
+        d.x = rv.x > 0.f ? g.x : 0.f; d.y = rv.y > 0.f ? g.y : 0.f;
+        d.z = rv.z > 0.f ? g.z : 0.f; d.w = rv.w > 0.f ? g.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(dres + i) = d;
+    }
+  };
+  if (regs) {
+#pragma unroll
+    for (int i = 0; i < BN_RT; ++i) {
+      const int r = r0 + rs + 16 * i;
+      if (r < r1) out(r, gv[i], xv[i]);
+    }
+  } else {
+    for (int r = r0 + rs; r < r1; r += 64) {
+      float4 g4[4], x4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 16 * u;
+        g4[u] = rr < r1 ? *reinterpret_cast<const float4*>(dy + (size_t)rr * C + c) : z;
+        x4[u] = rr < r1 ? *reinterpret_cast<const float4*>(x + (size_t)rr * C + c) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 16 * u < r1) out(r + 16 * u, g4[u], x4[u]);
+    }
+  }
+}
+static inline bool bn_vec_ok(int C, const void* a, const void* b, const void* c, const void* d) {
+  return (C & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+
 extern "C" int mmvae_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y,
                                   float* save_mean, float* save_rstd, float* run_mean, float* run_var, float* ws, int M,
                                   int C, float eps, float momentum, int res_relu, int eval_mode,
                                   mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && ws && M > 0 && C > 0);
   MMVAE_CHECK_ARG(!eval_mode || (run_mean && run_var));
-  const int nblk = bn_row_blocks(M), rows_per = (M + nblk - 1) / nblk;
+  const int nblk = bn_row_blocks(M), rows_per = bn_rows_per(M, nblk);
   const dim3 grid((C + 63) / 64, nblk);
+  if (bn_vec_ok(C, x, y, res, ws) && bn_vec_ok(C, gamma, beta, save_mean, save_rstd)) {
+    if (!eval_mode) hipLaunchKernelGGL(bn_stats4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, M, C, rows_per);
+    hipLaunchKernelGGL(bn_apply4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, gamma, beta, res, y, save_mean,
+                       save_rstd, run_mean, run_var, M, C, nblk, rows_per, eps, momentum, res_relu, eval_mode);
+    return mmvae_launch_status();
+  }
   if (!eval_mode) hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, M, C, rows_per);
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, gamma, beta, res, y, save_mean,
                      save_rstd, run_mean, run_var, M, C, nblk, rows_per, eps, momentum, res_relu, eval_mode);
@@ -263,8 +615,15 @@ extern "C" int mmvae_bn_train_bwd(const float* dy, const float* x, const float* 
   MMVAE_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && ws && M > 0 && C > 0);
   MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || (dgamma && dbeta));
   MMVAE_CHECK_ARG(!dres || !res_relu || res);
-  const int nblk = bn_row_blocks(M), rows_per = (M + nblk - 1) / nblk;
+  const int nblk = bn_row_blocks(M), rows_per = bn_rows_per(M, nblk);
   const dim3 grid((C + 63) / 64, nblk);
+  if (bn_vec_ok(C, dy, x, dx, ws) && bn_vec_ok(C, gamma, save_mean, save_rstd, res) && bn_vec_ok(C, dres, dgamma, dbeta, nullptr)) {
+    hipLaunchKernelGGL(bn_bwd_stats4_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd, ws, M,
+                       C, rows_per);
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean, save_rstd,
+                       ws, res, dx, dres, dgamma, dbeta, M, C, nblk, rows_per, res_relu, accumulate, eval_mode);
+    return mmvae_launch_status();
+  }
   hipLaunchKernelGGL(bn_bwd_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd, ws, M, C,
                      rows_per);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean, save_rstd, ws,

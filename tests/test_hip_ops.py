@@ -817,7 +817,10 @@ def test_conv_nhwc_matches_conv2d(ops, B, Cin, Cout, Hh, K, S, P, act, nchw):
 
 
 @pytest.mark.parametrize("M,C,training,res_mode", [(4096, 64, True, 0), (300, 256, True, 2), (16, 2048, True, 1),
-                                                    (520, 128, False, 2), (70000, 64, True, 0)])
+                                                    (520, 128, False, 2), (70000, 64, True, 0),
+                                                    # scalar fallback (C % 4 != 0); register-resident row blocks of 96
+                                                    # rows; the looping 16-byte form in eval mode
+                                                    (100, 6, True, 1), (24576, 64, True, 2), (40000, 128, False, 1)])
 def test_batch_norm_matches_torch(ops, M, C, training, res_mode):
     """nn.BatchNorm2d on an (M, C) matrix: batch statistics + running update (train) / running statistics (eval),
     optional residual (1: plain, 2: through a ReLU), forward and backward"""
