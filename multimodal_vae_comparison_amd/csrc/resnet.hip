@@ -281,14 +281,6 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(o + 4) = make_float4(mean.z, q.z, mean.w, q.w);
   }
 }
-// Chan merge of (count, mean, M2) pairs in double
-__device__ __forceinline__ void bn_chan(double& n, double& mean, double& m2, double nb, double mb, double qb) {
-  if (nb <= 0.0) return;
-  const double d = mb - mean, tot = n + nb;
-  mean += d * nb / tot;
-  m2 += qb + d * d * n * nb / tot;
-  n = tot;
-}
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, const float* __restrict__ part,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ res, float* __restrict__ y,
@@ -296,7 +288,7 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
                                                         float* __restrict__ run_mean, float* __restrict__ run_var,
                                                         int M, int C, int nblk, int rows_per, float eps, float momentum,
                                                         int res_relu, int eval_mode) {
-  __shared__ double sm[16][64][3];      // per row slice and channel: (n, mean, M2) of its share of the row blocks
+  __shared__ double sm[16][64];         // per row slice and channel: its share of a sum over the row blocks
   const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + 4 * cq;
   const bool cok = c < C;
@@ -322,36 +314,53 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
       rstd[k] = cok ? 1.0f / sqrtf(run_var[c + k] + eps) : 0.f;
     }
   } else {
-    // slice rs merges row blocks rs, rs + 16, ... of its 4 channels; the 16 slice results are merged in slice order
-    double n[4] = {0, 0, 0, 0}, mean[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
-    if (cok) {
+    // exact two-pass combination of the row blocks' (count, mean, M2), in double and without a division per block
+    // (a Chan merge per block and channel -- 128 double divisions per thread -- made this kernel 14 us when its three
+    // siblings took 6): mean = sum n_b mean_b / M, M2 = sum [M2_b + n_b (mean_b - mean)^2].  Slice rs adds row blocks
+    // rs, rs + 16, ...; the 16 slice sums are added in slice order.
+    auto slice_total = [&](const double (&v)[4], double (&tot)[4]) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sm[rs][4 * cq + k] = v[k];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sm[i][4 * cq + k];
+        tot[k] = t;
+      }
+    };
+    double sw[4] = {0, 0, 0, 0}, mean[4], sq[4] = {0, 0, 0, 0}, m2[4];
+    if (cok)
       for (int b = rs; b < nblk; b += 16) {
         const int br0 = b * rows_per;
         const double nb = (double)max(min(M, br0 + rows_per) - br0, 0);
         const float* pp = part + ((size_t)b * C + c) * 2;
         const float4 p0 = *reinterpret_cast<const float4*>(pp), p1 = *reinterpret_cast<const float4*>(pp + 4);
-        bn_chan(n[0], mean[0], m2[0], nb, (double)p0.x, (double)p0.y);
-        bn_chan(n[1], mean[1], m2[1], nb, (double)p0.z, (double)p0.w);
-        bn_chan(n[2], mean[2], m2[2], nb, (double)p1.x, (double)p1.y);
-        bn_chan(n[3], mean[3], m2[3], nb, (double)p1.z, (double)p1.w);
+        sw[0] += nb * (double)p0.x; sw[1] += nb * (double)p0.z; sw[2] += nb * (double)p1.x; sw[3] += nb * (double)p1.z;
       }
-    }
+    slice_total(sw, mean);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mean[k] /= (double)M;
+    if (cok)
+      for (int b = rs; b < nblk; b += 16) {
+        const int br0 = b * rows_per;
+        const double nb = (double)max(min(M, br0 + rows_per) - br0, 0);
+        const float* pp = part + ((size_t)b * C + c) * 2;
+        const float4 p0 = *reinterpret_cast<const float4*>(pp), p1 = *reinterpret_cast<const float4*>(pp + 4);
+        const double d0 = (double)p0.x - mean[0], d1 = (double)p0.z - mean[1], d2 = (double)p1.x - mean[2],
+                     d3 = (double)p1.z - mean[3];
+        sq[0] += (double)p0.y + nb * d0 * d0; sq[1] += (double)p0.w + nb * d1 * d1;
+        sq[2] += (double)p1.y + nb * d2 * d2; sq[3] += (double)p1.w + nb * d3 * d3;
+      }
+    slice_total(sq, m2);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      sm[rs][4 * cq + k][0] = n[k];
-      sm[rs][4 * cq + k][1] = mean[k];
-      sm[rs][4 * cq + k][2] = m2[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double tn = 0.0, tm = 0.0, tq = 0.0;
-      for (int i = 0; i < 16; ++i) bn_chan(tn, tm, tq, sm[i][4 * cq + k][0], sm[i][4 * cq + k][1], sm[i][4 * cq + k][2]);
-      mu[k] = (float)tm;
-      rstd[k] = (float)(1.0 / sqrt(tq / (double)M + (double)eps));
+      mu[k] = (float)mean[k];
+      rstd[k] = (float)(1.0 / sqrt(m2[k] / (double)M + (double)eps));
       if (blockIdx.y == 0 && rs == 0 && cok && run_mean) {
         run_mean[c + k] = (1.0f - momentum) * run_mean[c + k] + momentum * mu[k];
-        const float unbiased = (float)(tq / (double)(M > 1 ? M - 1 : 1));
+        const float unbiased = (float)(m2[k] / (double)(M > 1 ? M - 1 : 1));
         run_var[c + k] = (1.0f - momentum) * run_var[c + k] + momentum * unbiased;
       }
     }
