@@ -286,9 +286,48 @@ __global__ __launch_bounds__(256) void bias_group_grad_kernel(const float* __res
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) ws[(size_t)part * C + c] = acc;
 }
+// 16-byte form: workgroup = (chunk of 256 column quads, block of rows); a thread walks its quad down the rows with
+// coalesced float4 loads (8 in flight), adds the 4 components, and G / 4 neighbouring threads add up to one channel.
+// (The form above reads 64 contiguous bytes per row and channel: 181 us for the 63 MB of the MNIST-SVHN decoder's
+// 7680 x 2048 gradient; this one streams whole rows.)
+__global__ __launch_bounds__(256) void bias_group_grad4_kernel(const float* __restrict__ dy, float* __restrict__ ws,
+                                                               int rows, int C, int G, int rows_per) {
+  __shared__ float sums[256];
+  const int part = blockIdx.y, q4 = G >> 2;
+  const long n4 = (long)C * q4;                          // float4 per row
+  const long col = (long)blockIdx.x * 256 + threadIdx.x;
+  const int r0 = part * rows_per, r1 = min(rows, r0 + rows_per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < n4) {
+    const float4* p = reinterpret_cast<const float4*>(dy) + col;
+    int r = r0;
+    for (; r + 7 < r1; r += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; r < r1; ++r) {
+      const float4 v = p[(size_t)r * n4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  sums[threadIdx.x] = (a.x + a.y) + (a.z + a.w);
+  __syncthreads();
+  const int per = 256 / q4;                              // channels of this chunk
+  if ((int)threadIdx.x < per) {
+    const long c = (long)blockIdx.x * per + threadIdx.x;
+    if (c < C) {
+      float t = 0.f;
+      for (int i = 0; i < q4; ++i) t += sums[threadIdx.x * q4 + i];
+      ws[(size_t)part * C + c] = t;
+    }
+  }
+}
 extern "C" int mmvae_bias_group_parts(int rows) {
-  int parts = (rows + 127) / 128;
-  return parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+  int parts = (rows + 63) / 64;
+  return parts < 1 ? 1 : (parts > 128 ? 128 : parts);
 }
 extern "C" size_t mmvae_bias_group_ws_floats(int rows, int C) { return (size_t)mmvae_bias_group_parts(rows) * C; }
 extern "C" int mmvae_bias_group_add(float* y, const float* bias, int rows, int C, int G, mmvae_stream_t stream) {
@@ -306,8 +345,15 @@ extern "C" int mmvae_bias_group_grad(const float* dy, float* db, float* ws, int 
   MMVAE_CHECK_ARG(dy && db && ws && rows > 0 && C > 0 && G > 0);
   const int parts = mmvae_bias_group_parts(rows);
   const int rows_per = (rows + parts - 1) / parts;
-  hipLaunchKernelGGL(bias_group_grad_kernel, dim3(C, parts), dim3(256), 0, (hipStream_t)stream, dy, ws, rows, C, G,
-                     rows_per);
+  const int q4 = G >> 2;
+  if ((G & 3) == 0 && q4 <= 256 && 256 % q4 == 0 && (((uintptr_t)dy) & 15) == 0) {
+    const long n4 = (long)C * q4;
+    hipLaunchKernelGGL(bias_group_grad4_kernel, dim3((unsigned)((n4 + 255) / 256), parts), dim3(256), 0,
+                       (hipStream_t)stream, dy, ws, rows, C, G, rows_per);
+  } else {
+    hipLaunchKernelGGL(bias_group_grad_kernel, dim3(C, parts), dim3(256), 0, (hipStream_t)stream, dy, ws, rows, C, G,
+                       rows_per);
+  }
   int rc = mmvae_launch_status();
   if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   return mmvae_reduce_rows(ws, db, parts, C, C, accumulate, stream);
