@@ -116,7 +116,7 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
   ConvWgradArgs aw{x, dy, ws, B, x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro, 32, (long)32 * Cout * 16 + 32};
   bool launched = false;
-  gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles), [&](auto g) {
+  gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles, 2 * Hin), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH >= 3 && (G::CIN == 32 || G::LGH == 6)) {
       const int n_d = (int)gather_grid(B, Hin, G::TM);    // (weight gradient: small map = the gather's output map)
