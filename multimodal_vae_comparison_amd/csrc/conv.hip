@@ -74,7 +74,7 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
   // one instantiation per layer shape: the scatter plan is a function of the map size at a given batch, but both
   // template arguments must be compile-time, so the (few) combinations are enumerated by the two visitors
   bool launched = false;
-  scatter_visit(Hout, scatter_plan(tiles), [&](auto g) {
+  scatter_visit(Hout, scatter_plan(tiles, 32, Hout), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH <= 4) {
       const int n_d = (int)scatter_grid(B, Hout, G::TM);
