@@ -78,6 +78,21 @@ int mmvae_head_bcast_dropout_fwd(const float* v, float* out, int L, int N, int H
 int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L, int N, int H, int hd,
                                  const mmvae_dropout_t* drop, mmvae_stream_t stream);
 
+/* Feed-forward block of nn.TransformerEncoderLayer / DecoderLayer with d_model = 32 (the action towers, reference
+ * models/encoders.py:706-716, models/decoders.py:589-600) without materialising the (M, FF) hidden activation:
+ *   y = W2 dropout(gelu(W1 x + b1)) + b2;   x, y (M,32); w1 (FF,32), b1 (FF), w2 (32,FF), b2 (32); FF % 32 == 0.
+ * The dropout mask of hidden element (row, col) is that of mmvae_dropout_act_fwd at index row*FF + col (drop NULL or
+ * p == 0: none).  Backward recomputes the hidden tiles: dx (M,32; may be NULL) and mmvae_ffn32_bwd_parts(M, FF) partial
+ * rows of mmvae_ffn32_bwd_rowlen(FF) floats in ws, each [dW1 (FF,32) | db1 (FF) | dW2 (32,FF) | db2 (32)], to be summed
+ * by the caller (mmvae_reduce_rows / mmvae_reduce_segments). */
+int mmvae_ffn32_supported(int d_model, int FF);
+int mmvae_ffn32_bwd_parts(int M, int FF);
+size_t mmvae_ffn32_bwd_rowlen(int FF);
+int mmvae_ffn32_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int M,
+                    int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, float* dx,
+                    float* ws, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+
 int mmvae_version(void);
 const char* mmvae_arch(void); /* "gfx950" */
 

@@ -1,0 +1,241 @@
+// Feed-forward block of the action Transformer towers as three fused launches (gfx950, fp32 MFMA):
+//
+//     y = W2 . dropout(gelu(W1 . x + b1)) + b2          d_model = 32, FF = a multiple of 32 (1024 in the reference)
+//
+// (torch.nn.TransformerEncoderLayer / DecoderLayer `linear2(dropout(activation(linear1(x))))`, reference
+// models/encoders.py:706-716, models/decoders.py:589-600.)  Op by op the (rows x FF) hidden activation -- 52 MB for the
+// reference's 12 800 rows -- is written by linear1, read and rewritten by the activation-dropout pass, read by linear2,
+// and the same again twice in backward: ~0.5 GB of HBM traffic per layer and step.  Here it never leaves the registers:
+// every wave produces 32 x 32 tiles of it with 16 MFMAs, applies bias / GELU / the dropout mask (same element index as
+// mmvae_dropout_act: row * FF + column) on the accumulators and feeds them straight into the next MFMAs; backward
+// recomputes the tiles (K = 32: cheaper than reading them).
+//
+// Operand trick used throughout: v_mfma_f32_32x32x2_f32 leaves C[i][j] in lane (j, half) register r with
+// i = 8 (r >> 2) + 4 half + (r & 3).  The same register, read as the A operand of k-step s = r, supplies
+// A[row = lane & 31][k = the accumulator's i]: as long as the B operand walks k in that same order (k_s(half) =
+// 8 (s >> 2) + 4 half + (s & 3)) an accumulator tile is the next GEMM's A operand without a transposition through LDS.
+// Computing a tile as mfma(A = W1 rows, B = x rows) or as mfma(A = x rows, B = W1 rows) -- the same operand registers
+// with their roles swapped -- puts either the x row or the FF column on the lanes, whichever the consumer needs.
+#include "common.hpp"
+
+#define FFN_D 32
+
+struct FfnArgs {
+  const float *x, *dy, *w1, *b1, *w2, *b2;
+  float *y, *dx, *ws;
+  int M, FF, rows_per_slice, rowlen;
+  mmvae_dropout_t drop;
+};
+
+// lane (li, lh) of a wave: values row[2 kk + lh], kk = 0..15, of the 32-float row at p (zeros if !ok)
+__device__ __forceinline__ void ffn_row_pairs(const float* __restrict__ p, bool ok, int lh, float (&v)[16]) {
+  float4 q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = ok ? *reinterpret_cast<const float4*>(p + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[2 * j] = lh ? q[j].y : q[j].x;
+    v[2 * j + 1] = lh ? q[j].w : q[j].z;
+  }
+}
+__device__ __forceinline__ f32x16 ffn_zero() {
+  f32x16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  return a;
+}
+// the accumulator index i of register r in lane half lh
+__device__ __forceinline__ int ffn_i(int r, int lh) { return 8 * (r >> 2) + 4 * lh + (r & 3); }
+
+// sum of the 4 waves' 32 x 32 accumulators (register r <-> row ffn_i(r), lane li <-> column), + bias, -> out rows
+__device__ __forceinline__ void ffn_reduce_store(const f32x16& acc, float* __restrict__ red, int wave, int lane,
+                                                 float* __restrict__ out, int R0, int M, const float* __restrict__ bias) {
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const float b = bias ? bias[li] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * wave + i;
+    const float s = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
+    const int row = R0 + ffn_i(r, lh);
+    if (row < M) out[(size_t)row * FFN_D + li] = s + b;
+  }
+}
+
+// ---- forward: workgroup = one 32-row block, wave w = FF chunks w, w + 4, ... ------------------------------------------
+__global__ __launch_bounds__(256) void ffn32_fwd_kernel(FfnArgs a) {
+  __shared__ float red[4 * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int R0 = blockIdx.x * 32, FF = a.FF;
+  const DropKey dk = drop_key(a.drop);
+  float xv[16];
+  ffn_row_pairs(a.x + (size_t)(R0 + li) * FFN_D, R0 + li < a.M, lh, xv);
+  f32x16 acc2 = ffn_zero();
+  const uint32_t drow = (uint32_t)(R0 + li) * (uint32_t)FF;
+  for (int c0 = wave * 32; c0 < FF; c0 += 128) {
+    float w1v[16];
+    ffn_row_pairs(a.w1 + (size_t)(c0 + li) * FFN_D, true, lh, w1v);
+    float4 bq[4], w2q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bq[q] = *reinterpret_cast<const float4*>(a.b1 + c0 + 8 * q + 4 * lh);
+      w2q[q] = *reinterpret_cast<const float4*>(a.w2 + (size_t)li * FF + c0 + 8 * q + 4 * lh);
+    }
+    // h^T tile: register r <-> FF column c0 + ffn_i(r), lane li <-> x row
+    f32x16 h = ffn_zero();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) h = __builtin_amdgcn_mfma_f32_32x32x2f32(w1v[kk], xv[kk], h, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bias = (&bq[r >> 2].x)[r & 3];
+      const float act = dev_gelu(h[r] + bias) * drop_mul(dk, drow + (uint32_t)(c0 + ffn_i(r, lh)));
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(act, (&w2q[r >> 2].x)[r & 3], acc2, 0, 0, 0);
+    }
+  }
+  ffn_reduce_store(acc2, red, wave, lane, a.y, R0, a.M, a.b2);
+}
+
+// ---- backward, data gradient: dx = (dy W2 . mask . gelu'(h)) W1, same decomposition as forward ---------------------------
+__global__ __launch_bounds__(256) void ffn32_bwd_data_kernel(FfnArgs a) {
+  __shared__ float red[4 * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int R0 = blockIdx.x * 32, FF = a.FF;
+  const DropKey dk = drop_key(a.drop);
+  float xv[16], dyv[16];
+  ffn_row_pairs(a.x + (size_t)(R0 + li) * FFN_D, R0 + li < a.M, lh, xv);
+  ffn_row_pairs(a.dy + (size_t)(R0 + li) * FFN_D, R0 + li < a.M, lh, dyv);
+  f32x16 accdx = ffn_zero();
+  const uint32_t drow = (uint32_t)(R0 + li) * (uint32_t)FF;
+  for (int c0 = wave * 32; c0 < FF; c0 += 128) {
+    float w1v[16], w2t[16], w1n[16];
+    ffn_row_pairs(a.w1 + (size_t)(c0 + li) * FFN_D, true, lh, w1v);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) w2t[kk] = a.w2[(size_t)(2 * kk + lh) * FF + c0 + li];     // W2[out][ff = c0 + li]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w1n[s] = a.w1[(size_t)(c0 + ffn_i(s, lh)) * FFN_D + li];    // W1[ff_s][k = li]
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(a.b1 + c0 + 8 * q + 4 * lh);
+    f32x16 h = ffn_zero(), da = ffn_zero();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      h = __builtin_amdgcn_mfma_f32_32x32x2f32(w1v[kk], xv[kk], h, 0, 0, 0);
+      da = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[kk], dyv[kk], da, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pre = h[r] + (&bq[r >> 2].x)[r & 3];
+      const float dh = da[r] * drop_mul(dk, drow + (uint32_t)(c0 + ffn_i(r, lh))) * dev_gelu_grad(pre);
+      accdx = __builtin_amdgcn_mfma_f32_32x32x2f32(dh, w1n[r], accdx, 0, 0, 0);
+    }
+  }
+  ffn_reduce_store(accdx, red, wave, lane, a.dx, R0, a.M, nullptr);
+}
+
+// ---- backward, weight gradients: wave = one 32-column FF chunk, walks the row blocks of its row slice ----------------
+// partial row p (= row slice) of ws: [dW1 (FF x 32) | db1 (FF) | dW2 (32 x FF) | db2 (32)], rowlen floats apart
+__global__ __launch_bounds__(256) void ffn32_bwd_weight_kernel(FfnArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int FF = a.FF, c0 = (blockIdx.x * 4 + wave) * 32;
+  if (c0 >= FF) return;
+  const DropKey dk = drop_key(a.drop);
+  float w1v[16], w2t[16];
+  ffn_row_pairs(a.w1 + (size_t)(c0 + li) * FFN_D, true, lh, w1v);
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) w2t[kk] = a.w2[(size_t)(2 * kk + lh) * FF + c0 + li];
+  const float b1v = a.b1[c0 + li];
+  f32x16 accw1 = ffn_zero(), accw2 = ffn_zero();
+  float db1 = 0.f, db2 = 0.f;
+  const bool want_db2 = blockIdx.x == 0 && wave == 0;
+  const int r_beg = blockIdx.y * a.rows_per_slice, r_end = min(a.M, r_beg + a.rows_per_slice);
+  for (int R0 = r_beg; R0 < r_end; R0 += 32) {
+    float xv[16], dyv[16], xn[16], dyn[16];
+    const bool rok = R0 + li < r_end;
+    ffn_row_pairs(a.x + (size_t)(R0 + li) * FFN_D, rok, lh, xv);
+    ffn_row_pairs(a.dy + (size_t)(R0 + li) * FFN_D, rok, lh, dyv);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = R0 + ffn_i(s, lh);
+      const bool ok = row < r_end;
+      xn[s] = ok ? a.x[(size_t)row * FFN_D + li] : 0.f;
+      dyn[s] = ok ? a.dy[(size_t)row * FFN_D + li] : 0.f;
+    }
+    // h, da tiles: register r <-> row R0 + ffn_i(r), lane li <-> FF column c0 + li
+    f32x16 h = ffn_zero(), da = ffn_zero();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      h = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[kk], w1v[kk], h, 0, 0, 0);
+      da = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv[kk], w2t[kk], da, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = R0 + ffn_i(r, lh);
+      const float pre = h[r] + b1v;
+      const float m = drop_mul(dk, (uint32_t)row * (uint32_t)FF + (uint32_t)(c0 + li));
+      const float act = dev_gelu(pre) * m;                    // rows >= r_end: multiplied by dy = 0 below
+      const float dh = da[r] * m * dev_gelu_grad(pre);        // ... and da = 0 there
+      db1 += dh;
+      db2 += dyn[r];
+      accw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dh, xn[r], accw1, 0, 0, 0);     // dW1[ff][k = li]
+      accw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(dyn[r], act, accw2, 0, 0, 0);   // dW2[out][ff = c0 + li]
+    }
+  }
+  float* __restrict__ part = a.ws + (size_t)blockIdx.y * a.rowlen;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    part[(size_t)(c0 + ffn_i(r, lh)) * FFN_D + li] = accw1[r];
+    part[(size_t)FF * FFN_D + FF + (size_t)ffn_i(r, lh) * FF + c0 + li] = accw2[r];
+  }
+  db1 += __shfl_xor(db1, 32, 64);
+  db2 += __shfl_xor(db2, 32, 64);
+  if (lh == 0) {
+    part[(size_t)FF * FFN_D + c0 + li] = db1;
+    if (want_db2) part[(size_t)FF * FFN_D + FF + (size_t)FFN_D * FF + li] = db2;
+  }
+}
+
+static inline bool ffn_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int ffn_slices(int M, int FF) {
+  // row slices of the weight-gradient launch: ~2048 waves in flight, 8 to 13 row blocks per wave
+  const int nrb = (M + 31) / 32, chunks = FF / 32;
+  int s = (2048 + chunks - 1) / chunks;
+  const int lo = (nrb + 12) / 13;
+  if (s < lo) s = lo;
+  if (s > nrb) s = nrb;
+  if (s > 512) s = 512;
+  return s < 1 ? 1 : s;
+}
+extern "C" int mmvae_ffn32_supported(int d, int FF) { return d == FFN_D && FF >= 32 && FF % 32 == 0; }
+extern "C" int mmvae_ffn32_bwd_parts(int M, int FF) { return ffn_slices(M, FF); }
+extern "C" size_t mmvae_ffn32_bwd_rowlen(int FF) { return (size_t)FFN_D * FF + FF + (size_t)FFN_D * FF + FFN_D; }
+
+extern "C" int mmvae_ffn32_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* y, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && w1 && b1 && w2 && b2 && y && M > 0);
+  if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
+  if (!ffn_al16(x) || !ffn_al16(w1) || !ffn_al16(b1) || !ffn_al16(w2)) return MMVAE_ERR_ARG;
+  FfnArgs a{x, nullptr, w1, b1, w2, b2, y, nullptr, nullptr, M, FF, 0, 0, drop_arg(drop)};
+  hipLaunchKernelGGL(ffn32_fwd_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  return mmvae_launch_status();
+}
+// dx (M x 32) and the partial rows of the weight / bias gradients: mmvae_ffn32_bwd_parts(M, FF) rows of
+// mmvae_ffn32_bwd_rowlen(FF) floats in ws, each [dW1 (FF,32) | db1 (FF) | dW2 (32,FF) | db2 (32)]; every element of
+// every row is written.  dx may be NULL (no data gradient wanted).
+extern "C" int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2,
+                               float* dx, float* ws, int M, int FF, const mmvae_dropout_t* drop,
+                               mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && dy && w1 && b1 && w2 && ws && M > 0);
+  if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
+  if (!ffn_al16(x) || !ffn_al16(dy) || !ffn_al16(w1) || !ffn_al16(b1)) return MMVAE_ERR_ARG;
+  const int S = ffn_slices(M, FF);
+  int rps = ((M + S - 1) / S + 31) / 32 * 32;
+  FfnArgs a{x, dy, w1, b1, w2, nullptr, nullptr, dx, ws, M, FF, rps, (int)mmvae_ffn32_bwd_rowlen(FF), drop_arg(drop)};
+  if (dx) hipLaunchKernelGGL(ffn32_bwd_data_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ffn32_bwd_weight_kernel, dim3((FF / 32 + 3) / 4, S), dim3(256), 0, (hipStream_t)stream, a);
+  return mmvae_launch_status();
+}

@@ -102,14 +102,19 @@ class HipTransformerDecoderLayer(nn.Module):
             p = self.fused_params()
             return ops.txt_layer(x, mem, mask_u8, ops.TxtLayerMeta(d, ff, nh, True, ds), p,
                                  {k: v.grad for k, v in p.items()})
+        fused_ffn = encoders.FUSED_FFN and x.is_cuda and ops.ffn32_supported(d, ff)
+        ffn = lambda t, drop: ops.ffn32(t, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                        self.linear2.bias, drop)
         if ds is None:
             x = self.norm1(self.self_attn(x, mask_u8), x)
             x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
-            return self.norm3(self.linear2(self.linear1(x)), x)
+            return self.norm3(ffn(x, None) if fused_ffn else self.linear2(self.linear1(x)), x)
         L = x.shape[0]
         x = self.norm1(self.self_attn(x, mask_u8, ds["attn"]), x, ds["drop1"])
         ca = self.multihead_attn.value_path(mem, L, ds["xattn"])          # (L,N,d): weight dropout varies with l
         x = self.norm2(ca, x, ds["drop2"])
+        if fused_ffn:
+            return self.norm3(ffn(x, ds["ffn"]), x, ds["drop3"])
         h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])
         return self.norm3(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop3"])
 

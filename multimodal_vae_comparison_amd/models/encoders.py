@@ -227,6 +227,7 @@ class Enc_CNN(VaeEncoder):
 
 FUSED_TXT_LAYERS = os.environ.get("MMVAE_FUSED_TXT", "1") != "0"
 FUSED_HEADS = os.environ.get("MMVAE_FUSED_HEADS", "1") != "0"     # text encoder: heads inside the last layer's launch
+FUSED_FFN = os.environ.get("MMVAE_FUSED_FFN", "1") != "0"         # d_model-32 layers outside the fused-layer shapes
 
 
 class HipTransformerEncoderLayer(nn.Module):
@@ -264,12 +265,20 @@ class HipTransformerEncoderLayer(nn.Module):
             return ops.linear(z, heads[0], heads[1], H.ACT_NONE, heads[2], heads[3])
         if time_mean:
             return ops.mean_over_time(self.forward(x, mask_u8, ds))
+        fused_ffn = FUSED_FFN and x.is_cuda and ops.ffn32_supported(d, ff)
         if ds is None:
             x = self.norm1(self.self_attn(x, mask_u8), x)
+            if fused_ffn:
+                return self.norm2(self._ffn(x, None), x)
             return self.norm2(self.linear2(self.linear1(x)), x)
         x = self.norm1(self.self_attn(x, mask_u8, ds["attn"]), x, ds["drop1"])
+        if fused_ffn:      # the (L*N, ff) hidden activation never leaves the registers (csrc/ffn.hip)
+            return self.norm2(self._ffn(x, ds["ffn"]), x, ds["drop2"])
         h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])           # dropout(gelu(.)) materialised
         return self.norm2(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop2"])
+
+    def _ffn(self, x, drop):
+        return ops.ffn32(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop)
 
 
 class HipTransformerStack(nn.Module):

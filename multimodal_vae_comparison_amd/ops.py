@@ -2027,6 +2027,57 @@ class HeadBcastDropout(Function):
         return dv, None, None, None
 
 
+class Ffn32(Function):
+    """linear2(dropout(gelu(linear1(x)))) of a post-norm Transformer layer with d_model = 32, fused (csrc/ffn.hip): the
+    (rows, FF) hidden activation stays in registers, backward recomputes it.  x (..., 32); w1 (FF,32), b1 (FF),
+    w2 (32,FF), b2 (32); drop: DropSpec of the hidden dropout or None; g*: the parameters' flat gradient views."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2):
+        x = H.f32c(x)
+        M, FF = x.numel() // 32, w1.shape[0]
+        y = torch.empty_like(x)
+        _call("mmvae_ffn32_fwd", H.ptr(x), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(b2), H.ptr(y), M, FF,
+              _dp(drop, M * FF), H.stream())
+        ctx.save_for_backward(x, w1, b1, w2)
+        ctx.cfg = (drop, gw1, gb1, gw2, gb2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        drop, gw1, gb1, gw2, gb2 = ctx.cfg
+        dy = H.f32c(dy)
+        M, FF = x.numel() // 32, w1.shape[0]
+        lib = H.lib()
+        parts, rowlen = lib.mmvae_ffn32_bwd_parts(M, FF), lib.mmvae_ffn32_bwd_rowlen(FF)
+        defer = _defer(gw1, gb1, gw2, gb2)
+        ws = GradReducer.alloc(parts * rowlen, x.device) if defer else torch.empty(parts * rowlen, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(dx), H.ptr(ws), M, FF,
+              drop.c() if drop else None, H.stream())
+        offs = (0, 32 * FF, 32 * FF + FF, 64 * FF + FF)
+        lens = (32 * FF, FF, 32 * FF, 32)
+        rets = [None, None, None, None]
+        if defer:
+            for o, ln, g in zip(offs, lens, (gw1, gb1, gw2, gb2)):
+                GradReducer.add(ws.data_ptr() + 4 * o, g, parts, ln, rowlen)
+        else:
+            for i, (o, ln, g, like) in enumerate(zip(offs, lens, (gw1, gb1, gw2, gb2), (w1, b1, w2, b1[:32]))):
+                dst, acc, ret = _new_like_param(like, g)
+                _call("mmvae_reduce_rows", H.ptr(ws) + 4 * o, H.ptr(dst), parts, ln, rowlen, acc, H.stream())
+                rets[i] = ret
+        return (dx, *rets, None, None, None, None, None)
+
+
+def ffn32_supported(d, ff):
+    return bool(H.lib().mmvae_ffn32_supported(int(d), int(ff)))
+
+
+def ffn32(x, w1, b1, w2, b2, drop=None):
+    return Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad)
+
+
 def dropout_act(x, act, drop):
     return DropoutAct.apply(x, act, drop)
 

@@ -709,6 +709,47 @@ def test_adam_fold_flat_is_fold_then_adam(ops, hip_lib, rider):
     assert rc == 1      # MMVAE_ERR_ARG
 
 
+@pytest.mark.parametrize("M,FF,p", [(600, 1024, 0.1), (70, 128, 0.0), (12800, 1024, 0.1), (33, 96, 0.3), (1, 32, 0.5)])
+def test_ffn32_fused_matches_torch_and_op_by_op(ops, M, FF, p):
+    """csrc/ffn.hip: linear2(dropout(gelu(linear1(x)))) with d_model 32 in three fused launches (forward, data
+    gradient, weight gradients) against torch in fp64 with the very dropout mask the kernel used (extracted with
+    mmvae_dropout_mask: same element index row * FF + col as the op-by-op activation-dropout pass), ragged row counts
+    (partial row blocks, partial row slices), FF not a multiple of the 4-wave stride"""
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    g = torch.Generator().manual_seed(M + FF)
+    x = torch.randn(M, 32, generator=g).to(DEV).requires_grad_(True)
+    w1 = (torch.randn(FF, 32, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    b1 = (torch.randn(FF, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    w2 = (torch.randn(32, FF, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    b2 = torch.randn(32, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(M, 32, generator=g).to(DEV)
+    drop = None
+    mask = torch.ones(M, FF, dtype=torch.float64, device=DEV)
+    if p > 0:
+        st = DropoutState().to(DEV)
+        slot, call = st.begin()
+        drop = st.spec(slot, call, 3, p, "ffn")
+        mask = ops.dropout_mask(drop, M * FF).double().view(M, FF)
+        assert 0.5 * (1 - p) < float((mask > 0).double().mean()) <= 1.0
+    y = ops.ffn32(x, w1, b1, w2, b2, drop)
+    y.backward(dy)
+    xr, w1r, b1r, w2r, b2r = (t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    ref = (F.gelu(xr @ w1r.t() + b1r) * mask) @ w2r.t() + b2r
+    ref.backward(dy.double())
+    check(y, ref, 2e-6, "y")
+    for a, r, name in ((x, xr, "dx"), (w1, w1r, "dW1"), (b1, b1r, "db1"), (w2, w2r, "dW2"), (b2, b2r, "db2")):
+        check(a.grad, r.grad, 5e-6, name)
+    # ... and the op-by-op kernels on the same inputs and mask
+    x2, w12, b12, w22, b22 = (t.detach().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    h = ops.linear(x2, w12, b12, 0)
+    h = ops.dropout_act(h, 3, drop) if drop is not None else ops.dropout_act(h, 3, None)
+    y2 = ops.linear(h, w22, b22, 0)
+    y2.backward(dy)
+    check(y, y2, 2e-6, "y vs op-by-op")
+    check(x.grad, x2.grad, 5e-6, "dx vs op-by-op")
+    check(w1.grad, w12.grad, 5e-6, "dW1 vs op-by-op")
+
+
 @pytest.mark.parametrize("self_counting", [False, True])
 def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
     """self_counting: step = -1, the kernel bumps the device step counter itself (what FlatAdam uses)"""
