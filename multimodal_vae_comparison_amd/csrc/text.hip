@@ -356,11 +356,311 @@ __global__ __launch_bounds__(AM) void attn_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA form for 64 < L, S <= 128 with head_dim <= 16 (the action towers: Ta = 100, D / 2 = 16).  In the thread-per-row
+// kernels above every lane walks all S keys one after the other (two passes of ~250 VALU cycles per key: 38 us forward,
+// 66 us backward at Ta = 100 however many threads there are).  Here the four waves of a workgroup own 32 query rows (or
+// 32 keys) each and the three products of forward (Q K^T, P V) and five of backward (P^T dO, dO V^T, dS K, dS^T Q) are
+// v_mfma_f32_32x32x2_f32 tiles whose operands are read from LDS with conflict-free pitches (rows: 17 floats, the
+// L x S tile: 129); the softmax runs with two lanes per row (64 keys each).  Same arithmetic definition, dropout mask
+// indices and -inf semantics as the kernels above.
+// ---------------------------------------------------------------------------------------------
+#define AT_HD 16
+#define AT_HP 17
+#define AT_SP 129
+__device__ __forceinline__ int at_i(int r, int lh) { return 8 * (r >> 2) + 4 * lh + (r & 3); }
+// rows x hd floats (row r at src[(r N + n) ld + col0 ..]) -> dst[r][AT_HP], zero padded to 128 rows x 16 columns
+__device__ __forceinline__ void at_stage(float* __restrict__ dst, const float* __restrict__ src, int rows, int N, int n,
+                                         long ld, int col0, int hd, float mul, int tid) {
+  if (hd == AT_HD && (col0 & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+    // 4 x 16-byte loads per row, two rows' worth per thread in flight (512 quads for 128 rows)
+    float4 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 256 * u, r = e >> 2, c = e & 3;
+      v[u] = r < rows ? *reinterpret_cast<const float4*>(src + ((size_t)r * N + n) * ld + col0 + 4 * c)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 256 * u, r = e >> 2, c = e & 3;
+      float* d = dst + r * AT_HP + 4 * c;
+      d[0] = v[u].x * mul; d[1] = v[u].y * mul; d[2] = v[u].z * mul; d[3] = v[u].w * mul;
+    }
+    return;
+  }
+  for (int e = tid; e < 128 * AT_HD; e += 256) {
+    const int r = e >> 4, d = e & 15;
+    const bool ok = r < rows && d < hd;
+    const float v = src[ok ? ((size_t)r * N + n) * ld + col0 + d : (size_t)n * ld + col0];
+    dst[r * AT_HP + d] = ok ? v * mul : 0.f;
+  }
+}
+// max / sum over the 32 lanes of each wave half
+__device__ __forceinline__ float at_half_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float at_half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const uint8_t* __restrict__ kpm,
+                                                            float* __restrict__ out, float* __restrict__ probs, int L,
+                                                            int S, int N, int H, int hd, long ldq, long ldk, long ldv,
+                                                            int mask_is_valid, mmvae_dropout_t drop) {
+  __shared__ float sq[128 * AT_HP], sk[128 * AT_HP], sv[128 * AT_HP];
+  __shared__ float sp[128 * AT_SP];
+  __shared__ float smask[128];
+  const int n = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+  const float scale = 1.0f / sqrtf((float)hd);
+  at_stage(sq, q, L, N, n, ldq, h * hd, hd, scale, tid);
+  at_stage(sk, k, S, N, n, ldk, h * hd, hd, 1.0f, tid);
+  at_stage(sv, v, S, N, n, ldv, h * hd, hd, 1.0f, tid);
+  if (tid < 128)
+    smask[tid] = (tid >= S || (kpm && ((kpm[(size_t)n * S + tid] != 0) != (mask_is_valid != 0)))) ? 1.f : 0.f;
+  __syncthreads();
+  const int l0 = wave * 32;
+  if (l0 >= L) return;                      // (no barrier below: every wave works on its own 32 rows of the tile)
+  // ---- scores of rows l0 .. l0+31 against all keys: 4 accumulator tiles, register r <-> row l0 + at_i(r), lane li <->
+  //      key 32 kb + li.  The softmax runs on the accumulators: per row an in-lane maximum / sum over the 4 tiles and a
+  //      reduction over the 32 lanes of the half. ----
+  float qa[AT_HD / 2];
+#pragma unroll
+  for (int kk = 0; kk < AT_HD / 2; ++kk) qa[kk] = sq[(l0 + li) * AT_HP + 2 * kk + lh];
+  f32x16 acc[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+    if (kb * 32 < S) {
+#pragma unroll
+      for (int kk = 0; kk < AT_HD / 2; ++kk)
+        acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], sk[(kb * 32 + li) * AT_HP + 2 * kk + lh], acc[kb], 0, 0, 0);
+    }
+    const bool masked = smask[kb * 32 + li] != 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = masked ? -INFINITY : acc[kb][r];
+  }
+  const DropKey dkey = drop_key(drop);
+  const uint32_t dbase = (uint32_t)(((size_t)n * H + h) * L * S);
+  float* P = probs + ((size_t)n * H + h) * L * S;
+  float inv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float mx = at_half_max(fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r])));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float pe = expf(acc[kb][r] - mx);     // exp(-inf - mx) = 0 for masked keys; NaN for a fully masked row
+      acc[kb][r] = pe;
+      sum += pe;
+    }
+    inv[r] = 1.0f / at_half_sum(sum);
+  }
+  // normalised probabilities straight from the registers (lanes over the keys); dropped, unnormalised weights -> tile
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int s_ = kb * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int l = l0 + at_i(r, lh);
+      const float pe = acc[kb][r];
+      if (s_ < S && l < L) P[(size_t)l * S + s_] = pe * inv[r];
+      sp[l * AT_SP + s_] = s_ < S ? pe * drop_mul(dkey, dbase + (uint32_t)(l * S + s_)) : 0.f;
+    }
+  }
+  // ---- O = (P . mask) V ----
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  const int ksteps = (S + 1) >> 1;
+  const float* prow = sp + (l0 + li) * AT_SP;
+#pragma unroll 4
+  for (int kk = 0; kk < ksteps; ++kk) {
+    const int s_ = 2 * kk + lh;
+    const float b = li < AT_HD ? sv[s_ * AT_HP + li] : 0.f;
+    o = __builtin_amdgcn_mfma_f32_32x32x2f32(prow[s_], b, o, 0, 0, 0);
+  }
+  if (li < hd) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int l = l0 + at_i(r, lh);
+      if (l < L) out[((size_t)l * N + n) * ((size_t)H * hd) + h * hd + li] = o[r] * inv[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ probs,
+                                                            const float* __restrict__ dout, float* __restrict__ dq,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int L, int S,
+                                                            int N, int H, int hd, long ldq, long ldk, long ldv,
+                                                            mmvae_dropout_t drop) {
+  __shared__ float sq[128 * AT_HP], sk[128 * AT_HP], sv[128 * AT_HP], sdo[128 * AT_HP];
+  __shared__ float sp[128 * AT_SP];
+  const int n = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+  const long E = (long)H * hd;
+  const float scale = 1.0f / sqrtf((float)hd);
+  at_stage(sq, q, L, N, n, ldq, h * hd, hd, 1.0f, tid);
+  at_stage(sk, k, S, N, n, ldk, h * hd, hd, 1.0f, tid);
+  at_stage(sv, v, S, N, n, ldv, h * hd, hd, 1.0f, tid);
+  at_stage(sdo, dout, L, N, n, E, h * hd, hd, 1.0f, tid);
+  {   // P tile, zero padded to 128 x 128
+    const float* P = probs + ((size_t)n * H + h) * L * S;
+    if ((S & 3) == 0 && (((uintptr_t)P) & 15) == 0) {
+      // 32 quads per row slot: 8 independent 16-byte loads per thread and round (two rounds)
+#pragma unroll
+      for (int e0 = 0; e0 < 128 * 32; e0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid, l = e >> 5, c = e & 31;
+          v[u] = (l < L && 4 * c < S) ? *reinterpret_cast<const float4*>(P + (size_t)l * S + 4 * c)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid, l = e >> 5, c = e & 31;
+          float* d = sp + l * AT_SP + 4 * c;
+          d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+      }
+    } else {
+      for (int e = tid; e < 128 * 128; e += 256) {
+        const int l = e >> 7, s_ = e & 127;
+        sp[l * AT_SP + s_] = (l < L && s_ < S) ? P[(size_t)l * S + s_] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const DropKey dkey = drop_key(drop);
+  const uint32_t dbase = (uint32_t)(((size_t)n * H + h) * L * S);
+  const int b0 = wave * 32;                      // this wave's block of keys (dV, dK) and of query rows (dP, dQ)
+  const int lsteps = (L + 1) >> 1, ssteps = (S + 1) >> 1;
+  // ---- dV[s][d] = sum_l (P . mask)[l][s] dO[l][d] ----
+  if (b0 < S) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < lsteps; ++kk) {
+      const int l = 2 * kk + lh;
+      const float a = sp[l * AT_SP + b0 + li] * drop_mul(dkey, dbase + (uint32_t)(l * S + b0 + li));
+      const float b = li < AT_HD ? sdo[l * AT_HP + li] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (li < hd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s_ = b0 + at_i(r, lh);
+        if (s_ < S) dv[((size_t)s_ * N + n) * ldv + h * hd + li] = acc[r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- dS = P (dP . mask - delta), dP = dO V^T, delta[l] = sum_s P (dP . mask): rows b0 .. b0+31, in place over P ----
+  if (b0 < L) {
+    float da[AT_HD / 2];
+#pragma unroll
+    for (int kk = 0; kk < AT_HD / 2; ++kk) da[kk] = sdo[(b0 + li) * AT_HP + 2 * kk + lh];
+    f32x16 dp[4];
+    float part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[kb][r] = 0.f;
+      if (kb * 32 < S) {
+#pragma unroll
+        for (int kk = 0; kk < AT_HD / 2; ++kk)
+          dp[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[kk], sv[(kb * 32 + li) * AT_HP + 2 * kk + lh], dp[kb], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int l = b0 + at_i(r, lh), s_ = kb * 32 + li;
+          dp[kb][r] *= drop_mul(dkey, dbase + (uint32_t)(l * S + s_));
+          part[r] += sp[l * AT_SP + s_] * dp[kb][r];
+        }
+      }
+    }
+    // row sums over the 32 key lanes of each half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int o_ = 16; o_ > 0; o_ >>= 1) part[r] += __shfl_xor(part[r], o_, 64);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      if (kb * 32 < S) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int idx = (b0 + at_i(r, lh)) * AT_SP + kb * 32 + li;
+          sp[idx] = sp[idx] * (dp[kb][r] - part[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- dQ[l][d] = scale sum_s dS[l][s] K[s][d] ----
+  if (b0 < L) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < ssteps; ++kk) {
+      const int s_ = 2 * kk + lh;
+      const float b = li < AT_HD ? sk[s_ * AT_HP + li] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sp[(b0 + li) * AT_SP + s_], b, acc, 0, 0, 0);
+    }
+    if (li < hd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int l = b0 + at_i(r, lh);
+        if (l < L) dq[((size_t)l * N + n) * ldq + h * hd + li] = acc[r] * scale;
+      }
+    }
+  }
+  // ---- dK[s][d] = scale sum_l dS[l][s] Q[l][d] ----
+  if (b0 < S) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < lsteps; ++kk) {
+      const int l = 2 * kk + lh;
+      const float b = li < AT_HD ? sq[l * AT_HP + li] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sp[l * AT_SP + b0 + li], b, acc, 0, 0, 0);
+    }
+    if (li < hd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s_ = b0 + at_i(r, lh);
+        if (s_ < S) dk[((size_t)s_ * N + n) * ldk + h * hd + li] = acc[r] * scale;
+      }
+    }
+  }
+}
+static inline bool attn_use_mfma(int L, int S, int hd) {
+  static const int on = [] { const char* e = getenv("MMVAE_ATTN_MFMA"); return e ? atoi(e) : 1; }();
+  return on && hd <= AT_HD && (L > 64 || S > 64) && L <= 128 && S <= 128;
+}
+
 extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out,
                               float* probs, int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv,
                               int mask_is_valid, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
+  if (attn_use_mfma(L, S, hd)) {
+    hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L, S,
+                       N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
+    return mmvae_launch_status();
+  }
 #define ATT_FWD(AM, HD)                                                                                              \
   hipLaunchKernelGGL((attn_fwd_kernel<AM, HD>), dim3(N, H), dim3(AM), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, \
                      L, S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop))
@@ -374,6 +674,11 @@ extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, co
                               long ldv, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
+  if (attn_use_mfma(L, S, hd)) {
+    hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk,
+                       dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
+    return mmvae_launch_status();
+  }
 #define ATT_BWD(AM, HD)                                                                                              \
   hipLaunchKernelGGL((attn_bwd_kernel<AM, HD>), dim3(N, H), dim3(AM), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, \
                      dk, dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop))

@@ -558,6 +558,40 @@ def test_attention(ops, L, N, E, H_):
     check(qg.grad, qr.grad, 5e-5, "attn dqkv")
 
 
+@pytest.mark.parametrize("L,N,E,H_,p", [(100, 9, 32, 2, 0.1), (128, 3, 32, 2, 0.3), (65, 4, 24, 2, 0.1), (70, 2, 16, 4, 0.2),
+                                        (40, 5, 32, 2, 0.1), (100, 3, 64, 2, 0.1)])
+def test_attention_weight_dropout(ops, L, N, E, H_, p):
+    """attention with dropout on the softmax weights (nn.MultiheadAttention(dropout=p), the action towers' train mode)
+    against torch in fp64 using the very mask the kernel used (mmvae_dropout_mask, element ((n H + h) L + l) S + s):
+    the MFMA kernels (64 < L <= 128, head_dim <= 16, with head_dim 12 and 4 too) and the thread-per-row ones"""
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    g = torch.Generator().manual_seed(L * N + E)
+    qkv = torch.randn(L, N, 3 * E, generator=g)
+    lens = torch.randint(1, L + 1, (N,), generator=g)
+    lens[0] = L
+    kpm = torch.arange(L)[None, :] >= lens[:, None]
+    do = torch.randn(L, N, E, generator=g)
+    st = DropoutState().to(DEV)
+    slot, call = st.begin()
+    drop = st.spec(slot, call, 1, p, "attn")
+    mask = ops.dropout_mask(drop, N * H_ * L * L).double().view(N * H_, L, L)
+    qr = qkv.double().to(DEV).requires_grad_(True)
+    hd = E // H_
+    q, k, v = qr[..., :E], qr[..., E:2 * E], qr[..., 2 * E:]
+    q = q.reshape(L, N * H_, hd).transpose(0, 1) / math.sqrt(hd)
+    k = k.reshape(L, N * H_, hd).transpose(0, 1)
+    v = v.reshape(L, N * H_, hd).transpose(0, 1)
+    att = torch.bmm(q, k.transpose(1, 2)).reshape(N, H_, L, L).masked_fill(kpm.to(DEV)[:, None, None, :], float("-inf"))
+    att = F.softmax(att, -1).reshape(N * H_, L, L) * mask
+    ref = torch.bmm(att, v).transpose(0, 1).reshape(L, N, E)
+    ref.backward(do.double().to(DEV))
+    qg = qkv.to(DEV).requires_grad_(True)
+    out = ops.attention(qg, kpm.to(torch.uint8).to(DEV), H_, drop=drop)
+    out.backward(do.to(DEV))
+    check(out, ref, 2e-5, "attn out")
+    check(qg.grad, qr.grad, 5e-5, "attn dqkv")
+
+
 @pytest.mark.parametrize("L,N,d,bcast", [(5, 6, 54, False), (32, 128, 32, True), (1, 300, 8, False), (9, 7, 70, True)])
 def test_layernorm_residual(ops, L, N, d, bcast):
     g = torch.Generator().manual_seed(L + N + d)
