@@ -216,9 +216,30 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(mmvae_poe_fwd_args a, cons
 //   dmu_e = G_mu * T_e * varJ                                  + gk_e * mu_e / sp^2
 //   dlv_e = [G_mu (mu_e - muJ) varJ - G_var varJ^2] * (-exp(lv_e) T_e^2)  + gk_e * (lv_e / sp^2 - 1 / lv_e)
 //   dsp  += sum_j gk_j * (1 - (s_j^2 + mu_j^2) / sp^2) / sp
+// COHERENT: the partial rows were written by other workgroups of the SAME launch with agent-scope write-through stores
+// (poe_ws_store); read them with agent-scope loads that bypass the (per-XCD, non-coherent) L2
+template <bool COHERENT = false>
 __device__ __forceinline__ void poe_theta_body(const float* __restrict__ theta, const float* __restrict__ ws,
                                                float* __restrict__ dtheta, int nrows, int D, int accumulate,
                                                float (*part)[64 * POE_SLOTS]);
+__device__ __forceinline__ void poe_ws_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Last-workgroup election without __threadfence(): a release fence writes back -- and the matching acquire
+// invalidates -- the XCD's whole L2, under the feet of whatever else is running (the other tower's kernels share the
+// GPU with this launch).  The partial rows go out as agent-scope write-through stores; vmcnt(0) says they have
+// arrived; the ticket is a relaxed agent-scope atomic; the elected workgroup reads with agent-scope loads.
+__device__ __forceinline__ bool poe_last_workgroup(int* __restrict__ ticket, int* last_lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_lds = t == (int)gridDim.x - 1;
+    if (*last_lds) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return *last_lds != 0;
+}
 __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, const float* __restrict__ theta,
                                                       const float* __restrict__ dkl, float* __restrict__ ws, int E,
                                                       int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
@@ -326,33 +347,31 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
 #pragma unroll
   for (int s = 0; s < POE_SLOTS; ++s) {
     const int d = lane + 64 * s;
-    if (d < D) ws[(size_t)wave * D + d] = dsp[s];
+    if (d < D) {
+      if (ticket) poe_ws_store(ws + (size_t)wave * D + d, dsp[s]);
+      else ws[(size_t)wave * D + d] = dsp[s];
+    }
   }
   if (ticket) {
     // the prior-parameter gradient in the same launch: the last workgroup to finish folds every wave's partial row
     // (a second one-workgroup launch sat on the backward critical path between the fusion and the encoders)
     __shared__ float part[4][64 * POE_SLOTS];
     __shared__ int last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int t = atomicAdd(ticket, 1);
-      last = t == (int)gridDim.x - 1;
-      if (last) *ticket = 0;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    poe_theta_body(theta, ws, dtheta, nwaves, D, accumulate, part);
+    if (!poe_last_workgroup(ticket, &last)) return;
+    poe_theta_body<true>(theta, ws, dtheta, nwaves, D, accumulate, part);
   }
 }
 
 // dtheta_d (+)= D * s_d * (dsp_d - sum_k s_k dsp_k), dsp = sum over the per-wave partial rows.
 // 4 waves split the rows, 8 independent loads in flight per lane, LDS combine (D <= 256).
+template <bool COHERENT>
 __device__ __forceinline__ void poe_theta_body(const float* __restrict__ theta, const float* __restrict__ ws,
                                                float* __restrict__ dtheta, int nrows, int D, int accumulate,
                                                float (*part)[64 * POE_SLOTS]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto ld = [&](size_t i) -> float {
+    return COHERENT ? __hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ws[i];
+  };
 #pragma unroll
   for (int s = 0; s < POE_SLOTS; ++s) {
     const int d = lane + 64 * s;
@@ -362,11 +381,11 @@ __device__ __forceinline__ void poe_theta_body(const float* __restrict__ theta, 
       for (; r + 28 < nrows; r += 32) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(r + 4 * u) * D + d];
+        for (int u = 0; u < 8; ++u) v[u] = ld((size_t)(r + 4 * u) * D + d);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
       }
-      for (; r < nrows; r += 4) acc += ws[(size_t)r * D + d];
+      for (; r < nrows; r += 4) acc += ld((size_t)r * D + d);
     }
     part[wave][d] = acc;
   }
@@ -591,21 +610,15 @@ __global__ __launch_bounds__(256) void poe_bwd_fast_kernel(mmvae_poe_bwd_args a,
       if (live) a.dlv[e][oi] = dlv[e];
     }
   }
-  if (live) ws[(size_t)wave * D + lane] = dsp;
+  if (live) {
+    if (ticket) poe_ws_store(ws + (size_t)wave * D + lane, dsp);
+    else ws[(size_t)wave * D + lane] = dsp;
+  }
   if (ticket) {
     __shared__ float part[4][64 * POE_SLOTS];
     __shared__ int last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int t = atomicAdd(ticket, 1);
-      last = t == (int)gridDim.x - 1;
-      if (last) *ticket = 0;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    poe_theta_body(theta, ws, dtheta, nwaves, D, accumulate, part);
+    if (!poe_last_workgroup(ticket, &last)) return;
+    poe_theta_body<true>(theta, ws, dtheta, nwaves, D, accumulate, part);
   }
 }
 
