@@ -814,7 +814,8 @@ def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
 @pytest.mark.parametrize("dec,L,N,d,train", [(False, 32, 128, 54, False), (False, 32, 16, 54, True), (False, 5, 6, 54, True),
                                              (True, 32, 128, 32, False), (True, 32, 16, 32, True), (True, 9, 7, 32, True),
                                              (False, 6, 5, 32, True), (True, 6, 5, 54, True),
-                                             (False, 32, 128, 54, "mean"), (False, 7, 6, 54, "mean")])
+                                             (False, 32, 128, 54, "mean"), (False, 7, 6, 54, "mean"),
+                                             (True, 8, 32, 16, True), (True, 5, 3, 16, False)])
 def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
     """csrc/txtlayer.hip (one launch per layer and direction) against the op-by-op kernels (each checked against
     torch above): outputs, input gradients and every parameter gradient, with identical dropout masks."""
