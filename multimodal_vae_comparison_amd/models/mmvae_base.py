@@ -110,6 +110,27 @@ class TorchMMVAE(nn.Module):
         # actions on their own streams) crashes ROCm 7.2's hipGraphInstantiate (segmentation fault inside capture_end;
         # two branches and the eager three-stream path are fine) -- the towers beyond the first two share a stream
         max_side = int(os.environ.get("MMVAE_MAX_SIDE_STREAMS", "1"))
+        explicit = os.environ.get("MMVAE_TOWER_STREAMS")         # tuning knob, e.g. "0,0,1": stream index per tower
+        if explicit:
+            idx = [int(t) for t in explicit.split(",")]
+            assert len(idx) == len(names) and all(0 <= t <= max_side for t in idx)
+            out = []
+            for t in idx:
+                if t == 0:
+                    out.append(None)
+                else:
+                    s = ops.StreamPlan.get(f"tower{t}", device)
+                    ops.GradReducer.note_stream(device, s)
+                    out.append(s)
+            return out
+        if len(names) >= 3 and max_side == 1:
+            # two streams for three or more towers: the tower with the longest launch chain (number of sub-modules as the
+            # proxy: the 8 + 4-layer action Transformers, a ResNet-50) gets the side stream to itself, the others share
+            # the capture stream (BASELINE configs[4]: 4.48 vs 4.68 ms/step with text + actions sharing the side stream)
+            heavy = max(range(len(names)), key=lambda i: sum(1 for _ in self.vaes[names[i]].modules()))
+            s = ops.StreamPlan.get("tower1", device)
+            ops.GradReducer.note_stream(device, s)
+            return [s if i == heavy else None for i in range(len(names))]
         out, side = [], 0
         for i in range(len(names)):
             if i == main % len(names):
