@@ -84,7 +84,8 @@ int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L, int N, int
  * The dropout mask of hidden element (row, col) is that of mmvae_dropout_act_fwd at index row*FF + col (drop NULL or
  * p == 0: none).  Backward recomputes the hidden tiles: dx (M,32; may be NULL) and mmvae_ffn32_bwd_parts(M, FF) partial
  * rows of mmvae_ffn32_bwd_rowlen(FF) floats in ws, each [dW1 (FF,32) | db1 (FF) | dW2 (32,FF) | db2 (32)], to be summed
- * by the caller (mmvae_reduce_rows / mmvae_reduce_segments). */
+ * by the caller (mmvae_reduce_rows / mmvae_reduce_segments).  ws may be NULL too (data gradient only): the data- and
+ * the weight-gradient launch are independent and may go to different streams. */
 int mmvae_ffn32_supported(int d_model, int FF);
 int mmvae_ffn32_bwd_parts(int M, int FF);
 size_t mmvae_ffn32_bwd_rowlen(int FF);

@@ -261,17 +261,18 @@ extern "C" int mmvae_ffn32_fwd(const float* x, const float* w1, const float* b1,
 }
 // dx (M x 32) and the partial rows of the weight / bias gradients: mmvae_ffn32_bwd_parts(M, FF) rows of
 // mmvae_ffn32_bwd_rowlen(FF) floats in ws, each [dW1 (FF,32) | db1 (FF) | dW2 (32,FF) | db2 (32)]; every element of
-// every row is written.  dx may be NULL (no data gradient wanted).
+// every row is written.  dx may be NULL (no data gradient wanted) and so may ws (data gradient only): the two launches are
+// independent, a caller can put them on different streams.
 extern "C" int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2,
                                float* dx, float* ws, int M, int FF, const mmvae_dropout_t* drop,
                                mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(x && dy && w1 && b1 && w2 && ws && M > 0);
+  MMVAE_CHECK_ARG(x && dy && w1 && b1 && w2 && (ws || dx) && M > 0);
   if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
   if (!ffn_al16(x) || !ffn_al16(dy) || !ffn_al16(w1) || !ffn_al16(b1)) return MMVAE_ERR_ARG;
   const int S = ffn_slices(M, FF);
   int rps = ((M + S - 1) / S + 31) / 32 * 32;
   FfnArgs a{x, dy, w1, b1, w2, nullptr, nullptr, dx, ws, M, FF, rps, (int)mmvae_ffn32_bwd_rowlen(FF), drop_arg(drop)};
   if (dx) hipLaunchKernelGGL(ffn32_bwd_data_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(ffn32_bwd_weight_kernel, dim3((FF / 32 + 3) / 4, S), dim3(256), 0, (hipStream_t)stream, a);
+  if (ws) hipLaunchKernelGGL(ffn32_bwd_weight_kernel, dim3((FF / 32 + 3) / 4, S), dim3(256), 0, (hipStream_t)stream, a);
   return mmvae_launch_status();
 }

@@ -104,8 +104,12 @@ class TorchMMVAE(nn.Module):
         """stream per modality: modality `main` stays on the current stream (None), the others get side streams
         (ops.StreamPlan) so that independent towers overlap -- each of them alone cannot fill the chip at batch 128"""
         names = list(self.vaes.keys())
+        key = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0)
+        ops.StreamPlan.pair.pop(key, None)
         if not (ops.StreamPlan.enabled and device.type == "cuda") or len(names) < 2:
             return [None] * len(names)
+        # (the two streams of this step, for ops that park weight-gradient launches on the stream they are NOT on)
+        ops.StreamPlan.pair[key] = (torch.cuda.current_stream(device), ops.StreamPlan.get("tower1", device))
         # ONE side stream however many towers there are: a captured step with three parallel branches (image, text,
         # actions on their own streams) crashes ROCm 7.2's hipGraphInstantiate (segmentation fault inside capture_end;
         # two branches and the eager three-stream path are fine) -- the towers beyond the first two share a stream

@@ -245,6 +245,24 @@ class StreamPlan:
             cls._streams[key] = s
         return s
 
+    pair = {}      # device key -> (capture stream, tower side stream) of the step being built (mixers set / clear it)
+
+    @classmethod
+    def other_stream(cls, device):
+        """the step's stream that is NOT the current one (None outside a two-stream step or when switched off)"""
+        if os.environ.get("MMVAE_WGRAD_OTHER_STREAM", "1") != "1":
+            return None
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        pr = cls.pair.get(key)
+        if not pr:
+            return None
+        cur = torch.cuda.current_stream(device)
+        if cur == pr[0]:
+            return pr[1]
+        if cur == pr[1]:
+            return pr[0]
+        return None
+
     @classmethod
     def fork(cls, kind, device):
         """side stream that has waited for everything enqueued so far on the current stream"""
@@ -2054,8 +2072,27 @@ class Ffn32(Function):
         defer = _defer(gw1, gb1, gw2, gb2)
         ws = GradReducer.alloc(parts * rowlen, x.device) if defer else torch.empty(parts * rowlen, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(dx), H.ptr(ws), M, FF,
-              drop.c() if drop else None, H.stream())
+        dc = drop.c() if drop else None
+        other = StreamPlan.other_stream(x.device) if (dx is not None and defer and M * FF >= (1 << 20)) else None
+        if other is not None:
+            # the weight-gradient launch (nothing but the end-of-backward fold reads it) goes to the step's OTHER stream,
+            # which idles while a long tower's chain runs on this one; only dy and x have to exist, not the data gradient
+            cur = torch.cuda.current_stream(x.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(dx), None, M, FF, dc,
+                  H.stream())
+            other.wait_event(ev)
+            with torch.cuda.stream(other):
+                _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), None, H.ptr(ws), M, FF, dc,
+                      H.stream())
+            for t in (x, dy):
+                t.record_stream(other)
+            GradReducer.keep(x.device, x, dy)
+            GradReducer.note_stream(x.device, other)
+        else:
+            _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(dx), H.ptr(ws), M, FF, dc,
+                  H.stream())
         offs = (0, 32 * FF, 32 * FF + FF, 64 * FF + FF)
         lens = (32 * FF, FF, 32 * FF, 32)
         rets = [None, None, None, None]
