@@ -22,14 +22,17 @@ __global__ __launch_bounds__(256) void conv2d_bwd_fused_kernel(ConvScatterArgs a
   MMVAE_TRACE_STAMP(10 + G::LGH);
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
   if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
-  else conv_scatter_body<G>(ad, blockIdx.x - n_w, smem);
+  else   // (the data-gradient tiles XCD-contiguous, see xcd_contiguous: needs the body's first workgroup on XCD 0)
+    conv_scatter_body<G>(ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w), smem);
 }
 template <typename G, typename W>
 __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
   MMVAE_TRACE_STAMP(14 - G::LGH);
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
   if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
-  else conv_gather_body<G, G::RWONLY>(ad, blockIdx.x - n_w, smem);
+  else
+    conv_gather_body<G, G::RWONLY>(ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w),
+                                   smem);
 }
 
 // 32-channel weight gradients: 8-channel chunks (4 x splits workgroups) when 16-channel chunks would leave the chip

@@ -54,3 +54,14 @@ __host__ __device__ __forceinline__ bool conv_ep_supported(int ep) {
   return ep == MMVAE_EP_NONE || ep == MMVAE_EP_RELU || ep == MMVAE_EP_MUL_RELU_MASK || ep == MMVAE_EP_MUL_SILU_GRAD ||
          ep == MMVAE_EP_SIGMOID_CLAMP || ep == MMVAE_EP_SIGMOID;
 }
+
+// Workgroups are handed to the 8 XCDs round robin (physical id p runs on XCD p % 8, each with its own L2).  Consecutive
+// tiles share two of their ten staged input rows (and the four tiles of an image all of them, one row apart): the remap
+// gives every XCD a CONTIGUOUS eighth of the tiles, so a halo row is an L2 hit instead of a second HBM fetch.
+__device__ __forceinline__ int xcd_contiguous(unsigned p, unsigned n) {
+#ifdef MMVAE_NO_XCD_REMAP
+  return (int)p;
+#else
+  return (n & 7u) ? (int)p : (int)((p & 7u) * (n >> 3) + (p >> 3));
+#endif
+}

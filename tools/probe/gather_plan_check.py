@@ -8,7 +8,7 @@ from gtime import timeit
 from multimodal_vae_comparison_amd import hipops as H
 L = H.lib()
 plan = int(os.environ.get("MMVAE_GATHER_PLAN", "-1"))
-for B, Hin in ((128, 32), (128, 16), (97, 32)):
+for B, Hin in ((128, 32), (128, 16), (97, 32), (512, 32), (2048, 32)):
     g = torch.Generator().manual_seed(B)
     x = torch.randn(B, 32, Hin, Hin, generator=g).cuda(); w = (torch.randn(32, 32, 4, 4, generator=g) * .05).cuda()
     b = torch.randn(32, generator=g).cuda(); y = torch.empty(B, 32, Hin // 2, Hin // 2, device="cuda")
