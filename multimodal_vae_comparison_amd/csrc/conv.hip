@@ -37,9 +37,14 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
 
 // 32-channel weight gradients: 8-channel chunks (4 x splits workgroups) when 16-channel chunks would leave the chip
 // half empty.  MMVAE_WGRAD_QC = 16 | 8 forces one (tuning knob).
-static inline bool wgrad_qc8(int nsplit) {
+// (Round 2, in the step: with at most 8 macro tiles per split -- batch <= 128 on the 32-wide maps -- the 16-channel
+// chunks win, 0.4162 vs 0.4231 ms/step over three pairs: half as many weight-gradient workgroups beside the data-gradient
+// ones and the text tower's; with longer splits -- batch 256: 1.27 vs 1.33 ms -- the 8-channel chunks keep the
+// weight-gradient body from becoming the launch's long pole.)
+static inline bool wgrad_qc8(int nsplit, int n_macro) {
   static const int forced = getenv("MMVAE_WGRAD_QC") ? atoi(getenv("MMVAE_WGRAD_QC")) : 0;
   if (forced) return forced == 8;
+  if (n_macro <= 8 * nsplit) return false;
   return nsplit * 2 < 256;
 }
 
@@ -81,7 +86,7 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
     using G = decltype(g);
     if constexpr (G::LGH <= 4) {
       const int n_d = (int)scatter_grid(B, Hout, G::TM);
-      if (wgrad_qc8(nsplit)) {
+      if (wgrad_qc8(nsplit, n_macro)) {
         using W = WgradGeom<32, G::LGH, 8>;
         const int n_w = nsplit * W::NCH;
         hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
@@ -123,7 +128,7 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
     using G = decltype(g);
     if constexpr (G::LGH >= 3 && (G::CIN == 32 || G::LGH == 6)) {
       const int n_d = (int)gather_grid(B, Hin, G::TM);    // (weight gradient: small map = the gather's output map)
-      if (G::CIN == 32 && wgrad_qc8(nsplit)) {
+      if (G::CIN == 32 && wgrad_qc8(nsplit, n_macro)) {
         using W = WgradGeom<G::CIN, G::LGH - 1, G::CIN == 32 ? 8 : WGRAD_QC_DEFAULT(G::CIN)>;
         const int n_w = nsplit * W::NCH;
         hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
