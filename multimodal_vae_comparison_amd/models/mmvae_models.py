@@ -355,7 +355,8 @@ class POE(TorchMMVAE):
 class MOE(TorchMMVAE):
     """MMVAE, mixture of experts (mmvae_models.py:10-131): objective "elbo" with K = 1 and "dreg"
     with any K on towers that keep the K axis (the shipped configs/config_mnistsvhn.yml: MNIST / SVHN towers, K = 30,
-    `prior: laplace`).  `iwae` crashes in the reference; elbo with K > 1 fails there too.
+    `prior: laplace`).  `iwae` crashes in the reference: its intended formula is built on the same forward (parity
+    unpinned, MultimodalObjective.iwae); elbo with K > 1 fails there too.
 
     q_m = Normal | Laplace(mu_m, scale = lv_m) -- the config's `prior` key also names the posterior and the likelihood
     family (models/trainer.py:104) --, K samples z_m per modality; every modality is decoded from its own z
@@ -371,13 +372,13 @@ class MOE(TorchMMVAE):
         self.model_config = model_config
         self.modelName = "moe"
         obj = self.obj_fn.obj_name
-        if obj == "iwae":
-            self.obj_fn.iwae(None)                                # raises: the reference's iwae crashes
+        if obj == "iwae" and float(self.obj_fn.beta) != 1.0:
+            self.obj_fn.iwae(None)                                # raises: beta = 1 only
         if obj == "elbo" and self.K != 1:
             raise NotImplementedError("moe: obj elbo with K > 1 fails in the reference (mmvae_models.py:62); use dreg")
-        if obj == "dreg" and len(self.vaes) != 2:
-            raise NotImplementedError("moe dreg: the reference's cross-term indexing (mmvae_models.py:64-70) is only "
-                                      "meaningful for two modalities")
+        if obj in ("dreg", "iwae") and len(self.vaes) != 2:
+            raise NotImplementedError("moe dreg / iwae: the reference's cross-term indexing (mmvae_models.py:64-70) is "
+                                      "only meaningful for two modalities")
         for vae in self.vaes.values():
             if vae.prior_str not in ("normal", "gaussian", "laplace"):
                 raise NotImplementedError(f"prior: {vae.prior_str} is not on the MI355X path (normal, laplace are)")
@@ -396,7 +397,7 @@ class MOE(TorchMMVAE):
 
     def objective(self, data):
         """mmvae_models.py:32-78"""
-        if self.obj_fn.obj_name == "dreg":
+        if self.obj_fn.obj_name in ("dreg", "iwae"):        # same forward; the objective differs (objectives.py)
             return self._objective_dreg(data)
         self._begin_step()
         names = list(self.vaes.keys())

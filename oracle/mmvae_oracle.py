@@ -846,6 +846,38 @@ def moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior="normal", train=
             "_lw": lw, "_z": zs, "_enc": enc}
 
 
+def moe_iwae_objective(p, mods, batch, eps, n_latents, K, prior="normal", train=False):
+    """MultimodalObjective.iwae (models/objectives.py:342-359) as INTENDED -- PARITY UNPINNED: the reference's own code
+    crashes (`.cuda()` on a list at :353; (K,) reconstruction sums reshaped to (K,B) at :356), so this restates the
+    formula its lines spell, on the same forward as dreg (moe_dreg_objective) with the reconstruction terms kept per
+    sample:  lw_r[k,b] = log p(z_r) + lpx_own_r[k,b] + lpx_cross_r[k,b] - beta log-mean-exp_m log q_m(z_r);
+    loss = - sum_b log-mean-exp over cat_r(lw_r) (dim 0: the M K weights of sample b)."""
+    d = moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior, train)
+    M = len(mods)
+    lap = prior == "laplace"
+    logq = laplace_log_prob if lap else normal_log_prob
+    enc, zs = d["_enc"], d["_z"]
+    lam = resolve_llik_scaling(mods)
+    sig_p = prior_sigma(p["_pz_params.1"])
+    lws, recs = [], []
+    for r in range(M):
+        o = 1 - r
+        tgt = batch[f"mod_{r + 1}"]["data"]
+        own = decode(p, mods, r, zs[r], None, train)
+        cross = decode(p, mods, r, zs[o], None, train)
+        Bn = zs[r].shape[1]
+        lpx_own = -recon_lprob_k(own, tgt, K, False).reshape(K, Bn, -1).sum(-1) * lam[r]       # (K,B)
+        lpx_cross = -recon_lprob_k(cross, tgt, K, lap).reshape(K, Bn, -1).sum(-1) * lam[r]
+        lpz = normal_log_prob(zs[r], 0.0, sig_p).sum(-1)
+        lq = torch.stack([logq(zs[r], enc[m][0], enc[m][1]).sum(-1) for m in range(M)])
+        lqz = torch.logsumexp(lq, 0) - math.log(M)
+        lws.append(lpz + lpx_own + lpx_cross - lqz)
+        recs.append(torch.stack([lpx_own.sum(-1), lpx_cross.sum(-1)]))
+    lw = torch.cat(lws).double()                                                               # (M K, B)
+    loss = -(torch.logsumexp(lw, 0) - math.log(lw.shape[0])).sum()
+    return {"loss": loss, "kld": torch.tensor(0), "reconstruction_loss": torch.stack(recs), "_lw": lw}
+
+
 def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, obj="elbo", K=1, prior="normal"):
     """MOE.forward + objective (obj "elbo", K = 1), models/mmvae_models.py:32-117.
 
@@ -856,6 +888,8 @@ def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, obj="el
     """
     if obj == "dreg":
         return moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior, train)
+    if obj == "iwae":
+        return moe_iwae_objective(p, mods, batch, eps, n_latents, K, prior, train)
     assert obj == "elbo" and K == 1
     M = len(mods)
     lap = prior == "laplace"      # posterior Laplace(mu, scale = lv), cross likelihood Laplace, KL(Laplace || N(0,1))
