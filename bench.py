@@ -377,10 +377,6 @@ def extras(tr, a, dev, barrier):
         tr.load_batch_compact(host[it["i"] & 3])
         it["i"] += 1
 
-    def feed_prefetched():          # batch i was copied under step i-1; expand it, start copying batch i+1
-        tr.commit_prefetched()
-        it["i"] += 1
-        tr.prefetch_compact(host[it["i"] & 3])
     steps = max(20, a.steps // 2)
     dt, _ = _timed(tr, steps, 25, 1, barrier, pre=feed)     # (25 warm-up steps: stream / staging-buffer set-up is one-time)
     out["with_input_pipeline_serial"] = {"value": round(steps * B / dt, 1), "unit": "samples/s",
@@ -388,13 +384,20 @@ def extras(tr, a, dev, barrier):
                                          "what": "pinned uint8 image + int32 token batch (1.6 MB) H2D, device expansion, "
                                                  "captured step, one after the other on one stream, every step"}
     host = [tr.pack_compact_pinned(h) for h in host]      # one pinned buffer, one H2D copy per batch
-    tr.prefetch_compact(host[0])
-    dt, _ = _timed(tr, steps, 25, 1, barrier, pre=feed_prefetched)
+    pipe = tr.input_pipe(host[0])
+
+    def feed_pipe():                # expand batch i (copied under step i-1), start copying batch i+1: one library call
+        it["i"] += 1
+        pipe.step(host[it["i"] & 3])
+    pipe.prefetch(host[0])
+    dt, _ = _timed(tr, steps, 25, 1, barrier, pre=feed_pipe)
+    pipe.close()
     out["with_input_pipeline"] = {"value": round(steps * B / dt, 1), "unit": "samples/s",
                                   "ms_per_step": round(1e3 * dt / steps, 4),
                                   "what": "a fresh compact batch every step: ONE H2D copy of batch i+1 (packed pinned "
-                                          "buffer) on a copy stream under step i (MultimodalVAE.prefetch_compact), "
-                                          "device expansion + captured step on the main stream"}
+                                          "buffer) on a copy stream under step i, device expansion + captured step on "
+                                          "the main stream; the input step is one native call (csrc/input_pipe.hip, "
+                                          "MultimodalVAE.input_pipe)"}
     lb = {}
     for Bl in (512, 1000):
         t2, _, meta = _build("cfg2", Bl, dev, 0, 1, 1)

@@ -180,6 +180,18 @@ int mmvae_linear_bwd_data(const float* dy, const float* w, const float* aux, flo
 int mmvae_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, float* ws, int M, int N, int K,
                             long ldx, int x_act, int accumulate, mmvae_stream_t stream);
 size_t mmvae_linear_bwd_weight_ws_floats(int M, int N, int K);
+/* Several independent weight gradients (the (L*N)-row ones a fused text layer leaves behind) in ONE launch: every
+ * job gets exactly the tiling / split plan / partial layout of mmvae_linear_bwd_weight, so results are bit-identical to
+ * n_jobs separate calls -- which is also what happens when a job falls outside the shared-grid regime (the
+ * register-operand body; split jobs need accumulate == MMVAE_ACC_DEFER) or n_jobs > MMVAE_WGRAD_BATCH_MAX.
+ * Replaces the autograd-generated per-Linear weight-gradient matmuls of nn.TransformerEncoderLayer /
+ * nn.TransformerDecoderLayer.backward (reference models/encoders.py:818-824, models/decoders.py:698-704). */
+#define MMVAE_WGRAD_BATCH_MAX 8
+typedef struct {
+  const float* dy; const float* x; float* dw; float* db; float* ws;
+  int M, N, K; long ldx; int x_act, accumulate;
+} mmvae_wgrad_job_t;
+int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int n_jobs, mmvae_stream_t stream);
 /* both of the above in one grouped launch: dx = ep(dy W), dW (+)= dy^T act(x), db (+)= colsum(dy) */
 int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const float* aux, float* dx, float* dw,
                      float* db, float* ws, int M, int N, int K, long ldx, int x_act, int ep_mode, int accumulate,
@@ -527,6 +539,32 @@ int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float*
 int mmvae_expand_image_u8(const uint8_t* src, float* dst, long n, mmvae_stream_t stream);
 int mmvae_expand_text_tokens(const int32_t* tokens, const int32_t* lengths, float* onehot, uint8_t* mask, int B, int T,
                              int V, mmvae_stream_t stream);
+
+/* The input step as a native pipe: a packed pinned host batch (every tensor a 16-byte aligned slice of one buffer) is
+ * copied with ONE H2D transfer on the pipe's own copy stream into `staging` (device, `bytes` long, owned by the
+ * caller), under the step that is running; mmvae_input_pipe_commit then, on `stream`: waits for that copy, expands
+ * every modality into the step's static inputs (the two functions above), marks the staging buffer consumed and --
+ * `next_host_packed` != NULL -- starts the copy of the following batch behind that.  One call per step.
+ * Replaces, on the caller side of the path, the reference's per-step DataLoader -> device transfer of fp32 images and
+ * one-hot text (models/dataloader.py:120-126; tensors built by models/datasets.py:251-254, :272-281). */
+#define MMVAE_INPUT_MAX_MODS 8
+#define MMVAE_INPUT_IMAGE_U8 0
+#define MMVAE_INPUT_TEXT_TOKENS 1
+typedef struct mmvae_input_pipe mmvae_input_pipe_t;
+typedef struct {
+  int kind;         /* MMVAE_INPUT_IMAGE_U8 | MMVAE_INPUT_TEXT_TOKENS */
+  size_t src_off;   /* byte offset in the packed batch: uint8 pixels | (B,T) int32 tokens */
+  size_t len_off;   /* text: byte offset of the (B) int32 lengths */
+  float* dst;       /* fp32 image (n values) | one-hot (B,T,V) */
+  uint8_t* mask;    /* text: (B,T) bytes or NULL */
+  long n;           /* image: number of pixel values */
+  int B, T, V;      /* text */
+} mmvae_input_mod_t;
+int mmvae_input_pipe_create(mmvae_input_pipe_t** out, void* staging, size_t bytes);
+int mmvae_input_pipe_destroy(mmvae_input_pipe_t* pipe);
+int mmvae_input_pipe_prefetch(mmvae_input_pipe_t* pipe, const void* host_packed);
+int mmvae_input_pipe_commit(mmvae_input_pipe_t* pipe, const mmvae_input_mod_t* mods, int n_mods,
+                            const void* next_host_packed, mmvae_stream_t stream);
 
 /* y[t,b,:] = dropout(x[t,b,:] + pe[t,:]) -- Enc_Transformer / Dec_Transformer positional encoding
  * (models/encoders.py:721-723, models/decoders.py:607-608; PositionalEncoding try-branch nn_modules.py:430-438).

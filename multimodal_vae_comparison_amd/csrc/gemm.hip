@@ -896,6 +896,85 @@ extern "C" int mmvae_linear_bwd_weight(const float* dy, const float* x, float* d
                         MMVAE_EP_NONE, accumulate, sk, stream);
 }
 
+// ---- several weight gradients in ONE launch ------------------------------------------------------------------
+// The text towers' fused layer leaves 4 (encoder) or 6 (decoder) independent (L*N)-row weight gradients behind it,
+// each a handful of 32x32 tiles times its split count: 32 .. 128 workgroups and 6 - 16 us apiece when launched one
+// after the other.  Here every job keeps the tiling, split plan and partial layout mmvae_linear_bwd_weight would
+// give it (bit-identical results) and the workgroups of all jobs share one grid.
+struct GemmBatch {
+  GemmArgs g[MMVAE_WGRAD_BATCH_MAX];
+  int blk0[MMVAE_WGRAD_BATCH_MAX + 1];
+  int nx[MMVAE_WGRAD_BATCH_MAX], ny[MMVAE_WGRAD_BATCH_MAX], nz[MMVAE_WGRAD_BATCH_MAX];
+  unsigned deep;   // bit p: job p reduces in 64-deep slices
+  int n;
+};
+__global__ __launch_bounds__(512) void rgemm_batch_kernel(GemmBatch bt) {
+  __shared__ float red[8 * 16 * 64];
+  __shared__ float rsr[8 * 32];
+  int p = 0;
+  for (int q = 1; q < bt.n; ++q) p = ((int)blockIdx.x >= bt.blk0[q]) ? q : p;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const int local = blockIdx.x - bt.blk0[p];
+  const int bx = local % bt.nx[p], t = local / bt.nx[p];
+  const int by = t % bt.ny[p], bz = t / bt.ny[p];
+  const GemmArgs g = bt.g[p];
+  if (bt.deep >> p & 1u) rgemm_body<64, false, false>(g, bx, by, bz, bt.nz[p], red, rsr);
+  else rgemm_body<16, false, false>(g, bx, by, bz, bt.nz[p], red, rsr);
+}
+
+// fills `g` / grid of one job when it runs on the register-operand body with m-major dy and n-major x; false otherwise
+static bool wgrad_batch_plan(const mmvae_wgrad_job_t& j, GemmArgs& g, int& nx, int& ny, int& nz, bool& deep) {
+  if (!j.dy || !j.x || !j.dw || j.M <= 0 || j.N <= 0 || j.K <= 0) return false;
+  const int sk = wgrad_splitk(j.M, j.N, j.K);
+  // gemm problem: rows N, cols K, reduction M
+  g.A = j.dy; g.B = j.x; g.bias = nullptr; g.aux = nullptr; g.C = j.dw; g.a_rowsum = j.db; g.ws = j.ws;
+  g.M = j.N; g.N = j.K; g.K = j.M; g.sam = 1; g.sak = j.N; g.sbk = j.ldx; g.sbn = 1; g.ldc = j.K;
+  g.a_act = MMVAE_ACT_NONE; g.b_act = j.x_act; g.ep = MMVAE_EP_NONE; g.accumulate = j.accumulate ? 1 : 0;
+  int variant, kper;
+  nz = gemm_split_plan(g.M, g.N, g.K, sk, &variant, &kper);
+  g.kper = kper;
+  if (nz > 1 && !j.ws) return false;
+  if (gemm_big_bn(g, nz, false, false)) return false;
+  nx = (g.N + 31) / 32; ny = (g.M + 31) / 32;
+  const long tiles32 = (long)nx * ny;
+  static const bool rsplit = !(getenv("MMVAE_RGEMM_SPLIT") && atoi(getenv("MMVAE_RGEMM_SPLIT")) == 0);
+  if (!rgemm_enabled()) return false;
+  if (nz > 1) {
+    if (!(rsplit && tiles32 <= 64 && kper <= 1024 && j.accumulate == MMVAE_ACC_DEFER)) return false;
+    deep = rgemm_depth(kper) == 64;
+    return true;
+  }
+  // one split: mmvae_gemm_f32 takes the same body unless it prefers 16 x 16 tiles (no row sums asked for)
+  if (!(sk == 1 && tiles32 <= 1024 && g.K <= 1024) || (tiles32 <= 128 && !j.db)) return false;
+  g.kper = g.K;
+  deep = rgemm_depth(g.K) == 64;
+  return true;
+}
+
+extern "C" int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int n_jobs, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(jobs && n_jobs > 0);
+  bool ok = n_jobs >= 2 && n_jobs <= MMVAE_WGRAD_BATCH_MAX;
+  GemmBatch bt;
+  bt.deep = 0; bt.n = n_jobs; bt.blk0[0] = 0;
+  for (int p = 0; ok && p < n_jobs; ++p) {
+    bool deep = false;
+    ok = wgrad_batch_plan(jobs[p], bt.g[p], bt.nx[p], bt.ny[p], bt.nz[p], deep);
+    if (!ok) break;
+    if (deep) bt.deep |= 1u << p;
+    bt.blk0[p + 1] = bt.blk0[p] + bt.nx[p] * bt.ny[p] * bt.nz[p];
+  }
+  if (!ok) {   // any job outside that regime: one launch per job, as before
+    for (int p = 0; p < n_jobs; ++p) {
+      const mmvae_wgrad_job_t& j = jobs[p];
+      const int rc = mmvae_linear_bwd_weight(j.dy, j.x, j.dw, j.db, j.ws, j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate, stream);
+      if (rc) return rc;
+    }
+    return MMVAE_OK;
+  }
+  hipLaunchKernelGGL(rgemm_batch_kernel, dim3(bt.blk0[n_jobs]), dim3(512), 0, (hipStream_t)stream, bt);
+  return mmvae_launch_status();
+}
+
 // Fused nn.Linear backward: dx = ep(dy W) and dW (+)= dy^T act(x), db (+)= colsum(dy) in ONE grouped launch.
 // Falls back to two launches when either problem wants a different tiling.
 static inline bool linear_bwd_rgemm(int M, int N) { return rgemm_enabled() && M <= 256 && (N & 3) == 0 && N >= 4; }

@@ -86,6 +86,11 @@ SIGNATURES = {
     "mmvae_linear_bwd_data": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
     "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_linear_bwd_weight_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_linear_bwd_weight_batch": (c_i, [c_p, c_i, c_p]),
+    "mmvae_input_pipe_create": (c_i, [c_p, c_p, c_sz]),
+    "mmvae_input_pipe_destroy": (c_i, [c_p]),
+    "mmvae_input_pipe_prefetch": (c_i, [c_p, c_p]),
+    "mmvae_input_pipe_commit": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "mmvae_linear_bwd": (c_i, [c_p] * 8 + [c_i] * 3 + [c_l] + [c_i] * 3 + [c_p]),
     "mmvae_linear_bwd_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_head_softmax_fwd": (c_i, [c_p, c_i, c_i, c_p]),
@@ -203,6 +208,23 @@ class RowPtrs(ctypes.Structure):
 
 class GPtrs(ctypes.Structure):
     _fields_ = [("g", c_p * 4)]
+
+
+INPUT_MAX_MODS = 8
+INPUT_IMAGE_U8, INPUT_TEXT_TOKENS = 0, 1
+
+
+class InputMod(ctypes.Structure):
+    _fields_ = [("kind", c_i), ("src_off", c_sz), ("len_off", c_sz), ("dst", c_p), ("mask", c_p), ("n", c_l),
+                ("B", c_i), ("T", c_i), ("V", c_i)]
+
+
+WGRAD_BATCH_MAX = 8
+
+
+class WgradJob(ctypes.Structure):
+    _fields_ = [("dy", c_p), ("x", c_p), ("dw", c_p), ("db", c_p), ("ws", c_p), ("M", c_i), ("N", c_i), ("K", c_i),
+                ("ldx", c_l), ("x_act", c_i), ("accumulate", c_i)]
 
 
 class TxtLayerW(ctypes.Structure):

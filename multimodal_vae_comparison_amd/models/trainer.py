@@ -3,6 +3,7 @@ dependency: `get_model`, `training_step(batch, idx) -> loss`, `configure_optimiz
 drive it unchanged (nn.Module + the same hook names); `fused_step()` is the MI355X fast path used by bench.py:
 forward + backward of the whole objective replayed from ONE hipGraph, optional RCCL all-reduce of the flat
 gradient buffer, ONE fused Adam kernel."""
+import ctypes
 import os
 
 import torch
@@ -276,6 +277,12 @@ class MultimodalVAE(nn.Module):
         out["_packed"] = buf
         return out
 
+    def input_pipe(self, packed):
+        """The native form of prefetch_compact / commit_prefetched for batches made by `pack_compact_pinned` (all of
+        one layout, given by `packed`): InputPipe.prefetch(batch0) once, then InputPipe.step(next_batch) before every
+        replay -- ONE library call per step (csrc/input_pipe.hip)."""
+        return InputPipe(self, packed)
+
     def prefetch_compact(self, compact):
         """Start the host -> device copy of the NEXT batch (compact host format, pinned tensors) on a copy stream into
         staging buffers; it runs under the current step.  `commit_prefetched()` then expands the staged bytes into the
@@ -348,3 +355,74 @@ class MultimodalVAE(nn.Module):
         # ONE RCCL collective over the flat gradient buffer, then the Adam kernel with the 1/world mean folded in
         parallel.reduce_gradients_and_step(self.flat.grad, self.optimizer, self.dp_world, None, self.dp_force_collective)
         return self._static_out
+
+
+
+class InputPipe:
+    """Host side of csrc/input_pipe.hip: the packed pinned batch -> (copy stream) staging -> static inputs of the
+    captured step.  `step(next)` = wait for the staged batch, expand it, start copying `next` (or nothing for None)."""
+
+    def __init__(self, trainer, packed):
+        self._H = H
+        buf = packed["_packed"]
+        assert buf.is_pinned(), "pack_compact_pinned() batches only"
+        dev = trainer.flat.data.device
+        self.bytes = buf.numel()
+        self.staging = torch.empty(self.bytes, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        mods = []
+        for k, v in packed.items():
+            if k == "_packed":
+                continue
+            dst = trainer._static_batch[k]
+            m = H.InputMod()
+            if "u8" in v:
+                m.kind, m.src_off, m.dst, m.n = H.INPUT_IMAGE_U8, v["u8"].data_ptr() - base, dst["data"].data_ptr(), v["u8"].numel()
+                assert dst["data"].numel() == v["u8"].numel() and dst["data"].is_contiguous()
+            elif "tokens" in v:
+                Bt, Tt = v["tokens"].shape
+                assert v["tokens"].dtype == torch.int32 and v["lengths"].dtype == torch.int32
+                assert tuple(dst["data"].shape[:2]) == (Bt, Tt) and dst["data"].is_contiguous()
+                m.kind, m.src_off, m.len_off = H.INPUT_TEXT_TOKENS, v["tokens"].data_ptr() - base, v["lengths"].data_ptr() - base
+                m.dst, m.B, m.T, m.V = dst["data"].data_ptr(), Bt, Tt, dst["data"].shape[2]
+                mk = dst["masks"]
+                m.mask = mk.data_ptr() if mk is not None else None      # bool and uint8 masks are both one byte per token
+            else:
+                raise ValueError(f"modality {k}: the native pipe moves 'u8' images and 'tokens' text")
+            mods.append(m)
+        assert 0 < len(mods) <= H.INPUT_MAX_MODS
+        self._mods = (H.InputMod * len(mods))(*mods)
+        self._keep = trainer._static_batch      # the raw pointers above point into these tensors
+        h = ctypes.c_void_p()
+        rc = H.lib().mmvae_input_pipe_create(ctypes.byref(h), self.staging.data_ptr(), self.bytes)
+        if rc:
+            raise RuntimeError(f"mmvae_input_pipe_create: {rc}")
+        self._h = h
+
+    def _ptr(self, packed):
+        buf = packed["_packed"]
+        assert buf.numel() == self.bytes and buf.is_pinned()
+        return buf.data_ptr()
+
+    def prefetch(self, packed):
+        rc = self._H.lib().mmvae_input_pipe_prefetch(self._h, self._ptr(packed))
+        if rc:
+            raise RuntimeError(f"mmvae_input_pipe_prefetch: {rc}")
+
+    def step(self, next_packed=None):
+        rc = self._H.lib().mmvae_input_pipe_commit(self._h, self._mods, len(self._mods),
+                                                   self._ptr(next_packed) if next_packed is not None else None,
+                                                   self._H.stream())
+        if rc:
+            raise RuntimeError(f"mmvae_input_pipe_commit: {rc}")
+
+    def close(self):
+        if self._h is not None:
+            self._H.lib().mmvae_input_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1697,6 +1697,41 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
     return ret_w, ret_b
 
 
+# One launch for the weight gradients behind a fused text layer.  OFF by default: in the cfg2 step the six (four) small
+# launches trickle through beside the image tower's conv backward, the single 350-workgroup burst lands on it
+# (convT(16) backward 41.5 -> 46.5 us, step 0.414 -> 0.423 ms, 3 same-box pairs); alone the batch is 3x shorter.
+WGRAD_BATCH = os.environ.get("MMVAE_WGRAD_BATCH", "0") == "1"
+
+
+def _linear_wgrad_many(jobs):
+    """[_linear_wgrad(*job) for job in jobs]; with MMVAE_WGRAD_BATCH=1 ONE launch for all of them
+    (mmvae_linear_bwd_weight_batch: same tiling, split plan and partial layout per job, bit-identical results) when
+    every job accumulates into preset gradient views under the deferred reduction.  jobs: (dy2, x2, w, b, gw, gb)."""
+    if not WGRAD_BATCH or len(jobs) < 2 or len(jobs) > H.WGRAD_BATCH_MAX or not all(
+            _defer(gw, gb if b is not None else gw) for (_, _, _, b, gw, gb) in jobs):
+        return [_linear_wgrad(*j) for j in jobs]
+    lib = H.lib()
+    arr = (H.WgradJob * len(jobs))()
+    keep = []
+    for i, (dy2, x2, w, b, gw, gb) in enumerate(jobs):
+        M, N = dy2.shape
+        K = x2.shape[1]
+        nz = lib.mmvae_linear_bwd_weight_splits(M, N, K)
+        ws = GradReducer.alloc(lib.mmvae_linear_bwd_weight_ws_floats(M, N, K), dy2.device) if nz > 1 else None
+        db = gb if b is not None else None
+        j = arr[i]
+        j.dy, j.x, j.dw, j.db, j.ws = H.ptr(dy2), H.ptr(x2), H.ptr(gw), H.ptr(db), H.ptr(ws)
+        j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, H.ACT_NONE, H.ACC_DEFER
+        keep.append((ws, nz, gw, db, N, K))
+    _call("mmvae_linear_bwd_weight_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
+    for ws, nz, gw, db, N, K in keep:
+        if nz > 1:
+            GradReducer.add(ws.data_ptr(), gw, nz, N * K, N * K)
+            if db is not None:
+                GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
+    return [(None, None)] * len(jobs)
+
+
 class TxtLayerMeta:
     """static description of one fused transformer layer call (shapes + the DropSpecs of its dropout sites)"""
 
@@ -1835,13 +1870,22 @@ class TxtLayer(Function):
         M = L * N
         ret = {}
 
-        def wg(dyt, xt, wn, bn, wsl=None):
+        specs = [(T["d_qkv"].view(M, 3 * D), x.view(M, D), "in_w", "in_b", None),
+                 (T["d_a"].view(M, D), S["ao"].view(M, D), "out_w", "out_b", None),
+                 (T["d_h1"].view(M, FF), (S["x2"] if dec else S["x1"]).view(M, D), "l1_w", "l1_b", None),
+                 (T["d_f"].view(M, D), S["g"].view(M, FF), "l2_w", "l2_b", None)]
+        if dec:       # the cross attention over a length-1 memory only has value rows in its in_proj
+            specs += [(T["d_ca"].view(M, D), S["vb"].view(M, D), "x_out_w", "x_out_b", None),
+                      (T["d_v"], mem, "x_in_w", "x_in_b", slice(2 * D, 3 * D))]
+        jobs = []
+        for dyt, xt, wn, bn, wsl in specs:
             wt, bt, gw, gb = P[wn], P[bn], G.get(wn), G.get(bn)
-            if wsl is not None:       # a row slice of the parameter (value rows of the cross in_proj)
+            if wsl is not None:       # a row slice of the parameter
                 wt, bt = wt[wsl], bt[wsl]
                 gw = gw[wsl] if gw is not None else None
                 gb = gb[wsl] if gb is not None else None
-            rw, rb = _linear_wgrad(dyt, xt, wt, bt, gw, gb)
+            jobs.append((dyt, xt, wt, bt, gw, gb))
+        for (dyt, xt, wn, bn, wsl), (rw, rb) in zip(specs, _linear_wgrad_many(jobs)):
             if wsl is None:
                 ret[wn], ret[bn] = rw, rb
             elif rw is not None:      # no preset gradient views: embed the slice gradient in a full-size zero tensor
@@ -1850,14 +1894,6 @@ class TxtLayer(Function):
                 ret[wn], ret[bn] = fw, fb
             else:
                 ret[wn], ret[bn] = None, None
-
-        wg(T["d_qkv"].view(M, 3 * D), x.view(M, D), "in_w", "in_b")
-        wg(T["d_a"].view(M, D), S["ao"].view(M, D), "out_w", "out_b")
-        wg(T["d_h1"].view(M, FF), (S["x2"] if dec else S["x1"]).view(M, D), "l1_w", "l1_b")
-        wg(T["d_f"].view(M, D), S["g"].view(M, FF), "l2_w", "l2_b")
-        if dec:
-            wg(T["d_ca"].view(M, D), S["vb"].view(M, D), "x_out_w", "x_out_b")
-            wg(T["d_v"], mem, "x_in_w", "x_in_b", slice(2 * D, 3 * D))
         if ln_defer:
             for k, (gn, bn) in enumerate(ln_names):
                 GradReducer.add(lnws.data_ptr() + 4 * (k * 2 * D), G[gn], N, D, nln * 2 * D)

@@ -952,3 +952,49 @@ def test_maxpool_and_avgpool_match_torch(ops):
     out2.backward(d2.to(DEV))
     check(out2, ref2, 1e-6, "avgpool")
     check(x2g.grad, _nhwc(x2r.grad), 1e-6, "avgpool dx")
+
+
+@pytest.mark.parametrize("rows,D,FF,small", [(4096, 32, 128, 128), (4096, 54, 128, 0), (1536, 16, 128, 48), (300, 24, 40, 7)])
+def test_linear_bwd_weight_batch_is_the_separate_calls(hip_lib, rows, D, FF, small):
+    """mmvae_linear_bwd_weight_batch: the weight gradients a fused text layer leaves behind (4 for the encoder, 6 for
+    the decoder, the last over the batch rows only) in one launch -- every partial and every directly written gradient
+    bit-identical to the one-call-per-job form, and their sum against float64."""
+    import ctypes
+    from multimodal_vae_comparison_amd import hipops as H
+    lib = H.lib()
+    g = torch.Generator().manual_seed(rows + D)
+    shapes = [(rows, 3 * D, D), (rows, D, D), (rows, FF, D), (rows, D, FF)]
+    if small:
+        shapes += [(rows, D, D), (small, D, D)]
+    prob = [(torch.randn(M, N, generator=g).to(DEV), torch.randn(M, K, generator=g).to(DEV)) for M, N, K in shapes]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def buffers():
+        out = []
+        for (M, N, K) in shapes:
+            nz = lib.mmvae_linear_bwd_weight_splits(M, N, K)
+            nws = lib.mmvae_linear_bwd_weight_ws_floats(M, N, K)
+            out.append((torch.full((N, K), 0.5, device=DEV), torch.full((N,), 0.25, device=DEV),
+                        torch.zeros(max(nws, 1), device=DEV), nz))
+        return out
+
+    one, many = buffers(), buffers()
+    for (dy, x), (dw, db, ws, nz), (M, N, K) in zip(prob, one, shapes):
+        assert lib.mmvae_linear_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), M, N,
+                                           K, K, H.ACT_NONE, H.ACC_DEFER, st) == 0
+    arr = (H.WgradJob * len(shapes))()
+    for j, (dy, x), (dw, db, ws, nz), (M, N, K) in zip(arr, prob, many, shapes):
+        j.dy, j.x, j.dw, j.db, j.ws = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr()
+        j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, H.ACT_NONE, H.ACC_DEFER
+    assert lib.mmvae_linear_bwd_weight_batch(ctypes.cast(arr, ctypes.c_void_p), len(shapes), st) == 0
+    torch.cuda.synchronize()
+    for (dy, x), (dw1, db1, ws1, nz), (dw2, db2, ws2, _), (M, N, K) in zip(prob, one, many, shapes):
+        assert torch.equal(ws1, ws2) and torch.equal(dw1, dw2) and torch.equal(db1, db2), (M, N, K)
+        ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+        if nz > 1:      # deferred: nz partial slices [dW | db]
+            got_w = ws2[:nz * N * K].view(nz, N, K).double().sum(0)
+            got_b = ws2[nz * N * K:nz * (N * K + N)].view(nz, N).double().sum(0)
+        else:           # one split: accumulated straight into the (preset) gradient
+            got_w, got_b = dw2.double() - 0.5, db2.double() - 0.25
+        check(got_w, ref_w, 5e-5, f"dw {M, N, K}")
+        check(got_b, ref_b, 5e-5, f"db {M, N, K}")

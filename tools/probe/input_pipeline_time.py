@@ -22,19 +22,29 @@ def run(pre, n=300):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n):
         pre(); tr.fused_step(1)
+    t1 = time.perf_counter()      # everything enqueued: (t1 - t0) / n close to the total = the host is the limiter
     torch.cuda.synchronize()
+    enq[0] = (t1 - t0) / n * 1e6
     return (time.perf_counter() - t0) / n * 1e6
+enq = [0.0]
 def both():
     tr.commit_prefetched(); i[0] += 1; tr.prefetch_compact(host[i[0] & 3])
 def copy_only():
     i[0] += 1; tr.prefetch_compact(host[i[0] & 3])
 def host_only():       # the same python work without any GPU operation of the input step
     i[0] += 1
-print(f"replay only          {run(lambda: None):7.1f} us/step")
-print(f"+ expansion only     {run(tr.commit_prefetched):7.1f}")
-print(f"+ copy only          {run(copy_only):7.1f}")
-print(f"+ copy + expansion   {run(both):7.1f}")
+print(f"replay only          {run(lambda: None):7.1f} us/step   (host enqueue {enq[0]:.1f})")
+print(f"+ expansion only     {run(tr.commit_prefetched):7.1f}   (host enqueue {enq[0]:.1f})")
+print(f"+ copy only          {run(copy_only):7.1f}   (host enqueue {enq[0]:.1f})")
+print(f"+ copy + expansion   {run(both):7.1f}   (host enqueue {enq[0]:.1f})")
 host = [tr.pack_compact_pinned(h) for h in host]
 tr._staging = {}
 tr.prefetch_compact(host[0]); tr.commit_prefetched(); torch.cuda.synchronize()
-print(f"+ ONE copy + expansion {run(both):7.1f}   (pack_compact_pinned)")
+print(f"+ ONE copy + expansion {run(both):7.1f}   (pack_compact_pinned; host enqueue {enq[0]:.1f})")
+print(f"  same, 100 steps      {run(both, 100):7.1f}   (host enqueue {enq[0]:.1f})")
+pipe = tr.input_pipe(host[0])
+pipe.prefetch(host[0])
+def native():
+    i[0] += 1; pipe.step(host[i[0] & 3])
+print(f"+ native pipe (one call) {run(native):7.1f}   (host enqueue {enq[0]:.1f})")
+print(f"replay only (again)  {run(lambda: None):7.1f}   (host enqueue {enq[0]:.1f})")
