@@ -908,6 +908,9 @@ struct GemmBatch {
   unsigned deep;   // bit p: job p reduces in 64-deep slices
   int n;
 };
+// ANY_DEEP = false: no job of the launch takes the 64-deep slices -- 60 VGPRs instead of 172, so the workgroups fit
+// beside the conv kernels of the other stream instead of waiting for a whole free CU
+template <bool ANY_DEEP>
 __global__ __launch_bounds__(512) void rgemm_batch_kernel(GemmBatch bt) {
   __shared__ float red[8 * 16 * 64];
   __shared__ float rsr[8 * 32];
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(512) void rgemm_batch_kernel(GemmBatch bt) {
   const int bx = local % bt.nx[p], t = local / bt.nx[p];
   const int by = t % bt.ny[p], bz = t / bt.ny[p];
   const GemmArgs g = bt.g[p];
-  if (bt.deep >> p & 1u) rgemm_body<64, false, false>(g, bx, by, bz, bt.nz[p], red, rsr);
+  if (ANY_DEEP && (bt.deep >> p & 1u)) rgemm_body<64, false, false>(g, bx, by, bz, bt.nz[p], red, rsr);
   else rgemm_body<16, false, false>(g, bx, by, bz, bt.nz[p], red, rsr);
 }
 
@@ -971,7 +974,8 @@ extern "C" int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int 
     }
     return MMVAE_OK;
   }
-  hipLaunchKernelGGL(rgemm_batch_kernel, dim3(bt.blk0[n_jobs]), dim3(512), 0, (hipStream_t)stream, bt);
+  if (bt.deep) hipLaunchKernelGGL(rgemm_batch_kernel<true>, dim3(bt.blk0[n_jobs]), dim3(512), 0, (hipStream_t)stream, bt);
+  else hipLaunchKernelGGL(rgemm_batch_kernel<false>, dim3(bt.blk0[n_jobs]), dim3(512), 0, (hipStream_t)stream, bt);
   return mmvae_launch_status();
 }
 

@@ -1699,7 +1699,8 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
 
 # One launch for the weight gradients behind a fused text layer.  OFF by default: in the cfg2 step the six (four) small
 # launches trickle through beside the image tower's conv backward, the single 350-workgroup burst lands on it
-# (convT(16) backward 41.5 -> 46.5 us, step 0.414 -> 0.423 ms, 3 same-box pairs); alone the batch is 3x shorter.
+# (step 0.414 -> 0.417 ms, 3 same-box pairs; 0.423 before the batch kernel got its 60-VGPR variant); alone the batch
+# is 1.5 - 3x shorter.
 WGRAD_BATCH = os.environ.get("MMVAE_WGRAD_BATCH", "0") == "1"
 
 
