@@ -203,20 +203,73 @@ __device__ __forceinline__ void rs_lincomb_body(const rs_lincomb_t& lc) {
   }
 }
 
+// Block geometry of the partial-sum kernels: NRG row groups x (256 / NRG) float4 lanes = 1024 / NRG columns.  Wide (NRG 4,
+// 256 columns) for the usual 16 - 64 partial rows; narrow (NRG 16, 64 columns) for segments with many rows (the
+// 3-channel conv layers leave 512).  The row walk is a block's serial chain -- 8 loads in flight per step -- and a
+// 512-row segment took 16 steps in the wide form: the longest chain of the whole end-of-step launch (the step's time
+// followed the row count at ~0.6 us per 32 rows).
+#define RS_NARROW_ROWS 128
+__host__ __device__ static inline int rs_cols(bool narrow) { return narrow ? 64 : RS_COLS; }
+
+// a += sum over rows ry, ry + NRG, ... of the 4 columns [i, i + 4) of one partial region
+template <int NRG>
+__device__ __forceinline__ void rs_row_sum(const float* __restrict__ src, const int n_rows, const long stride, const long i,
+                                           const long len, const bool vec, const int ry, float4& a) {
+  if (i >= len) return;
+  if (vec) {
+    int r = ry;
+    for (; r + 7 * NRG < n_rows; r += 8 * NRG) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + NRG * u) * stride + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; r < n_rows; r += NRG) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * stride + i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  } else {     // unaligned chain: the same 4 columns as dwords, still 32 independent loads in flight
+    float* ap = &a.x;
+    int r = ry;
+    for (; r + 7 * NRG < n_rows; r += 8 * NRG) {
+      float v[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][c] = src[(size_t)(r + NRG * u) * stride + (i + c < len ? i + c : i)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ap[c] += v[u][c];
+    }
+    for (; r < n_rows; r += NRG) {
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = src[(size_t)r * stride + (i + c < len ? i + c : i)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ap[c] += v[c];
+    }
+  }
+}
+
 template <bool TAIL>
-__global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t, rs_lincomb_t lc) {
+__global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segments_t t, rs_lincomb_t lc,
+                                                              unsigned long long narrow) {
   MMVAE_TRACE_STAMP(21);
   if (TAIL && blockIdx.x == gridDim.x - 1) {
     rs_lincomb_body(lc);
     return;
   }
-  __shared__ float4 part[4][64];
+  __shared__ float4 part[256];      // [row group][float4 lane]
   int sg = 0;
   while (sg + 1 < t.n && (int)blockIdx.x >= t.blk0[sg + 1]) ++sg;   // uniform scan over head segments, n <= 64
   float* __restrict__ dst = t.dst[sg];
   const long len = t.len[sg];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const long i = ((long)blockIdx.x - t.blk0[sg]) * RS_COLS + 4 * cx;
+  const bool nar = narrow >> sg & 1ull;
+  const int LN = nar ? 16 : 64, NRG = 256 / LN;                       // float4 lanes per row group, row groups
+  const int cx = threadIdx.x & (LN - 1), ry = threadIdx.x / LN;
+  const long i = ((long)blockIdx.x - t.blk0[sg]) * (4 * LN) + 4 * cx;
   bool vec = (len & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
   for (int cur = sg; cur >= 0; cur = t.next[cur])
     vec = vec && (((uintptr_t)t.src[cur]) & 15) == 0 && (t.stride[cur] & 3) == 0;
@@ -225,56 +278,21 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(mmvae_reduce_segme
   // regions with the SAME destination: they are chained (`next`) and summed by the same block -- two blocks
   // doing dst += concurrently would race.
   for (int cur = sg; cur >= 0; cur = t.next[cur]) {
-    const float* __restrict__ src = t.src[cur];
-    const int n_rows = t.rows[cur];
-    const long stride = t.stride[cur];
-    if (vec) {
-      if (i < len) {
-        int r = ry;
-        for (; r + 28 < n_rows; r += 32) {
-          float4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + 4 * u) * stride + i);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-        }
-        for (; r < n_rows; r += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * stride + i);
-          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
-      }
-    } else if (i < len) {     // unaligned chain: the same 4 columns as dwords, still 32 independent loads in flight
-      float* ap = &a.x;
-      int r = ry;
-      for (; r + 28 < n_rows; r += 32) {
-        float v[8][4];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[u][c] = src[(size_t)(r + 4 * u) * stride + (i + c < len ? i + c : i)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ap[c] += v[u][c];
-      }
-      for (; r < n_rows; r += 4) {
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = src[(size_t)r * stride + (i + c < len ? i + c : i)];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ap[c] += v[c];
-      }
-    }
+    if (nar) rs_row_sum<16>(t.src[cur], t.rows[cur], t.stride[cur], i, len, vec, ry, a);
+    else rs_row_sum<4>(t.src[cur], t.rows[cur], t.stride[cur], i, len, vec, ry, a);
   }
-  part[ry][cx] = a;
+  part[ry * LN + cx] = a;
   __syncthreads();
   if (ry == 0) {
-    const float4 p0 = part[0][cx], p1 = part[1][cx], p2 = part[2][cx], p3 = part[3][cx];
-    const float s[4] = {p0.x + p1.x + p2.x + p3.x, p0.y + p1.y + p2.y + p3.y, p0.z + p1.z + p2.z + p3.z,
-                        p0.w + p1.w + p2.w + p3.w};
+    float4 sm = part[cx];
+    for (int k = 1; k < NRG; ++k) {
+      const float4 pk = part[k * LN + cx];
+      sm.x += pk.x; sm.y += pk.y; sm.z += pk.z; sm.w += pk.w;
+    }
+    const float sv[4] = {sm.x, sm.y, sm.z, sm.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      if (i + c < len) dst[i + c] += s[c];
+      if (i + c < len) dst[i + c] += sv[c];
   }
 }
 static int reduce_segments_impl(const mmvae_reduce_segments_t* table, const rs_lincomb_t* tail, mmvae_stream_t stream) {
@@ -310,16 +328,21 @@ static int reduce_segments_impl(const mmvae_reduce_segments_t* table, const rs_l
   }
   o.n = n_heads;   // the device scan only walks head slots
   int blocks = 0;
+  unsigned long long narrow = 0;
   for (int k = 0; k < n_heads; ++k) {
+    int max_rows = 0;
+    for (int cur = k; cur >= 0; cur = o.next[cur]) max_rows = o.rows[cur] > max_rows ? o.rows[cur] : max_rows;
+    const bool nar = max_rows >= RS_NARROW_ROWS;
+    if (nar) narrow |= 1ull << k;
     o.blk0[k] = blocks;
-    blocks += (o.len[k] + RS_COLS - 1) / RS_COLS;
+    blocks += (o.len[k] + rs_cols(nar) - 1) / rs_cols(nar);
   }
   t = o;
   if (tail) {
-    hipLaunchKernelGGL(reduce_segments_kernel<true>, dim3(blocks + 1), dim3(256), 0, (hipStream_t)stream, t, *tail);
+    hipLaunchKernelGGL(reduce_segments_kernel<true>, dim3(blocks + 1), dim3(256), 0, (hipStream_t)stream, t, *tail, narrow);
   } else {
     rs_lincomb_t none{};
-    hipLaunchKernelGGL(reduce_segments_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, none);
+    hipLaunchKernelGGL(reduce_segments_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, none, narrow);
   }
   return mmvae_launch_status();
 }
@@ -358,6 +381,7 @@ struct af_table_t {
   af_seg_t seg[MMVAE_MAX_SEGMENTS];      // heads first, sorted by dst_off; chained members behind
   int pblk0[MMVAE_MAX_SEGMENTS + 2];     // first workgroup of plain range k = [end of head k-1, start of head k)
   int n_heads, fold_blocks, plain_blocks;
+  unsigned long long narrow;             // bit k: head k is folded by narrow blocks (64 columns x 16 row groups)
 };
 struct af_adam_t {
   float *p, *g, *m, *v, *vmax;
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(256) void adam_fold_kernel(af_adam_t A, af_table_t 
   }
   __shared__ float bc[2];
   __shared__ double pw[2];
-  __shared__ float4 part[4][64];
+  __shared__ float4 part[256];      // [row group][float4 lane]
   if (threadIdx.x == 0) {      // this launch IS step (*step_dev + 1), see adam_amsgrad_kernel
     const int st = A.step_dev[0] + 1;
     const double* run = reinterpret_cast<const double*>(A.step_dev + 2);
@@ -399,67 +423,32 @@ __global__ __launch_bounds__(256) void adam_fold_kernel(af_adam_t A, af_table_t 
     while (sg + 1 < t.n_heads && bid >= t.seg[sg + 1].blk0) ++sg;      // uniform scan over the heads
     const long len = t.seg[sg].len;
     const long off = t.seg[sg].dst_off;
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const long i = ((long)bid - t.seg[sg].blk0) * RS_COLS + 4 * cx;
+    const bool nar = t.narrow >> sg & 1ull;                            // block geometry: see rs_row_sum
+    const int LN = nar ? 16 : 64, NRG = 256 / LN, cols = 4 * LN;
+    const int cx = threadIdx.x & (LN - 1), ry = threadIdx.x / LN;
+    const long i = ((long)bid - t.seg[sg].blk0) * cols + 4 * cx;
     bool vec = (len & 3) == 0;
     for (int cur = sg; cur >= 0; cur = t.seg[cur].next)
       vec = vec && (((uintptr_t)t.seg[cur].src) & 15) == 0 && (t.seg[cur].stride & 3) == 0;
-    // this thread's own column (tid) of the 256: issued before the partial sums, consumed after them
-    const long e = ((long)bid - t.seg[sg].blk0) * RS_COLS + threadIdx.x;
-    const bool mine = e < len;
+    // this thread's own column (tid) of the block's `cols`: issued before the partial sums, consumed after them
+    const long e = ((long)bid - t.seg[sg].blk0) * cols + threadIdx.x;
+    const bool mine = (int)threadIdx.x < cols && e < len;
     const long fe = off + e;
     float P = 0.f, G = 0.f, M = 0.f, V = 0.f, X = 0.f;
     if (mine) { P = A.p[fe]; G = A.g[fe]; M = A.m[fe]; V = A.v[fe]; X = A.vmax[fe]; }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int cur = sg; cur >= 0; cur = t.seg[cur].next) {
-      const float* __restrict__ src = t.seg[cur].src;
-      const int n_rows = t.seg[cur].rows;
-      const long stride = t.seg[cur].stride;
-      if (vec) {
-        if (i < len) {
-          int r = ry;
-          for (; r + 28 < n_rows; r += 32) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + 4 * u) * stride + i);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-          }
-          for (; r < n_rows; r += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * stride + i);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-          }
-        }
-      } else if (i < len) {
-        float* ap = &a.x;
-        int r = ry;
-        for (; r + 28 < n_rows; r += 32) {
-          float v[8][4];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[u][c] = src[(size_t)(r + 4 * u) * stride + (i + c < len ? i + c : i)];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ap[c] += v[u][c];
-        }
-        for (; r < n_rows; r += 4) {
-          float v[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = src[(size_t)r * stride + (i + c < len ? i + c : i)];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ap[c] += v[c];
-        }
-      }
+      if (nar) rs_row_sum<16>(t.seg[cur].src, t.seg[cur].rows, t.seg[cur].stride, i, len, vec, ry, a);
+      else rs_row_sum<4>(t.seg[cur].src, t.seg[cur].rows, t.seg[cur].stride, i, len, vec, ry, a);
     }
-    part[ry][cx] = a;
+    part[ry * LN + cx] = a;
     __syncthreads();
     if (mine) {
-      const float* pf = reinterpret_cast<const float*>(&part[0][0]);
+      const float* pf = reinterpret_cast<const float*>(&part[0]);
       const int c = threadIdx.x;                 // column c = lane (c >> 2), component (c & 3)
-      const float s = pf[c] + pf[256 + c] + pf[512 + c] + pf[768 + c];
-      G += s;
+      float sm = pf[c];
+      for (int k = 1; k < NRG; ++k) sm += pf[k * cols + c];
+      G += sm;
       update1(P, G, M, V, X, bc[0], bc[1]);
       A.p[fe] = P; A.m[fe] = M; A.v[fe] = V; A.vmax[fe] = X;
       A.g[fe] = A.zero_grad ? 0.f : G;
@@ -561,7 +550,12 @@ extern "C" int mmvae_adam_fold_flat(float* p, float* g, float* m, float* v, floa
   for (int k = 0; k < n_heads; ++k) {
     const int hs = head[k];
     o.seg[k] = af_seg_t{t.src[hs], (int)(t.dst[hs] - g), (int)t.len[hs], (int)t.stride[hs], (short)t.rows[hs], (short)-1, blocks};
-    blocks += (int)((t.len[hs] + RS_COLS - 1) / RS_COLS);
+    int max_rows = t.rows[hs];
+    for (int s = 0; s < t.n; ++s)
+      if (s != hs && t.dst[s] == t.dst[hs] && t.len[s] == t.len[hs] && t.rows[s] > max_rows) max_rows = t.rows[s];
+    const bool nar = max_rows >= RS_NARROW_ROWS;       // the same choice as reduce_segments_impl: same summation order
+    if (nar) o.narrow |= 1ull << k;
+    blocks += (int)((t.len[hs] + rs_cols(nar) - 1) / rs_cols(nar));
     int last = k;
     for (int s = 0; s < t.n; ++s) {
       if (s == hs || t.dst[s] != t.dst[hs] || t.len[s] != t.len[hs]) continue;

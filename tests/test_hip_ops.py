@@ -652,7 +652,10 @@ def test_reduce_segments(ops, hip_lib):
         (128 * 16416, 16416, 33, 8748, 8748 + 162), (128 * 16416 + 8748, 25164, 33, 162, 8748 + 162),
         (3000001, 30001, 7, 1001, 1003),                                       # nothing aligned
         (3100000, 0, 5, 16384, 16384),                                         # chained onto segment 0 (same dst, len)
-        (3300000, 33000, 1, 64, 64)]
+        (3300000, 33000, 1, 64, 64),
+        # >= 128 rows: folded by the narrow blocks (64 columns x 16 row groups) -- a 3-channel conv layer's 512 partial
+        # rows, and an unaligned one
+        (2400100, 34000, 512, 1568, 1600), (3500001, 36001, 130, 77, 79)]
     t = H.ReduceSegments()
     for j, (so, do, r, ln, sd) in enumerate(specs):
         t.src[j], t.dst[j] = arena.data_ptr() + 4 * so, flat.data_ptr() + 4 * do
@@ -688,7 +691,8 @@ def test_adam_fold_flat_is_fold_then_adam(ops, hip_lib, rider):
     specs = [  # (src offset, dst offset, rows, len, stride), unsorted on purpose
         (128 * 16416, 16416, 33, 8748, 8748 + 162), (0, 0, 128, 16384, 16416), (16384, 16384, 128, 32, 16416),
         (128 * 16416 + 8748, 25164, 33, 162, 8748 + 162), (3000001, 30001, 7, 1001, 1003),
-        (3100000, 0, 5, 16384, 16384), (3300000, 33000, 1, 64, 64), (3400000, n - 13, 9, 13, 16)]
+        (3100000, 0, 5, 16384, 16384), (3300000, 33000, 1, 64, 64), (3400000, n - 13, 9, 13, 16),
+        (2400100, 34000, 512, 1568, 1600), (3500001, 36001, 130, 77, 79)]      # narrow-block segments (>= 128 rows)
     state = {}
     for name in ("a", "b"):
         gg = torch.Generator().manual_seed(6)
