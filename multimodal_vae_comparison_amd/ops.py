@@ -1697,18 +1697,23 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
     return ret_w, ret_b
 
 
-# One launch for the weight gradients behind a fused text layer.  OFF by default: in the cfg2 step the six (four) small
-# launches trickle through beside the image tower's conv backward, the single 350-workgroup burst lands on it
-# (step 0.414 -> 0.417 ms, 3 same-box pairs; 0.423 before the batch kernel got its 60-VGPR variant); alone the batch
-# is 1.5 - 3x shorter.
-WGRAD_BATCH = os.environ.get("MMVAE_WGRAD_BATCH", "0") == "1"
+# One launch for the weight gradients behind a fused text layer (mmvae_linear_bwd_weight_batch): 8 graph nodes fewer
+# per cfg2 step.  Below batch ~100 the step is bound by the host's graph launch (~4.8 us per node), and fewer nodes is
+# what pays: B=16 0.331 -> 0.286 ms, B=32 0.336 -> 0.291, B=64 0.355 -> 0.330, B=96 0.385 -> 0.378.  At B=128 the GPU is
+# the limit and the six (four) small launches trickle through beside the image tower's conv backward better than one
+# 350-workgroup burst (0.414 -> 0.417 ms, 3 same-box pairs).  MMVAE_WGRAD_BATCH = auto (default: batch when a layer has
+# at most WGRAD_BATCH_ROWS rows) | 1 | 0.
+_WGRAD_BATCH_ENV = os.environ.get("MMVAE_WGRAD_BATCH", "auto")
+WGRAD_BATCH = True if _WGRAD_BATCH_ENV == "1" else False if _WGRAD_BATCH_ENV == "0" else None      # None: by size
+WGRAD_BATCH_ROWS = 3072
 
 
 def _linear_wgrad_many(jobs):
-    """[_linear_wgrad(*job) for job in jobs]; with MMVAE_WGRAD_BATCH=1 ONE launch for all of them
+    """[_linear_wgrad(*job) for job in jobs]; when batching applies (WGRAD_BATCH above) ONE launch for all of them
     (mmvae_linear_bwd_weight_batch: same tiling, split plan and partial layout per job, bit-identical results) when
     every job accumulates into preset gradient views under the deferred reduction.  jobs: (dy2, x2, w, b, gw, gb)."""
-    if not WGRAD_BATCH or len(jobs) < 2 or len(jobs) > H.WGRAD_BATCH_MAX or not all(
+    batch = WGRAD_BATCH if WGRAD_BATCH is not None else max(j[0].shape[0] for j in jobs) <= WGRAD_BATCH_ROWS
+    if not batch or len(jobs) < 2 or len(jobs) > H.WGRAD_BATCH_MAX or not all(
             _defer(gw, gb if b is not None else gw) for (_, _, _, b, gw, gb) in jobs):
         return [_linear_wgrad(*j) for j in jobs]
     lib = H.lib()
