@@ -64,6 +64,10 @@ typedef struct {
 } mmvae_dropout_t;
 #define MMVAE_DROPOUT_SLOTS 16
 int mmvae_dropout_advance(uint32_t* state, uint32_t slot, mmvae_stream_t stream);
+/* mmvae_dropout_advance(states[i], 0) for n distinct towers in ONE launch: forward call 0 of every tower of a training
+ * step, issued before the towers fork onto their streams */
+#define MMVAE_DROPOUT_ADVANCE_MAX 16
+int mmvae_dropout_advance_many(uint32_t* const* states, int n, mmvae_stream_t stream);
 /* out[i] = 0 or 1/(1-p): the multiplicative mask of element i (test / inspection helper) */
 int mmvae_dropout_mask(const mmvae_dropout_t* drop, float* out, long n, mmvae_stream_t stream);
 /* y = dropout(act(x)) elementwise; dx = dy * mask * act'(x).  act: MMVAE_ACT_NONE or MMVAE_ACT_GELU */

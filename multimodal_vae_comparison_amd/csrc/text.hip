@@ -933,6 +933,34 @@ extern "C" int mmvae_dropout_advance(uint32_t* state, uint32_t slot, mmvae_strea
   hipLaunchKernelGGL(dropout_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, slot);
   return mmvae_launch_status();
 }
+// call 0 of up to MMVAE_DROPOUT_ADVANCE_MAX towers in one launch (start of a training step, before the towers fork onto
+// their streams): one graph node instead of a one-thread launch at the head of every tower's chain
+struct DropAdvanceMany {
+  uint32_t* st[MMVAE_DROPOUT_ADVANCE_MAX];
+  int n;
+};
+__global__ void dropout_advance_many_kernel(DropAdvanceMany a) {
+  const int i = threadIdx.x;
+  if (i < a.n) {
+    uint32_t* st = a.st[i];
+    const uint32_t c = st[1] + 1u;
+    st[1] = c;
+    st[2] = c;      // slot 0
+  }
+}
+extern "C" int mmvae_dropout_advance_many(uint32_t* const* states, int n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(states && n > 0 && n <= MMVAE_DROPOUT_ADVANCE_MAX);
+  DropAdvanceMany a;
+  for (int i = 0; i < n; ++i) {
+    if (!states[i]) return MMVAE_ERR_ARG;
+    for (int j = 0; j < i; ++j)
+      if (states[j] == states[i]) return MMVAE_ERR_ARG;      // one advance per state
+    a.st[i] = states[i];
+  }
+  a.n = n;
+  hipLaunchKernelGGL(dropout_advance_many_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  return mmvae_launch_status();
+}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, mmvae_dropout_t drop) {
   const DropKey dk = drop_key(drop);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = drop_mul(dk, (uint32_t)i);

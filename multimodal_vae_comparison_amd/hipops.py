@@ -187,6 +187,7 @@ SIGNATURES = {
     "mmvae_avgpool_fwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_avgpool_bwd": (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),
+    "mmvae_dropout_advance_many": (c_i, [c_p, c_i, c_p]),
     "mmvae_dropout_mask": (c_i, [c_dp, c_p, c_l, c_p]),
     "mmvae_dropout_act_fwd": (c_i, [c_p, c_p, c_l, c_i, c_dp, c_p]),
     "mmvae_dropout_act_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_dp, c_p]),
@@ -220,6 +221,7 @@ class InputMod(ctypes.Structure):
 
 
 WGRAD_BATCH_MAX = 8
+DROPOUT_ADVANCE_MAX = 16
 
 
 class WgradJob(ctypes.Structure):

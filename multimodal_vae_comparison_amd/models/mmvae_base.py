@@ -8,8 +8,13 @@ import torch.distributions as dist
 import torch.nn as nn
 
 from .. import ops
+from .nn_modules import DropoutState
 from .objectives import MultimodalObjective
 from .output_storage import VAEOutput
+
+# the decoders' first dropout-counter advance rides on the first encoder's launch (DropoutState.link;
+# MMVAE_DROPOUT_LINK=0: one one-thread launch at the head of every tower's chain)
+LINK_DROPOUT_ADVANCE = os.environ.get("MMVAE_DROPOUT_LINK", "1") == "1"
 
 
 def normal(loc, scale):
@@ -79,11 +84,16 @@ class TorchMMVAE(nn.Module):
     def _begin_step(self):
         """start of an objective() call: per-step dropout call counters back to 0"""
         ops.GradReducer.begin_step(self._rng_state.device)
+        groups = ([], [])
         for vae in self.vaes.values():
-            for part in (vae.enc, vae.dec):
+            for k, part in enumerate((vae.enc, vae.dec)):
                 st = getattr(part, "drop_state", None)
                 if st is not None:
                     st.reset_calls()
+                    if part.training:
+                        groups[k].append(st)
+        if LINK_DROPOUT_ADVANCE:
+            DropoutState.link(*groups)
 
     # ---- noise ----------------------------------------------------------------------------------
     def _draw(self, B, D, device):

@@ -58,15 +58,40 @@ class DropoutState(nn.Module):
         st[0] = (torch.initial_seed() ^ DropoutState._next_seed[0]) & 0x7FFFFFFF
         self.register_buffer("state", st, persistent=False)
         self.call = 0
+        self.pre = False      # call 0 of this step was advanced by another tower's launch: begin() launches nothing
+        self.lead = None      # encoder state: the decoder states whose call 0 rides on this state's first advance
         self.prefix = ""
 
     def reset_calls(self):
         self.call = 0
+        self.pre = False
+        self.lead = None
+
+    @staticmethod
+    def link(enc_states, dec_states):
+        """Start of a training step: the first encoder tower that draws a mask also advances call 0 of every DECODER
+        tower's state in the same launch (one graph node less per decoder, nothing at the head of the decoders' chains).
+        Safe across streams because every mixer joins all encoder streams at the fusion before any decoder starts;
+        the other encoders, which may run beside the leading one, advance their own."""
+        dec_states = [s for s in dec_states if s.state.is_cuda]
+        if not enc_states or not dec_states or len(dec_states) + 1 > H.DROPOUT_ADVANCE_MAX:
+            return
+        for s in enc_states:
+            s.lead = dec_states      # whichever encoder comes first takes them (the list is emptied then)
 
     def begin(self):
         slot = self.call % H.DROPOUT_SLOTS
         self.call += 1
-        ops.dropout_advance(self.state, slot)
+        if self.pre and self.call == 1:
+            self.pre = False
+        elif self.call == 1 and self.lead:
+            followers = [s for s in self.lead if s is not self and s.call == 0 and not s.pre]
+            del self.lead[:]
+            ops.dropout_advance_many([self.state] + [s.state for s in followers])
+            for s in followers:
+                s.pre = True
+        else:
+            ops.dropout_advance(self.state, slot)
         return slot, self.call - 1
 
     def spec(self, slot, call, site, p, name):

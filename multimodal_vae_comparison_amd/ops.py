@@ -314,6 +314,12 @@ def dropout_advance(state, slot):
     _call("mmvae_dropout_advance", H.ptr(state), int(slot), H.stream())
 
 
+def dropout_advance_many(states):
+    """dropout_advance(st, 0) for every state tensor in `states` (distinct towers) in one launch"""
+    arr = (ctypes.c_void_p * len(states))(*[H.ptr(t) for t in states])
+    _call("mmvae_dropout_advance_many", ctypes.cast(arr, ctypes.c_void_p), len(states), H.stream())
+
+
 def dropout_mask(drop, n):
     out = torch.empty(n, device=drop.state.device)
     _call("mmvae_dropout_mask", drop.c(), H.ptr(out), n, H.stream())

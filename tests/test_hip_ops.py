@@ -1002,3 +1002,20 @@ def test_linear_bwd_weight_batch_is_the_separate_calls(hip_lib, rows, D, FF, sma
             got_w, got_b = dw2.double() - 0.5, db2.double() - 0.25
         check(got_w, ref_w, 5e-5, f"dw {M, N, K}")
         check(got_b, ref_b, 5e-5, f"db {M, N, K}")
+
+
+def test_dropout_advance_many(ops, hip_lib):
+    """mmvae_dropout_advance_many == mmvae_dropout_advance(state, 0) on every state; duplicates are refused"""
+    import ctypes
+    from multimodal_vae_comparison_amd import hipops as H
+    a = [torch.tensor([7 + i, 10 * i, 0, 5, 0] + [0] * 13, dtype=torch.int32, device=DEV) for i in range(5)]
+    b = [t.clone() for t in a]
+    for t in a:
+        ops.dropout_advance(t, 0)
+    ops.dropout_advance_many(b)
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), i
+        assert int(y[1]) == 10 * i + 1 and int(y[2]) == 10 * i + 1 and int(y[3]) == 5 and int(y[0]) == 7 + i
+    arr = (ctypes.c_void_p * 2)(b[0].data_ptr(), b[0].data_ptr())
+    assert hip_lib.mmvae_dropout_advance_many(ctypes.cast(arr, ctypes.c_void_p), 2, H.stream()) != 0
