@@ -233,6 +233,17 @@ def dominant_kernel_roofline(meta, device):
         flops = 2.0 * N * 64 * 64 * 32 * 16
         kernel = f"conv_scatter_kernel<ScatterGeom<3,*,*,64>> (Dec_SVHN conv3 fwd, N={N})"
         traffic, src = None, None
+    elif meta.get("K", 1) > 1:
+        # K-sample MoE on the CdSprites+ towers: both decoders decode M*K*B latent samples, the image decoder's
+        # ConvTranspose2d 32->32 at 16x16 -> 32x32 (scatter form) is the largest launch: 2 * N*16*16*32 * 32*16 FLOP
+        N = B * len(meta["mods"]) * meta["K"]
+        x = torch.randn(N, 32, 16, 16, device=device)
+        w = torch.randn(32, 32, 4, 4, device=device) * 0.05
+        b = torch.zeros(32, device=device)
+        us = _event_time_us(lambda: ops.convT2d_k4s2(x, w, b, H.ACT_RELU, 0), reps=20)
+        flops = 2.0 * N * 16 * 16 * 32 * 512
+        kernel = f"conv_scatter_kernel<ScatterGeom<4,*,*,32>> (Dec_CNN convT2 fwd, N={N})"
+        traffic, src = None, None
     else:
         x = torch.randn(B, 32, 32, 32, device=device)
         w = torch.randn(32, 32, 4, 4, device=device) * 0.05

@@ -273,12 +273,15 @@ int mmvae_normal_logratio_bwd(const float* packed_r, const float* z, const float
  * Reconstruction losses (per-sample sums), ReconLoss.* in models/objectives.py
  * ---------------------------------------------------------------------------------------------- */
 /* bce (objectives.py:392-406) on x_hat = clamp(sigmoid(logit),1e-6,1-1e-6) (decoders.py:96-97):
- *   row_loss[b] = sum_f -[t log xh + (1-t) log(1-xh)];  x_hat (B,F) given (already clamped). */
-int mmvae_bce_rowsum_fwd(const float* x_hat, const float* target, float* row_loss, int B, int F,
+ *   row_loss[b] = sum_f -[t log xh + (1-t) log(1-xh)];  x_hat (B,F) given (already clamped).
+ * target_rows: the target has that many rows and row b of x_hat is compared with target row b % target_rows -- a
+ * K-sample decoder output (K*B rows) against the target repeated K times (BaseObjective.reshape_for_loss,
+ * objectives.py:118-120) without materialising the repeat; also in _sigmoid_clamp_bwd and ce_over_time_fwd / _bwd. */
+int mmvae_bce_rowsum_fwd(const float* x_hat, const float* target, float* row_loss, int B, int F, int target_rows,
                          mmvae_stream_t stream);
 /* dlogit[b,f] = g[b] * (xh - t) * [1e-6 < xh < 1-1e-6]  (gradient through sigmoid+clamp+bce) */
 int mmvae_bce_sigmoid_clamp_bwd(const float* x_hat, const float* target, const float* g_row, float* dlogit,
-                                int B, int F, mmvae_stream_t stream);
+                                int B, int F, int target_rows, mmvae_stream_t stream);
 /* true gradient wrt x_hat: dxh[b,f] = g[b] * (xh - t) / max(xh (1 - xh), 1e-12)  (torch's bce backward) */
 int mmvae_bce_rowsum_bwd(const float* x_hat, const float* target, const float* g_row, float* dxhat, int B, int F,
                          mmvae_stream_t stream);
@@ -296,13 +299,37 @@ int mmvae_bce_rowsum_seeded(const float* x_hat, const float* target, float* row_
 int mmvae_ce_over_time_seeded(const float* logits, const float* target, float* row_loss, float seed, float* dlogits,
                               int B, int T, int V, mmvae_stream_t stream);
 
+/* Element-wise forms of the loss-plugin contract `ReconLoss.<name>(output, target, bs) -> (bs, -1)`
+ * (models/objectives.py:389-509); the mixers' objective() uses the per-sample row sums instead.
+ * lprob (:409-424): out[i] = -log p(target[i % target_n]) under Normal / Laplace(loc[i], scale) as a DOUBLE (the
+ *   reference casts the fp32 element), NaN -> 0 (no gradient); scale <= 0: scale := loc.  bwd: g (n doubles).
+ * optimal_sigma (:503-509): out[i] = detach(((t - x) / sigma)^2) + log_sigma + log sqrt(2 pi), ONE log_sigma =
+ *   softclip(log sqrt(mean (t - x)^2), -6) per call; stats (4 floats) = {mean square, log_sigma, raw log sigma};
+ *   ws: mmvae_optimal_sigma_ws_floats(1, n) floats.  bwd: g (n floats), gradient through log_sigma only.
+ * pointwise: kind 0 = l1 |x - t| (:427-442), 1 = mse (x - t)^2 (:444-459); row sums (target row b % target_rows) with
+ *   their backward, and elements: mmvae_pointwise_elem writes the loss (g == NULL) or g * d loss / d x. */
+int mmvae_lprob_elem_fwd(const float* loc, const float* target, double* out, long n, long target_n, float scale,
+                         int laplace, mmvae_stream_t stream);
+int mmvae_lprob_elem_bwd(const float* loc, const float* target, const double* g, float* dloc, long n, long target_n,
+                         float scale, int laplace, mmvae_stream_t stream);
+int mmvae_optimal_sigma_elem_fwd(const float* loc, const float* target, float* out, float* stats, float* ws, long n,
+                                 mmvae_stream_t stream);
+int mmvae_optimal_sigma_elem_bwd(const float* loc, const float* target, const float* g, const float* stats, float* ws,
+                                 float* dloc, long n, mmvae_stream_t stream);
+int mmvae_pointwise_rowsum_fwd(const float* x, const float* target, float* row_loss, int B, int F, int target_rows,
+                               int kind, mmvae_stream_t stream);
+int mmvae_pointwise_rowsum_bwd(const float* x, const float* target, const float* g_row, float* dx, int B, int F,
+                               int target_rows, int kind, mmvae_stream_t stream);
+int mmvae_pointwise_elem(const float* x, const float* target, const float* g, float* out, long n, int kind,
+                         mmvae_stream_t stream);
+
 /* category_ce (objectives.py:486-500): softmax over TIME.  logits/target (B,T,V) ->
  *   loss (B,V) = -sum_t tgt * log_softmax_t(logits);  row_loss[b] = sum_v loss[b,v]  (either may be NULL) */
 int mmvae_ce_over_time_fwd(const float* logits, const float* target, float* loss, float* row_loss, int B, int T,
-                           int V, mmvae_stream_t stream);
+                           int V, int target_rows, mmvae_stream_t stream);
 /* dlogits[b,t,v] = g[b,v] * (softmax_t(logits)[t] * sum_t' tgt[t'] - tgt[t]);  g (B,V) or g_row (B) */
 int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float* g, const float* g_row,
-                           float* dlogits, int B, int T, int V, mmvae_stream_t stream);
+                           float* dlogits, int B, int T, int V, int target_rows, mmvae_stream_t stream);
 
 /* ReconLoss.lprob (models/objectives.py:409-424): row[b] = sum_f -log p(target[b,f]) under Normal (laplace = 0) or
  * Laplace(loc[b,f], scale); elements in fp32, the row sum in fp64 (the reference sums the elements as doubles), NaN
@@ -412,7 +439,8 @@ int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW,
  *   packed[m] (B, 2D) = [mu_m | scale_m] head outputs (softmax + 1e-6 already applied); laplace[m] != 0: q_m is a
  *   Laplace (the config's `prior` key also selects the posterior family, models/trainer.py:104), else a Normal.
  *   eps[m] (K,B,D): standard Normal / Laplace variates (mmvae_randn / mmvae_rand_laplace);  z[m] (K,B,D) out.
- *   lat (M,K,B)   = sum_d log N(z_r[k,b]; 0, softmax(theta) D) - log-mean-exp_m sum_d log q_m(z_r[k,b])
+ *   lat (M,K,B)   = sum_d log N(z_r[k,b]; 0, softmax(theta) D) - beta * log-mean-exp_m sum_d log q_m(z_r[k,b])
+ *                   (beta = 1 for dreg, objectives.py:372; the objective's beta for iwae, objectives.py:356)
  *   pi  (M,K,B,M) = softmax_m of those row sums (saved for the backward pass).
  * bwd: dlat (M,K,B), dz[m] (K,B,D) or NULL -> dpacked[m] (B,2D) [written], dtheta_rows (B,D) [row b = sample b's
  *   contribution to d theta; the caller folds the rows; NULL = not wanted].  D <= 256, 2 <= M <= 4.
@@ -433,9 +461,9 @@ typedef struct {
   int laplace[MMVAE_MOE_MAX_MODS];
 } mmvae_moe_k_bwd_args;
 int mmvae_moe_ksample_fwd(const mmvae_moe_k_args* a, const float* theta, float* lat, float* pi, int M, int K, int B,
-                          int D, mmvae_stream_t stream);
+                          int D, float beta, mmvae_stream_t stream);
 int mmvae_moe_ksample_bwd(const mmvae_moe_k_bwd_args* a, const float* theta, const float* dlat, const float* pi,
-                          float* dtheta_rows, int M, int K, int B, int D, mmvae_stream_t stream);
+                          float* dtheta_rows, int M, int K, int B, int D, float beta, mmvae_stream_t stream);
 /* DReG loss (objectives.py:375-387).  own[r] / cross[r] (K*B): POSITIVE per-sample reconstruction sums of modality r
  * decoded from its own / the other modality's samples (mmvae_lprob_rowsum_fwd); lam[r] = llik_scaling.
  *   lw[r,k] = sum_b lat[r,k,b] - lam_r sum_b (own_r + cross_r)[k,b]   (fp64 sums);  w = softmax_k lw, detached;
@@ -455,6 +483,16 @@ int mmvae_dreg_loss_fwd(const float* lat, const mmvae_dreg_rows* rows, double* o
                         mmvae_stream_t stream);
 int mmvae_dreg_loss_bwd(const double* out, const double* g, const mmvae_dreg_rows_grad* rows, float* dlat, int M, int K,
                         int B, mmvae_stream_t stream);
+/* IWAE loss (MultimodalObjective.iwae, objectives.py:342-359; the K > 1 AND B > 1 case is a defined extension, see
+ * models/objectives.py of this package).  Same inputs as the DReG loss, per SAMPLE instead of summed over the batch:
+ *   lw[r,k,b] = lat[r,k,b] - lam_r (own_r + cross_r)[k,b];  loss = -sum_b (logsumexp_{r,k} lw[.,.,b] - log(M K)), fp64
+ *   out (doubles, mmvae_iwae_loss_out_doubles): [0] loss | lse (B) | lpx (M,2,K*B) [own, cross]
+ * bwd: g = d loss (device double) -> dlat = -g softmax_{rk}(lw), d own = d cross = g softmax lam_r. */
+size_t mmvae_iwae_loss_out_doubles(int M, int K, int B);
+int mmvae_iwae_loss_fwd(const float* lat, const mmvae_dreg_rows* rows, double* out, int M, int K, int B,
+                        mmvae_stream_t stream);
+int mmvae_iwae_loss_bwd(const float* lat, const double* out, const double* g, const mmvae_dreg_rows_grad* rows,
+                        float* dlat, int M, int K, int B, mmvae_stream_t stream);
 /* `prior: laplace` with the elbo objective: KL(Laplace(mu, s) || N(0,1)) row sums (torch's _kl_laplace_normal reached
  * through utils.kl_divergence, utils.py:399-402; models/mmvae_models.py:45) and the importance ratio of :56-62 under
  * Laplace posteriors (gradient into packed_r only, as mmvae_normal_logratio_*). */

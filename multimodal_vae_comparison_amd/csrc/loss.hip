@@ -18,16 +18,19 @@ __device__ __forceinline__ float bce_dlogit(float x, float t, float g) {
 }
 // SEEDED: the upstream gradient of every row is the known constant `seed` (the ELBO weight of this term), so the
 // logit gradient is written by the same pass over x_hat and target -- backward of the loss costs no launch.
+// trows: the target has that many rows and output row b is paired with target row b % trows (a K-sample decoder output
+// against the target repeated K times, BaseObjective.reshape_for_loss, objectives.py:118-120 -- never materialised)
 template <bool SEEDED>
 __global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
                                                          float* __restrict__ row, int F, float seed,
-                                                         float* __restrict__ dl) {
+                                                         float* __restrict__ dl, int trows) {
   __shared__ float red[4];
   const size_t base = (size_t)blockIdx.x * F;
+  const size_t tbase = (size_t)(blockIdx.x % trows) * F;
   float acc = 0.f;
   if ((F & 3) == 0) {
     const float4* x4 = reinterpret_cast<const float4*>(xh + base);
-    const float4* t4 = reinterpret_cast<const float4*>(tg + base);
+    const float4* t4 = reinterpret_cast<const float4*>(tg + tbase);
     float4* d4 = reinterpret_cast<float4*>(dl + base);
     const int n4 = F / 4;
     int i = threadIdx.x;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict
     }
   } else {
     for (int i = threadIdx.x; i < F; i += 256) {
-      const float x = xh[base + i], t = tg[base + i];
+      const float x = xh[base + i], t = tg[tbase + i];
       acc += bce_term(x, t);
       if (SEEDED) dl[base + i] = bce_dlogit(x, t, seed);
     }
@@ -72,14 +75,17 @@ __global__ __launch_bounds__(256) void bce_elem_kernel(const float* __restrict__
 }
 
 // d/dlogit of bce(clamp(sigmoid(logit))) = (xh - t) where the clamp is inactive, else 0
+// (rows on grid.x, column chunks on grid.y: a K-sample batch has M K B rows, more than grid.y's 65535)
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
-                                                      const float* __restrict__ grow, float* __restrict__ dl, int F) {
-  const size_t base = (size_t)blockIdx.y * F;
-  const float g = grow[blockIdx.y];
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+                                                      const float* __restrict__ grow, float* __restrict__ dl, int F,
+                                                      int trows) {
+  const size_t base = (size_t)blockIdx.x * F;
+  const size_t tbase = (size_t)(blockIdx.x % trows) * F;
+  const float g = grow[blockIdx.x];
+  const int i = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (i + 3 < F && (F & 3) == 0) {
     float4 x = *reinterpret_cast<const float4*>(xh + base + i);
-    float4 t = *reinterpret_cast<const float4*>(tg + base + i);
+    float4 t = *reinterpret_cast<const float4*>(tg + tbase + i);
     float4 o;
     o.x = (x.x > BCE_ETA && x.x < 1.0f - BCE_ETA) ? g * (x.x - t.x) : 0.f;
     o.y = (x.y > BCE_ETA && x.y < 1.0f - BCE_ETA) ? g * (x.y - t.y) : 0.f;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
   } else {
     for (int j = i; j < F && j < i + 4; ++j) {
       float x = xh[base + j];
-      dl[base + j] = (x > BCE_ETA && x < 1.0f - BCE_ETA) ? g * (x - tg[base + j]) : 0.f;
+      dl[base + j] = (x > BCE_ETA && x < 1.0f - BCE_ETA) ? g * (x - tg[tbase + j]) : 0.f;
     }
   }
 }
@@ -98,9 +104,9 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void bce_rowsum_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ tg,
                                                              const float* __restrict__ grow, float* __restrict__ dx,
                                                              int F) {
-  const size_t base = (size_t)blockIdx.y * F;
-  const float g = grow[blockIdx.y];
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < F; j += gridDim.x * 256) {
+  const size_t base = (size_t)blockIdx.x * F;
+  const float g = grow[blockIdx.x];
+  for (int j = blockIdx.y * 256 + threadIdx.x; j < F; j += gridDim.y * 256) {
     const float x = xh[base + j];
     dx[base + j] = g * (x - tg[base + j]) / fmaxf((1.0f - x) * x, 1e-12f);
   }
@@ -118,7 +124,7 @@ extern "C" int mmvae_bce_rowsum_bwd(const float* x_hat, const float* target, con
   MMVAE_CHECK_ARG(x_hat && target && g_row && dxhat && B > 0 && F > 0);
   int bx = (F + 255) / 256;
   if (bx > 16) bx = 16;
-  hipLaunchKernelGGL(bce_rowsum_bwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x_hat, target, g_row, dxhat,
+  hipLaunchKernelGGL(bce_rowsum_bwd_kernel, dim3(B, bx), dim3(256), 0, (hipStream_t)stream, x_hat, target, g_row, dxhat,
                      F);
   return mmvae_launch_status();
 }
@@ -131,10 +137,10 @@ extern "C" int mmvae_sigmoid_clamp_bwd(const float* dy, const float* y, float* d
 }
 
 extern "C" int mmvae_bce_rowsum_fwd(const float* x_hat, const float* target, float* row_loss, int B, int F,
-                                    mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(x_hat && target && row_loss && B > 0 && F > 0);
+                                    int target_rows, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && row_loss && B > 0 && F > 0 && target_rows > 0);
   hipLaunchKernelGGL(bce_rowsum_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, x_hat, target, row_loss, F,
-                     0.f, nullptr);
+                     0.f, nullptr, target_rows);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_bce_rowsum_seeded(const float* x_hat, const float* target, float* row_loss, float seed,
@@ -142,7 +148,7 @@ extern "C" int mmvae_bce_rowsum_seeded(const float* x_hat, const float* target, 
   MMVAE_CHECK_ARG(x_hat && target && row_loss && dlogit && B > 0 && F > 0);
   if ((F & 3) == 0 && (((uintptr_t)dlogit) & 15) != 0) return MMVAE_ERR_ARG;
   hipLaunchKernelGGL(bce_rowsum_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, x_hat, target, row_loss, F,
-                     seed, dlogit);
+                     seed, dlogit, B);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_bce_elem_fwd(const float* x_hat, const float* target, float* loss, long n,
@@ -155,10 +161,10 @@ extern "C" int mmvae_bce_elem_fwd(const float* x_hat, const float* target, float
   return mmvae_launch_status();
 }
 extern "C" int mmvae_bce_sigmoid_clamp_bwd(const float* x_hat, const float* target, const float* g_row,
-                                           float* dlogit, int B, int F, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(x_hat && target && g_row && dlogit && B > 0 && F > 0);
-  hipLaunchKernelGGL(bce_bwd_kernel, dim3((F + 1023) / 1024, B), dim3(256), 0, (hipStream_t)stream, x_hat, target,
-                     g_row, dlogit, F);
+                                           float* dlogit, int B, int F, int target_rows, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x_hat && target && g_row && dlogit && B > 0 && F > 0 && target_rows > 0);
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(B, (F + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, x_hat, target,
+                     g_row, dlogit, F, target_rows);
   return mmvae_launch_status();
 }
 
@@ -197,11 +203,12 @@ __global__ __launch_bounds__(256) void lprob_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ grow, float* __restrict__ dl, int F,
                                                         int trows, float scale, int laplace, int lap_rows, int perm_c,
                                                         int logit_grad) {
-  if (lap_rows > 0) laplace = (laplace >> (blockIdx.y / lap_rows)) & 1;
-  const size_t base = (size_t)blockIdx.y * F;
-  const size_t tbase = (size_t)(blockIdx.y % trows) * F;
-  const float g = grow[blockIdx.y];
-  const int i = blockIdx.x * 256 + threadIdx.x;     // index into loc's memory: coalesced loads / stores there
+  // rows on grid.x (M K B of them with K samples: more than grid.y's 65535), column chunks on grid.y
+  if (lap_rows > 0) laplace = (laplace >> (blockIdx.x / lap_rows)) & 1;
+  const size_t base = (size_t)blockIdx.x * F;
+  const size_t tbase = (size_t)(blockIdx.x % trows) * F;
+  const float g = grow[blockIdx.x];
+  const int i = blockIdx.y * 256 + threadIdx.x;     // index into loc's memory: coalesced loads / stores there
   if (i >= F) return;
   // the target element paired with loc element i = (c, p) of a (perm_c, F / perm_c) plane set is j = p * perm_c + c
   const int j = perm_c > 0 ? (i % (F / perm_c)) * perm_c + i / (F / perm_c) : i;
@@ -235,7 +242,7 @@ extern "C" int mmvae_lprob_rowsum_bwd(const float* loc, const float* target, con
                                       int logit_grad, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(loc && target && g_row && dloc && B > 0 && F > 0 && target_rows > 0 && lap_block_rows >= 0);
   MMVAE_CHECK_ARG(perm_c >= 0 && (perm_c == 0 || F % perm_c == 0));
-  hipLaunchKernelGGL(lprob_bwd_kernel, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, loc, target, g_row,
+  hipLaunchKernelGGL(lprob_bwd_kernel, dim3(B, (F + 255) / 256), dim3(256), 0, (hipStream_t)stream, loc, target, g_row,
                      dloc, F, target_rows, scale, laplace, lap_block_rows, perm_c, logit_grad);
   return mmvae_launch_status();
 }
@@ -332,15 +339,188 @@ extern "C" int mmvae_optimal_sigma_bwd(const float* loc, const float* target, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Element-wise forms behind the loss-plugin contract ReconLoss.<name>(output, target, bs) -> (bs, -1)
+// (objectives.py:389-509); the mixers' objective() uses the row-sum kernels above.
+//   lprob (:409-424): -log p(t) per element, fp32 as torch.distributions computes it, THEN cast to double, NaN -> 0
+//   optimal_sigma (:503-509): detach(((t - x) / sigma)^2) + log_sigma + log sqrt(2 pi), one log_sigma per call
+//   l1 (:427-442), mse (:444-459): |x - t|, (x - t)^2
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lprob_elem_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                         double* __restrict__ out, long n, long tn, float scale,
+                                                         int laplace) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = loc[i];
+    const float lp = lprob_logp(x, tg[i % tn], scale > 0.f ? scale : x, laplace);
+    out[i] = lp == lp ? -(double)lp : 0.0;
+  }
+}
+__global__ __launch_bounds__(256) void lprob_elem_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                             const double* __restrict__ g, float* __restrict__ dl,
+                                                             long n, long tn, float scale, int laplace) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = loc[i], t = tg[i % tn], d = t - x;
+    const bool own = !(scale > 0.f);
+    const float s = own ? x : scale;
+    const float lp = lprob_logp(x, t, s, laplace);
+    float v;
+    if (laplace) {
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      v = -sg / s;
+      if (own) v += 1.0f / s - fabsf(d) / (s * s);
+    } else {
+      v = -d / (s * s);
+      if (own) v += 1.0f / s - (d * d) / (s * s * s);
+    }
+    dl[i] = (lp == lp && v == v) ? (float)(g[i] * (double)v) : 0.f;
+  }
+}
+extern "C" int mmvae_lprob_elem_fwd(const float* loc, const float* target, double* out, long n, long target_n,
+                                    float scale, int laplace, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && out && n > 0 && target_n > 0 && n % target_n == 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lprob_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, loc, target, out, n,
+                     target_n, scale, laplace);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_lprob_elem_bwd(const float* loc, const float* target, const double* g, float* dloc, long n,
+                                    long target_n, float scale, int laplace, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && g && dloc && n > 0 && target_n > 0 && n % target_n == 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lprob_elem_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, loc, target, g,
+                     dloc, n, target_n, scale, laplace);
+  return mmvae_launch_status();
+}
+
+__global__ __launch_bounds__(256) void optsig_elem_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                          const float* __restrict__ ws, int nparts,
+                                                          float* __restrict__ out, float* __restrict__ stats, long n) {
+  __shared__ float red[4];
+  float msq, ls_raw, ls;
+  optsig_stats(ws, nparts, n, red, &msq, &ls_raw, &ls);
+  const float inv = expf(-ls), c = ls + HALF_LOG_2PI;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float q = (tg[i] - loc[i]) * inv;
+    out[i] = q * q + c;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[0] = msq;
+    stats[1] = ls;
+    stats[2] = ls_raw;
+  }
+}
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ g, float* __restrict__ ws, long n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += g[i];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+// the only gradient path is log_sigma: d out_i / d log_sigma = 1 for every element
+__global__ __launch_bounds__(256) void optsig_elem_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ tg,
+                                                              const float* __restrict__ ws, int nparts,
+                                                              const float* __restrict__ stats, float* __restrict__ dl,
+                                                              long n) {
+  __shared__ float red[4];
+  float gs = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) gs += ws[i];
+  gs = block_sum_256(gs, red);
+  const float coef = -gs * dev_sigmoid(stats[2] + 6.0f) / ((float)n * stats[0]);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dl[i] = coef * (tg[i] - loc[i]);
+}
+extern "C" int mmvae_optimal_sigma_elem_fwd(const float* loc, const float* target, float* out, float* stats, float* ws,
+                                            long n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && out && stats && ws && n > 0);
+  const int parts = optsig_parts(n);
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sqerr_partial_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, loc, target, ws, n);
+  hipLaunchKernelGGL(optsig_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, loc, target, ws,
+                     parts, out, stats, n);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_optimal_sigma_elem_bwd(const float* loc, const float* target, const float* g, const float* stats,
+                                            float* ws, float* dloc, long n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(loc && target && g && stats && ws && dloc && n > 0);
+  const int parts = optsig_parts(n);
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sum_partial_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, g, ws, n);
+  hipLaunchKernelGGL(optsig_elem_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, loc, target, ws,
+                     parts, stats, dloc, n);
+  return mmvae_launch_status();
+}
+
+// l1 / mse: kind 0 = |x - t|, 1 = (x - t)^2.  Row sums (the objective) and elements (the plugin contract).
+__device__ __forceinline__ float pw_term(float x, float t, int kind) {
+  const float d = x - t;
+  return kind ? d * d : fabsf(d);
+}
+__device__ __forceinline__ float pw_grad(float x, float t, int kind) {
+  const float d = x - t;
+  return kind ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));      // torch: sign(0) = 0
+}
+__global__ __launch_bounds__(256) void pw_rowsum_kernel(const float* __restrict__ x, const float* __restrict__ tg,
+                                                        float* __restrict__ row, int F, int trows, int kind) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * F, tbase = (size_t)(blockIdx.x % trows) * F;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < F; i += 256) acc += pw_term(x[base + i], tg[tbase + i], kind);
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) row[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void pw_rowsum_bwd_kernel(const float* __restrict__ x, const float* __restrict__ tg,
+                                                            const float* __restrict__ grow, float* __restrict__ dx,
+                                                            int F, int trows, int kind) {
+  const size_t base = (size_t)blockIdx.x * F, tbase = (size_t)(blockIdx.x % trows) * F;
+  const float g = grow[blockIdx.x];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < F; i += gridDim.y * 256)
+    dx[base + i] = g * pw_grad(x[base + i], tg[tbase + i], kind);
+}
+__global__ __launch_bounds__(256) void pw_elem_kernel(const float* __restrict__ x, const float* __restrict__ tg,
+                                                      const float* __restrict__ g, float* __restrict__ out, long n,
+                                                      int kind) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = g ? g[i] * pw_grad(x[i], tg[i], kind) : pw_term(x[i], tg[i], kind);
+}
+extern "C" int mmvae_pointwise_rowsum_fwd(const float* x, const float* target, float* row_loss, int B, int F,
+                                          int target_rows, int kind, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && target && row_loss && B > 0 && F > 0 && target_rows > 0 && (kind == 0 || kind == 1));
+  hipLaunchKernelGGL(pw_rowsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, target, row_loss, F, target_rows,
+                     kind);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_pointwise_rowsum_bwd(const float* x, const float* target, const float* g_row, float* dx, int B,
+                                          int F, int target_rows, int kind, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && target && g_row && dx && B > 0 && F > 0 && target_rows > 0 && (kind == 0 || kind == 1));
+  int by = (F + 255) / 256;
+  if (by > 16) by = 16;
+  hipLaunchKernelGGL(pw_rowsum_bwd_kernel, dim3(B, by), dim3(256), 0, (hipStream_t)stream, x, target, g_row, dx, F,
+                     target_rows, kind);
+  return mmvae_launch_status();
+}
+/* g == NULL: out = loss elements; g != NULL: out = g * d loss / d x */
+extern "C" int mmvae_pointwise_elem(const float* x, const float* target, const float* g, float* out, long n, int kind,
+                                    mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && target && out && n > 0 && (kind == 0 || kind == 1));
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pw_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, target, g, out, n,
+                     kind);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // category_ce: softmax over TIME (objectives.py:499-500).  One 64-thread block per
 // sample; lanes over the vocabulary (coalesced rows of V floats), serial loop over T (<= a few hundred).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void ce_time_fwd_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
                                                          float* __restrict__ loss, float* __restrict__ row, int T,
-                                                         int V) {
+                                                         int V, int trows) {
   const int b = blockIdx.x;
   const float* L = lg + (size_t)b * T * V;
-  const float* Tg = tg + (size_t)b * T * V;
+  const float* Tg = tg + (size_t)(b % trows) * T * V;
   float rsum = 0.f;
   for (int v = threadIdx.x; v < V; v += 64) {
     float mx = -INFINITY;
@@ -363,10 +543,10 @@ __global__ __launch_bounds__(64) void ce_time_fwd_kernel(const float* __restrict
 
 __global__ __launch_bounds__(64) void ce_time_bwd_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
                                                          const float* __restrict__ g, const float* __restrict__ grow,
-                                                         float* __restrict__ dl, int T, int V) {
+                                                         float* __restrict__ dl, int T, int V, int trows) {
   const int b = blockIdx.x;
   const float* L = lg + (size_t)b * T * V;
-  const float* Tg = tg + (size_t)b * T * V;
+  const float* Tg = tg + (size_t)(b % trows) * T * V;
   float* D = dl + (size_t)b * T * V;
   for (int v = threadIdx.x; v < V; v += 64) {
     const float gv = g ? g[(size_t)b * V + v] : grow[b];
@@ -388,7 +568,7 @@ __global__ __launch_bounds__(64) void ce_time_bwd_kernel(const float* __restrict
 #define CE_TILE 4096
 __global__ __launch_bounds__(256) void ce_time_fwd_tile_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
                                                               float* __restrict__ loss, float* __restrict__ row, int T,
-                                                              int V, float seed, float* __restrict__ dl) {
+                                                              int V, float seed, float* __restrict__ dl, int trows) {
   // dl != NULL: every row's upstream gradient is the constant `seed`; the logit gradient is written from the same
   // staged tile (see bce_rowsum_kernel<true>)
   __shared__ float sl[CE_TILE], st[CE_TILE];
@@ -396,7 +576,7 @@ __global__ __launch_bounds__(256) void ce_time_fwd_tile_kernel(const float* __re
   __shared__ float red[4];
   const int b = blockIdx.x, n = T * V;
   const float* L = lg + (size_t)b * n;
-  const float* Tg = tg + (size_t)b * n;
+  const float* Tg = tg + (size_t)(b % trows) * n;
   for (int e = threadIdx.x; e < n; e += 256) {
     sl[e] = L[e];
     st[e] = Tg[e];
@@ -433,12 +613,12 @@ __global__ __launch_bounds__(256) void ce_time_fwd_tile_kernel(const float* __re
 }
 __global__ __launch_bounds__(256) void ce_time_bwd_tile_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
                                                               const float* __restrict__ g, const float* __restrict__ grow,
-                                                              float* __restrict__ dl, int T, int V) {
+                                                              float* __restrict__ dl, int T, int V, int trows) {
   __shared__ float sl[CE_TILE], st[CE_TILE];
   __shared__ float s_mx[256], s_k[256], s_gv[256];   // per column: max, ts / sum exp, upstream gradient (V <= 256)
   const int b = blockIdx.x, n = T * V;
   const float* L = lg + (size_t)b * n;
-  const float* Tg = tg + (size_t)b * n;
+  const float* Tg = tg + (size_t)(b % trows) * n;
   for (int e = threadIdx.x; e < n; e += 256) {
     sl[e] = L[e];
     st[e] = Tg[e];
@@ -465,14 +645,14 @@ __global__ __launch_bounds__(256) void ce_time_bwd_tile_kernel(const float* __re
 }
 
 extern "C" int mmvae_ce_over_time_fwd(const float* logits, const float* target, float* loss, float* row_loss, int B,
-                                      int T, int V, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(logits && target && (loss || row_loss) && B > 0 && T > 0 && V > 0);
+                                      int T, int V, int target_rows, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(logits && target && (loss || row_loss) && B > 0 && T > 0 && V > 0 && target_rows > 0);
   if (T * V <= CE_TILE && V <= 256)
     hipLaunchKernelGGL(ce_time_fwd_tile_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, loss,
-                       row_loss, T, V, 0.f, nullptr);
+                       row_loss, T, V, 0.f, nullptr, target_rows);
   else
     hipLaunchKernelGGL(ce_time_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, loss, row_loss, T,
-                       V);
+                       V, target_rows);
   return mmvae_launch_status();
 }
 /* row sums + logit gradient for a constant upstream gradient `seed` in one launch; MMVAE_ERR_UNSUPPORTED when the
@@ -482,18 +662,18 @@ extern "C" int mmvae_ce_over_time_seeded(const float* logits, const float* targe
   MMVAE_CHECK_ARG(logits && target && row_loss && dlogits && B > 0 && T > 0 && V > 0);
   if (!(T * V <= CE_TILE && V <= 256)) return MMVAE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ce_time_fwd_tile_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target,
-                     (float*)nullptr, row_loss, T, V, seed, dlogits);
+                     (float*)nullptr, row_loss, T, V, seed, dlogits, B);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_ce_over_time_bwd(const float* logits, const float* target, const float* g, const float* g_row,
-                                      float* dlogits, int B, int T, int V, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(logits && target && (g || g_row) && dlogits && B > 0 && T > 0 && V > 0);
+                                      float* dlogits, int B, int T, int V, int target_rows, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(logits && target && (g || g_row) && dlogits && B > 0 && T > 0 && V > 0 && target_rows > 0);
   if (T * V <= CE_TILE && V <= 256)
     hipLaunchKernelGGL(ce_time_bwd_tile_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, g, g_row,
-                       dlogits, T, V);
+                       dlogits, T, V, target_rows);
   else
     hipLaunchKernelGGL(ce_time_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, target, g, g_row, dlogits,
-                       T, V);
+                       T, V, target_rows);
   return mmvae_launch_status();
 }
 

@@ -45,13 +45,14 @@ __device__ __forceinline__ float logq_elem(float z, float mu, float s, int lapla
 
 // ---------------------------------------------------------------------------------------------
 // forward: one wave per (r, k, b).  z_r[k,b,:] = mu_r[b,:] + s_r[b,:] * e_r[k,b,:];
-//   lat[r,k,b] = sum_d log N(z; 0, sp_d) - log-mean-exp_m sum_d log q_m(z)        (objectives.py:368-372)
-//   pi[r,k,b,m] = softmax_m (sum_d log q_m(z))  -- d lat / d (log q_m row sum) = -pi, kept for the backward pass
+//   lat[r,k,b] = sum_d log N(z; 0, sp_d) - beta * log-mean-exp_m sum_d log q_m(z)
+//   (dreg: beta = 1, objectives.py:368-372; iwae: the objective's beta, objectives.py:356)
+//   pi[r,k,b,m] = softmax_m (sum_d log q_m(z))  -- d lat / d (log q_m row sum) = -beta pi, kept for the backward pass
 // ---------------------------------------------------------------------------------------------
 template <int M>
 __global__ __launch_bounds__(256) void moe_ksample_fwd_kernel(mmvae_moe_k_args a, const float* __restrict__ theta,
                                                               float* __restrict__ lat, float* __restrict__ pi, int K,
-                                                              int B, int D) {
+                                                              int B, int D, float beta) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)M * K * B) return;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void moe_ksample_fwd_kernel(mmvae_moe_k_args a
 #pragma unroll
   for (int m = 0; m < M; ++m) se += expf(lq[m] - mx);
   if (lane == 0) {
-    lat[row] = lpz - (mx + logf(se) - logf((float)M));
+    lat[row] = lpz - beta * (mx + logf(se) - logf((float)M));
 #pragma unroll
     for (int m = 0; m < M; ++m) pi[row * M + m] = expf(lq[m] - mx) / se;
   }
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(256) void moe_ksample_fwd_kernel(mmvae_moe_k_args a
 // ---------------------------------------------------------------------------------------------
 // backward: one wave per sample b, lanes over d, serial over (r, k): no atomics, every (b, d) gradient is one
 // register sum.  Inputs: dlat (M,K,B), dz_r (K,B,D) from the decoders (NULL = none).
-//   d lat / d z       = -z / sp^2 - sum_m pi_m d log q_m / d z
-//   d lat / d (mu_m)  = -pi_m d log q_m / d mu_m,  same for the scale
+//   d lat / d z       = -z / sp^2 - beta sum_m pi_m d log q_m / d z
+//   d lat / d (mu_m)  = -beta pi_m d log q_m / d mu_m,  same for the scale
 //   z = mu_r + s_r e  =>  dmu_r += dz_total, ds_r += dz_total * e
 //   theta: dsp_d = sum g (z^2 / sp^3 - 1 / sp);  dtheta_j = D sm_j (dsp_j - sum_d dsp_d sm_d)  -> dtheta_rows[b, :]
 // ---------------------------------------------------------------------------------------------
@@ -108,7 +109,8 @@ template <int M>
 __global__ __launch_bounds__(256) void moe_ksample_bwd_kernel(mmvae_moe_k_bwd_args a, const float* __restrict__ theta,
                                                               const float* __restrict__ dlat,
                                                               const float* __restrict__ pi,
-                                                              float* __restrict__ dtheta_rows, int K, int B, int D) {
+                                                              float* __restrict__ dtheta_rows, int K, int B, int D,
+                                                              float beta) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void moe_ksample_bwd_kernel(mmvae_moe_k_bwd_ar
         dsp[s] += g * (z * z * isp * isp * isp - isp);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          const float c = -g * pi[row * M + m];
+          const float c = -g * beta * pi[row * M + m];
           const float is = 1.0f / sc[m];
           const float df = z - mu[m];
           if (a.laplace[m]) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void moe_ksample_bwd_kernel(mmvae_moe_k_bwd_ar
 }
 
 extern "C" int mmvae_moe_ksample_fwd(const mmvae_moe_k_args* a, const float* theta, float* lat, float* pi, int M, int K,
-                                     int B, int D, mmvae_stream_t stream) {
+                                     int B, int D, float beta, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && lat && pi && K > 0 && B > 0 && D > 0);
   if (M < 2 || M > MMVAE_MOE_MAX_MODS || D > 64 * MOE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   for (int m = 0; m < M; ++m) MMVAE_CHECK_ARG(a->packed[m] && a->eps[m] && a->z[m]);
@@ -186,15 +188,15 @@ extern "C" int mmvae_moe_ksample_fwd(const mmvae_moe_k_args* a, const float* the
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   switch (M) {
-    case 2: hipLaunchKernelGGL(moe_ksample_fwd_kernel<2>, grid, block, 0, st, *a, theta, lat, pi, K, B, D); break;
-    case 3: hipLaunchKernelGGL(moe_ksample_fwd_kernel<3>, grid, block, 0, st, *a, theta, lat, pi, K, B, D); break;
-    default: hipLaunchKernelGGL(moe_ksample_fwd_kernel<4>, grid, block, 0, st, *a, theta, lat, pi, K, B, D); break;
+    case 2: hipLaunchKernelGGL(moe_ksample_fwd_kernel<2>, grid, block, 0, st, *a, theta, lat, pi, K, B, D, beta); break;
+    case 3: hipLaunchKernelGGL(moe_ksample_fwd_kernel<3>, grid, block, 0, st, *a, theta, lat, pi, K, B, D, beta); break;
+    default: hipLaunchKernelGGL(moe_ksample_fwd_kernel<4>, grid, block, 0, st, *a, theta, lat, pi, K, B, D, beta); break;
   }
   return mmvae_launch_status();
 }
 
 extern "C" int mmvae_moe_ksample_bwd(const mmvae_moe_k_bwd_args* a, const float* theta, const float* dlat,
-                                     const float* pi, float* dtheta_rows, int M, int K, int B, int D,
+                                     const float* pi, float* dtheta_rows, int M, int K, int B, int D, float beta,
                                      mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && dlat && pi && K > 0 && B > 0 && D > 0);
   if (M < 2 || M > MMVAE_MOE_MAX_MODS || D > 64 * MOE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
@@ -202,9 +204,9 @@ extern "C" int mmvae_moe_ksample_bwd(const mmvae_moe_k_bwd_args* a, const float*
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   switch (M) {
-    case 2: hipLaunchKernelGGL(moe_ksample_bwd_kernel<2>, grid, block, 0, st, *a, theta, dlat, pi, dtheta_rows, K, B, D); break;
-    case 3: hipLaunchKernelGGL(moe_ksample_bwd_kernel<3>, grid, block, 0, st, *a, theta, dlat, pi, dtheta_rows, K, B, D); break;
-    default: hipLaunchKernelGGL(moe_ksample_bwd_kernel<4>, grid, block, 0, st, *a, theta, dlat, pi, dtheta_rows, K, B, D); break;
+    case 2: hipLaunchKernelGGL(moe_ksample_bwd_kernel<2>, grid, block, 0, st, *a, theta, dlat, pi, dtheta_rows, K, B, D, beta); break;
+    case 3: hipLaunchKernelGGL(moe_ksample_bwd_kernel<3>, grid, block, 0, st, *a, theta, dlat, pi, dtheta_rows, K, B, D, beta); break;
+    default: hipLaunchKernelGGL(moe_ksample_bwd_kernel<4>, grid, block, 0, st, *a, theta, dlat, pi, dtheta_rows, K, B, D, beta); break;
   }
   return mmvae_launch_status();
 }
@@ -301,6 +303,92 @@ extern "C" int mmvae_dreg_loss_bwd(const double* out, const double* g, const mmv
   const long n = (long)M * K * B;
   hipLaunchKernelGGL(dreg_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, g,
                      *rows, dlat, M, K, B);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// IWAE loss (MultimodalObjective.iwae, objectives.py:342-359): per sample b over the M*K importance weights
+//   lw[r,k,b] = lat[r,k,b] - lam_r (own_r[k,b] + cross_r[k,b])     (lat already holds log p(z) - beta lqz, :356)
+//   loss = - sum_b ( logsumexp_{r,k} lw[.,.,b] - log(M K) )        (fp64: the reference's lprob terms are double)
+// out (doubles): [0] loss | lse (B) | rec (M,2,K*B) = lpx_own, lpx_cross per r (the logged reconstruction_loss).
+// One thread per sample (M K <= a few hundred serial fp64 terms, B threads), then one workgroup folds the B terms
+// in a fixed order (no atomics).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iwae_loss_rows_kernel(const float* __restrict__ lat, mmvae_dreg_rows rows,
+                                                             double* __restrict__ out, int M, int K, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  double* lse = out + 1;
+  double* rec = lse + B;
+  const size_t KB = (size_t)K * B;
+  double mx = -INFINITY;
+  for (int r = 0; r < M; ++r) {
+    const double lam = (double)rows.lam[r];
+    for (int k = 0; k < K; ++k) {
+      const size_t i = (size_t)k * B + b;
+      const double o = -lam * (double)rows.own[r][i], c = -lam * (double)rows.cross[r][i];
+      rec[((size_t)r * 2 + 0) * KB + i] = o;
+      rec[((size_t)r * 2 + 1) * KB + i] = c;
+      mx = fmax(mx, (double)lat[(size_t)r * KB + i] + o + c);
+    }
+  }
+  double se = 0.0;
+  for (int r = 0; r < M; ++r)
+    for (int k = 0; k < K; ++k) {
+      const size_t i = (size_t)k * B + b;
+      se += exp((double)lat[(size_t)r * KB + i] + rec[((size_t)r * 2 + 0) * KB + i] + rec[((size_t)r * 2 + 1) * KB + i] - mx);
+    }
+  lse[b] = mx + log(se);
+}
+__global__ __launch_bounds__(256) void iwae_loss_sum_kernel(double* __restrict__ out, int MK, int B) {
+  __shared__ double part[256];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) acc += out[1 + b];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = -(part[0] - (double)B * log((double)MK));
+}
+// backward: d loss / d lw[r,k,b] = -g softmax_{rk}(lw)[b]  =>  dlat = that, d own = d cross = +g softmax lam_r
+__global__ __launch_bounds__(256) void iwae_loss_bwd_kernel(const float* __restrict__ lat, const double* __restrict__ out,
+                                                            const double* __restrict__ g, mmvae_dreg_rows_grad rows,
+                                                            float* __restrict__ dlat, int M, int K, int B) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const size_t KB = (size_t)K * B;
+  if (i >= (long)M * KB) return;
+  const int r = (int)(i / KB);
+  const size_t j = (size_t)i - (size_t)r * KB;
+  const int b = (int)(j % B);
+  const double* rec = out + 1 + B;
+  const double lw = (double)lat[i] + rec[((size_t)r * 2 + 0) * KB + j] + rec[((size_t)r * 2 + 1) * KB + j];
+  const double w = g[0] * exp(lw - out[1 + b]);
+  dlat[i] = (float)(-w);
+  const float v = (float)(w * (double)rows.lam[r]);
+  rows.own[r][j] = v;
+  rows.cross[r][j] = v;
+}
+extern "C" size_t mmvae_iwae_loss_out_doubles(int M, int K, int B) { return (size_t)1 + B + (size_t)M * 2 * K * B; }
+extern "C" int mmvae_iwae_loss_fwd(const float* lat, const mmvae_dreg_rows* rows, double* out, int M, int K, int B,
+                                   mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(lat && rows && out && K > 0 && B > 0);
+  if (M < 2 || M > MMVAE_MOE_MAX_MODS) return MMVAE_ERR_UNSUPPORTED;
+  for (int m = 0; m < M; ++m) MMVAE_CHECK_ARG(rows->own[m] && rows->cross[m]);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(iwae_loss_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, lat, *rows, out, M, K, B);
+  hipLaunchKernelGGL(iwae_loss_sum_kernel, dim3(1), dim3(256), 0, st, out, M * K, B);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_iwae_loss_bwd(const float* lat, const double* out, const double* g, const mmvae_dreg_rows_grad* rows,
+                                   float* dlat, int M, int K, int B, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(lat && out && g && rows && dlat && K > 0 && B > 0);
+  if (M < 2 || M > MMVAE_MOE_MAX_MODS) return MMVAE_ERR_UNSUPPORTED;
+  for (int m = 0; m < M; ++m) MMVAE_CHECK_ARG(rows->own[m] && rows->cross[m]);
+  const long n = (long)M * K * B;
+  hipLaunchKernelGGL(iwae_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lat,
+                     out, g, *rows, dlat, M, K, B);
   return mmvae_launch_status();
 }
 

@@ -139,11 +139,22 @@ class FlatAdam(torch.optim.Optimizer):
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """torch.optim.Adam only creates state for parameters that have received a gradient: a reference checkpoint of
+        `mixing: moe, obj: elbo` has no entry for the model-level prior `_pz_params.1` (requires_grad, never touched by
+        MOE.objective; mmvae_base.py:37).  So the PARAMETER LIST (`param_groups[0]["params"]`) must match the model;
+        state entries may be missing (their moments stay zero), present ones must match in size."""
         params = self.flat.params_in_model_order
         steps = set()
-        if sd["state"] and len(sd["state"]) != len(params):
-            raise RuntimeError(f"optimizer state has {len(sd['state'])} entries, the model has {len(params)} trainable "
-                               f"parameters")
+        listed = sd["param_groups"][0].get("params")
+        if listed is not None and len(listed) != len(params):
+            raise RuntimeError(f"optimizer param group lists {len(listed)} parameters, the model has {len(params)} "
+                               f"trainable parameters")
+        extra = [i for i in sd["state"] if not (isinstance(i, int) and 0 <= i < len(params))]
+        if extra:
+            raise RuntimeError(f"optimizer state has entries for unknown parameter indices {extra[:5]}")
+        self.m.zero_()
+        self.v.zero_()
+        self.vmax.zero_()
         for i, p in enumerate(params):
             st = sd["state"].get(i)
             if st is None:

@@ -100,15 +100,22 @@ SIGNATURES = {
     "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
                                        c_i, c_i, c_i, c_p]),
     "mmvae_poe_ws_floats": (c_sz, [c_i, c_i]),
-    "mmvae_bce_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 2 + [c_p]),
-    "mmvae_bce_sigmoid_clamp_bwd": (c_i, [c_p] * 4 + [c_i] * 2 + [c_p]),
+    "mmvae_bce_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
+    "mmvae_bce_sigmoid_clamp_bwd": (c_i, [c_p] * 4 + [c_i] * 3 + [c_p]),
     "mmvae_bce_rowsum_bwd": (c_i, [c_p] * 4 + [c_i] * 2 + [c_p]),
     "mmvae_sigmoid_clamp_bwd": (c_i, [c_p] * 3 + [c_l] + [c_p]),
     "mmvae_bce_elem_fwd": (c_i, [c_p] * 3 + [c_l] + [c_p]),
     "mmvae_bce_rowsum_seeded": (c_i, [c_p] * 3 + [c_f] + [c_p] + [c_i] * 2 + [c_p]),
     "mmvae_ce_over_time_seeded": (c_i, [c_p] * 3 + [c_f] + [c_p] + [c_i] * 3 + [c_p]),
-    "mmvae_ce_over_time_fwd": (c_i, [c_p] * 4 + [c_i] * 3 + [c_p]),
-    "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_p]),
+    "mmvae_lprob_elem_fwd": (c_i, [c_p] * 3 + [c_l, c_l, c_f, c_i, c_p]),
+    "mmvae_lprob_elem_bwd": (c_i, [c_p] * 4 + [c_l, c_l, c_f, c_i, c_p]),
+    "mmvae_optimal_sigma_elem_fwd": (c_i, [c_p] * 5 + [c_l, c_p]),
+    "mmvae_optimal_sigma_elem_bwd": (c_i, [c_p] * 6 + [c_l, c_p]),
+    "mmvae_pointwise_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 4 + [c_p]),
+    "mmvae_pointwise_rowsum_bwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_p]),
+    "mmvae_pointwise_elem": (c_i, [c_p] * 4 + [c_l, c_i, c_p]),
+    "mmvae_ce_over_time_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_p]),
+    "mmvae_ce_over_time_bwd": (c_i, [c_p] * 5 + [c_i] * 4 + [c_p]),
     "mmvae_lincomb_rows_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rows_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_expand_image_u8": (c_i, [c_p, c_p, c_l, c_p]),
@@ -167,8 +174,11 @@ SIGNATURES = {
     "mmvae_expmul_bwd": (c_i, [c_p] * 5 + [c_i, c_p]),
     "mmvae_moe_elbo_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_moe_elbo_bwd": (c_i, [c_p, c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
-    "mmvae_moe_ksample_fwd": (c_i, [ctypes.POINTER(MoeKArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
-    "mmvae_moe_ksample_bwd": (c_i, [ctypes.POINTER(MoeKBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mmvae_moe_ksample_fwd": (c_i, [ctypes.POINTER(MoeKArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "mmvae_moe_ksample_bwd": (c_i, [ctypes.POINTER(MoeKBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "mmvae_iwae_loss_out_doubles": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "mmvae_iwae_loss_fwd": (c_i, [c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
+    "mmvae_iwae_loss_bwd": (c_i, [c_p, c_p, c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_dreg_loss_fwd": (c_i, [c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_dreg_loss_bwd": (c_i, [c_p, c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_kl_laplace_normal_fwd": (c_i, [c_p, c_p, c_i, c_i, c_p]),

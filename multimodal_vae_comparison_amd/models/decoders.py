@@ -126,7 +126,13 @@ class HipTransformerDecoderStack(nn.Module):
 
 
 class Dec_TxtTransformer(VaeDecoder):
-    """models/decoders.py:668-723"""
+    """models/decoders.py:668-723.
+
+    K = 1 latent sample: the reference's behaviour (memory of length 1).  K > 1: the reference attends over the K
+    samples as a length-K memory and returns ONE (B,T,V) output that its own loss code then cannot reshape
+    (objectives.py:120) -- no objective runs through it.  DEFINED EXTENSION here (parity unpinned; restated
+    in oracle/mmvae_oracle.py: dec_txt_transformer keep_k): every sample is decoded on its own, (K,B) flattened into
+    the batch axis exactly as Dec_CNN does (decoders.py:73-76): output (K*B, T, V), row k*B + b."""
 
     def __init__(self, latent_dim, data_dim, latent_private, ff_size=128, num_layers=1, num_heads=2, dropout=0.1,
                  activation="gelu"):
@@ -163,17 +169,16 @@ class Dec_TxtTransformer(VaeDecoder):
         z = z.unsqueeze(0) if z.dim() == 2 else z
         mask = batch["masks"]
         K, bs, D = z.shape
-        if K != 1:
-            # the reference attends over the K samples as a length-K memory and then fails to reshape
-            # (SURVEY 0.4 / Appendix B17); only K = 1 is defined
-            raise NotImplementedError("Dec_TxtTransformer is defined for K = 1 latent sample only")
         if mask is None:
             mask = torch.ones(bs, self.data_dim[0], dtype=torch.bool, device=z.device)
         mask = mask.to(z.device)
+        if K != 1:          # K-preserving extension (class docstring): K * B independent sequences
+            mask = mask.repeat(K, 1)
+            bs = K * bs
         T = mask.shape[1]
         mask_u8 = ops.as_u8(mask)
         x = self._timequeries(T, bs, D, z.device)
-        mem = z.reshape(bs, D)                     # K = 1: a view (z[0] would cost a select-backward fill + copy)
+        mem = z.reshape(bs, D)                     # a view (z[0] would cost a select-backward fill + copy)
         p = self.dropout
         nl = len(self.seqTransDecoder.layers)
         if self.training and p > 0:       # nn.Dropout sites of the reference: PE + 6 per layer

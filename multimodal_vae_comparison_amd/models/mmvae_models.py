@@ -353,10 +353,11 @@ class POE(TorchMMVAE):
 
 
 class MOE(TorchMMVAE):
-    """MMVAE, mixture of experts (mmvae_models.py:10-131): objective "elbo" with K = 1 and "dreg"
+    """MMVAE, mixture of experts (mmvae_models.py:10-131): objective "elbo" with K = 1, "dreg"
     with any K on towers that keep the K axis (the shipped configs/config_mnistsvhn.yml: MNIST / SVHN towers, K = 30,
-    `prior: laplace`).  `iwae` crashes in the reference: its intended formula is built on the same forward (parity
-    unpinned, MultimodalObjective.iwae); elbo with K > 1 fails there too.
+    `prior: laplace`) and "iwae" with any K on any towers (literal where the reference runs -- B = 1 or K = 1 --, a
+    defined extension with the K-preserving text decoder beyond: MultimodalObjective.iwae; BASELINE configs[2] =
+    iwae, K = 8, CdSprites+ towers).  elbo with K > 1 fails in the reference.
 
     q_m = Normal | Laplace(mu_m, scale = lv_m) -- the config's `prior` key also names the posterior and the likelihood
     family (models/trainer.py:104) --, K samples z_m per modality; every modality is decoded from its own z
@@ -372,8 +373,6 @@ class MOE(TorchMMVAE):
         self.model_config = model_config
         self.modelName = "moe"
         obj = self.obj_fn.obj_name
-        if obj == "iwae" and float(self.obj_fn.beta) != 1.0:
-            self.obj_fn.iwae(None)                                # raises: beta = 1 only
         if obj == "elbo" and self.K != 1:
             raise NotImplementedError("moe: obj elbo with K > 1 fails in the reference (mmvae_models.py:62); use dreg")
         if obj in ("dreg", "iwae") and len(self.vaes) != 2:
@@ -434,9 +433,11 @@ class MOE(TorchMMVAE):
         return {"loss": loss, "reconstruction_loss": lpx, "kld": kld}
 
     def _objective_dreg(self, data):
-        """MOE.objective's non-elbo branch + MultimodalObjective.dreg (mmvae_models.py:63-78, objectives.py:361-387).
-        Every decoder decodes ALL M*K*B latent samples in one pass (rows [r*K*B, (r+1)*K*B) are z_r): its own block is
-        the own reconstruction, the other block the cross reconstruction."""
+        """MOE.objective's non-elbo branch + MultimodalObjective.dreg / .iwae (mmvae_models.py:63-78,
+        objectives.py:342-387).  Every decoder decodes ALL M*K*B latent samples in one pass (rows [r*K*B, (r+1)*K*B) are
+        z_r): its own block is the own reconstruction, the other block the cross reconstruction.  dreg: `lprob` towers
+        that keep K (its lw sums over the batch per k, which only those towers' (K,) sums allow); iwae: any tower, the
+        target rows repeat over (r, k) inside the loss kernels (row % B)."""
         self._begin_step()
         names = list(self.vaes.keys())
         M, K, D = len(names), int(self.K), self.n_latents
@@ -445,20 +446,23 @@ class MOE(TorchMMVAE):
         B = packed[0].shape[0]
         eps = [self._draw_k(m, K, B, D, dev) for m in range(M)]
         theta = self._pz_params[1]
-        lat, z = ops.moe_ksample(theta, packed, eps, self._laplace, theta.grad)          # z: (M,K,B,D)
+        iwae = self.obj_fn.obj_name == "iwae"
+        # lat = log p(z) - beta lqz: dreg has no beta (objectives.py:372), iwae multiplies lqz by it (:356)
+        lat, z = ops.moe_ksample(theta, packed, eps, self._laplace, theta.grad,
+                                 beta=float(self.obj_fn.beta) if iwae else 1.0)          # z: (M,K,B,D)
         KB = K * B
         rows, lam = [], []
         for r, n in enumerate(names):
             vae = self.vaes[n]
-            if vae.ltype != "lprob" or data[n]["masks"] is not None:
+            if not iwae and (vae.ltype != "lprob" or data[n]["masks"] is not None):
                 raise NotImplementedError("moe dreg: recon_loss lprob on unmasked modalities (the MNIST / SVHN towers) "
                                           "is what keeps the K axis in the reference")
             self.obj_fn.set_ltype(vae.ltype)
             o = 1 - r
-            out, _ = vae.dec({"latents": z.view(M * K, B, D), "masks": None})          # (M*K, B, ...)
+            out, _ = vae.dec({"latents": z.view(M * K, B, D), "masks": data[n]["masks"]})     # (M*K, B, ...) / (M*K*B, ...)
             # own block r: dist.Normal (:101-103); cross block o: vae.px_z = the config's `prior` family (:115)
             lap_mask = (1 << o) if self._laplace[r] else 0
-            rs = recon_rowsum("lprob", out, data[n], laplace=(lap_mask, KB))            # (M*K*B,)
+            rs = recon_rowsum(vae.ltype, out, data[n], laplace=(lap_mask, KB))          # (M*K*B,)
             rows += [rs[r * KB:(r + 1) * KB], rs[o * KB:(o + 1) * KB]]
             lam.append(float(vae.llik_scaling))
         return self.obj_fn.calculate_loss({"lat": lat, "rows": rows, "lam": lam})
@@ -557,8 +561,9 @@ class DMVAE(TorchMMVAE):
                 return recon_rowsum(vae.ltype, out, mods[n])
             own = rec(z_sh[i])
             ind.append(own)
+            joint = rec(zj[0])       # decode order own, joint, cross as the reference's forward (mmvae_models.py:494-502)
             cross = [rec(z_cr[(i, m)]) for m in range(M) if m != i]
-            rows += [own, kl_sh[i], rec(zj[0]), klj[M]] + cross + [kl_pr[i]]
+            rows += [own, kl_sh[i], joint, klj[M]] + cross + [kl_pr[i]]
             W_loss += [lam, beta, lam, beta] + [lam] * len(cross) + [beta * len(cross)]
             W_kld += [0.0, 1.0 / M, 0.0, 0.0] + [0.0] * len(cross) + [0.0]
         out = ops.lincomb_rows(rows, [W_loss, W_kld])

@@ -33,12 +33,18 @@ class MultimodalVAE(nn.Module):
         self.optimizer = None
         self.flat = None
         self.model = None
+        self.logged = {}            # name -> last logged scalar (the record `self.log` keeps when no Lightning Trainer is attached)
         self.get_model()
         self.to(device)
         self.flat = flatmod.FlatParams(self.model)
         self._graph = None
         self.dp_world = 1           # ranks the flat gradients are summed over (parallel.setup_replica sets it)
         self.dp_force_collective = False
+        if self.config.pre_trained:
+            # models/trainer.py:95-97: warm start from a Lightning checkpoint (reference key names).  The reference hands
+            # the path to load_from_checkpoint; here the weights go INTO the flat buffer views of the model the config
+            # describes -- a missing file or a mismatching layout is an error, never a silent training from scratch
+            self.load_checkpoint(self.config.pre_trained, strict=True)
 
     def get_model(self):
         """models/trainer.py:91-115"""
@@ -60,16 +66,55 @@ class MultimodalVAE(nn.Module):
         return self.model
 
     def configure_optimizers(self):
-        """models/trainer.py:75-89: Adam(lr, amsgrad=True) over the trainable parameters"""
-        if self.config.optimizer.lower() != "adam":
+        """models/trainer.py:75-89: Adam(lr, amsgrad=True) over the trainable parameters.  `optimizer: adabelief`
+        (:82-86) imports the third-party adabelief_pytorch package, which the reference does not vendor: not on this
+        path, refused loudly (as any other name is by the reference's own NotImplementedError)."""
+        name = self.config.optimizer.lower()
+        if name == "adabelief":
+            raise NotImplementedError("optimizer: adabelief needs the un-vendored adabelief_pytorch package "
+                                      "(reference models/trainer.py:82-86); the MI355X path implements adam (amsgrad)")
+        if name != "adam":
             raise NotImplementedError(self.config.optimizer)
         self.optimizer = flatmod.FlatAdam(self.flat, lr=float(self.config.lr))
         return self.optimizer
 
+    def log(self, name, value, batch_size=None, **kw):
+        """Lightning's `self.log` when no Trainer is attached: keep the last value per name in `self.logged` (device
+        scalars: no host synchronisation here) and hand it to `log_hook(name, value, batch_size)` when one is set."""
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
+        hook = getattr(self, "log_hook", None)
+        if hook is not None:
+            hook(name, self.logged[name], batch_size)
+
+    def _log_losses(self, loss_d, prefix, tag):
+        """the logging loop shared by training_step / validation_step / test_step (models/trainer.py:121-127,134-140,
+        147-153): `<prefix>_<key>` = value.sum() for every key of the objective's dict, `Mod_<i>_<Tag>Loss` = sum of
+        the i-th entry of `reconstruction_loss`"""
+        for key in loss_d.keys():
+            if key != "reconstruction_loss":
+                self.log("{}_{}".format(prefix, key), loss_d[key].sum(), batch_size=self.config.batch_size)
+            else:
+                for i, p_l in enumerate(loss_d[key]):
+                    self.log("Mod_{}_{}Loss".format(i, tag), p_l.sum(), batch_size=self.config.batch_size)
+
     def training_step(self, train_batch, batch_idx=0):
-        """models/trainer.py:117-128 (logging left to the caller: the dict is kept in `last_losses`)"""
+        """models/trainer.py:117-128"""
         loss_d = self.model.objective(train_batch)
         self.last_losses = loss_d
+        self._log_losses(loss_d, "train", "Train")
+        return loss_d["loss"]
+
+    def validation_step(self, val_batch, batch_idx=0):
+        """models/trainer.py:130-141: the same objective on the validation batch (Lightning puts the module in eval mode
+        and disables gradients around it; a caller without Lightning does the same), logged as val_* / Mod_i_ValLoss"""
+        loss_d = self.model.objective(val_batch)
+        self._log_losses(loss_d, "val", "Val")
+        return loss_d["loss"]
+
+    def test_step(self, test_batch, batch_idx=0):
+        """models/trainer.py:143-154: logged as test_* / Mod_i_TestLoss"""
+        loss_d = self.model.objective(test_batch)
+        self._log_losses(loss_d, "test", "Test")
         return loss_d["loss"]
 
     # ---- checkpoints (SURVEY 8(f) rank 2) -----------------------------------------------------------
@@ -129,6 +174,12 @@ class MultimodalVAE(nn.Module):
         `batch`'s shapes into a hipGraph.  `batch` tensors become the static input buffers: copy new data into them
         (`load_batch`) before each replay."""
         assert self.optimizer is not None, "call configure_optimizers() first"
+        # the collective and the 1/world mean come from parallel.setup_replica (dp_world, optimizer.grad_scale), not from
+        # this argument: a caller that asks for a multi-rank step without having set the replica up would otherwise train
+        # diverging replicas without a word (ADVICE r2)
+        assert world_size == 1 or world_size == self.dp_world or self.dp_force_collective, \
+            f"capture(world_size={world_size}) but the trainer is set up for {self.dp_world} rank(s): call " \
+            f"parallel.setup_replica(trainer, rank, world_size) first"
         self._static_batch = batch
         self._one = torch.ones((), device=self.flat.data.device)     # loss.backward() seed: no fill kernel per step
         from .. import ops
@@ -203,9 +254,12 @@ class MultimodalVAE(nn.Module):
             if self._collective_in_graph:
                 try:
                     out = record(True)
-                except RuntimeError as e:          # the runtime refused to capture the collective: launch it after the graph
+                    why = self._validate_graph_collective()
+                except RuntimeError as e:          # the runtime refused to capture the collective
+                    why = f"all-reduce not capturable here ({e})"
+                if why is not None:                # launch it after the graph instead (the round-1 step structure)
                     import warnings
-                    warnings.warn(f"all-reduce not capturable here ({e}); using the post-graph tail")
+                    warnings.warn(f"{why}; using the post-graph tail")
                     self._collective_in_graph = False
                     torch.cuda.synchronize()
                     self._graph = torch.cuda.CUDAGraph()
@@ -217,6 +271,37 @@ class MultimodalVAE(nn.Module):
             pass
         self.flat.zero_grad()
         return out
+
+    def _validate_graph_collective(self):
+        """A captured RCCL all-reduce has to prove itself before the step relies on it (the path had only ever
+        run on a one-rank group): ONE replay of the freshly captured graph -- backward, in-graph all-reduce, Adam --
+        and then the replicas must still hold bit-identical parameters (min == max of a checksum over the ranks, the
+        check bench.py reports as `replicas_in_sync`).  Parameters, optimiser state, noise counters and the step count
+        are restored afterwards, so training starts from the same state either way.  Returns None when the graph is
+        good, else the reason; every rank reaches the same verdict (the failure flag is reduced with MAX)."""
+        dist = torch.distributed
+        opt = self.optimizer
+        keep = [t.clone() for t in (self.flat.data, opt.m, opt.v, opt.vmax, opt.step_dev)]
+        bad, why = 0.0, None
+        try:
+            self._graph.replay()
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            bad, why = 1.0, f"replay of the graph with the captured all-reduce failed ({e})"
+        cs = self.flat.data.double().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        flag = torch.tensor([bad + float(not bool(torch.isfinite(cs).all())) + float(lo.item() != hi.item())],
+                            device=cs.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        for t, k in zip((self.flat.data, opt.m, opt.v, opt.vmax, opt.step_dev), keep):
+            t.copy_(k)
+        self.flat.zero_grad()
+        torch.cuda.synchronize()
+        if float(flag.item()) != 0.0:
+            return why or "replicas diverged after one replay of the graph with the captured all-reduce"
+        return None
 
     def _fwd_bwd(self, batch):
         """forward + backward of the objective; mixers whose loss is linear in per-tower terms provide
@@ -297,10 +382,14 @@ class MultimodalVAE(nn.Module):
         packed = compact.get("_packed")
         with torch.cuda.stream(cs):
             if packed is not None:
+                # the device views below are cut from the FIRST packed batch's layout: a later batch of the same size
+                # but another layout (offsets, shapes, dtypes) must rebuild them, not be expanded through stale offsets
+                sig = _packed_signature(compact)
                 dbuf = getattr(self, "_staging_packed", None)
-                if dbuf is None or dbuf.numel() != packed.numel():
+                if dbuf is None or dbuf.numel() != packed.numel() or getattr(self, "_staging_sig", None) != sig:
                     dbuf = self._staging_packed = torch.empty(packed.numel(), dtype=torch.uint8, device=dev)
                     self._staging = {}
+                    self._staging_sig = sig
                 dbuf.copy_(packed, non_blocking=True)
                 if not self._staging:       # device views with the host buffer's offsets, built once
                     base = packed.data_ptr()
@@ -335,6 +424,8 @@ class MultimodalVAE(nn.Module):
 
     def fused_step(self, world_size=1):
         """one optimisation step on the static batch: graph replay -> (all-reduce) -> fused Adam"""
+        assert world_size == 1 or world_size == self.dp_world or self.dp_force_collective, \
+            f"fused_step(world_size={world_size}) on a trainer set up for {self.dp_world} rank(s)"
         self._graph.replay()
         if self._adam_in_graph:
             assert world_size == 1, "captured with the optimiser step inside the graph"
@@ -356,6 +447,13 @@ class MultimodalVAE(nn.Module):
         parallel.reduce_gradients_and_step(self.flat.grad, self.optimizer, self.dp_world, None, self.dp_force_collective)
         return self._static_out
 
+
+
+def _packed_signature(packed):
+    """layout of a pack_compact_pinned() batch: (key, name, byte offset, shape, dtype) of every tensor in the buffer"""
+    base = packed["_packed"].data_ptr()
+    return tuple((k, name, t.data_ptr() - base, tuple(t.shape), str(t.dtype))
+                 for k, v in packed.items() if k != "_packed" for name, t in v.items())
 
 
 class InputPipe:
@@ -392,6 +490,8 @@ class InputPipe:
             mods.append(m)
         assert 0 < len(mods) <= H.INPUT_MAX_MODS
         self._mods = (H.InputMod * len(mods))(*mods)
+        self._sig = _packed_signature(packed)   # every later batch must have exactly this layout
+        self._checked = set()
         self._keep = trainer._static_batch      # the raw pointers above point into these tensors
         h = ctypes.c_void_p()
         rc = H.lib().mmvae_input_pipe_create(ctypes.byref(h), self.staging.data_ptr(), self.bytes)
@@ -401,8 +501,14 @@ class InputPipe:
 
     def _ptr(self, packed):
         buf = packed["_packed"]
-        assert buf.numel() == self.bytes and buf.is_pinned()
-        return buf.data_ptr()
+        ptr = buf.data_ptr()
+        if ptr not in self._checked:        # (a ring of pinned batches: each buffer's layout is checked once)
+            assert buf.numel() == self.bytes and buf.is_pinned()
+            if _packed_signature(packed) != self._sig:
+                raise ValueError("InputPipe: this packed batch has another layout (offsets / shapes / dtypes) than the "
+                                 "one the pipe was created for")
+            self._checked.add(ptr)
+        return ptr
 
     def prefetch(self, packed):
         rc = self._H.lib().mmvae_input_pipe_prefetch(self._h, self._ptr(packed))

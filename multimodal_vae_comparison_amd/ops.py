@@ -490,20 +490,25 @@ class BceSigmoidRowsum(Function):
 
     @staticmethod
     def forward(ctx, y_raw, target):
+        """target: (B, ...) or, for a K-sample output, (B / K, ...) -- output row r is paired with target row
+        r % (B / K) (the repeat of BaseObjective.reshape_for_loss, objectives.py:118-120, is never materialised)"""
         y_raw, target = H.f32c(y_raw), H.f32c(target)
         B = y_raw.shape[0]
         F_ = y_raw.numel() // B
+        trows = target.numel() // F_
+        assert trows * F_ == target.numel() and B % trows == 0
         row = torch.empty(B, device=y_raw.device)
         cs = ConstSeed.current
         ctx.seeded = None
-        if cs is not None and y_raw.requires_grad:
+        if cs is not None and y_raw.requires_grad and trows == B:
             dl = torch.empty_like(y_raw)
             _call("mmvae_bce_rowsum_seeded", H.ptr(y_raw), H.ptr(target), H.ptr(row), cs.value, H.ptr(dl), B, F_,
                   H.stream())
             ctx.seeded = (cs.seed.data_ptr(), dl)
         else:
-            _call("mmvae_bce_rowsum_fwd", H.ptr(y_raw), H.ptr(target), H.ptr(row), B, F_, H.stream())
+            _call("mmvae_bce_rowsum_fwd", H.ptr(y_raw), H.ptr(target), H.ptr(row), B, F_, trows, H.stream())
         ctx.save_for_backward(y_raw, target)
+        ctx.trows = trows
         return row
 
     @staticmethod
@@ -514,7 +519,7 @@ class BceSigmoidRowsum(Function):
         B = y.shape[0]
         dl = torch.empty_like(y)
         _call("mmvae_bce_sigmoid_clamp_bwd", H.ptr(y), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(dl), B, y.numel() // B,
-              H.stream())
+              ctx.trows, H.stream())
         return dl, None
 
 
@@ -1100,7 +1105,7 @@ class BceRowsum(Function):
         B = x_hat.shape[0]
         F = x_hat.numel() // B
         row = torch.empty(B, device=x_hat.device)
-        _call("mmvae_bce_rowsum_fwd", H.ptr(x_hat), H.ptr(target), H.ptr(row), B, F, H.stream())
+        _call("mmvae_bce_rowsum_fwd", H.ptr(x_hat), H.ptr(target), H.ptr(row), B, F, B, H.stream())
         ctx.save_for_backward(x_hat, target)
         return row
 
@@ -1192,6 +1197,124 @@ class OptimalSigmaRowsum(Function):
         return d, None
 
 
+class LprobElem(Function):
+    """ReconLoss.lprob element-wise (models/objectives.py:409-424): -log p(target) under Normal / Laplace(loc, scale)
+    as float64, NaN -> 0; `scale` None = scale := loc.  target may hold fewer (repeating) elements than loc."""
+
+    @staticmethod
+    def forward(ctx, loc, target, scale, laplace):
+        loc, target = H.f32c(loc), H.f32c(target)
+        out = torch.empty(loc.shape, dtype=torch.float64, device=loc.device)
+        sc = -1.0 if scale is None else float(scale)
+        _call("mmvae_lprob_elem_fwd", H.ptr(loc), H.ptr(target), H.ptr(out), loc.numel(), target.numel(), sc,
+              int(bool(laplace)), H.stream())
+        ctx.save_for_backward(loc, target)
+        ctx.cfg = (sc, int(bool(laplace)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, target = ctx.saved_tensors
+        g = g.to(torch.float64).contiguous()
+        d = torch.empty_like(loc)
+        _call("mmvae_lprob_elem_bwd", H.ptr(loc), H.ptr(target), H.ptr(g), H.ptr(d), loc.numel(), target.numel(),
+              ctx.cfg[0], ctx.cfg[1], H.stream())
+        return d, None, None, None
+
+
+class OptimalSigmaElem(Function):
+    """ReconLoss.optimal_sigma element-wise (models/objectives.py:503-509)"""
+
+    @staticmethod
+    def forward(ctx, loc, target):
+        loc, target = H.f32c(loc), H.f32c(target)
+        n = loc.numel()
+        out = torch.empty_like(loc)
+        stats = torch.empty(4, device=loc.device)
+        ws = torch.empty(H.lib().mmvae_optimal_sigma_ws_floats(1, n), device=loc.device)
+        _call("mmvae_optimal_sigma_elem_fwd", H.ptr(loc), H.ptr(target), H.ptr(out), H.ptr(stats), H.ptr(ws), n,
+              H.stream())
+        ctx.save_for_backward(loc, target, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, target, stats = ctx.saved_tensors
+        n = loc.numel()
+        d = torch.empty_like(loc)
+        ws = torch.empty(H.lib().mmvae_optimal_sigma_ws_floats(1, n), device=loc.device)
+        _call("mmvae_optimal_sigma_elem_bwd", H.ptr(loc), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(stats), H.ptr(ws),
+              H.ptr(d), n, H.stream())
+        return d, None
+
+
+PW_L1, PW_MSE = 0, 1
+
+
+class PointwiseRowsum(Function):
+    """row[b] = sum_f |x - t| (kind PW_L1; ReconLoss.l1, objectives.py:427-442) or (x - t)^2 (PW_MSE; :444-459);
+    target rows repeat (row b against target row b % target rows)"""
+
+    @staticmethod
+    def forward(ctx, x, target, kind):
+        x, target = H.f32c(x), H.f32c(target)
+        B = x.shape[0]
+        F_ = x.numel() // B
+        trows = target.numel() // F_
+        assert trows * F_ == target.numel() and B % trows == 0
+        row = torch.empty(B, device=x.device)
+        _call("mmvae_pointwise_rowsum_fwd", H.ptr(x), H.ptr(target), H.ptr(row), B, F_, trows, int(kind), H.stream())
+        ctx.save_for_backward(x, target)
+        ctx.cfg = (B, F_, trows, int(kind))
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target = ctx.saved_tensors
+        B, F_, trows, kind = ctx.cfg
+        d = torch.empty_like(x)
+        _call("mmvae_pointwise_rowsum_bwd", H.ptr(x), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(d), B, F_, trows, kind,
+              H.stream())
+        return d, None, None
+
+
+class PointwiseElem(Function):
+    """element-wise l1 / mse (the literal ReconLoss.l1 / .mse outputs)"""
+
+    @staticmethod
+    def forward(ctx, x, target, kind):
+        x, target = H.f32c(x), H.f32c(target)
+        out = torch.empty_like(x)
+        _call("mmvae_pointwise_elem", H.ptr(x), H.ptr(target), None, H.ptr(out), x.numel(), int(kind), H.stream())
+        ctx.save_for_backward(x, target)
+        ctx.kind = int(kind)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target = ctx.saved_tensors
+        d = torch.empty_like(x)
+        _call("mmvae_pointwise_elem", H.ptr(x), H.ptr(target), H.ptr(H.f32c(g)), H.ptr(d), x.numel(), ctx.kind,
+              H.stream())
+        return d, None, None
+
+
+def lprob_elem(loc, target, scale=0.75, laplace=False):
+    return LprobElem.apply(loc, target, scale, laplace)
+
+
+def optimal_sigma_elem(loc, target):
+    return OptimalSigmaElem.apply(loc, target)
+
+
+def pointwise_rowsum(x, target, kind):
+    return PointwiseRowsum.apply(x, target, kind)
+
+
+def pointwise_elem(x, target, kind):
+    return PointwiseElem.apply(x, target, kind)
+
+
 def lprob_rowsum(loc, target, scale=0.75, laplace=False, perm_c=0, logit_grad=False):
     return LprobRowsum.apply(loc, target, scale, laplace, perm_c, logit_grad)
 
@@ -1234,18 +1357,22 @@ class CeOverTime(Function):
     def forward(ctx, logits, target, per_v):
         logits, target = H.f32c(logits), H.f32c(target)
         B, T, V = logits.shape
+        trows = target.shape[0]       # < B: K-sample logits, row r against target row r % trows (see BceSigmoidRowsum)
+        assert tuple(target.shape[1:]) == (T, V) and B % trows == 0
         dev = logits.device
         loss = torch.empty(B, V, device=dev) if per_v else None
         row = None if per_v else torch.empty(B, device=dev)
         cs = ConstSeed.current
         ctx.seeded = None
-        if cs is not None and not per_v and logits.requires_grad and T * V <= 4096 and V <= 256:
+        ctx.trows = trows
+        if cs is not None and not per_v and logits.requires_grad and T * V <= 4096 and V <= 256 and trows == B:
             dl = torch.empty_like(logits)
             _call("mmvae_ce_over_time_seeded", H.ptr(logits), H.ptr(target), H.ptr(row), cs.value, H.ptr(dl), B, T, V,
                   H.stream())
             ctx.seeded = (cs.seed.data_ptr(), dl)
         else:
-            _call("mmvae_ce_over_time_fwd", H.ptr(logits), H.ptr(target), H.ptr(loss), H.ptr(row), B, T, V, H.stream())
+            _call("mmvae_ce_over_time_fwd", H.ptr(logits), H.ptr(target), H.ptr(loss), H.ptr(row), B, T, V, trows,
+                  H.stream())
         ctx.save_for_backward(logits, target)
         ctx.per_v = per_v
         return loss if per_v else row
@@ -1259,7 +1386,7 @@ class CeOverTime(Function):
         g = H.f32c(g)
         dl = torch.empty_like(logits)
         _call("mmvae_ce_over_time_bwd", H.ptr(logits), H.ptr(target), H.ptr(g) if ctx.per_v else None,
-              None if ctx.per_v else H.ptr(g), H.ptr(dl), B, T, V, H.stream())
+              None if ctx.per_v else H.ptr(g), H.ptr(dl), B, T, V, ctx.trows, H.stream())
         return dl, None, None
 
 
@@ -1469,7 +1596,7 @@ class MoeKSample(Function):
     sum_d log p(z) - log-mean-exp_m sum_d log q_m(z) and z (M,K,B,D) (one tensor: the decoders take all of it)."""
 
     @staticmethod
-    def forward(ctx, theta, gtheta, laplace, M, *tensors):
+    def forward(ctx, theta, gtheta, laplace, M, beta, *tensors):
         packed = [H.f32c(t) for t in tensors[:M]]
         eps = [H.f32c(t) for t in tensors[M:2 * M]]
         K, B, D = eps[0].shape
@@ -1482,15 +1609,16 @@ class MoeKSample(Function):
         for m in range(M):
             a.packed[m], a.eps[m], a.z[m], a.laplace[m] = packed[m].data_ptr(), eps[m].data_ptr(), zs[m].data_ptr(), \
                 int(laplace[m])
-        _call("mmvae_moe_ksample_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(lat), H.ptr(pi), M, K, B, D, H.stream())
+        _call("mmvae_moe_ksample_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(lat), H.ptr(pi), M, K, B, D, float(beta),
+              H.stream())
         ctx.save_for_backward(theta, pi, z, *packed, *eps)
-        ctx.cfg = (gtheta, tuple(int(x) for x in laplace), M, K, B, D)
+        ctx.cfg = (gtheta, tuple(int(x) for x in laplace), M, K, B, D, float(beta))
         ctx.set_materialize_grads(False)
         return lat, z
 
     @staticmethod
     def backward(ctx, dlat, dz):
-        gtheta, laplace, M, K, B, D = ctx.cfg
+        gtheta, laplace, M, K, B, D, beta = ctx.cfg
         theta, pi, z = ctx.saved_tensors[:3]
         packed = ctx.saved_tensors[3:3 + M]
         eps = ctx.saved_tensors[3 + M:3 + 2 * M]
@@ -1509,7 +1637,7 @@ class MoeKSample(Function):
         if ctx.needs_input_grad[0] or gtheta is not None:
             rows = GradReducer.alloc(B * D, dev) if _defer(gtheta) else torch.empty(B, D, device=dev)
         _call("mmvae_moe_ksample_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dlat), H.ptr(pi), H.ptr(rows), M, K, B, D,
-              H.stream())
+              beta, H.stream())
         if rows is not None:
             if _defer(gtheta):
                 GradReducer.add(rows.data_ptr(), gtheta, B, D, D)
@@ -1517,12 +1645,12 @@ class MoeKSample(Function):
                 gtheta += rows.sum(0).view_as(gtheta)
             else:
                 ret = rows.sum(0).view_as(theta)
-        return (ret, None, None, None, *dpacked, *([None] * M))
+        return (ret, None, None, None, None, *dpacked, *([None] * M))
 
 
-def moe_ksample(theta, packed, eps, laplace, gtheta=None):
-    """-> lat (M,K,B), z (M,K,B,D)"""
-    return MoeKSample.apply(theta, gtheta, laplace, len(packed), *packed, *eps)
+def moe_ksample(theta, packed, eps, laplace, gtheta=None, beta=1.0):
+    """-> lat (M,K,B) = log p(z) - beta log-mean-exp_m log q_m(z), z (M,K,B,D)"""
+    return MoeKSample.apply(theta, gtheta, laplace, len(packed), beta, *packed, *eps)
 
 
 class DregLoss(Function):
@@ -1563,6 +1691,47 @@ class DregLoss(Function):
 
 def dreg_loss(lat, lam, rows):
     return DregLoss.apply(lat, lam, len(lam), *rows)
+
+
+class IwaeLoss(Function):
+    """MultimodalObjective.iwae (objectives.py:342-359) from the latent terms `lat` (M,K,B) = log p(z) - beta lqz and
+    the positive per-sample reconstruction sums own_r / cross_r (K*B): returns (loss fp64 scalar, lpx (M,2,K*B) fp64
+    [logged]).  csrc/moe.hip: iwae_loss_*."""
+
+    @staticmethod
+    def forward(ctx, lat, lam, M, *rows):
+        lat = H.f32c(lat)
+        rows = [H.f32c(r).reshape(-1) for r in rows]
+        _, K, B = lat.shape
+        assert len(rows) == 2 * M and all(r.numel() == K * B for r in rows)
+        out = torch.empty(H.lib().mmvae_iwae_loss_out_doubles(M, K, B), dtype=torch.float64, device=lat.device)
+        t = H.DregRows()
+        for r in range(M):
+            t.own[r], t.cross[r], t.lam[r] = rows[2 * r].data_ptr(), rows[2 * r + 1].data_ptr(), float(lam[r])
+        _call("mmvae_iwae_loss_fwd", H.ptr(lat), ctypes.byref(t), H.ptr(out), M, K, B, H.stream())
+        ctx.save_for_backward(lat, out)
+        ctx.cfg = (tuple(float(x) for x in lam), M, K, B)
+        rec = out[1 + B:].view(M, 2, K * B)
+        ctx.mark_non_differentiable(rec)
+        return out[0], rec
+
+    @staticmethod
+    def backward(ctx, g, _grec):
+        lat, out = ctx.saved_tensors
+        lam, M, K, B = ctx.cfg
+        dev = out.device
+        g = g.to(torch.float64).reshape(1).contiguous()
+        dlat = torch.empty(M, K, B, device=dev)
+        drows = [torch.empty(K * B, device=dev) for _ in range(2 * M)]
+        t = H.DregRows()
+        for r in range(M):
+            t.own[r], t.cross[r], t.lam[r] = drows[2 * r].data_ptr(), drows[2 * r + 1].data_ptr(), lam[r]
+        _call("mmvae_iwae_loss_bwd", H.ptr(lat), H.ptr(out), H.ptr(g), ctypes.byref(t), H.ptr(dlat), M, K, B, H.stream())
+        return (dlat, None, None, *drows)
+
+
+def iwae_loss(lat, lam, rows):
+    return IwaeLoss.apply(lat, lam, len(lam), *rows)
 
 
 def normal_logratio(packed_r, packed_o, z):

@@ -297,6 +297,24 @@ def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
                           p[f"{pre}.enc.logvar_layer.weight"], p[f"{pre}.enc.logvar_layer.bias"])
 
 
+# Test infrastructure for ReLU kinks (tests/test_parity_e2e.py: _relu_masks_of): a pre-activation within fp32 rounding of
+# zero takes either side of the kink depending on the summation order, and that ONE element moves whole rows of the
+# upstream weight gradients.  With RELU_MASKS = {site: [mask of call 0, call 1, ...]} (site = the name of the layer that
+# produces the pre-activation, e.g. "vaes.mod_1.dec.lin2"; the masks are `pre-activation > 0` as the implementation under
+# test saw them) every ReLU becomes `x * mask`: the same piecewise-linear branch on both sides, so every gradient can be
+# held to the plain 1e-4.  None (the default): torch.relu.
+RELU_MASKS = None
+
+
+def _relu(x, site):
+    if RELU_MASKS is None:
+        return torch.relu(x)
+    calls = RELU_MASKS.setdefault("_calls", {})
+    k = calls.get(site, 0)
+    calls[site] = k + 1
+    return x * RELU_MASKS[site][k].reshape(x.shape).to(x.dtype)
+
+
 def dec_cnn(p, pre, z, data_dim=(64, 64, 3)):
     """Dec_CNN.forward, models/decoders.py:71-98.  z (K,B,D') -> recon (K*B, 64,64,3)-*viewed* NCHW memory."""
     if z.dim() == 2:
@@ -304,11 +322,11 @@ def dec_cnn(p, pre, z, data_dim=(64, 64, 3)):
     K, B = z.shape[0], z.shape[1]
     x = z
     for n in ("lin1", "lin2", "lin3"):
-        x = torch.relu(F.linear(x, p[f"{pre}.dec.{n}.module.weight"], p[f"{pre}.dec.{n}.module.bias"]))
+        x = _relu(F.linear(x, p[f"{pre}.dec.{n}.module.weight"], p[f"{pre}.dec.{n}.module.bias"]), f"{pre}.dec.{n}")
     x = x.reshape(B * K, 32, 4, 4)
     for n in ("convT_64", "convT1", "convT2"):
-        x = torch.relu(F.conv_transpose2d(x, p[f"{pre}.dec.{n}.module.weight"], p[f"{pre}.dec.{n}.module.bias"],
-                                          stride=2, padding=1))
+        x = _relu(F.conv_transpose2d(x, p[f"{pre}.dec.{n}.module.weight"], p[f"{pre}.dec.{n}.module.bias"],
+                                     stride=2, padding=1), f"{pre}.dec.{n}")
     x = F.conv_transpose2d(x, p[f"{pre}.dec.convT3.module.weight"], p[f"{pre}.dec.convT3.module.bias"],
                            stride=2, padding=1)
     d = torch.sigmoid(x.reshape(K, B, *data_dim)).clamp(ETA, 1 - ETA)   # decoders.py:96-97 (view, no permute)
@@ -420,10 +438,21 @@ def enc_txt_transformer(p, pre, data, mask, train=False):
                           p[f"{pre}.enc.logvar_layer.module.weight"], p[f"{pre}.enc.logvar_layer.module.bias"])
 
 
-def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
-    """Dec_TxtTransformer.forward, models/decoders.py:708-723.  z (K,B,D') is the *memory* (length K)."""
+def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False, keep_k=False):
+    """Dec_TxtTransformer.forward, models/decoders.py:708-723.  z (K,B,D') is the *memory* (length K): for K > 1 the
+    reference attends over the K samples and returns ONE (B,T,V) output, which its loss code then cannot reshape
+    (objectives.py:120) -- no objective with K > 1 runs through it.
+
+    keep_k (DEFINED EXTENSION, PARITY UNPINNED for K > 1; identical to the reference for K = 1): every latent sample
+    is decoded on its own, as Dec_CNN does by flattening (K,B) into the batch axis (decoders.py:73-76): memory
+    (1, K*B, D'), masks repeated K times, output (K*B, T, V) with row k*B + b = sample k of batch element b."""
     if z.dim() == 2:
         z = z.unsqueeze(0)
+    if keep_k and z.shape[0] > 1:
+        K = z.shape[0]
+        z = z.reshape(1, -1, z.shape[-1])
+        if mask is not None:
+            mask = mask.repeat(K, 1)
     B, D = z.shape[1], z.shape[-1]
     if mask is None:
         mask = torch.ones(B, data_dim[0], dtype=torch.bool)
@@ -439,8 +468,8 @@ def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False):
 def enc_mnist(p, pre, x):
     """Enc_MNIST.forward, models/encoders.py:252-265"""
     h = x.reshape(x.shape[0], -1).to(torch.get_default_dtype())
-    h = F.relu(F.linear(h, p[f"{pre}.enc.enc.0.0.weight"], p[f"{pre}.enc.enc.0.0.bias"]))
-    h = F.relu(F.linear(h, p[f"{pre}.enc.enc.1.0.weight"], p[f"{pre}.enc.enc.1.0.bias"]))
+    h = _relu(F.linear(h, p[f"{pre}.enc.enc.0.0.weight"], p[f"{pre}.enc.enc.0.0.bias"]), f"{pre}.enc.enc.0.0")
+    h = _relu(F.linear(h, p[f"{pre}.enc.enc.1.0.weight"], p[f"{pre}.enc.enc.1.0.bias"]), f"{pre}.enc.enc.1.0")
     return process_output(h, p[f"{pre}.enc.hidden_mu.weight"], p[f"{pre}.enc.hidden_mu.bias"],
                           p[f"{pre}.enc.hidden_logvar.weight"], p[f"{pre}.enc.hidden_logvar.bias"])
 
@@ -448,8 +477,8 @@ def enc_mnist(p, pre, x):
 def dec_mnist(p, pre, z, data_dim=(28, 28, 1)):
     """Dec_MNIST.forward, models/decoders.py:252-270: (K=1,B,D') -> sigmoid MLP -> reshape (B,28,28,1) -> permute to
     (B,1,28,28)"""
-    h = F.relu(F.linear(z, p[f"{pre}.dec.dec.0.0.weight"], p[f"{pre}.dec.dec.0.0.bias"]))
-    h = F.relu(F.linear(h, p[f"{pre}.dec.dec.1.0.weight"], p[f"{pre}.dec.dec.1.0.bias"]))
+    h = _relu(F.linear(z, p[f"{pre}.dec.dec.0.0.weight"], p[f"{pre}.dec.dec.0.0.bias"]), f"{pre}.dec.dec.0.0")
+    h = _relu(F.linear(h, p[f"{pre}.dec.dec.1.0.weight"], p[f"{pre}.dec.dec.1.0.bias"]), f"{pre}.dec.dec.1.0")
     x = torch.sigmoid(F.linear(h, p[f"{pre}.dec.fc3.weight"], p[f"{pre}.dec.fc3.bias"]))
     d = x.reshape(*z.shape[:-1], *data_dim)
     if d.dim() == 5:
@@ -461,7 +490,8 @@ def enc_svhn(p, pre, x):
     """Enc_SVHN.forward, models/encoders.py:458-478"""
     h = x.to(torch.get_default_dtype())
     for i, pad in enumerate((1, 1, 1, 0)):
-        h = F.relu(F.conv2d(h, p[f"{pre}.enc.conv{i + 1}.weight"], p[f"{pre}.enc.conv{i + 1}.bias"], stride=2, padding=pad))
+        h = _relu(F.conv2d(h, p[f"{pre}.enc.conv{i + 1}.weight"], p[f"{pre}.enc.conv{i + 1}.bias"], stride=2, padding=pad),
+                  f"{pre}.enc.conv{i + 1}")
     h = h.reshape(h.shape[0], -1)
     return process_output(h, p[f"{pre}.enc.hidden_mu.weight"], p[f"{pre}.enc.hidden_mu.bias"],
                           p[f"{pre}.enc.hidden_logvar.weight"], p[f"{pre}.enc.hidden_logvar.bias"])
@@ -471,10 +501,10 @@ def dec_svhn(p, pre, z):
     """Dec_SVHN.forward, models/decoders.py:118-147: the output is permuted to (B,32,32,3) -- the loss then RESHAPES
     the NCHW target to that shape (objectives.py:120), it does not permute it"""
     zs = z.squeeze(0) if z.dim() == 3 else z
-    h = F.relu(F.linear(zs, p[f"{pre}.dec.linear.weight"], p[f"{pre}.dec.linear.bias"])).reshape(-1, 128, 1, 1)
-    h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv1.weight"], p[f"{pre}.dec.conv1.bias"], stride=1, padding=0))
-    h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv2.weight"], p[f"{pre}.dec.conv2.bias"], stride=2, padding=1))
-    h = F.relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv3.weight"], p[f"{pre}.dec.conv3.bias"], stride=2, padding=1))
+    h = _relu(F.linear(zs, p[f"{pre}.dec.linear.weight"], p[f"{pre}.dec.linear.bias"]), f"{pre}.dec.linear").reshape(-1, 128, 1, 1)
+    h = _relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv1.weight"], p[f"{pre}.dec.conv1.bias"], stride=1, padding=0), f"{pre}.dec.conv1")
+    h = _relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv2.weight"], p[f"{pre}.dec.conv2.bias"], stride=2, padding=1), f"{pre}.dec.conv2")
+    h = _relu(F.conv_transpose2d(h, p[f"{pre}.dec.conv3.weight"], p[f"{pre}.dec.conv3.bias"], stride=2, padding=1), f"{pre}.dec.conv3")
     h = F.conv_transpose2d(h, p[f"{pre}.dec.conv4.weight"], p[f"{pre}.dec.conv4.bias"], stride=2, padding=1)
     d = torch.sigmoid(h).permute(0, 2, 3, 1)
     if z.dim() == 3 and z.shape[0] > 1:                 # K > 1: (K,B,32,32,3), decoders.py:119,145-146
@@ -540,13 +570,13 @@ def encode(p, mods, i, inp, train=False):
     return _ENC[mods[i]["enc"]](p, f"vaes.mod_{i + 1}", inp, train)
 
 
-def decode(p, mods, i, z, mask, train=False):
+def decode(p, mods, i, z, mask, train=False, keep_k=False):
     m = mods[i]
     pre = f"vaes.mod_{i + 1}"
     if m["dec"] == "CNN":
         return dec_cnn(p, pre, z, tuple(m["data_dim"]))
     if m["dec"] == "TxtTransformer":
-        return dec_txt_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
+        return dec_txt_transformer(p, pre, z, mask, tuple(m["data_dim"]), train, keep_k)
     if m["dec"] == "Transformer":
         return dec_transformer(p, pre, z, mask, tuple(m["data_dim"]), train)
     if m["dec"] == "MNIST":
@@ -647,8 +677,19 @@ def recon_optimal_sigma(loc, target):
     return (sq + log_sigma + 0.5 * math.log(2 * math.pi)).reshape(B, -1)
 
 
+def recon_l1(x, target):
+    """ReconLoss.l1, models/objectives.py:427-442: torch.nn.L1Loss(reduction="none")"""
+    return (x - target.to(torch.get_default_dtype()).reshape(x.shape).detach()).abs().reshape(target.shape[0], -1)
+
+
+def recon_mse(x, target):
+    """ReconLoss.mse, models/objectives.py:444-459: torch.nn.MSELoss(reduction="none")"""
+    return ((x - target.to(torch.get_default_dtype()).reshape(x.shape).detach()) ** 2).reshape(target.shape[0], -1)
+
+
 _RECON = {"bce": lambda o, t, sc: recon_bce(o, t), "category_ce": lambda o, t, sc: recon_category_ce(o, t),
-          "lprob": lambda o, t, sc: recon_lprob(o, t, sc), "optimal_sigma": lambda o, t, sc: recon_optimal_sigma(o, t)}
+          "lprob": lambda o, t, sc: recon_lprob(o, t, sc), "optimal_sigma": lambda o, t, sc: recon_optimal_sigma(o, t),
+          "l1": lambda o, t, sc: recon_l1(o, t), "mse": lambda o, t, sc: recon_mse(o, t)}
 
 
 def recon_loss(ltype, out, target):
@@ -846,36 +887,63 @@ def moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior="normal", train=
             "_lw": lw, "_z": zs, "_enc": enc}
 
 
-def moe_iwae_objective(p, mods, batch, eps, n_latents, K, prior="normal", train=False):
-    """MultimodalObjective.iwae (models/objectives.py:342-359) as INTENDED -- PARITY UNPINNED: the reference's own code
-    crashes (`.cuda()` on a list at :353; (K,) reconstruction sums reshaped to (K,B) at :356), so this restates the
-    formula its lines spell, on the same forward as dreg (moe_dreg_objective) with the reconstruction terms kept per
-    sample:  lw_r[k,b] = log p(z_r) + lpx_own_r[k,b] + lpx_cross_r[k,b] - beta log-mean-exp_m log q_m(z_r);
-    loss = - sum_b log-mean-exp over cat_r(lw_r) (dim 0: the M K weights of sample b)."""
-    d = moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior, train)
+def recon_loss_k(ltype, out, target, K, laplace=False):
+    """BaseObjective.recon_loss_fn with K samples (objectives.py:30-52 + reshape_for_loss :103-125): the output is
+    sliced to the mask length (then scale := loc for lprob), the target is repeated K times along its first axis and
+    reshaped like the output, bs = the output's leading axis; positive loss (out.shape[0], -1)."""
+    masked = target["masks"] is not None
+    if masked:
+        out = out[:, : target["masks"].shape[1]]
+    data = target["data"]
+    t = data.to(torch.get_default_dtype()).repeat(K, *([1] * (data.dim() - 1))).reshape(out.shape).detach()
+    if ltype == "lprob":
+        if masked:
+            return recon_lprob(out, t, out, laplace)
+        return recon_lprob_k(out, data, K, laplace)
+    return _RECON[ltype](out, t, None)
+
+
+def moe_iwae_objective(p, mods, batch, eps, n_latents, K, prior="normal", train=False, beta=1.0):
+    """MOE.objective's non-elbo branch + MultimodalObjective.iwae, models/mmvae_models.py:63-78 and
+    models/objectives.py:342-359, LITERALLY (tests/golden/moe_*_iwae_*.npz, generated from the reference under the
+    tuple-`.cuda()` shim of tests/golden/ref_harness.py, pin it):
+      lpx_r = (own, cross) reconstruction sums over everything but the decoders' LEADING axis (rows n0), times llik_scaling;
+      lpz (K,B) = sum_d log N(z_r; 0, softmax(theta) D);  lqz (K,B) = log-mean-exp_m sum_d log q_m(z_r);
+      lw_r = lpz + (lpx_own + lpx_cross).reshape(K, B) - beta * lqz                                    (:356)
+      loss = - sum_b log-mean-exp over cat_r(lw_r) along dim 0 (the M K weights of sample b);  kld = tensor(0);
+      reconstruction_loss = (M, 2, n0).
+    The reshape at :356 needs n0 == K * B.  The reference's towers give n0 = K (MNIST / SVHN keep K and recon_loss_fn's
+    batch axis is then K), n0 = B (any tower at K = 1) or crash in the text decoder (K > 1): so it runs at B = 1 or at
+    K = 1 only.  EXTENSION (parity unpinned beyond those two edges, which the fixtures pin): the per-(k, b) row sums are
+    used for every K and B -- K-preserving towers are summed per sample instead of per k, and the text decoder decodes
+    every sample (dec_txt_transformer keep_k).  fp64 where a `lprob` term is (the reference's .double()), else fp32."""
     M = len(mods)
+    assert M == 2, "MOE iwae: the reference's cross-term indexing (mmvae_models.py:64-70) is only meaningful for M = 2"
     lap = prior == "laplace"
     logq = laplace_log_prob if lap else normal_log_prob
-    enc, zs = d["_enc"], d["_z"]
+    enc = [encode(p, mods, i, batch[f"mod_{i + 1}"], train) for i in range(M)]
+    B = enc[0][0].shape[0]
+    zs = [enc[i][0] + enc[i][1] * eps[i].reshape(K, B, n_latents) for i in range(M)]            # (K,B,D)
     lam = resolve_llik_scaling(mods)
     sig_p = prior_sigma(p["_pz_params.1"])
     lws, recs = [], []
     for r in range(M):
         o = 1 - r
-        tgt = batch[f"mod_{r + 1}"]["data"]
-        own = decode(p, mods, r, zs[r], None, train)
-        cross = decode(p, mods, r, zs[o], None, train)
-        Bn = zs[r].shape[1]
-        lpx_own = -recon_lprob_k(own, tgt, K, False).reshape(K, Bn, -1).sum(-1) * lam[r]       # (K,B)
-        lpx_cross = -recon_lprob_k(cross, tgt, K, lap).reshape(K, Bn, -1).sum(-1) * lam[r]
-        lpz = normal_log_prob(zs[r], 0.0, sig_p).sum(-1)
-        lq = torch.stack([logq(zs[r], enc[m][0], enc[m][1]).sum(-1) for m in range(M)])
+        tgt = batch[f"mod_{r + 1}"]
+        own = decode(p, mods, r, zs[r], tgt["masks"], train, keep_k=True)
+        cross = decode(p, mods, r, zs[o], tgt["masks"], train, keep_k=True)
+        # own: dist.Normal (:101-103); cross: vae.px_z = the config's `prior` family (:115)
+        lpx_own = (-recon_loss_k(mods[r]["ltype"], own, tgt, K, False) * lam[r]).reshape(K * B, -1).sum(-1)
+        lpx_cross = (-recon_loss_k(mods[r]["ltype"], cross, tgt, K, lap) * lam[r]).reshape(K * B, -1).sum(-1)
+        lpz = normal_log_prob(zs[r], 0.0, sig_p).sum(-1)                                       # (K,B)
+        lq = torch.stack([logq(zs[r], enc[m][0], enc[m][1]).sum(-1) for m in range(M)])        # (M,K,B)
         lqz = torch.logsumexp(lq, 0) - math.log(M)
-        lws.append(lpz + lpx_own + lpx_cross - lqz)
-        recs.append(torch.stack([lpx_own.sum(-1), lpx_cross.sum(-1)]))
-    lw = torch.cat(lws).double()                                                               # (M K, B)
+        lws.append(lpz + (lpx_own + lpx_cross).reshape(K, B) - beta * lqz)
+        recs.append(torch.stack([lpx_own, lpx_cross]))
+    lw = torch.cat(lws)                                                                        # (M K, B)
     loss = -(torch.logsumexp(lw, 0) - math.log(lw.shape[0])).sum()
-    return {"loss": loss, "kld": torch.tensor(0), "reconstruction_loss": torch.stack(recs), "_lw": lw}
+    return {"loss": loss, "kld": torch.tensor(0), "reconstruction_loss": torch.stack(recs), "_lw": lw, "_z": zs,
+            "_enc": enc}
 
 
 def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, obj="elbo", K=1, prior="normal"):
@@ -889,7 +957,7 @@ def moe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, obj="el
     if obj == "dreg":
         return moe_dreg_objective(p, mods, batch, eps, n_latents, K, prior, train)
     if obj == "iwae":
-        return moe_iwae_objective(p, mods, batch, eps, n_latents, K, prior, train)
+        return moe_iwae_objective(p, mods, batch, eps, n_latents, K, prior, train, beta)
     assert obj == "elbo" and K == 1
     M = len(mods)
     lap = prior == "laplace"      # posterior Laplace(mu, scale = lv), cross likelihood Laplace, KL(Laplace || N(0,1))

@@ -90,6 +90,31 @@ CASES += [
 ]
 
 
+# obj iwae, LITERAL (models/objectives.py:342-359) under ref_harness.install_tuple_cuda_shim(): the line
+# `lw = lpz + lpx_z.reshape(*lpz.shape) - beta * lqz_x` (:356) only runs where the decoders' leading axis has K*B rows --
+# K-preserving towers (MNIST / SVHN: leading axis K) at B = 1, any towers at K = 1 (leading axis B) -- and these cases pin
+# it there: K = 3 / 8, both posterior families, beta != 1, the CdSprites+ towers with a ragged text mask.
+CASE_OPTS.update({
+    "moe_ms_b1_d8_iwae_k3_normal": {"obj": "iwae", "K": 3, "prior": "normal"},
+    "moe_ms_b1_d8_iwae_k8_laplace": {"obj": "iwae", "K": 8, "prior": "laplace"},
+    "moe_ms_b4_d8_iwae_k1_laplace": {"obj": "iwae", "K": 1, "prior": "laplace"},
+    "moe_b5_t6_d8_iwae_k1": {"obj": "iwae", "K": 1, "prior": "normal"},
+})
+for _n in ("moe_ms_b1_d8_iwae_k3_normal", "moe_ms_b1_d8_iwae_k8_laplace", "moe_ms_b4_d8_iwae_k1_laplace"):
+    CASE_MODS[_n] = MS_AUTO
+CASES += [
+    ("moe_ms_b1_d8_iwae_k3_normal", "moe", 1, 0, 8, None, "eval", 1.0),
+    ("moe_ms_b1_d8_iwae_k8_laplace", "moe", 1, 0, 8, None, "eval", 2.0),
+    ("moe_ms_b4_d8_iwae_k1_laplace", "moe", 4, 0, 8, None, "eval", 0.5),
+    ("moe_b5_t6_d8_iwae_k1", "moe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.5),
+]
+
+
+# recon_loss l1 / mse (models/objectives.py:427-459) through a mixer: image mse, text l1, beta != 1
+CASE_MODS["mopoe_b5_t6_d8_mse_l1"] = [dict(MODS[0], ltype="mse"), dict(MODS[1], ltype="l1")]
+CASES += [("mopoe_b5_t6_d8_mse_l1", "mopoe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.5)]
+
+
 # the unimodal case (models/trainer.py:112-113): one VAE trained with UnimodalObjective.elbo
 CASE_MODS["vae_cnn2_b5_d8"] = [MODS[0]]
 CASE_MODS["vae_txt_b5_t6_d8"] = [MODS[1]]
@@ -187,6 +212,8 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     meta = {"name": name, "mixing": mixing, "B": B, "T": T, "D": D, "beta": beta, "seed": seed, "mode": mode,
             "mods": mods, "lr": 1e-4}
     meta.update(opts)
+    if opts.get("obj") == "iwae":
+        meta["shims"] = [ref_harness.install_tuple_cuda_shim()]
     if opts:
         meta["llik"] = [float(v.llik_scaling) for v in model.vaes.values()]     # "auto" resolved by the reference
 
@@ -206,13 +233,15 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
     meta["n_eps"] = len(tape.draws)
     out["loss"] = res["loss"].detach().numpy()
     out["kld"] = res["kld"].detach().numpy()
+    if opts.get("obj") == "iwae":       # one (M, 2, rows) tensor [own, cross], rows = the decoders' leading axis
+        res["reconstruction_loss"] = list(res["reconstruction_loss"])
     if mixing == "vae":      # (B, F) / (B, D) element tensors: keep the per-sample sums
         out["rec_0"] = res["reconstruction_loss"].detach().double().sum(-1).numpy()
         out["kld"] = res["kld"].detach().sum(-1).numpy()
     else:
         for i, r in enumerate(res["reconstruction_loss"]):
             out[f"rec_{i}"] = r.detach().numpy()
-    if mixing == "moe" and opts.get("obj", "elbo") == "elbo":      # MoE leaves the trainable model prior untouched: the reference has no gradient for it
+    if mixing == "moe" and opts.get("obj", "elbo") == "elbo":      # MoE elbo leaves the trainable model prior untouched: the reference has no gradient for it
         for k, q in model.named_parameters():
             if q.requires_grad and q.grad is None:
                 q.grad = torch.zeros_like(q)

@@ -12,7 +12,11 @@ imports it.  Recipe = SURVEY.md Appendix C:
   * recording / replaying of the standard-normal draws behind `Normal.rsample`
     (torch/distributions/normal.py -> torch.distributions.utils._standard_normal) and of the draws behind
     `Laplace.rsample` (recorded as the standard-Laplace variate e = -sign(u) log1p(-|u|) of torch's uniform u, so that
-    z = loc + scale * e exactly as for the Normal case).
+    z = loc + scale * e exactly as for the Normal case);
+  * `install_tuple_cuda_shim()` (iwae fixtures only, recorded in their `meta["shims"]`): MultimodalObjective.iwae calls
+    `data["pz_params"].cuda()` on the TUPLE that `MOE.pz_params` returns (models/objectives.py:353) -- the same class of
+    hard-coded device move as the tensor `.cuda()` calls above, only spelled on a tuple; the property hands back a tuple
+    subclass whose `.cuda()` is the identity, nothing else changes.
 """
 import importlib.machinery
 import os
@@ -95,6 +99,23 @@ def install():
 
     nn.Module.to = _mto
     install._done = True
+
+
+class CudaTuple(tuple):
+    """a tuple whose `.cuda()` is the identity (objectives.py:353 calls it on MOE.pz_params)"""
+
+    def cuda(self, *a, **k):
+        return self
+
+
+def install_tuple_cuda_shim():
+    """MOE.pz_params -> CudaTuple(same two tensors).  Idempotent; returns the shim's name for fixture metadata."""
+    import models.mmvae_models as mm
+    if not getattr(install_tuple_cuda_shim, "_done", False):
+        orig = mm.MOE.pz_params
+        mm.MOE.pz_params = property(lambda self: CudaTuple(orig.fget(self)))
+        install_tuple_cuda_shim._done = True
+    return "MOE.pz_params returns a tuple subclass with an identity .cuda() (objectives.py:353)"
 
 
 class EpsTape:
