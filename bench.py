@@ -41,6 +41,10 @@ def parse():
     p.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the non-headline figures (input pipeline, large batch)")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="process-group backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo moves the CUDA "
+                        "buffers through the host and lets several ranks share one GPU (N > 1 readiness test on a "
+                        "1-GPU box: LOCAL_RANK is taken modulo the visible device count)")
     p.add_argument("--force-collective", action="store_true",
                    help="one GPU, but the multi-GPU step structure (graph, RCCL all-reduce over 1 rank, Adam launch)")
     return p.parse_args()
@@ -299,10 +303,13 @@ def main():
     from multimodal_vae_comparison_amd import parallel
     from multimodal_vae_comparison_amd.synthetic import step_flops_per_sample, workload
     # torchrun: the process group comes up before anything touches the GPU
-    rank, local, world = parallel.init_from_env("nccl")
+    ndev = torch.cuda.device_count()           # (counting devices does not initialise the GPU)
+    local_env = int(os.environ.get("LOCAL_RANK", 0))
+    dev_index = local_env % max(ndev, 1) if a.backend == "gloo" else local_env
+    rank, local, world = parallel.init_from_env(a.backend, torch.device("cuda", dev_index))
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # --force-collective (testing on one GPU): take the multi-GPU structure of the step -- graph without the optimiser,
     # one RCCL all-reduce of the flat gradients, separate Adam launch -- with a single-rank process group
     path_world = world
@@ -347,11 +354,18 @@ def main():
                               sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
                "final_loss": round(loss, 3)}
         if world > 1 or path_world > 1:
-            res["config"]["collective"] = ("one all-reduce of the flat gradient buffer per step, captured into the step's "
-                                           "hipGraph with the Adam launch" if getattr(tr, "_collective_in_graph", False)
-                                           else "one all-reduce of the flat gradient buffer per step after the graph")
-            if in_sync is not None:
-                res["config"]["replicas_in_sync"] = in_sync
+            # top level, so that the driver's scaling record can read them: which collective path the step took and
+            # whether the replicas still hold bit-identical parameters after the timed steps
+            in_graph = bool(getattr(tr, "_collective_in_graph", False))
+            res["collective"] = {"path": "in graph" if in_graph else "after graph", "backend": a.backend,
+                                 "what": ("one all-reduce of the flat gradient buffer per step, captured into the step's "
+                                          "hipGraph with the Adam launch (validated by one replay + cross-rank checksum "
+                                          "at capture)" if in_graph else
+                                          "one all-reduce of the flat gradient buffer per step after the graph, then the "
+                                          "fused Adam launch"),
+                                 "bytes": int(tr.flat.grad.numel() * 4)}
+            res["replicas_in_sync"] = in_sync
+            res["config"]["collective"] = res["collective"]["what"]
     if world == 1 and rank == 0:
         res["roofline"] = dominant_kernel_roofline(meta, dev)
         if not a.no_extras and path_world == 1 and a.config == "cfg2":

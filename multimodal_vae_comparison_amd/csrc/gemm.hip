@@ -485,13 +485,17 @@ static bool rgemm_enabled() {
 // stage's MFMAs).  Same GemmArgs / split-K partial layout / epilogue semantics as gemm_kernel.
 // Requires 16-byte aligned operands along their contiguous axis (the dispatcher checks; else the staged kernel runs).
 // ------------------------------------------------------------------------------------------------
-#define GB_BM 128
+// Round 3: BM is a template parameter too.  128 x (128 | 64) for the big grids; 64 x 64 (one accumulator per wave) for
+// the batch-row linears at mid-size batches (M = 512 .. 2000 rows x 512 columns: 128 workgroups at M = 1000, where the
+// register-operand kernel -- built for M <= 256 -- ran at 10 TFLOP/s and 128-row tiles would leave 3/4 of the chip idle).
 #define GB_BK 16
-template <int BN, bool A_KMAJOR, bool B_KMAJOR>
+template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
-  constexpr int BM = GB_BM, BK = GB_BK;
+  constexpr int BK = GB_BK;
   constexpr int AP = BM + 4, BP = BN + 4;
+  constexpr int TM = BM / 64;                 // 32-row MFMA tiles per wave along M (2 | 1)
   constexpr int TN = BN / 64;                 // 32-column MFMA tiles per wave along N
+  constexpr int NA4 = BM * BK / 4 / 256;      // float4 of the A tile per thread (2 | 1)
   constexpr int NB4 = BN * BK / 4 / 256;      // float4 of the B tile per thread (2 | 1)
   __shared__ __attribute__((aligned(16))) float As[2][BK * AP];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BP];
@@ -504,11 +508,11 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
 
   // ---- staging slots.  k-contiguous operand: float4 = 4 k of one row (row = slot % R, k4 = slot / R);
   //      row-contiguous operand: float4 = 4 rows of one k (r4 = slot % (R/4), k = slot / (R/4))
-  long a_off[2];
-  int a_lds[2], a_k[2];
-  bool a_ok[2];
+  long a_off[NA4];
+  int a_lds[NA4], a_k[NA4];
+  bool a_ok[NA4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NA4; ++i) {
     const int q = tid + 256 * i;
     if (A_KMAJOR) {
       const int m = q % BM, k4 = q / BM;
@@ -544,12 +548,12 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
       b_lds[i] = k * BP + 4 * n4;
     }
   }
-  float4 ra[2], rb[NB4];
+  float4 ra[NA4], rb[NB4];
   unsigned oka = 0, okb = 0;
   auto load_stage = [&](int k0) {
     oka = okb = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA4; ++i) {
       // k-contiguous: the float4 covers k0+a_k .. +3 (K % 4 == 0: all in or all out); row-contiguous: one k
       const bool ok = a_ok[i] && (k0 + a_k[i] < kend);
       oka |= (ok ? 1u : 0u) << i;
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA4; ++i) {
       float4 v = (oka >> i & 1u) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (g.a_act != MMVAE_ACT_NONE) act4(v, g.a_act);
       float* d = As[buf] + a_lds[i];
@@ -588,9 +592,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
     }
   };
 
-  f32x16 acc[2][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -607,14 +611,14 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) load_stage(k0 + BK);
-    const float* __restrict__ a_s = As[buf] + lh * AP + wm * 64 + li;
+    const float* __restrict__ a_s = As[buf] + lh * AP + wm * (BM / 2) + li;
     const float* __restrict__ b_s = Bs[buf] + lh * BP + wn * (BN / 2) + li;
     // operands of k pair kp+1 are read from LDS while the MFMAs of pair kp issue (hipcc otherwise sinks every ds_read
     // next to its consumer, see conv_gather.inc)
-    float av[2][2], bv[2][TN];
+    float av[2][TM], bv[2][TN];
     auto load_ops = [&](int kp, int ob) {
-      av[ob][0] = a_s[2 * kp * AP];
-      av[ob][1] = a_s[2 * kp * AP + 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[ob][i] = a_s[2 * kp * AP + 32 * i];
 #pragma unroll
       for (int j = 0; j < TN; ++j) bv[ob][j] = b_s[2 * kp * BP + 32 * j];
     };
@@ -625,8 +629,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][0], bv[kp & 1][j], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][1], bv[kp & 1][j], acc[1][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][i], bv[kp & 1][j], acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -650,10 +655,10 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
     const int col = n0 + wn * (BN / 2) + 32 * j + li;
     const float bias_v = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + wm * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.M && col < g.N) {
           float v = acc[i][j][r] + bias_v;
           const long o = (long)row * ldc + col;
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
 
 // shapes the large-tile kernel takes: big enough to fill the chip with 128-row tiles, float4-loadable operands
 // shapes the large-tile kernel takes: enough 128-row tiles to put >= 2 workgroups on every CU, float4-loadable
-// operands.  Returns the N tile (128 | 64) or 0.
+// operands.  Returns the N tile (128 | 64) or 0; -64: the 64 x 64 tiles (mid-size M, see gemm_big_kernel).
 static inline int gemm_big_bn(const GemmArgs& g, int nz, bool ak, bool bk_major) {
   static const int on = [] { const char* e = getenv("MMVAE_GEMM_BIG"); return e ? atoi(e) : 1; }();
   if (!on) return 0;
@@ -691,19 +696,25 @@ static inline int gemm_big_bn(const GemmArgs& g, int nz, bool ak, bool bk_major)
   const long rows = (g.M + 127) / 128;
   if (rows * ((g.N + 127) / 128) * nz >= 512 && g.N > 64) return 128;
   if (rows * ((g.N + 63) / 64) * nz >= 384) return 64;
+  // mid-size problems past the register-operand regime (M <= 256 rows): 64 x 64 tiles once they give >= 64 workgroups
+  static const int on64 = [] { const char* e = getenv("MMVAE_GEMM_BIG64"); return e ? atoi(e) : 1; }();
+  if (on64 && g.M > 256 && g.N >= 64 && g.K >= 64 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nz >= 64) return -64;
   return 0;
 }
 static void gemm_big_launch(const GemmArgs& g, int bn, int nz, bool ak, bool bk_major, hipStream_t st) {
-  const dim3 grid((g.N + bn - 1) / bn, (g.M + 127) / 128, nz);
-#define GB_LAUNCH(BN)                                                                                   \
-  do {                                                                                                  \
-    if (ak && bk_major) hipLaunchKernelGGL((gemm_big_kernel<BN, true, true>), grid, dim3(256), 0, st, g);   \
-    else if (ak) hipLaunchKernelGGL((gemm_big_kernel<BN, true, false>), grid, dim3(256), 0, st, g);         \
-    else if (!bk_major) hipLaunchKernelGGL((gemm_big_kernel<BN, false, false>), grid, dim3(256), 0, st, g); \
-    else hipLaunchKernelGGL((gemm_big_kernel<BN, false, true>), grid, dim3(256), 0, st, g);                 \
+  const int bm = bn < 0 ? 64 : 128;
+  if (bn < 0) bn = -bn;
+  const dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, nz);
+#define GB_LAUNCH(BM, BN)                                                                                   \
+  do {                                                                                                      \
+    if (ak && bk_major) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, g);   \
+    else if (ak) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, g);         \
+    else if (!bk_major) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, g); \
+    else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, g);                 \
   } while (0)
-  if (bn == 128) GB_LAUNCH(128);
-  else GB_LAUNCH(64);
+  if (bm == 64) GB_LAUNCH(64, 64);
+  else if (bn == 128) GB_LAUNCH(128, 128);
+  else GB_LAUNCH(128, 64);
 #undef GB_LAUNCH
 }
 

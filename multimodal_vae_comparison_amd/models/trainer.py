@@ -169,10 +169,11 @@ class MultimodalVAE(nn.Module):
             self.flat.zero_grad()
 
     # ---- MI355X fast path ------------------------------------------------------------------------
-    def capture(self, batch, world_size=1):
+    def capture(self, batch, world_size=1, optimizer_in_graph=None):
         """Capture objective + backward (+ the Adam step when there is no collective between them, world_size 1) for
         `batch`'s shapes into a hipGraph.  `batch` tensors become the static input buffers: copy new data into them
-        (`load_batch`) before each replay."""
+        (`load_batch`) before each replay.  optimizer_in_graph=False keeps the optimiser step out of a one-rank graph
+        (fused_step then launches it after the replay: the replayed gradients stay readable in between)."""
         assert self.optimizer is not None, "call configure_optimizers() first"
         # the collective and the 1/world mean come from parallel.setup_replica (dp_world, optimizer.grad_scale), not from
         # this argument: a caller that asks for a multi-rank step without having set the replica up would otherwise train
@@ -202,7 +203,7 @@ class MultimodalVAE(nn.Module):
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
-        self._adam_in_graph = world_size == 1
+        self._adam_in_graph = world_size == 1 if optimizer_in_graph is None else bool(optimizer_in_graph) and world_size == 1
         # MMVAE_GRAPH_COLLECTIVE=1 (data parallel): the all-reduce of the flat gradients and the Adam launch are captured
         # INTO the step's graph (RCCL collectives are stream-capturable): the whole N > 1 step is one graph launch, with
         # no host-side launches between the backward pass, the collective and the optimiser

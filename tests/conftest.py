@@ -33,6 +33,21 @@ def load_golden(name):
     return meta, d
 
 
+def load_full_grads(name):
+    """every element of every parameter gradient of the reference for `name` (tests/golden/full_grads, one small case
+    per mixer), or None"""
+    path = os.path.join(GOLDEN_DIR, "full_grads", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
+def full_grad_cases():
+    d = os.path.join(GOLDEN_DIR, "full_grads")
+    return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".npz")) if os.path.isdir(d) else []
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The C-ABI library; skips (CPU box) are not allowed to hide a missing build on the GPU box."""

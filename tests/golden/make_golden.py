@@ -126,6 +126,11 @@ CASES += [
 ]
 
 
+# one small case per mixer also keeps EVERY element of every parameter gradient (tests/golden/full_grads/<case>.npz, keys
+# = the reference's parameter names): the other fixtures hold 3 norms + 96 evenly spaced samples per tensor
+FULL_GRADS = {"mopoe_b6_t5_d8", "poe_b4_t5_d8", "moe_b5_t6_d8", "dmvae_b5_t6_d8p4"}
+
+
 def build_reference(mixing, D, beta, private=None, mods=None, obj="elbo", K=1, prior="normal"):
     if mixing == "vae":
         m = mods[0]
@@ -274,6 +279,10 @@ def run_case(name, mixing, B, T, D, lengths, mode, beta, seed=0):
         if p.requires_grad:
             assert p.grad is not None, k
             out[f"g/{k}"] = gw.summarize(p.grad)
+    if name in FULL_GRADS:
+        os.makedirs(os.path.join(HERE, "full_grads"), exist_ok=True)
+        np.savez_compressed(os.path.join(HERE, "full_grads", name + ".npz"),
+                            **{k: p.grad.detach().numpy() for k, p in model.named_parameters() if p.requires_grad})
     # one optimiser step exactly as models/trainer.py:79-81
     opt = torch.optim.Adam(filter(lambda q: q.requires_grad, model.parameters()), lr=meta["lr"], amsgrad=True)
     opt.step()

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import forward_cases, golden_cases, load_golden
+from conftest import forward_cases, full_grad_cases, golden_cases, load_full_grads, load_golden
 from oracle import golden_weights as gw
 from oracle import mmvae_oracle as orc
 
@@ -97,6 +97,27 @@ def test_gradients_and_adam_match_reference(name):
         bad = (np.abs(a - b) > 1e-6 * np.maximum(np.abs(b), 1e-3)) & well
         assert not bad.any(), f"adam {k}: {bad.sum()}/{well.sum()} well-conditioned elements differ"
         assert np.abs(a - b).max() <= 2.0 * meta["lr"] * 1.001, f"adam {k}: step larger than 2*lr"
+
+
+@pytest.mark.parametrize("name", full_grad_cases())
+def test_every_gradient_element_matches_reference(name):
+    """one small case per mixer keeps the reference's FULL parameter gradients: every tensor to 1e-4 of its maximum, and
+    element-wise 1e-3 on the elements within a factor 20 of that maximum"""
+    meta, g = load_golden(name)
+    full = load_full_grads(name)
+    p, out = _run(meta, g)
+    out["loss"].backward()
+    assert set(full) == set(p)
+    for k, t in p.items():
+        a = (t.grad if t.grad is not None else torch.zeros_like(t)).double().numpy()
+        b = full[k].astype(np.float64)
+        assert a.shape == b.shape, k
+        _close(a, b, 1e-4, f"grad {k}", floor=0.02)
+        big = np.abs(b).max()
+        well = np.abs(b) >= 0.05 * big
+        if big > 0 and well.any():
+            el = (np.abs(a - b)[well] / np.abs(b)[well]).max()
+            assert el <= 1e-3, f"grad {k}: element-wise rel err {el:.2e}"
 
 
 def test_chunk_bounds():

@@ -15,6 +15,7 @@ for ov in ("0", "1"):
     tr = MultimodalVAE(cdsprites_config("mopoe", 32, batch_size=128, lr=1e-3), device=dev)
     tr.model.train(); tr.configure_optimizers()
     batch = cdsprites_batch(128, 32, seed=1, device=dev)
+    tr.dp_force_collective = True            # (a probe: the two-graph structure without a process group)
     tr.capture(batch, world_size=2)          # multi-GPU structure; no process group: fused_step(1) skips the collectives
     assert (tr._graph2 is not None) == (ov == "1")
     # identical generator / dropout counters at the first replayed step (the two paths warm up a different number of times)
