@@ -696,8 +696,12 @@ static inline int gemm_big_bn(const GemmArgs& g, int nz, bool ak, bool bk_major)
   const long rows = (g.M + 127) / 128;
   if (rows * ((g.N + 127) / 128) * nz >= 512 && g.N > 64) return 128;
   if (rows * ((g.N + 63) / 64) * nz >= 384) return 64;
-  // mid-size problems past the register-operand regime (M <= 256 rows): 64 x 64 tiles once they give >= 64 workgroups
-  static const int on64 = [] { const char* e = getenv("MMVAE_GEMM_BIG64"); return e ? atoi(e) : 1; }();
+  // mid-size problems past the register-operand regime (M <= 256 rows): 64 x 64 tiles once they give >= 64 workgroups.
+  // MEASURED AND OFF BY DEFAULT (round 3, profiles/r03_b_b1000_kernel_stats.csv): 1000 x 512 x 512 takes 34 us on these
+  // tiles against 17.7 us on the register-operand kernel -- 128 workgroups, one per CU, with 8 MFMAs per wave between two
+  // barriers: a 16-deep stage hides 0.23 us of the ~1.5 us global-load latency; the register-operand kernel keeps a
+  // 64-deep slice of loads in flight per wave on 512 workgroups.  MMVAE_GEMM_BIG64=1 selects it (tests cover it).
+  static const int on64 = [] { const char* e = getenv("MMVAE_GEMM_BIG64"); return e ? atoi(e) : 0; }();
   if (on64 && g.M > 256 && g.N >= 64 && g.K >= 64 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nz >= 64) return -64;
   return 0;
 }
