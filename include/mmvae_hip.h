@@ -493,6 +493,30 @@ int mmvae_iwae_loss_fwd(const float* lat, const mmvae_dreg_rows* rows, double* o
                         mmvae_stream_t stream);
 int mmvae_iwae_loss_bwd(const float* lat, const double* out, const double* g, const mmvae_dreg_rows_grad* rows,
                         float* dlat, int M, int K, int B, mmvae_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * Enc_TxtRNN (models/encoders.py:840-869): Embedding -> bidirectional one-layer GRU(512) -> output[-1] -> sum of the
+ * directions -> Linear -> chunk -> softmax + eta.  A DEFINED path, parity unpinned against the reference (its forward
+ * crashes on its own batch format); oracle/mmvae_oracle.py: enc_txt_rnn, pinned to torch.nn.GRU.
+ *   token_ids: onehot (B,T,V) -> ids (T,B) int32 [argmax; all-zero padding rows = token 0] + canonical one-hot (T*B,V).
+ *   pt (3H,V) = W_ih E^T (the embedding folded into the input projection), bih / whh (3H,H) / bhh: torch's GRU
+ *   parameters (gate order r, z, n).  forward: hs (T+1,B,H) with hs[0] = 0 given, hs[t+1] = h after step t (one launch
+ *   per step: the (B,H)x(H,3H) product on 16x16x4 fp32 MFMA tiles with the gates in the epilogue);
+ *   saved (4,T,B,H) = r | z | n | q (q = W_hn h + b_hn).  H % 64 == 0.
+ *   backward: dh (B,H) = d loss / d h_T in (destroyed) -> dgx, dgh (T,B,3H): the input-side / hidden-side gate
+ *   derivatives of every step (d Pt^T, d b_ih = reductions of dgx; d W_hh, d b_hh = reductions of dgh over hs[0:T]).
+ *   cell0: the reverse direction at the last position = ONE cell step from h = 0 on the last token; out = hfwd + h;
+ *   saved (3,B,H) = r | z | n;  bwd: dout (B,H) -> dgx, dgh (B,3H).
+ * ---------------------------------------------------------------------------------------------- */
+int mmvae_gru_token_ids(const float* onehot, int* ids, float* onehot_tb, int B, int T, int V, mmvae_stream_t stream);
+int mmvae_gru_forward(const float* pt, const float* bih, const float* whh, const float* bhh, const int* ids, float* hs,
+                      float* saved, int T, int B, int H, int V, mmvae_stream_t stream);
+int mmvae_gru_backward(float* dh, const float* whh, const float* hs, const float* saved, float* dgx, float* dgh, int T,
+                       int B, int H, mmvae_stream_t stream);
+int mmvae_gru_cell0_fwd(const float* pt, const float* bih, const float* bhh, const int* ids, const float* hfwd,
+                        float* out, float* saved, int B, int H, int V, mmvae_stream_t stream);
+int mmvae_gru_cell0_bwd(const float* dout, const float* saved, const float* bhh, float* dgx, float* dgh, int B, int H,
+                        mmvae_stream_t stream);
+
 /* `prior: laplace` with the elbo objective: KL(Laplace(mu, s) || N(0,1)) row sums (torch's _kl_laplace_normal reached
  * through utils.kl_divergence, utils.py:399-402; models/mmvae_models.py:45) and the importance ratio of :56-62 under
  * Laplace posteriors (gradient into packed_r only, as mmvae_normal_logratio_*). */

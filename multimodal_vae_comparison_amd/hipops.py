@@ -176,6 +176,11 @@ SIGNATURES = {
     "mmvae_moe_elbo_bwd": (c_i, [c_p, c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_moe_ksample_fwd": (c_i, [ctypes.POINTER(MoeKArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_moe_ksample_bwd": (c_i, [ctypes.POINTER(MoeKBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "mmvae_gru_token_ids": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
+    "mmvae_gru_forward": (c_i, [c_p] * 7 + [c_i] * 4 + [c_p]),
+    "mmvae_gru_backward": (c_i, [c_p] * 6 + [c_i] * 3 + [c_p]),
+    "mmvae_gru_cell0_fwd": (c_i, [c_p] * 7 + [c_i] * 3 + [c_p]),
+    "mmvae_gru_cell0_bwd": (c_i, [c_p] * 5 + [c_i] * 2 + [c_p]),
     "mmvae_iwae_loss_out_doubles": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "mmvae_iwae_loss_fwd": (c_i, [c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),
     "mmvae_iwae_loss_bwd": (c_i, [c_p, c_p, c_p, ctypes.POINTER(DregRows), c_p, c_i, c_i, c_i, c_p]),

@@ -225,6 +225,56 @@ class Enc_CNN(VaeEncoder):
         return self.process_output(self.resnet(x), H.ACT_SILU)
 
 
+class _GruParams(nn.Module):
+    """the parameters of torch.nn.GRU(H, H, 1, bidirectional=True) under torch's names and in torch's order, initialised
+    as nn.GRU.reset_parameters does (U(-1/sqrt(H), 1/sqrt(H))); gate order r, z, n in the stacked (3H, .) tensors"""
+
+    def __init__(self, hidden):
+        super().__init__()
+        k = 1.0 / (hidden ** 0.5)
+        for sfx in ("", "_reverse"):
+            for name, shape in (("weight_ih_l0", (3 * hidden, hidden)), ("weight_hh_l0", (3 * hidden, hidden)),
+                                ("bias_ih_l0", (3 * hidden,)), ("bias_hh_l0", (3 * hidden,))):
+                self.register_parameter(name + sfx, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+
+class Enc_TxtRNN(VaeEncoder):
+    """models/encoders.py:840-869: Embedding(njoints*nfeats, 512) -> bidirectional one-layer GRU(512) -> `output[-1]` ->
+    sum of the two directions -> Linear(512, 2 D') -> chunk -> softmax + eta.
+
+    A DEFINED path, PARITY UNPINNED against the reference: its own forward crashes on the batch format the data module
+    produces (the (B,T,V) one-hot cast to long and embedded gives nn.GRU a 5-D tensor) and there is no
+    Dec_TxtRNN (pair it with `decoder: TxtTransformer`).  What its lines spell for a batch of token ids is restated in
+    oracle/mmvae_oracle.py: enc_txt_rnn (checked against torch.nn.GRU itself, tests/test_oracle_txtrnn.py): ids = argmax
+    of the one-hot rows (a padding row is token 0 -- the reference never reads `masks`), sequence-first layout,
+    `output[-1]` = the forward direction's state after all T steps + the reverse direction's state after its FIRST step.
+    Parameters carry torch's names (embed.weight, gru.weight_ih_l0[_reverse], ..., o2p.*) so a reference state_dict
+    loads.  Kernels: csrc/gru.hip."""
+
+    def __init__(self, latent_dim, data_dim, latent_private, enc_mu_logvar, hidden_size=512, n_layers=1, bidirectional=True):
+        super().__init__(latent_dim, data_dim, latent_private, enc_mu_logvar, net_type=NetworkTypes.TXTTRANSFORMER)
+        assert n_layers == 1 and bidirectional, "Enc_TxtRNN: the reference's configuration (one layer, bidirectional)"
+        self.input_size = data_dim[-1] * data_dim[-2]
+        self.hidden_size, self.n_layers, self.bidirectional = hidden_size, n_layers, bidirectional
+        self.embed = nn.Embedding(self.input_size, hidden_size)
+        self.gru = _GruParams(hidden_size)
+        self.o2p = HipLinear(hidden_size, self.out_dim * 2)
+
+    def forward(self, batch):
+        x = batch["data"] if isinstance(batch, dict) else batch
+        g = self.gru
+        ids, oh = ops.gru_token_ids(x)                                      # (T,B) int32, (T*B, V)
+        T, B = ids.shape
+        E = self.embed.weight
+        # the embedding folded into the input projections: pt (3H, V) = W_ih E^T (gx_t = pt[:, id_t] + b_ih)
+        pt = ops.linear(g.weight_ih_l0, E, None, H.ACT_NONE, E.grad, None)
+        pt_r = ops.linear(g.weight_ih_l0_reverse, E, None, H.ACT_NONE, E.grad, None)
+        h_fwd = ops.gru_forward(pt, g.bias_ih_l0, g.weight_hh_l0, g.bias_hh_l0, ids, oh, g.weight_hh_l0.grad,
+                                g.bias_hh_l0.grad)
+        out = ops.gru_cell0(pt_r, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse, ids[T - 1], oh[(T - 1) * B:], h_fwd)
+        return self.finish_heads(self.o2p(out))                             # [mu | logvar head] = o2p's two halves
+
+
 FUSED_TXT_LAYERS = os.environ.get("MMVAE_FUSED_TXT", "1") != "0"
 FUSED_HEADS = os.environ.get("MMVAE_FUSED_HEADS", "1") != "0"     # text encoder: heads inside the last layer's launch
 FUSED_FFN = os.environ.get("MMVAE_FUSED_FFN", "1") != "0"         # d_model-32 layers outside the fused-layer shapes

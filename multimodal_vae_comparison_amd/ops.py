@@ -2351,6 +2351,94 @@ def permute_mask(x, mask_u8):
 # ----------------------------------------------------------------------------------------------
 # optimiser / utilities (no autograd)
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# Enc_TxtRNN: embedding-folded bidirectional GRU, last position only (csrc/gru.hip)
+# ----------------------------------------------------------------------------------------------
+def gru_token_ids(onehot):
+    """(B,T,V) one-hot -> ids (T,B) int32 [argmax; padding rows = token 0], canonical one-hot rows (T*B, V)"""
+    onehot = H.f32c(onehot)
+    B, T, V = onehot.shape
+    ids = torch.empty(T, B, dtype=torch.int32, device=onehot.device)
+    oh = torch.empty(T * B, V, device=onehot.device)
+    _call("mmvae_gru_token_ids", H.ptr(onehot), H.ptr(ids), H.ptr(oh), B, T, V, H.stream())
+    return ids, oh
+
+
+class GruForward(Function):
+    """h_T of a one-layer GRU over T steps from h_0 = 0 (torch.nn.GRU's equations, gate order r, z, n), the input
+    projection given as the embedding-folded table pt (3H,V) = W_ih E^T: gx_t = pt[:, id_t] + b_ih.
+    Backward: T steps of gate derivatives + dh_{t-1} += dGh W_hh, then d W_hh / d b_hh and d pt / d b_ih as two
+    (T B)-row reductions on the MFMA weight-gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, pt, b_ih, w_hh, b_hh, ids, oh, gw_hh, gb_hh):
+        pt, b_ih, w_hh, b_hh = H.f32c(pt), H.f32c(b_ih), H.f32c(w_hh), H.f32c(b_hh)
+        T, B = ids.shape
+        Hd, V = w_hh.shape[1], pt.shape[1]
+        dev = pt.device
+        hs = torch.empty(T + 1, B, Hd, device=dev)
+        fill(hs[0], 0.0)
+        saved = torch.empty(4, T, B, Hd, device=dev)
+        _call("mmvae_gru_forward", H.ptr(pt), H.ptr(b_ih), H.ptr(w_hh), H.ptr(b_hh), H.ptr(ids), H.ptr(hs), H.ptr(saved),
+              T, B, Hd, V, H.stream())
+        ctx.save_for_backward(pt, b_ih, w_hh, b_hh, hs, saved, oh)
+        ctx.cfg = (T, B, Hd, V, gw_hh, gb_hh)
+        return hs[T]
+
+    @staticmethod
+    def backward(ctx, dhT):
+        pt, b_ih, w_hh, b_hh, hs, saved, oh = ctx.saved_tensors
+        T, B, Hd, V, gw_hh, gb_hh = ctx.cfg
+        dev = pt.device
+        dh = H.f32c(dhT).clone()
+        dgx = torch.empty(T, B, 3 * Hd, device=dev)
+        dgh = torch.empty(T, B, 3 * Hd, device=dev)
+        _call("mmvae_gru_backward", H.ptr(dh), H.ptr(w_hh), H.ptr(hs), H.ptr(saved), H.ptr(dgx), H.ptr(dgh), T, B, Hd,
+              H.stream())
+        # d W_hh (3H,H) = sum_t dGh_t^T h_{t-1}, d b_hh = column sums: reduction over the T*B rows
+        ret_whh, ret_bhh = _linear_wgrad(dgh.view(T * B, 3 * Hd), hs[:T].reshape(T * B, Hd), w_hh, b_hh, gw_hh, gb_hh)
+        # d pt (3H,V) = sum_t dGx_t^T onehot(id_t), d b_ih = column sums
+        d_pt, d_bih = _linear_wgrad(dgx.view(T * B, 3 * Hd), oh, pt, b_ih, None, None)
+        return d_pt, d_bih, ret_whh, ret_bhh, None, None, None, None
+
+
+class GruCell0(Function):
+    """out = h_fwd + GRU cell step from h = 0 on the last token (the reverse direction at the last position)"""
+
+    @staticmethod
+    def forward(ctx, pt, b_ih, b_hh, ids_last, oh_last, h_fwd, w_hh_shape):
+        pt, b_ih, b_hh, h_fwd = H.f32c(pt), H.f32c(b_ih), H.f32c(b_hh), H.f32c(h_fwd)
+        B, Hd = h_fwd.shape
+        V = pt.shape[1]
+        out = torch.empty_like(h_fwd)
+        saved = torch.empty(3, B, Hd, device=pt.device)
+        _call("mmvae_gru_cell0_fwd", H.ptr(pt), H.ptr(b_ih), H.ptr(b_hh), H.ptr(ids_last), H.ptr(h_fwd), H.ptr(out),
+              H.ptr(saved), B, Hd, V, H.stream())
+        ctx.save_for_backward(pt, b_ih, b_hh, saved, oh_last)
+        ctx.cfg = (B, Hd, V)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pt, b_ih, b_hh, saved, oh_last = ctx.saved_tensors
+        B, Hd, V = ctx.cfg
+        dout = H.f32c(dout)
+        dgx = torch.empty(B, 3 * Hd, device=pt.device)
+        dgh = torch.empty(B, 3 * Hd, device=pt.device)
+        _call("mmvae_gru_cell0_bwd", H.ptr(dout), H.ptr(saved), H.ptr(b_hh), H.ptr(dgx), H.ptr(dgh), B, Hd, H.stream())
+        d_pt, d_bih = _linear_wgrad(dgx, oh_last, pt, b_ih, None, None)
+        _, d_bhh = _linear_wgrad(dgh, oh_last, pt, b_hh, None, None)      # column sums of dGh (the dW half is unused)
+        return d_pt, d_bih, d_bhh, None, None, dout, None
+
+
+def gru_forward(pt, b_ih, w_hh, b_hh, ids, oh, gw_hh=None, gb_hh=None):
+    return GruForward.apply(pt, b_ih, w_hh, b_hh, ids, oh, gw_hh, gb_hh)
+
+
+def gru_cell0(pt, b_ih, b_hh, ids_last, oh_last, h_fwd):
+    return GruCell0.apply(pt, b_ih, b_hh, ids_last, oh_last, h_fwd, None)
+
+
 def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=None, grad_scale=1.0, zero_grad=True):
     _call("mmvae_adam_amsgrad_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), lr, beta1, beta2,
           eps, int(step), H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())

@@ -79,6 +79,9 @@ WORKLOADS = {
              "moe", CD_MODS, 32, 256, 32, {"obj": "iwae", "K": 8}),
     "cfg3_elbo": ("configs[2] with the objective the reference can run on these towers: MMVAE (MoE), obj elbo K=1, "
                   "CdSprites+ L5 shapes, n_latents=32, batch=256, T=32", "moe", CD_MODS, 32, 256, 32, {}),
+    "cfg2_rnn": ("configs[1] with `encoder: TxtRNN` for the text modality (Embedding -> bi-GRU(512) -> Linear; a defined "
+                 "path, the reference's crashes): MoPoE, CNN2 image tower, TxtRNN encoder + TxtTransformer decoder, "
+                 "n_latents=32, batch=128, T=32", "mopoe", [CD_MODS[0], dict(CD_MODS[1], enc="TxtRNN")], 32, 128, 32, {}),
     "cfg4": ("configs[3]: DMVAE shared/private latents on MNIST-SVHN, MLP + conv towers, n_latents=20 + 10 private, "
              "lprob, batch=512", "dmvae", [dict(m, private=10) for m in MS_MODS], 20, 512, 0, {}),
     "cfg5": ("configs[4]: MoPoE on image + text + action sequences (Ta=100, 8/4-layer ff-1024 Transformer towers), "
@@ -113,7 +116,9 @@ def workload(name, batch=None, device="cpu", seed=1):
 def tower_macs(m, D, T=32):
     Dp = D + (m.get("private") or 0)
     enc = {"CNN": 335_000_000 + 1000 * 2 * Dp,            # ResNet-50 at 64x64 (~335 MMAC) + heads
-           "CNN2": 7372800 - 32768 + 512 * 2 * Dp, "TxtTransformer": 929664 * T // 32, "MNIST": 784 * 400 + 400 * 400 + 400 * 2 * Dp,
+           "CNN2": 7372800 - 32768 + 512 * 2 * Dp, "TxtTransformer": 929664 * T // 32,
+           "TxtRNN": T * 3 * 512 * 512 + 3 * 512 * 512 + 512 * 2 * Dp,      # T recurrent steps (W_hh) + the reverse cell + o2p
+           "MNIST": 784 * 400 + 400 * 400 + 400 * 2 * Dp,
            "SVHN": 393216 + 2097152 + 1048576 + 131072 + 128 * 2 * Dp}
     dec = {"CNN": 7618560 - 32 * 512 + Dp * 512, "TxtTransformer": 556032 * T // 32, "MNIST": Dp * 400 + 400 * 400 + 400 * 784,
            "SVHN": Dp * 128 + 131072 + 1048576 + 2097152 + 393216}

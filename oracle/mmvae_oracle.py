@@ -45,6 +45,7 @@ ETA = 1e-6          # utils.py:254  Constants.eta
 DROPOUT_P = 0.1     # models/encoders.py:790, models/decoders.py:669 (ctor defaults)
 LN_EPS = 1e-5       # torch.nn.LayerNorm default
 ENC_TRANSFORMER_LAYERS, DEC_TRANSFORMER_LAYERS, TRANSFORMER_FF = 8, 4, 1024   # encoders.py:659, decoders.py:542
+TXTRNN_HIDDEN = 512    # Enc_TxtRNN ctor default hidden_size, encoders.py:841
 
 
 # ----------------------------------------------------------------------------------------------
@@ -94,6 +95,18 @@ def tower_param_shapes(prefix, enc, dec, data_dim, n_latents, private=None):
         s[f"{prefix}.enc.mu_layer.module.bias"] = (Dp,)
         s[f"{prefix}.enc.logvar_layer.module.weight"] = (Dp, d)
         s[f"{prefix}.enc.logvar_layer.module.bias"] = (Dp,)
+    elif enc == "TxtRNN":
+        # Enc_TxtRNN ctor, models/encoders.py:840-852: Embedding(njoints*nfeats, 512), bidirectional one-layer
+        # GRU(512, 512) (torch's parameter names), Linear(512, 2 D'); no mu_layer / logvar_layer
+        feats, H = data_dim[-1] * data_dim[-2], TXTRNN_HIDDEN
+        s[f"{prefix}.enc.embed.weight"] = (feats, H)
+        for sfx in ("", "_reverse"):
+            s[f"{prefix}.enc.gru.weight_ih_l0{sfx}"] = (3 * H, H)
+            s[f"{prefix}.enc.gru.weight_hh_l0{sfx}"] = (3 * H, H)
+            s[f"{prefix}.enc.gru.bias_ih_l0{sfx}"] = (3 * H,)
+            s[f"{prefix}.enc.gru.bias_hh_l0{sfx}"] = (3 * H,)
+        s[f"{prefix}.enc.o2p.weight"] = (2 * Dp, H)
+        s[f"{prefix}.enc.o2p.bias"] = (2 * Dp,)
     elif enc == "MNIST":
         # Enc_MNIST ctor, models/encoders.py:226-250: 784 -> 400 -> 400 (ReLU), heads hidden_mu / hidden_logvar
         s[f"{prefix}.enc.enc.0.0.weight"] = (400, 784)
@@ -465,6 +478,47 @@ def dec_txt_transformer(p, pre, z, mask, data_dim=(45, 27, 1), train=False, keep
     return out.permute(1, 0, 2) * mask.unsqueeze(-1).to(torch.get_default_dtype())    # (B,T,V), zero at padding
 
 
+def gru_cell(x_proj, h, w_hh, b_hh):
+    """one step of torch.nn.GRU (its documented equations; gate order r, z, n in the stacked weights):
+    r = sigma(W_ir x + b_ir + W_hr h + b_hr), z = sigma(W_iz x + b_iz + W_hz h + b_hz),
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) * n + z * h.   x_proj = W_i x + b_i (B, 3H)."""
+    H = h.shape[-1]
+    gh = F.linear(h, w_hh, b_hh)
+    r = torch.sigmoid(x_proj[:, :H] + gh[:, :H])
+    z = torch.sigmoid(x_proj[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(x_proj[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def enc_txt_rnn(p, pre, data, mask=None):
+    """Enc_TxtRNN.forward, models/encoders.py:854-869, as a DEFINED path -- PARITY UNPINNED: the reference's own forward
+    crashes (`self.embed(x.long()).unsqueeze(1)` on the (B,T,V) one-hot batch hands nn.GRU a 5-D tensor -> ValueError;
+    SURVEY 0.4), and there is no Dec_TxtRNN.  What its lines spell for a batch of token ids, restated here:
+      ids (B,T) = the one-hot rows' token (argmax; an all-zero padding row is token 0 -- the reference never looks at
+        `mask`), embedded = Embedding(ids) laid out sequence-first (T,B,512) as nn.GRU's default expects (the
+        `.unsqueeze(1)` of :857 is that layout for one sequence);
+      output, _ = bidirectional one-layer GRU (dropout 0.1 acts between layers only: none here);
+      output[-1] (:862) = the LAST time position: the forward direction's final state after all T steps, and the
+        reverse direction's state after its FIRST step (it starts at position T-1 from h = 0);
+      sum of the two halves (:864), o2p, chunk(2) -> mu, softmax(logvar) + eta (:866-869).
+    The arithmetic of torch.nn.GRU / nn.Embedding is restated from their documented equations (gru_cell) and checked
+    against torch.nn.GRU itself in tests/test_oracle_txtrnn.py."""
+    B, T, V = data.shape
+    ids = data.argmax(-1).t()                                              # (T,B)
+    E = p[f"{pre}.enc.embed.weight"]
+    x = E[ids]                                                             # (T,B,H)
+    H = E.shape[1]
+    g = f"{pre}.enc.gru."
+    h = torch.zeros(B, H, dtype=E.dtype)
+    for t in range(T):
+        h = gru_cell(F.linear(x[t], p[g + "weight_ih_l0"], p[g + "bias_ih_l0"]), h, p[g + "weight_hh_l0"], p[g + "bias_hh_l0"])
+    hb = gru_cell(F.linear(x[T - 1], p[g + "weight_ih_l0_reverse"], p[g + "bias_ih_l0_reverse"]),
+                  torch.zeros(B, H, dtype=E.dtype), p[g + "weight_hh_l0_reverse"], p[g + "bias_hh_l0_reverse"])
+    ps = F.linear(h + hb, p[f"{pre}.enc.o2p.weight"], p[f"{pre}.enc.o2p.bias"])
+    mu, lv = torch.chunk(ps, 2, dim=1)
+    return mu, F.softmax(lv, dim=-1) + ETA
+
+
 def enc_mnist(p, pre, x):
     """Enc_MNIST.forward, models/encoders.py:252-265"""
     h = x.reshape(x.shape[0], -1).to(torch.get_default_dtype())
@@ -562,6 +616,7 @@ _ENC = {"CNN2": lambda p, pre, d, train: enc_cnn2(p, pre, d["data"]),
         "CNN": lambda p, pre, d, train: enc_cnn_resnet50(p, pre, d["data"], train),
         "TxtTransformer": lambda p, pre, d, train: enc_txt_transformer(p, pre, d["data"], d["masks"], train),
         "Transformer": lambda p, pre, d, train: enc_transformer(p, pre, d["data"], d["masks"], train),
+        "TxtRNN": lambda p, pre, d, train: enc_txt_rnn(p, pre, d["data"], d["masks"]),
         "MNIST": lambda p, pre, d, train: enc_mnist(p, pre, d["data"]),
         "SVHN": lambda p, pre, d, train: enc_svhn(p, pre, d["data"])}
 
