@@ -282,7 +282,7 @@ def _timed(tr, steps, warmup, path_world, barrier, pre=None):
     return time.perf_counter() - t0, out
 
 
-def _build(name, batch, dev, rank, world, path_world):
+def _build(name, batch, dev, rank, world, path_world, input_ring=None):
     from multimodal_vae_comparison_amd import parallel
     from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
     from multimodal_vae_comparison_amd.synthetic import workload
@@ -294,7 +294,7 @@ def _build(name, batch, dev, rank, world, path_world):
     if path_world > 1:
         # broadcast of the flat parameters, 1/world folded into Adam, per-rank noise / dropout streams
         parallel.setup_replica(tr, rank, world)
-    tr.capture(data, path_world)       # world 1: the Adam step is part of the captured graph
+    tr.capture(data, path_world, input_ring=input_ring)       # world 1: the Adam step is part of the captured graph
     return tr, desc, meta
 
 
@@ -423,6 +423,17 @@ def extras(tr, a, dev, barrier):
                                           "buffer) on a copy stream under step i, device expansion + captured step on "
                                           "the main stream; the input step is one native call (csrc/input_pipe.hip, "
                                           "MultimodalVAE.input_pipe)"}
+    # the input step INSIDE the graph: head = expansion of the staged batch, tail = pull of the next ring slot on the text
+    # tower's stream; no runtime call per step besides the graph launch (MultimodalVAE.capture(..., input_ring=...))
+    t3, _, _ = _build("cfg2", B, dev, 0, 1, 1, input_ring=host)
+    dt, _ = _timed(t3, steps, 25, 1, barrier)
+    out["with_input_pipeline_in_graph"] = {"value": round(steps * B / dt, 1), "unit": "samples/s",
+                                           "ms_per_step": round(1e3 * dt / steps, 4),
+                                           "what": "a fresh compact batch every step, the input step captured into the "
+                                                   "step's hipGraph: expansion launches at its head, the pull of the next "
+                                                   "pinned ring slot over the host link at the tail of the text tower's "
+                                                   "stream, slot counter on the device (GraphInputRing)"}
+    del t3
     lb = {}
     for Bl in (512, 1000):
         t2, _, meta = _build("cfg2", Bl, dev, 0, 1, 1)

@@ -605,6 +605,13 @@ int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float* dx, float*
 int mmvae_expand_image_u8(const uint8_t* src, float* dst, long n, mmvae_stream_t stream);
 int mmvae_expand_text_tokens(const int32_t* tokens, const int32_t* lengths, float* onehot, uint8_t* mask, int B, int T,
                              int V, mmvae_stream_t stream);
+/* The host-to-device transfer of the NEXT batch as a node inside the captured step: ring_dev = device array of n_ring
+ * pinned (device-visible, 16-byte aligned) host batches of `bytes` bytes; ctr_dev = two device words {count, ticket}
+ * (zeroed once); the launch copies bytes [offset, offset + bytes) of ring[count % n_ring] into the same range of
+ * `staging` and, when `advance` is set, advances count itself (a batch may be pulled in several parts: the last one
+ * advances). */
+int mmvae_input_ring_pull(const void* const* ring_dev, int n_ring, unsigned* ctr_dev, void* staging, size_t offset,
+                          size_t bytes, int advance, mmvae_stream_t stream);
 
 /* The input step as a native pipe: a packed pinned host batch (every tensor a 16-byte aligned slice of one buffer) is
  * copied with ONE H2D transfer on the pipe's own copy stream into `staging` (device, `bytes` long, owned by the

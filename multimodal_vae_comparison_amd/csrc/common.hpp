@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t drop_fmix(uint32_t h) {  // murmur3 finalise
   return h;
 }
 struct DropKey {
-  uint32_t key;
+  uint32_t key, thr;
   float p, inv_keep;
   bool on;
 };
@@ -77,14 +77,29 @@ __device__ __forceinline__ DropKey drop_key(const mmvae_dropout_t& d) {
   k.on = d.state != nullptr && d.p > 0.f;
   k.p = d.p;
   k.inv_keep = k.on ? 1.0f / (1.0f - d.p) : 1.0f;
+  k.thr = (uint32_t)(d.p * 65536.0f + 0.5f);      // p in units of 2^-16 (|p - thr / 65536| <= 7.7e-6)
   k.key = k.on ? drop_fmix(d.state[0] ^ (d.state[2 + d.slot] * 0x9E3779B1u) ^ (d.site * 0x85EBCA77u + 0x165667B1u)) : 0u;
   return k;
+}
+// Round 3: ONE hash serves TWO consecutive elements -- element idx takes the 16-bit half (idx & 1) of
+// fmix(key + (idx >> 1) C) and is kept when that half >= p 2^16.  The murmur finaliser costs two quarter-rate integer
+// multiplies (+ one for the index): kernels whose lanes own runs of consecutive elements (the fused feed-forward block:
+// 16 hidden elements per lane and tile between its MFMAs) now pay it once per pair (drop_pair_hash / _lo / _hi);
+// everything else keeps calling drop_mul per element and gets the same mask.
+__device__ __forceinline__ uint32_t drop_pair_hash(const DropKey& k, uint32_t pair) {
+  return drop_fmix(k.key + pair * 0x9E3779B1u);
+}
+__device__ __forceinline__ float drop_pair_lo(const DropKey& k, uint32_t h) {
+  return (!k.on || (h & 0xFFFFu) >= k.thr) ? k.inv_keep : 0.0f;
+}
+__device__ __forceinline__ float drop_pair_hi(const DropKey& k, uint32_t h) {
+  return (!k.on || (h >> 16) >= k.thr) ? k.inv_keep : 0.0f;
 }
 // multiplicative mask of element idx: 0 or 1/(1-p)
 __device__ __forceinline__ float drop_mul(const DropKey& k, uint32_t idx) {
   if (!k.on) return 1.0f;
-  const uint32_t h = drop_fmix(k.key + idx * 0x9E3779B1u);
-  return ((float)(h >> 8) * (1.0f / 16777216.0f) >= k.p) ? k.inv_keep : 0.0f;
+  const uint32_t h = drop_pair_hash(k, idx >> 1);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= k.thr ? k.inv_keep : 0.0f;
 }
 static inline mmvae_dropout_t drop_arg(const mmvae_dropout_t* d) {
   mmvae_dropout_t z = {nullptr, 0u, 0u, 0.f};

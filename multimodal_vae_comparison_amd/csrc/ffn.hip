@@ -120,10 +120,12 @@ __global__ __launch_bounds__(256) void ffn32_fwd_kernel(FfnArgs a) {
     f32x16 h = ffn_zero();
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) h = __builtin_amdgcn_mfma_f32_32x32x2f32(w1v[kk], xv[kk], h, 0, 0, 0);
+    uint32_t hh = 0u;      // registers r, r + 1 (r even) are consecutive columns of an even-aligned pair: one mask hash
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float bias = (&bq[r >> 2].x)[r & 3];
-      const float act = ffn_gelu(h[r] + bias) * drop_mul(dk, drow + (uint32_t)(c0 + ffn_i(r, lh)));
+      if ((r & 1) == 0) hh = drop_pair_hash(dk, (drow + (uint32_t)(c0 + ffn_i(r, lh))) >> 1);
+      const float act = ffn_gelu(h[r] + bias) * ((r & 1) ? drop_pair_hi(dk, hh) : drop_pair_lo(dk, hh));
       acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(act, (&w2q[r >> 2].x)[r & 3], acc2, 0, 0, 0);
     }
   }
@@ -158,12 +160,14 @@ __global__ __launch_bounds__(256) void ffn32_bwd_data_kernel(FfnArgs a) {
       h = __builtin_amdgcn_mfma_f32_32x32x2f32(w1v[kk], xv[kk], h, 0, 0, 0);
       da = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[kk], dyv[kk], da, 0, 0, 0);
     }
+    uint32_t hh = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float pre = h[r] + (&bq[r >> 2].x)[r & 3];
       float g_, dg;
       ffn_gelu_both(pre, g_, dg);
-      const float dh = da[r] * drop_mul(dk, drow + (uint32_t)(c0 + ffn_i(r, lh))) * dg;
+      if ((r & 1) == 0) hh = drop_pair_hash(dk, (drow + (uint32_t)(c0 + ffn_i(r, lh))) >> 1);
+      const float dh = da[r] * ((r & 1) ? drop_pair_hi(dk, hh) : drop_pair_lo(dk, hh)) * dg;
       accdx = __builtin_amdgcn_mfma_f32_32x32x2f32(dh, w1n[r], accdx, 0, 0, 0);
     }
   }

@@ -20,6 +20,52 @@ __global__ __launch_bounds__(256) void pull_kernel(const u32x4* __restrict__ src
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// The same transfer as a node INSIDE the captured step (round 3): the source is slot (count % n_ring) of a ring of pinned
+// batches whose addresses sit in a device table, and the launch advances the count itself (last-workgroup ticket, as the
+// noise generators do) -- the graph replays with no per-step runtime call besides its own launch.
+__global__ __launch_bounds__(256) void pull_ring_kernel(const u32x4* const* __restrict__ ring, int n_ring,
+                                                        unsigned* __restrict__ ctr, u32x4* __restrict__ dst, size_t off16,
+                                                        size_t n16, int advance) {
+  const u32x4* __restrict__ src = ring[ctr[0] % (unsigned)n_ring] + off16;
+  dst += off16;
+  const size_t stride = (size_t)gridDim.x * 256;
+  // 8 independent 16-byte loads over the host link in flight per thread before the first store (a round trip is ~2 us)
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n16; i0 += 8 * stride) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < n16) v[u] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < n16) dst[i] = v[u];
+    }
+  }
+  __syncthreads();
+  if (advance && threadIdx.x == 0) {
+    const unsigned ticket = atomicAdd(ctr + 1, 1u);
+    if (ticket == gridDim.x - 1) {      // every workgroup has read ctr[0] (it did before its copy loop)
+      ctr[1] = 0u;
+      ctr[0] += 1u;
+    }
+  }
+}
+extern "C" int mmvae_input_ring_pull(const void* const* ring_dev, int n_ring, unsigned* ctr_dev, void* staging,
+                                     size_t offset, size_t bytes, int advance, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(ring_dev && n_ring > 0 && ctr_dev && staging && bytes > 0);
+  if ((((uintptr_t)staging) | bytes | offset) & 15) return MMVAE_ERR_ARG;
+  const size_t n16 = bytes / 16;
+  size_t blocks = (n16 + 8 * 256 - 1) / (8 * 256);
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pull_ring_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const u32x4* const*>(ring_dev), n_ring, ctr_dev, static_cast<u32x4*>(staging),
+                     offset / 16, n16, advance);
+  return mmvae_launch_status();
+}
+
 struct mmvae_input_pipe {
   hipStream_t copy;
   hipEvent_t staged;     // recorded on the copy stream after the H2D copy

@@ -176,6 +176,7 @@ SIGNATURES = {
     "mmvae_moe_elbo_bwd": (c_i, [c_p, c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_moe_ksample_fwd": (c_i, [ctypes.POINTER(MoeKArgs), c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "mmvae_moe_ksample_bwd": (c_i, [ctypes.POINTER(MoeKBwdArgs), c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "mmvae_input_ring_pull": (c_i, [c_p, c_i, c_p, c_p, ctypes.c_size_t, ctypes.c_size_t, c_i, c_p]),
     "mmvae_gru_token_ids": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
     "mmvae_gru_forward": (c_i, [c_p] * 7 + [c_i] * 4 + [c_p]),
     "mmvae_gru_backward": (c_i, [c_p] * 6 + [c_i] * 3 + [c_p]),

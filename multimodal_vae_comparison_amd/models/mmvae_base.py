@@ -69,13 +69,23 @@ class TorchMMVAE(nn.Module):
                 vae.llik_scaling = float(vae.llik_scaling)
 
     def _require_normal_priors(self):
-        """`prior: laplace` makes the reference build Laplace posteriors / likelihoods (models/trainer.py:104); only the
-        MoE mixer carries that arithmetic on this path (the shipped configs use it there only) -- anything else must
-        not silently compute Normal terms"""
+        """`prior:` names the per-VAE prior / posterior / likelihood classes (models/trainer.py:104).  MoPoE and DMVAE
+        build their posteriors with a hard-coded dist.Normal (mmvae_models.py:363-365,480-485), so there the config's
+        family only reaches the LIKELIHOOD `vae.px_z` (:369,495-501): `normal` and `laplace` are on this path (laplace =
+        a Laplace log-prob under recon_loss lprob; every other loss only reads the likelihood's loc), pinned by the
+        reference fixtures *_lprob_laplace.  Anything else must not silently compute Normal terms."""
         for name, vae in self.vaes.items():
-            if vae.prior_str not in ("normal", "gaussian"):
-                raise NotImplementedError(f"{self.modelName}: prior '{vae.prior_str}' ({name}) is only wired for "
-                                          f"mixing: moe on the MI355X path")
+            if vae.prior_str not in ("normal", "gaussian", "laplace"):
+                raise NotImplementedError(f"{self.modelName}: prior '{vae.prior_str}' ({name}) is not on the MI355X path "
+                                          f"(normal, laplace are)")
+
+    def _lap(self, vae):
+        """is this VAE's likelihood `px_z` a Laplace (`prior: laplace`)?"""
+        return vae.prior_str == "laplace"
+
+    def _px(self, vae, loc, scale):
+        """`vae.px_z(loc, scale)` (mmvae_models.py:369,495): the likelihood object of the inference forward()"""
+        return dist.Laplace(loc, scale, validate_args=False) if self._lap(vae) else normal(loc, scale)
 
     @property
     def latent_factorization(self):

@@ -142,9 +142,9 @@ class MoPOE(TorchMMVAE):
                 out, _ = vae.dec({"latents": zi.unsqueeze(0), "masks": mods[n]["masks"]})
                 if seeds is not None:      # the term's upstream gradient is known: its kernel also writes its backward
                     with ops.ConstSeed(seeds[i], W[0][i]):
-                        r = recon_rowsum(vae.ltype, out, mods[n])
+                        r = recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
                 else:
-                    r = recon_rowsum(vae.ltype, out, mods[n])
+                    r = recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
                 recs[i] = ops.mark_tensor(r, f"dec {n} recon")   # (B,) = -lpx_z / llik_scaling
             _uses(recs[i], cur)
         self._fusion_inputs = packed        # the towers' packed head outputs: where the backward can be cut in two
@@ -256,7 +256,7 @@ class MoPOE(TorchMMVAE):
             eps = torch.stack([self._draw(j_mu.shape[0], j_mu.shape[1], j_mu.device) for _ in range(K)])
             z = j_mu + j_var * eps
             z_d[mod] = {"latents": z, "masks": inputs[mod]["masks"]}
-            px_d[mod] = normal(*vae.dec(z_d[mod]))
+            px_d[mod] = self._px(vae, *vae.dec(z_d[mod]))
         return self.make_output_dict(qz_d, px_d, z_d, qz_joint)
 
 
@@ -558,7 +558,7 @@ class DMVAE(TorchMMVAE):
 
             def rec(z, i=i, n=n, vae=vae):
                 out, _ = vae.dec({"latents": torch.cat([z, z_pr[i]], -1).unsqueeze(0), "masks": mods[n]["masks"]})
-                return recon_rowsum(vae.ltype, out, mods[n])
+                return recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
             own = rec(z_sh[i])
             ind.append(own)
             joint = rec(zj[0])       # decode order own, joint, cross as the reference's forward (mmvae_models.py:494-502)
@@ -604,7 +604,7 @@ class DMVAE(TorchMMVAE):
             else:
                 z_private = draw(vae.private_latents)
             masks = x[n]["masks"]
-            dec = lambda z: normal(*vae.dec({"latents": torch.cat([z, z_private], -1), "masks": masks}))
+            dec = lambda z: self._px(vae, *vae.dec({"latents": torch.cat([z, z_private], -1), "masks": masks}))
             zss[n] = {"latents": z_shared, "masks": masks}
             px_zs[n] = dec(z_shared)
             joint_px_zs[n] = dec(z_joint)

@@ -169,11 +169,14 @@ class MultimodalVAE(nn.Module):
             self.flat.zero_grad()
 
     # ---- MI355X fast path ------------------------------------------------------------------------
-    def capture(self, batch, world_size=1, optimizer_in_graph=None):
+    def capture(self, batch, world_size=1, optimizer_in_graph=None, input_ring=None):
         """Capture objective + backward (+ the Adam step when there is no collective between them, world_size 1) for
         `batch`'s shapes into a hipGraph.  `batch` tensors become the static input buffers: copy new data into them
         (`load_batch`) before each replay.  optimizer_in_graph=False keeps the optimiser step out of a one-rank graph
-        (fused_step then launches it after the replay: the replayed gradients stay readable in between)."""
+        (fused_step then launches it after the replay: the replayed gradients stay readable in between).
+        input_ring: a list of `pack_compact_pinned()` host batches of one layout -- the INPUT STEP becomes part of the
+        graph (GraphInputRing): replay j trains on ring[j % len(ring)], with no runtime call per step but the graph
+        launch itself."""
         assert self.optimizer is not None, "call configure_optimizers() first"
         # the collective and the 1/world mean come from parallel.setup_replica (dp_world, optimizer.grad_scale), not from
         # this argument: a caller that asks for a multi-rank step without having set the replica up would otherwise train
@@ -201,6 +204,7 @@ class MultimodalVAE(nn.Module):
             self.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self._input_ring = GraphInputRing(self, input_ring) if input_ring else None
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         self._adam_in_graph = world_size == 1 if optimizer_in_graph is None else bool(optimizer_in_graph) and world_size == 1
@@ -239,10 +243,20 @@ class MultimodalVAE(nn.Module):
                 kw = {"capture_error_mode": "thread_local"} if with_collective else {}
                 with torch.cuda.graph(self._graph, **kw):
                     ops.Marks.mark("step start")
+                    if self._input_ring is not None:
+                        # head: the staged compact batch -> the step's static inputs; the NEXT batch is pulled under
+                        # this step, behind the side (text) tower's last backward launch
+                        ring = self._input_ring
+                        ring.expand()
+                        ring.done = False
+                        ops.GradReducer.side_tail = ops.GradReducer.pre_join = ring.pull_next
                     # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
                     ops.GradReducer.defer_next = self._adam_in_graph and os.environ.get("MMVAE_ADAM_FOLD", "1") == "1"
                     res = self._fwd_bwd(batch)
                     ops.GradReducer.defer_next = False
+                    ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
+                    if self._input_ring is not None:
+                        self._input_ring.pull_next(self.flat.data.device, [])     # (no hook point ran: pull here)
                     ops.Marks.mark("backward done")
                     if self._adam_in_graph:
                         self.optimizer.step()
@@ -256,6 +270,8 @@ class MultimodalVAE(nn.Module):
                 try:
                     out = record(True)
                     why = self._validate_graph_collective()
+                    if self._input_ring is not None:
+                        self._input_ring.reprime()      # the validation replay consumed a slot
                 except RuntimeError as e:          # the runtime refused to capture the collective
                     why = f"all-reduce not capturable here ({e})"
                 if why is not None:                # launch it after the graph instead (the round-1 step structure)
@@ -427,12 +443,13 @@ class MultimodalVAE(nn.Module):
         """one optimisation step on the static batch: graph replay -> (all-reduce) -> fused Adam"""
         assert world_size == 1 or world_size == self.dp_world or self.dp_force_collective, \
             f"fused_step(world_size={world_size}) on a trainer set up for {self.dp_world} rank(s)"
+        out = self._static_out
         self._graph.replay()
         if self._adam_in_graph:
             assert world_size == 1, "captured with the optimiser step inside the graph"
-            return self._static_out
+            return out
         if self._collective_in_graph:
-            return self._static_out
+            return out
         if self._graph2 is not None:
             # decoders' half of the flat gradients on the wire while the encoders' backward runs
             g, k = self.flat.grad, self.flat.split
@@ -446,8 +463,91 @@ class MultimodalVAE(nn.Module):
             return self._static_out
         # ONE RCCL collective over the flat gradient buffer, then the Adam kernel with the 1/world mean folded in
         parallel.reduce_gradients_and_step(self.flat.grad, self.optimizer, self.dp_world, None, self.dp_force_collective)
-        return self._static_out
+        return out
 
+
+
+class GraphInputRing:
+    """The input step INSIDE the captured training step (round 3).  A ring of pinned compact host
+    batches (`MultimodalVAE.pack_compact_pinned`, one layout) is registered once; the graph then holds
+      head:  the two expansion launches, staging buffer -> the step's static fp32 inputs (mmvae_expand_*);
+      tail:  the pull of the NEXT ring slot over the host link into the staging buffer (mmvae_input_ring_pull: source =
+             slot `count % n` of a device-resident table of the pinned batches, the launch advances `count`), queued on the
+             side (text) tower's stream behind its last backward launch (GradReducer.side_tail; at the end-of-backward
+             join for models without that point).
+    Replay j trains on ring[j % n]; the host makes NO runtime call per step besides the graph launch (the native pipe is
+    one library call = ~7 runtime calls around every launch).  A loader refills slots behind the device: `consumed()`.
+    Measured (cfg2, same box): bare replay 0.410, this 0.450-0.455, native pipe 0.485 ms/step.  Three other layouts were
+    measured and dropped (tools/probe/ring_time.py): the expansion launches beside the optimiser on the side stream (two
+    more cross-stream edges: 0.470), the pull in two halves at the text stream's two idle windows (no gain), and pull +
+    expansion as ONE node writing the other of two input-buffer sets with the step captured twice, ping / pong (0.473:
+    alternating two graph executables costs 20 us per step by itself)."""
+
+    def __init__(self, trainer, ring):
+        assert len(ring) >= 1
+        sig = _packed_signature(ring[0])
+        for b in ring:
+            assert b["_packed"].is_pinned() and _packed_signature(b) == sig, "ring slots: pinned, one layout"
+        self.ring = list(ring)                       # keeps the pinned buffers alive
+        dev = trainer.flat.data.device
+        self.dev = dev
+        buf = ring[0]["_packed"]
+        self.bytes = buf.numel()
+        assert self.bytes % 16 == 0 and all(b["_packed"].data_ptr() % 16 == 0 for b in ring), "16-byte aligned slots"
+        self.staging = torch.empty(self.bytes, dtype=torch.uint8, device=dev)
+        self.table = torch.tensor([b["_packed"].data_ptr() for b in ring], dtype=torch.int64, device=dev)
+        self.ctr = torch.zeros(2, dtype=torch.int32, device=dev)
+        base = buf.data_ptr()
+        self.mods = []
+        for k, v in ring[0].items():
+            if k == "_packed":
+                continue
+            dst = trainer._static_batch[k]
+            if "u8" in v:
+                o = v["u8"].data_ptr() - base
+                self.mods.append(("u8", self.staging[o:o + v["u8"].numel()], dst["data"]))
+            elif "tokens" in v:
+                o, ol = v["tokens"].data_ptr() - base, v["lengths"].data_ptr() - base
+                tok = self.staging[o:o + v["tokens"].numel() * 4].view(torch.int32).view(v["tokens"].shape)
+                ln = self.staging[ol:ol + v["lengths"].numel() * 4].view(torch.int32)
+                m = dst["masks"]
+                self.mods.append(("tokens", tok, ln, dst["data"], m.view(torch.uint8) if m is not None and m.dtype == torch.bool else m))
+            else:
+                raise ValueError(f"modality {k}: the in-graph input step moves 'u8' images and 'tokens' text")
+        self._keep = trainer._static_batch
+        self.reprime()
+
+    def reprime(self):
+        """counter 0, slot 0 in the staging buffer (count becomes 1): the state the recorded step starts from"""
+        self.ctr.zero_()
+        self.done = False
+        self.pull_next(self.dev, [])
+        torch.cuda.synchronize()
+
+    def expand(self):
+        from .. import ops
+        for m in self.mods:
+            if m[0] == "u8":
+                ops.expand_image_u8(m[1], m[2])
+            else:
+                ops.expand_text_tokens(m[1], m[2], m[3], m[4])
+
+    def pull_next(self, device, side_streams):
+        """queue the pull of the next slot (once per recorded step): on the current stream -- the side tower's when its
+        last backward launch calls this --, or on the last of `side_streams`"""
+        if self.done:
+            return
+        self.done = True
+        st = side_streams[-1] if side_streams else None
+        with torch.cuda.stream(st):
+            rc = H.lib().mmvae_input_ring_pull(self.table.data_ptr(), len(self.ring), self.ctr.data_ptr(),
+                                               self.staging.data_ptr(), 0, self.bytes, 1, H.stream())
+        if rc:
+            raise RuntimeError(f"mmvae_input_ring_pull: {rc}")
+
+    def consumed(self):
+        """number of slots the device has pulled so far (host synchronisation: a loader's flow control)"""
+        return int(self.ctr[0].item())
 
 
 def _packed_signature(packed):

@@ -40,6 +40,15 @@ class GradReducer:
     # table in `deferred`; FlatAdam.step() takes it and folds + updates in ONE launch (mmvae_adam_fold_flat).
     defer_next = False
     deferred = None
+    # pre_join(device, side_streams): called at the end of the backward pass right BEFORE the side streams are joined --
+    # the place where a tower's stream has finished its gradient work and idles until the optimiser (trainer.capture
+    # queues the next batch's host-to-device pull there: MultimodalVAE.capture(..., input_ring=...))
+    pre_join = None
+    # side_tail: the same work queued EARLIER when the side tower announces its last backward launch (EmbedPE.backward
+    # calls run_side_tail): hipGraph submits nodes in capture order, so a node captured at the very end of the backward
+    # pass is submitted -- and starts -- late however long its stream has been idle (measured: the pull queued at the
+    # join started ~30 us after the text stream went idle and delayed the optimiser by as much)
+    side_tail = None
     _arena = {}
     _state = {}
     _side = {}        # device key -> {"wgrad": Stream, "tower": Stream}: see StreamPlan below
@@ -99,6 +108,13 @@ class GradReducer:
             torch.autograd.Variable._execution_engine.queue_callback(lambda: cls.flush(dev))
 
     @classmethod
+    def run_side_tail(cls, device):
+        fn, cls.side_tail = cls.side_tail, None
+        if fn is not None:
+            fn(device, [])                      # on the CURRENT stream = the side tower's
+
+
+    @classmethod
     def keep(cls, device, *tensors):
         """hold tensors that a side-stream kernel still reads until the end-of-backward join"""
         cls._st(device)[1]["keep"].extend(t for t in tensors if t is not None)
@@ -132,6 +148,8 @@ class GradReducer:
         cls.launch_pending(device)
         _, st = cls._st(device)
         cur = torch.cuda.current_stream(device)
+        if cls.pre_join is not None:
+            cls.pre_join(device, [s_ for s_ in st["used"] if s_ != cur])
         for side in st["used"]:               # join every side stream that carried gradient work
             if side != cur:
                 cur.wait_stream(side)
@@ -1807,6 +1825,7 @@ class EmbedPE(Function):
             ws = H.workspace(nws, dx.device)
             _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, dpc,
                   H.stream())
+        GradReducer.run_side_tail(dx.device)      # the text encoder's LAST backward launch: its stream idles from here on
         return None, ret, None, None, None, None
 
 

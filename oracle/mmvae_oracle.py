@@ -742,19 +742,21 @@ def recon_mse(x, target):
     return ((x - target.to(torch.get_default_dtype()).reshape(x.shape).detach()) ** 2).reshape(target.shape[0], -1)
 
 
-_RECON = {"bce": lambda o, t, sc: recon_bce(o, t), "category_ce": lambda o, t, sc: recon_category_ce(o, t),
-          "lprob": lambda o, t, sc: recon_lprob(o, t, sc), "optimal_sigma": lambda o, t, sc: recon_optimal_sigma(o, t),
-          "l1": lambda o, t, sc: recon_l1(o, t), "mse": lambda o, t, sc: recon_mse(o, t)}
+_RECON = {"bce": lambda o, t, sc, lap=False: recon_bce(o, t), "category_ce": lambda o, t, sc, lap=False: recon_category_ce(o, t),
+          "lprob": lambda o, t, sc, lap=False: recon_lprob(o, t, sc, lap),
+          "optimal_sigma": lambda o, t, sc, lap=False: recon_optimal_sigma(o, t),
+          "l1": lambda o, t, sc, lap=False: recon_l1(o, t), "mse": lambda o, t, sc, lap=False: recon_mse(o, t)}
 
 
-def recon_loss(ltype, out, target):
+def recon_loss(ltype, out, target, laplace=False):
     """BaseObjective.recon_loss_fn, models/objectives.py:30-52: slice to the mask length (and, with masks, the
-    likelihood's scale becomes its loc), positive loss."""
+    likelihood's scale becomes its loc), positive loss.  laplace: the likelihood is `vae.px_z` = Laplace (the config's
+    `prior: laplace`, models/trainer.py:104; only `lprob` looks at the family)."""
     scale = None
     if target["masks"] is not None:
         out = out[:, : target["masks"].shape[1]]
         scale = out
-    return _RECON[ltype](out, target["data"], scale)
+    return _RECON[ltype](out, target["data"], scale, laplace)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -795,7 +797,7 @@ def mopoe_forward(p, mods, batch, eps, n_latents, train=False):
             "joint": (j_mu, j_var), "z": zs, "recon": recons}
 
 
-def mopoe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+def mopoe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, prior="normal", **_):
     """MoPOE.objective, models/mmvae_models.py:296-320 + weighted_group_kld, models/objectives.py:184-201."""
     M = len(mods)
     fw = mopoe_forward(p, mods, batch, eps, n_latents, train)
@@ -807,7 +809,9 @@ def mopoe_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
     lpx_zs = []
     for i in range(M):
         scale = float(mods[i].get("llik_scaling", 1.0))
-        lpx = -recon_loss(mods[i]["ltype"], fw["recon"][i], batch[f"mod_{i + 1}"]) * scale
+        # `prior: laplace`: MoPOE.forward hard-codes dist.Normal posteriors (mmvae_models.py:363-365); only the
+        # likelihood `vae.px_z` (:369) follows the config -- a Laplace log-prob for recon_loss lprob
+        lpx = -recon_loss(mods[i]["ltype"], fw["recon"][i], batch[f"mod_{i + 1}"], prior == "laplace") * scale
         lpx_zs.append(lpx.sum(-1))
     lpx = torch.stack(lpx_zs).sum(0).mean()
     loss = -(lpx - beta * group)
@@ -824,7 +828,7 @@ def poe_subset_order(n_mods, order=None):
     return [c for n in range(1, n_mods + 1) for c in itertools.combinations(idx, n)]
 
 
-def poe_objective(p, mods, batch, eps, n_latents, beta=1.0, order=None, train=False):
+def poe_objective(p, mods, batch, eps, n_latents, beta=1.0, order=None, train=False, prior="normal", **_):
     """POE.objective / forward / modality_mixing, models/mmvae_models.py:159-232."""
     M = len(mods)
     B = next(batch[f"mod_{i + 1}"]["data"].shape[0] for i in range(M) if batch[f"mod_{i + 1}"]["data"] is not None)
@@ -847,7 +851,8 @@ def poe_objective(p, mods, batch, eps, n_latents, beta=1.0, order=None, train=Fa
         for i in range(M):
             mask = batch[f"mod_{i + 1}"]["masks"] if i in S else None   # absent modality: masks None, utils.py:104-106
             rec = decode(p, mods, i, z, mask, train)
-            lpx = (-recon_loss(mods[i]["ltype"], rec, batch[f"mod_{i + 1}"]) * float(mods[i].get("llik_scaling", 1.0))).sum(-1)
+            # (POE.forward: qz_x = dist.Normal hard-coded :200, px = vae.px_z :204 -- the config's `prior` family)
+            lpx = (-recon_loss(mods[i]["ltype"], rec, batch[f"mod_{i + 1}"], prior == "laplace") * float(mods[i].get("llik_scaling", 1.0))).sum(-1)
             loc.append(lpx)
             if i == s_idx:
                 lpx_rec[i].append(lpx)
@@ -1080,7 +1085,7 @@ def moe_forward(p, mods, batch, eps, n_latents, train=False):
     return q, z, px, cross
 
 
-def dmvae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
+def dmvae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False, prior="normal", **_):
     """DMVAE.forward + objective, models/mmvae_models.py:436-503 (all modalities present, K = 1).
 
     Encoder outputs (B, D+P) are split into shared [:D] / private [D:] AFTER the softmax over all D+P columns
@@ -1107,7 +1112,8 @@ def dmvae_objective(p, mods, batch, eps, n_latents, beta=1.0, train=False):
         mask = tgt["masks"]
         z_sh = sh[i][0] + sh[i][1] * nxt(D)
         z_pr = pr[i][0] + pr[i][1] * nxt(pr[i][0].shape[1])
-        rec = lambda z: (-recon_loss(mods[i]["ltype"], decode(p, mods, i, torch.cat([z, z_pr], -1), mask, train), tgt) * lam).sum(-1)
+        # (DMVAE.forward: posteriors from the model-level self.qz_x = Normal :480-485, likelihoods vae.px_z :495-501)
+        rec = lambda z: (-recon_loss(mods[i]["ltype"], decode(p, mods, i, torch.cat([z, z_pr], -1), mask, train), tgt, prior == "laplace") * lam).sum(-1)
         lpx_own = rec(z_sh)
         lpx_joint = rec(z_joint)
         lpx_cross, kl_priv = [], []

@@ -115,6 +115,18 @@ CASE_MODS["mopoe_b5_t6_d8_mse_l1"] = [dict(MODS[0], ltype="mse"), dict(MODS[1], 
 CASES += [("mopoe_b5_t6_d8_mse_l1", "mopoe", 5, 6, 8, [6, 2, 4, 3, 1], "eval", 1.5)]
 
 
+# `prior: laplace` outside mixing moe: MoPoE / DMVAE build their posteriors with a hard-coded dist.Normal
+# (mmvae_models.py:363-365,480-485) -- the config's family only reaches the LIKELIHOOD `vae.px_z` (:369,495), i.e.
+# recon_loss lprob takes a Laplace log-prob.  (POE refuses non-gaussian priors itself, mmvae_models.py:152.)
+CASE_OPTS.update({"mopoe_ms_b5_d8_lprob_laplace": {"obj": "elbo", "K": 1, "prior": "laplace"},
+                  "dmvae_ms_b5_d8p4_lprob_laplace": {"obj": "elbo", "K": 1, "prior": "laplace"}})
+CASE_MODS["mopoe_ms_b5_d8_lprob_laplace"] = MS
+CASE_MODS["dmvae_ms_b5_d8p4_lprob_laplace"] = MS
+PRIVATE["dmvae_ms_b5_d8p4_lprob_laplace"] = 4
+CASES += [("mopoe_ms_b5_d8_lprob_laplace", "mopoe", 5, 0, 8, None, "eval", 1.5),
+          ("dmvae_ms_b5_d8p4_lprob_laplace", "dmvae", 5, 0, 8, None, "eval", 0.5)]
+
+
 # the unimodal case (models/trainer.py:112-113): one VAE trained with UnimodalObjective.elbo
 CASE_MODS["vae_cnn2_b5_d8"] = [MODS[0]]
 CASE_MODS["vae_txt_b5_t6_d8"] = [MODS[1]]
