@@ -349,6 +349,7 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{desc}; Adam(amsgrad) lr 1e-4, beta 1, train mode (dropout on)",
                           "global_batch": B * world, "parallelism": f"dp{world}",
+                          "abi_calls_per_step": getattr(tr, "abi_calls_in_graph", None),
                           "step_mflop_per_sample": round(flops / 1e6, 1),
                           "step_flops_fraction_of_f32_mfma_peak": round(
                               sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
@@ -368,6 +369,9 @@ def main():
             res["config"]["collective"] = res["collective"]["what"]
     if world == 1 and rank == 0:
         res["roofline"] = dominant_kernel_roofline(meta, dev)
+        # context for the dominant-kernel figure: the WHOLE step's algorithmic FLOPs over its wall time, same peak
+        res["roofline"]["step_frac"] = res["config"]["step_flops_fraction_of_f32_mfma_peak"]
+        res["roofline"]["step_achieved"] = round(sps * flops / 1e12, 2)
         if not a.no_extras and path_world == 1 and a.config == "cfg2":
             res["extras"] = extras(tr, a, dev, barrier)
         if not a.no_cpu_baseline:

@@ -206,6 +206,9 @@ class MultimodalVAE(nn.Module):
         torch.cuda.synchronize()
         self._input_ring = GraphInputRing(self, input_ring) if input_ring else None
         self._graph = torch.cuda.CUDAGraph()
+        dump = os.environ.get("MMVAE_GRAPH_DUMP")          # a DOT file of the captured step (node count: bench.py)
+        if dump:
+            self._graph.enable_debug_mode()
         self._graph2 = None
         self._adam_in_graph = world_size == 1 if optimizer_in_graph is None else bool(optimizer_in_graph) and world_size == 1
         # MMVAE_GRAPH_COLLECTIVE=1 (data parallel): the all-reduce of the flat gradients and the Adam launch are captured
@@ -241,6 +244,7 @@ class MultimodalVAE(nn.Module):
         else:
             def record(with_collective):
                 kw = {"capture_error_mode": "thread_local"} if with_collective else {}
+                calls0 = ops.CALLS[0]
                 with torch.cuda.graph(self._graph, **kw):
                     ops.Marks.mark("step start")
                     if self._input_ring is not None:
@@ -265,6 +269,7 @@ class MultimodalVAE(nn.Module):
                     if with_collective:
                         parallel.reduce_gradients_and_step(self.flat.grad, self.optimizer, self.dp_world, None,
                                                            self.dp_force_collective)
+                self.abi_calls_in_graph = ops.CALLS[0] - calls0      # C-ABI calls of one captured step (~ graph kernel nodes)
                 return res
             if self._collective_in_graph:
                 try:
@@ -284,8 +289,11 @@ class MultimodalVAE(nn.Module):
             else:
                 out = record(False)
         self._static_out = out
-        if self._adam_in_graph:                      # the capture pass does not execute: nothing to undo
-            pass
+        if dump:
+            try:
+                self._graph.debug_dump(dump)
+            except Exception as e:                   # (diagnostics only)
+                print(f"MMVAE_GRAPH_DUMP: {e}")
         self.flat.zero_grad()
         return out
 

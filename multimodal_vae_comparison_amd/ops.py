@@ -21,7 +21,11 @@ _DACT = {H.ACT_NONE: H.EP_NONE, H.ACT_SILU: H.EP_MUL_SILU_GRAD, H.ACT_RELU: H.EP
          H.ACT_GELU: H.EP_MUL_GELU_GRAD}
 
 
+CALLS = [0]      # C-ABI calls issued so far (trainer.capture reports how many one captured step holds)
+
+
 def _call(name, *args):
+    CALLS[0] += 1
     H.check(getattr(H.lib(), name)(*args), name)
 
 

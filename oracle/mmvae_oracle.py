@@ -289,18 +289,18 @@ def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
                             training=bool(train), momentum=0.1, eps=1e-5)
 
     h = F.conv2d(x.to(torch.get_default_dtype()), p[f"{r}.conv1.weight"], None, stride=2, padding=3)
-    h = F.max_pool2d(F.relu(bn(h, f"{r}.bn1")), 3, 2, 1)
+    h = F.max_pool2d(_relu(bn(h, f"{r}.bn1"), f"{r}.bn1"), 3, 2, 1)
     for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
         for b in range(blocks):
             k = f"{r}.layer{li + 1}.{b}"
             st = stride if b == 0 else 1
-            o = F.relu(bn(F.conv2d(h, p[f"{k}.conv1.weight"]), f"{k}.bn1"))
-            o = F.relu(bn(F.conv2d(o, p[f"{k}.conv2.weight"], None, stride=st, padding=1), f"{k}.bn2"))
+            o = _relu(bn(F.conv2d(h, p[f"{k}.conv1.weight"]), f"{k}.bn1"), f"{k}.bn1")
+            o = _relu(bn(F.conv2d(o, p[f"{k}.conv2.weight"], None, stride=st, padding=1), f"{k}.bn2"), f"{k}.bn2")
             o = bn(F.conv2d(o, p[f"{k}.conv3.weight"]), f"{k}.bn3")
             idn = h
             if b == 0:
                 idn = bn(F.conv2d(h, p[f"{k}.downsample.0.weight"], None, stride=st), f"{k}.downsample.1")
-            h = F.relu(o + idn)
+            h = _relu(o + idn, f"{k}.bn3")      # (the block's output: bn3 + identity, rectified)
             if taps is not None:        # (tests) the stage outputs, to localise a mismatch
                 h.retain_grad()
                 taps.append((k, h))
