@@ -431,6 +431,64 @@ int mmvae_avgpool_fwd(const float* x, float* y, int B, int HW, int C, int in_act
 int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW, int C, int in_act,
                       mmvae_stream_t stream);
 
+/* ---- fused convolution + BatchNorm engine of the bottleneck stack (csrc/rconv.hip; replaces the reference's
+ * torchvision Bottleneck.forward = conv1x1 -> bn -> relu -> conv3x3 -> bn -> relu -> conv1x1 -> bn (+ shortcut) and its
+ * autograd backward, models/encoders.py:108).  Weights are channels-last: (Cout, T = k*k taps, Cin) in memory behind the
+ * (Cout, Cin, k, k) parameter view.  A convolution's output stays RAW (pre-BatchNorm); its consumers apply
+ * bn(y) = fma(y - mean, sc, beta), sc = gamma * rstd, and the ReLU while staging their LDS tiles.  `pre`: how the input is
+ * consumed -- 0 as it is, 1 relu(x), 2 relu(bn(x)) with (xmean, xsc, xbeta).  tbl: per-geometry source-row tables of
+ * mmvae_rc_tables (NULL = 1x1 / stride 1).  All channel counts % 64 == 0. */
+/* fwd (T, B*Ho*Wo) and bwd (T, B*H*W) int32 tables of a K x K / stride S / padding P convolution (-1 = no source) */
+int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, int S, int P, mmvae_stream_t stream);
+/* rows per statistics partial the kernels use for an (M rows, N columns) output: part buffers hold
+ * ceil(M / that) * N * 2 floats, counters N / 32 tickets (zero once; the kernels re-arm them) */
+int mmvae_rc_row_tile(int M, int N);
+/* y (M, Cout) = conv(pre(x)); with part != NULL also the BatchNorm that follows: batch mean / rstd / sc = gamma rstd out,
+ * running statistics moved (eval != 0: mean / rstd / sc from the running statistics, nothing moved) */
+int mmvae_rc_conv_fwd(const float* x, const float* w, const float* xmean, const float* xsc, const float* xbeta,
+                      const int* tbl, float* y, int M, int Cin, int Cout, int T, int pre, const float* gamma,
+                      const float* beta, float* run_mean, float* run_var, float* mean, float* rstd, float* sc,
+                      float* part, unsigned* counter, float eps, float momentum, int eval, mmvae_stream_t stream);
+/* a BatchNorm whose output gradient a kernel produces: the kernel sums (G, G xhat) over the rows and its last workgroup
+ * writes dgamma / dbeta ((+)= per acc) and pqr (3, C) with  dL/dY = G p + Y q + r  (torch.nn.BatchNorm2d backward,
+ * training mode; eval: p = gamma rstd, q = r = 0) */
+typedef struct {
+  const float* Y;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  float* pqr;
+  float* dgamma;
+  float* dbeta;
+  float* part;
+  unsigned* counter;
+  int acc;
+  int eval;
+} mmvae_rc_stat_t;
+/* out (Min, Cin) = mask * (conv_transpose(dY) + add), dY = G p + Y q + r per output channel (pqr NULL: dY = G);
+ * mask: 0 none, 1 mY > 0, 2 bn(mY) > 0 with (mmean, msc, mbeta); nstat BatchNorms (same rows / channels as out) get
+ * their backward statistics from the epilogue */
+int mmvae_rc_conv_dgrad(const float* G, const float* Y, const float* pqr, const float* w, const int* tbl,
+                        const float* add, int mask, const float* mY, const float* mmean, const float* msc,
+                        const float* mbeta, float* out, int M, int Min, int Cin, int Cout, int T, int nstat,
+                        const mmvae_rc_stat_t* st0, const mmvae_rc_stat_t* st1, mmvae_stream_t stream);
+/* the same statistics for a gradient produced elsewhere (pooling backward) */
+int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream);
+/* dw (Cout, T, Cin) (+)= dY^T pre(x) per tap; ws / counter: mmvae_rc_wgrad_ws_floats / _tickets (tickets zero once) */
+int mmvae_rc_wgrad_splits(int M, int Cin, int Cout, int T);
+size_t mmvae_rc_wgrad_ws_floats(int M, int Cin, int Cout, int T);
+size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T);
+int mmvae_rc_conv_wgrad(const float* G, const float* Y, const float* pqr, const float* x, const float* xmean,
+                        const float* xsc, const float* xbeta, const int* tbl, float* dw, float* ws, unsigned* counter,
+                        int M, int Cin, int Cout, int T, int pre, int accumulate, mmvae_stream_t stream);
+/* end of a bottleneck: out = bn3(Y3) + (bn_d(R) when mr != NULL, else relu?(R)) */
+int mmvae_rc_blockout(const float* Y3, const float* m3, const float* sc3, const float* b3, const float* R,
+                      const float* mr, const float* scr, const float* br, int res_relu, float* out, long rows, int C,
+                      mmvae_stream_t stream);
+/* out = bn(Y) in the engine's own arithmetic (diagnostics, ReLU-mask export) */
+int mmvae_rc_bn_apply(const float* Y, const float* mean, const float* sc, const float* beta, float* out, long rows, int C,
+                      mmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * MoE with K samples per posterior + the DReG objective: the shipped configs/config_mnistsvhn.yml (mixing moe,
  * obj dreg, K 30, prior laplace).  Replaces MOE.forward's `q_m.rsample([K])` (models/mmvae_models.py:96-100),

@@ -11,7 +11,25 @@ import torch.nn as nn
 from . import ops
 
 
+def _channels_last(p):
+    """a (Cout, Cin, kh, kw) parameter whose memory is (Cout, kh, kw, Cin) (the ResNet tower's k x k weights)"""
+    return p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+
+
 class FlatParams:
+    @staticmethod
+    def view_of(buf, o, p):
+        """the slice of a flat buffer that belongs to parameter p, with p's shape AND memory layout"""
+        if _channels_last(p):
+            co, ci, kh, kw = p.shape
+            return buf[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return buf[o:o + p.numel()].view(p.shape)
+
+    @staticmethod
+    def flatten_like(t, p):
+        """a tensor of p's shape as the flat run of elements in p's memory order"""
+        return t.permute(0, 2, 3, 1).reshape(-1) if _channels_last(p) else t.reshape(-1)
+
     def __init__(self, module: nn.Module):
         params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         by_id = {id(p): (n, p) for n, p in params}
@@ -50,9 +68,11 @@ class FlatParams:
         self.n_params = sum(p.numel() for _, p in params)
         self.index = {}
         for p, o in offs:
-            self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
-            p.data = self.data[o:o + p.numel()].view(p.shape)
-            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            self.data[o:o + p.numel()].copy_(self.flatten_like(p.data, p))
+            view = self.view_of(self.data, o, p)
+            grad = self.view_of(self.grad, o, p)
+            p.data = view
+            p.grad = grad
             self.index[by_id[id(p)][0]] = (o, tuple(p.shape))
         self.params = [p for p, _ in offs]
         self.offset_of = {id(p): o for p, o in offs}
@@ -62,7 +82,7 @@ class FlatParams:
         """(re)attach the flat gradient views (after an optimizer.zero_grad(set_to_none=True))"""
         for name_off, p in zip(self.index.values(), self.params):
             o, shape = name_off
-            p.grad = self.grad[o:o + p.numel()].view(shape)
+            p.grad = self.view_of(self.grad, o, p)
 
     def zero_grad(self):
         ops.fill(self.grad, 0.0)
@@ -129,9 +149,9 @@ class FlatAdam(torch.optim.Optimizer):
         for i, p in enumerate(self.flat.params_in_model_order):
             o = self.flat.offset_of[id(p)]
             sl = slice(o, o + p.numel())
-            state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.m[sl].view(p.shape).clone(),
-                        "exp_avg_sq": self.v[sl].view(p.shape).clone(),
-                        "max_exp_avg_sq": self.vmax[sl].view(p.shape).clone()}
+            vo = lambda buf: FlatParams.view_of(buf, o, p).clone()
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": vo(self.m), "exp_avg_sq": vo(self.v),
+                        "max_exp_avg_sq": vo(self.vmax)}
         g = self.param_groups[0]
         group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": True,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
@@ -164,10 +184,11 @@ class FlatAdam(torch.optim.Optimizer):
                                    f"{tuple(p.shape)} has {p.numel()}")
             o = self.flat.offset_of[id(p)]
             sl = slice(o, o + p.numel())
-            self.m[sl].copy_(st["exp_avg"].reshape(-1))
-            self.v[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            fl = lambda t: FlatParams.flatten_like(t.reshape(p.shape), p)
+            self.m[sl].copy_(fl(st["exp_avg"]))
+            self.v[sl].copy_(fl(st["exp_avg_sq"]))
             if "max_exp_avg_sq" in st:
-                self.vmax[sl].copy_(st["max_exp_avg_sq"].reshape(-1))
+                self.vmax[sl].copy_(fl(st["max_exp_avg_sq"]))
             steps.add(int(float(st["step"])))
         assert len(steps) <= 1, f"per-parameter step counts differ: {steps}"
         self.step_dev.zero_()                     # the running beta powers are rebuilt by the kernel (pow()) once

@@ -59,6 +59,11 @@ class DregRows(ctypes.Structure):      # also mmvae_dreg_rows_grad (same layout,
     _fields_ = [("own", c_p * MOE_MAX_MODS), ("cross", c_p * MOE_MAX_MODS), ("lam", c_f * MOE_MAX_MODS)]
 
 
+class RcStat(ctypes.Structure):      # mmvae_rc_stat_t: a BatchNorm whose backward statistics a kernel produces
+    _fields_ = [("Y", c_p), ("mean", c_p), ("rstd", c_p), ("gamma", c_p), ("pqr", c_p), ("dgamma", c_p), ("dbeta", c_p),
+                ("part", c_p), ("counter", c_p), ("acc", c_i), ("eval", c_i)]
+
+
 c_dp = ctypes.POINTER(Dropout)
 DROPOUT_SLOTS = 16
 
@@ -202,6 +207,17 @@ SIGNATURES = {
     "mmvae_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p]),
     "mmvae_avgpool_fwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_avgpool_bwd": (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p]),
+    "mmvae_rc_tables": (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
+    "mmvae_rc_row_tile": (c_i, [c_i, c_i]),
+    "mmvae_rc_conv_fwd": (c_i, [c_p] * 7 + [c_i] * 5 + [c_p] * 9 + [c_f, c_f, c_i, c_p]),
+    "mmvae_rc_conv_dgrad": (c_i, [c_p] * 6 + [c_i] + [c_p] * 5 + [c_i] * 6 + [ctypes.POINTER(RcStat)] * 2 + [c_p]),
+    "mmvae_rc_bn_bwd_stats": (c_i, [c_p, ctypes.POINTER(RcStat), c_i, c_i, c_p]),
+    "mmvae_rc_wgrad_splits": (c_i, [c_i] * 4),
+    "mmvae_rc_wgrad_ws_floats": (c_sz, [c_i] * 4),
+    "mmvae_rc_wgrad_tickets": (c_sz, [c_i] * 3),
+    "mmvae_rc_conv_wgrad": (c_i, [c_p] * 11 + [c_i] * 6 + [c_p]),
+    "mmvae_rc_blockout": (c_i, [c_p] * 8 + [c_i, c_p, c_l, c_i, c_p]),
+    "mmvae_rc_bn_apply": (c_i, [c_p] * 5 + [c_l, c_i, c_p]),
     "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),
     "mmvae_dropout_advance_many": (c_i, [c_p, c_i, c_p]),
     "mmvae_dropout_mask": (c_i, [c_dp, c_p, c_l, c_p]),

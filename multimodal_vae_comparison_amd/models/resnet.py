@@ -9,10 +9,12 @@ of a bottleneck) is laid out here from scratch with torchvision's parameter / bu
 Without it the tower starts from torchvision's own random initialisation (kaiming-normal fan-out convolutions,
 BatchNorm weight 1 / bias 0, default Linear) -- there is no network here to fetch the ImageNet file from.
 
-MI355X mapping: activations are NHWC (rows, C) matrices inside the tower, so that all 53 convolutions run on the fp32
-MFMA GEMM kernels (1x1: one GEMM; 3x3 / 7x7: im2col + GEMM with the weight in its stored layout); BatchNorm (training:
-per-rank batch statistics, running statistics updated in the same launch), max / average pooling are HBM-bound
-kernels of csrc/resnet.hip.  Layers emit pre-activations; the consumers apply the ReLUs while staging.
+MI355X mapping: activations are NHWC (rows, C) matrices inside the tower.  The 16 bottlenecks (52 of the 53
+convolutions, 52 BatchNorms) run on the fused convolution + BatchNorm engine of csrc/rconv.hip (host side: rconv.py):
+implicit GEMM on fp32 MFMA with the im2col tiles staged in LDS, BatchNorm statistics in the GEMM epilogues, normalise +
+ReLU in the consumer GEMM's staging, the BatchNorm backward folded into the data- / weight-gradient GEMMs.  k x k
+weights are stored channels-last behind their (Cout, Cin, k, k) parameter view (state_dict values are unchanged).  The
+stem (7x7 convolution, BatchNorm, max pooling) and the global average pooling are kernels of csrc/resnet.hip.
 Parity: pinned against an oracle restatement of the same published topology with synthetic weights
 (oracle/mmvae_oracle.py: enc_cnn_resnet50); UNPINNED against torchvision itself, which is absent in this image."""
 import math
@@ -23,6 +25,7 @@ import torch.nn as nn
 
 from .. import hipops as H
 from .. import ops
+from .. import rconv
 from .nn_modules import HipLinear
 
 LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))      # (planes, blocks, stride of the first block)
@@ -32,10 +35,12 @@ EXPANSION = 4
 class ConvW(nn.Module):
     """nn.Conv2d(bias=False) parameters, torchvision's initialisation (kaiming_normal_, fan_out, relu)"""
 
-    def __init__(self, cin, cout, k, stride, pad):
+    def __init__(self, cin, cout, k, stride, pad, channels_last=False):
         super().__init__()
         w = torch.empty(cout, cin, k, k)
         nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+        if channels_last and k > 1:     # memory (cout, k, k, cin): the fused engine reduces over contiguous channels
+            w = w.contiguous(memory_format=torch.channels_last)
         self.weight = nn.Parameter(w)
         self.k, self.stride, self.pad = k, stride, pad
 
@@ -61,7 +66,9 @@ class BatchNorm2d(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x, res=None, res_relu=False):
+    def forward(self, x, res=None, res_relu=False, tap=False):
+        if tap:         # the fused engine (rconv.py) shows its BatchNorm outputs to forward hooks through this call
+            return x
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, res,
                               res_relu, self.momentum, self.eps)
 
@@ -74,7 +81,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.conv1 = ConvW(inplanes, planes, 1, 1, 0)
         self.bn1 = BatchNorm2d(planes)
-        self.conv2 = ConvW(planes, planes, 3, stride, 1)
+        self.conv2 = ConvW(planes, planes, 3, stride, 1, channels_last=True)
         self.bn2 = BatchNorm2d(planes)
         self.conv3 = ConvW(planes, planes * EXPANSION, 1, 1, 0)
         self.bn3 = BatchNorm2d(planes * EXPANSION)
@@ -83,20 +90,18 @@ class Bottleneck(nn.Module):
             self.downsample = nn.ModuleList([ConvW(inplanes, planes * EXPANSION, 1, stride, 0),
                                              BatchNorm2d(planes * EXPANSION)])
 
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = rconv.Block(self)
+        return self._engine
+
     def forward(self, s, B, Hh, W, in_act=H.ACT_RELU):
         """s: (B*H*W, inplanes), consumed through `in_act` (RELU; NONE for the max-pooled stem output)"""
-        h, _, _ = self.conv1(s, B, Hh, W, in_act)
-        h = self.bn1(h)
-        h, Ho, Wo = self.conv2(h, B, Hh, W, H.ACT_RELU)
-        h = self.bn2(h)
-        h, _, _ = self.conv3(h, B, Ho, Wo, H.ACT_RELU)
-        if self.downsample is not None:
-            idn, _, _ = self.downsample[0](s, B, Hh, W, in_act)
-            idn = self.downsample[1](idn)
-            out = self.bn3(h, res=idn, res_relu=False)
-        else:
-            out = self.bn3(h, res=s, res_relu=(in_act == H.ACT_RELU))
-        return out, Ho, Wo
+        st = self.conv2.stride
+        out = rconv.bottleneck_stack(s, [self.engine()], B, Hh, W, in_act, self.training)
+        return out, (Hh - 1) // st + 1, (W - 1) // st + 1
 
 
 class ResNet50(nn.Module):
@@ -125,11 +130,11 @@ class ResNet50(nn.Module):
         h = self.bn1(h)
         h = ops.MaxPool3x3S2.apply(h, B, Hh, W, H.ACT_RELU)              # relu then maxpool
         Hh, W = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
-        act = H.ACT_NONE                                                  # the pooled values are already rectified
-        for li in range(4):
-            for blk in getattr(self, f"layer{li + 1}"):
-                h, Hh, W = blk(h, B, Hh, W, act)
-                act = H.ACT_RELU
+        # the pooled values are already rectified (ACT_NONE); all 16 bottlenecks are one autograd node
+        blocks = [blk for li in range(4) for blk in getattr(self, f"layer{li + 1}")]
+        h = rconv.bottleneck_stack(h, [blk.engine() for blk in blocks], B, Hh, W, H.ACT_NONE, self.training)
+        for blk in blocks:
+            Hh, W = (Hh - 1) // blk.conv2.stride + 1, (W - 1) // blk.conv2.stride + 1
         h = ops.AvgPoolGlobal.apply(h, B, Hh * W, H.ACT_RELU)
         return self.fc(h)
 
