@@ -440,15 +440,15 @@ int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW,
  * mmvae_rc_tables (NULL = 1x1 / stride 1).  All channel counts % 64 == 0. */
 /* fwd (T, B*Ho*Wo) and bwd (T, B*H*W) int32 tables of a K x K / stride S / padding P convolution (-1 = no source) */
 int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, int S, int P, mmvae_stream_t stream);
-/* rows per statistics partial the kernels use for an (M rows, N columns) output: part buffers hold
- * ceil(M / that) * N * 2 floats, counters N / 32 tickets (zero once; the kernels re-arm them) */
+/* rows per statistics partial the kernels use for an (M rows, N columns) output.  With R = ceil(M / that) row tiles a
+ * `part` buffer holds (R + ceil(R / 16)) * N * 2 floats and a `counter` buffer (N / 32) * (1 + ceil(R / 16)) tickets
+ * (zero once; the kernels re-arm them): more than 16 row tiles elect their finalizer in two levels. */
 int mmvae_rc_row_tile(int M, int N);
-/* y (M, Cout) = conv(pre(x)); with part != NULL also the BatchNorm that follows: batch mean / rstd / sc = gamma rstd out,
- * running statistics moved (eval != 0: mean / rstd / sc from the running statistics, nothing moved) */
-int mmvae_rc_conv_fwd(const float* x, const float* w, const float* xmean, const float* xsc, const float* xbeta,
-                      const int* tbl, float* y, int M, int Cin, int Cout, int T, int pre, const float* gamma,
-                      const float* beta, float* run_mean, float* run_var, float* mean, float* rstd, float* sc,
-                      float* part, unsigned* counter, float eps, float momentum, int eval, mmvae_stream_t stream);
+/* forward / data-gradient GEMMs with few output tiles split their reduction (K channels x T taps) over workgroups:
+ * ws = mmvae_rc_conv_ws_floats(M, N, K, T) floats and ceil(M / 32) * (N / 32) tile tickets (zero once) for an (M, N)
+ * output (forward: N = Cout, K = Cin; data gradient: M = Min, N = Cin, K = Cout) */
+int mmvae_rc_conv_splits(int M, int N, int K, int T);
+size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T);
 /* a BatchNorm whose output gradient a kernel produces: the kernel sums (G, G xhat) over the rows and its last workgroup
  * writes dgamma / dbeta ((+)= per acc) and pqr (3, C) with  dL/dY = G p + Y q + r  (torch.nn.BatchNorm2d backward,
  * training mode; eval: p = gamma rstd, q = r = 0) */
@@ -465,22 +465,84 @@ typedef struct {
   int acc;
   int eval;
 } mmvae_rc_stat_t;
-/* out (Min, Cin) = mask * (conv_transpose(dY) + add), dY = G p + Y q + r per output channel (pqr NULL: dY = G);
- * mask: 0 none, 1 mY > 0, 2 bn(mY) > 0 with (mmean, msc, mbeta); nstat BatchNorms (same rows / channels as out) get
- * their backward statistics from the epilogue */
-int mmvae_rc_conv_dgrad(const float* G, const float* Y, const float* pqr, const float* w, const int* tbl,
-                        const float* add, int mask, const float* mY, const float* mmean, const float* msc,
-                        const float* mbeta, float* out, int M, int Min, int Cin, int Cout, int T, int nstat,
-                        const mmvae_rc_stat_t* st0, const mmvae_rc_stat_t* st1, mmvae_stream_t stream);
+/* forward: y (M, Cout) = conv(pre(x)); with part != NULL also the BatchNorm that follows: batch mean / rstd /
+ * sc = gamma rstd out, running statistics moved (eval != 0: mean / rstd / sc from the running statistics, nothing moved) */
+typedef struct {
+  const float* x;
+  const float* w;
+  const float* xmean;
+  const float* xsc;
+  const float* xbeta;
+  const int* tbl;
+  float* y;
+  float* ws;
+  unsigned* tile_ticket;
+  int M, Cin, Cout, T, pre;
+  const float* gamma;
+  const float* beta;
+  float* run_mean;
+  float* run_var;
+  float* mean;
+  float* rstd;
+  float* sc;
+  float* part;
+  unsigned* counter;
+  float eps, momentum;
+  int eval;
+} mmvae_rc_fwd_t;
+/* data gradient: out (Min, Cin) = mask * (conv_transpose(dY) + add), dY = G p + Y q + r per output channel (pqr NULL:
+ * dY = G); add: (Min, Cin), or -- with add_tbl (Min) -- row add_tbl[m] of it (-1: none); mask: 0 none, 1 mY > 0,
+ * 2 bn(mY) > 0 with (mmean, msc, mbeta); nstat BatchNorms (same rows / channels as out) get their backward
+ * statistics from the epilogue */
+typedef struct {
+  const float* G;
+  const float* Y;
+  const float* pqr;
+  const float* w;
+  const int* tbl;
+  const float* add;
+  const int* add_tbl;
+  int mask;
+  const float* mY;
+  const float* mmean;
+  const float* msc;
+  const float* mbeta;
+  float* out;
+  float* ws;
+  unsigned* tile_ticket;
+  int M, Min, Cin, Cout, T, nstat;
+  mmvae_rc_stat_t st[2];
+} mmvae_rc_dgrad_t;
+/* weight gradient: dw (Cout, T, Cin) (+)= dY^T pre(x) per tap; ws / counter: mmvae_rc_wgrad_ws_floats / _tickets */
+typedef struct {
+  const float* G;
+  const float* Y;
+  const float* pqr;
+  const float* x;
+  const float* xmean;
+  const float* xsc;
+  const float* xbeta;
+  const int* tbl;
+  float* dw;
+  float* ws;
+  unsigned* counter;
+  int M, Cin, Cout, T, pre, accumulate;
+} mmvae_rc_wgrad_t;
+/* up to MMVAE_RC_MAX_JOBS independent jobs in ONE launch (a layer's data + weight gradient, a block's first convolution
+ * + projection shortcut); kind: 0 forward (f), 1 data gradient (d), 2 weight gradient (w) */
+#define MMVAE_RC_MAX_JOBS 4
+typedef struct {
+  int kind;
+  mmvae_rc_fwd_t f;
+  mmvae_rc_dgrad_t d;
+  mmvae_rc_wgrad_t w;
+} mmvae_rc_job_t;
+int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t stream);
 /* the same statistics for a gradient produced elsewhere (pooling backward) */
 int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream);
-/* dw (Cout, T, Cin) (+)= dY^T pre(x) per tap; ws / counter: mmvae_rc_wgrad_ws_floats / _tickets (tickets zero once) */
 int mmvae_rc_wgrad_splits(int M, int Cin, int Cout, int T);
 size_t mmvae_rc_wgrad_ws_floats(int M, int Cin, int Cout, int T);
 size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T);
-int mmvae_rc_conv_wgrad(const float* G, const float* Y, const float* pqr, const float* x, const float* xmean,
-                        const float* xsc, const float* xbeta, const int* tbl, float* dw, float* ws, unsigned* counter,
-                        int M, int Cin, int Cout, int T, int pre, int accumulate, mmvae_stream_t stream);
 /* end of a bottleneck: out = bn3(Y3) + (bn_d(R) when mr != NULL, else relu?(R)) */
 int mmvae_rc_blockout(const float* Y3, const float* m3, const float* sc3, const float* b3, const float* R,
                       const float* mr, const float* scr, const float* br, int res_relu, float* out, long rows, int C,

@@ -64,6 +64,10 @@ __device__ __forceinline__ bool rc_last_workgroup(unsigned* __restrict__ ticket,
   return *last_lds != 0;
 }
 
+// workgroup coordinates of a job (its own blockIdx / gridDim when the job is a launch of its own; a slice of the
+// linear grid when several independent jobs share one launch: rc_group_kernel)
+struct RcBlk { int bx, by, bz, gx, gy; };
+
 // Staging of an R x BK operand tile into LDS as [k][r] (pitch R + 1, odd: conflict-free for both the transposing store
 // and the per-lane MFMA fragment reads).  KMAJOR: consecutive threads walk k (the source is k-contiguous), a thread's
 // slots are rows rl + i RSTEP; otherwise consecutive threads walk the rows and the slots are k = kl + i KSTEP.
@@ -159,96 +163,139 @@ struct RcFwdArgs {
   const float* xbeta;
   const int* tbl;         // (T, M) source row of (tap, output row), -1 = padding; NULL: identity (T = 1, Min = M)
   float* y;               // (M, Cout)
-  int M, Cin, Cout, T, pre;
+  float* ws;              // nz > 1: (nz, M, Cout) partial outputs
+  unsigned* tile_ticket;  // nz > 1: one per output tile
+  int M, Cin, Cout, T, pre, nz;
   RcBnFwd bn;             // bn.part == NULL: no statistics
 };
 
-template <int BN>
-__device__ __forceinline__ void rc_bn_fwd_finalize(const RcBnFwd& bn, double* __restrict__ dl, int nparts, int BMrows,
-                                                   int M, int C, int n, int col, int rg) {
+#define RC_GROUP 16   // row tiles whose statistics partials one representative workgroup condenses
+// Merge of the partial pairs p in [pb, pe) of column n, all 256 threads of the workgroup (thread = (col, rg)), loads of 8
+// partials per thread in flight.  MEANVAR: pairs are (mean, M2) of rows_per rows each (the part that covers the end of
+// the M rows: fewer), merged as double sums shifted by the first part's mean -- no division per part, no cancellation
+// that double does not absorb; out (count, mean, M2).  Otherwise plain sums of both members; out (-, sum0, sum1).
+template <int BN, bool MEANVAR>
+__device__ __forceinline__ void rc_merge(const float* __restrict__ part, int C, int n, int pb, int pe, int rows_per, int M,
+                                         double* __restrict__ dl, int col, int rg, double& o0, double& o1, double& o2) {
   constexpr int RG = 256 / BN;
-  // pass 1: mean = sum cnt_p mean_p / M; pass 2: M2 = sum [M2_p + cnt_p (mean_p - mean)^2]  (exact two-pass merge of
-  // the row tiles' (mean, M2); this thread's partials stay in registers between the passes when they fit)
-  constexpr int KEEP = 16;
-  float pm[KEEP], pq[KEEP];
-  double s = 0.0;
-  int cnt_i = 0;
-  for (int p0 = rg; p0 < nparts; p0 += RG * KEEP) {
+  const double r = MEANVAR ? (double)rc_ld(part + ((size_t)pb * C + n) * 2) : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int p0 = pb + rg; p0 < pe; p0 += RG * 8) {
+    float a[8], b[8];
 #pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-      const int p = p0 + i * RG;
-      pm[i] = rc_ld(bn.part + ((size_t)min(p, nparts - 1) * C + n) * 2);
+    for (int i = 0; i < 8; ++i) {
+      const int p = min(p0 + i * RG, pe - 1);
+      a[i] = rc_ld(part + ((size_t)p * C + n) * 2);
+      b[i] = rc_ld(part + ((size_t)p * C + n) * 2 + 1);
     }
 #pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int p = p0 + i * RG;
-      if (p < nparts) s += (double)min(BMrows, M - p * BMrows) * (double)pm[i];
-    }
-    ++cnt_i;
-  }
-  __syncthreads();
-  dl[rg * BN + col] = s;
-  __syncthreads();
-  double mean = 0.0;
-  for (int g = 0; g < RG; ++g) mean += dl[g * BN + col];
-  mean /= (double)M;
-  double q = 0.0;
-  for (int p0 = rg; p0 < nparts; p0 += RG * KEEP) {
-    if (cnt_i > 1) {
-#pragma unroll
-      for (int i = 0; i < KEEP; ++i) {
-        const int p = p0 + i * RG;
-        pm[i] = rc_ld(bn.part + ((size_t)min(p, nparts - 1) * C + n) * 2);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-      const int p = p0 + i * RG;
-      pq[i] = rc_ld(bn.part + ((size_t)min(p, nparts - 1) * C + n) * 2 + 1);
-    }
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-      const int p = p0 + i * RG;
-      if (p < nparts) {
-        const double d = (double)pm[i] - mean;
-        q += (double)pq[i] + (double)min(BMrows, M - p * BMrows) * d * d;
+      if (p < pe) {
+        if (MEANVAR) {
+          const double cnt = (double)min(rows_per, M - p * rows_per), d = (double)a[i] - r;
+          s0 += cnt;
+          s1 += cnt * d;
+          s2 += (double)b[i] + cnt * d * d;
+        } else {
+          s1 += (double)a[i];
+          s2 += (double)b[i];
+        }
       }
     }
   }
   __syncthreads();
-  dl[rg * BN + col] = q;
+  dl[(rg * BN + col) * 3] = s0;
+  dl[(rg * BN + col) * 3 + 1] = s1;
+  dl[(rg * BN + col) * 3 + 2] = s2;
   __syncthreads();
-  if (rg == 0) {
-    double c2 = 0.0;
-    for (int g = 0; g < RG; ++g) c2 += dl[g * BN + col];
-    const double cn = (double)M, var = c2 / cn;
-    double rs = 1.0 / sqrt(var + (double)bn.eps);
-    if (bn.eval) {
-      mean = (double)bn.run_mean[n];
-      rs = 1.0 / sqrt((double)bn.run_var[n] + (double)bn.eps);
-    } else if (bn.run_mean) {
-      const double mo = (double)bn.momentum, unb = cn > 1.0 ? c2 / (cn - 1.0) : var;
-      bn.run_mean[n] = (float)((1.0 - mo) * (double)bn.run_mean[n] + mo * mean);
-      bn.run_var[n] = (float)((1.0 - mo) * (double)bn.run_var[n] + mo * unb);
+  s0 = 0.0; s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int g = 0; g < RG; ++g) { s0 += dl[(g * BN + col) * 3]; s1 += dl[(g * BN + col) * 3 + 1]; s2 += dl[(g * BN + col) * 3 + 2]; }
+  if (MEANVAR) { o0 = s0; o1 = r + s1 / s0; o2 = s2 - s1 * s1 / s0; } else { o0 = 0.0; o1 = s1; o2 = s2; }
+}
+
+// Where the statistics of one column tile live.  Level 0: one partial pair per row tile; with more than RC_GROUP row
+// tiles the last workgroup of every group of RC_GROUP condenses them into one level-1 pair (so that a ticket never sees
+// more than RC_GROUP ... nrow / RC_GROUP arrivals: ~50 ns each, serialised on one address) and the representatives
+// elect the finalizer.  counter: [column tiles] final tickets, then [column tiles][groups] group tickets.
+struct RcLevels {
+  int nrow, ngrp, grp, g0, g1;
+  __device__ __forceinline__ RcLevels(int nrow_, int by) : nrow(nrow_) {
+    ngrp = nrow > RC_GROUP ? (nrow + RC_GROUP - 1) / RC_GROUP : 0;
+    grp = by / RC_GROUP;
+    g0 = grp * RC_GROUP;
+    g1 = min(nrow, g0 + RC_GROUP);
+  }
+  __device__ __forceinline__ float* level1(float* part, int C) const { return part + (size_t)nrow * C * 2; }
+};
+
+template <int BN>
+__device__ __forceinline__ void rc_bn_fwd_finalize(const RcBnFwd& bn, double mean, double m2, int M, int n) {
+  const double cn = (double)M, var = m2 / cn;
+  double rs = 1.0 / sqrt(var + (double)bn.eps);
+  if (bn.eval) {
+    mean = (double)bn.run_mean[n];
+    rs = 1.0 / sqrt((double)bn.run_var[n] + (double)bn.eps);
+  } else if (bn.run_mean) {
+    const double mo = (double)bn.momentum, unb = cn > 1.0 ? m2 / (cn - 1.0) : var;
+    bn.run_mean[n] = (float)((1.0 - mo) * (double)bn.run_mean[n] + mo * mean);
+    bn.run_var[n] = (float)((1.0 - mo) * (double)bn.run_var[n] + mo * unb);
+  }
+  bn.mean[n] = (float)mean;
+  bn.rstd[n] = (float)rs;
+  bn.sc[n] = (float)((double)bn.gamma[n] * rs);
+}
+
+// The complete values of this workgroup's output tile.  nz == 1: the LDS tile.  nz > 1 (split of the reduction over
+// blockIdx.z, 32 x 32 tiles only): every split leaves its partial tile in ws [z][rows][N]; the last one to arrive sums
+// them in z order (NR x 8 loads in flight) and carries on alone -- false for the others.
+template <class TL, int BM, int BN>
+__device__ __forceinline__ bool rc_tile_values(const float* __restrict__ smem, float* __restrict__ ws,
+                                               unsigned* __restrict__ ticket, int nz, int zi, size_t zstride, int m0, int n0,
+                                               int N, int cnt, int col, int rg, float (&v)[TL::NR], int* last) {
+#pragma unroll
+  for (int j = 0; j < TL::NR; ++j) v[j] = TL::tile_at(smem, rg + j * TL::RG, col);
+  if (nz == 1) return true;
+  if constexpr (TL::NR <= 4) {
+#pragma unroll
+    for (int j = 0; j < TL::NR; ++j) {
+      const int row = rg + j * TL::RG;
+      if (row < cnt) rc_st(ws + (size_t)zi * zstride + (size_t)(m0 + row) * N + n0 + col, v[j]);
     }
-    bn.mean[n] = (float)mean;
-    bn.rstd[n] = (float)rs;
-    bn.sc[n] = (float)((double)bn.gamma[n] * rs);
+    if (!rc_last_workgroup(ticket, (unsigned)nz, last)) return false;
+#pragma unroll
+    for (int j = 0; j < TL::NR; ++j) v[j] = 0.f;
+    for (int z0 = 0; z0 < nz; z0 += 8) {
+      float t[TL::NR][8];
+#pragma unroll
+      for (int j = 0; j < TL::NR; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          t[j][i] = rc_ld(ws + (size_t)min(z0 + i, nz - 1) * zstride + (size_t)(m0 + min(rg + j * TL::RG, cnt - 1)) * N +
+                          n0 + col);
+#pragma unroll
+      for (int j = 0; j < TL::NR; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (z0 + i < nz) v[j] += t[j][i];
+    }
+    return true;
+  } else {
+    return false;   // the dispatcher never splits the 64 x 64 tiling
   }
 }
 
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
+__device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
+                                          int* __restrict__ lastp) {
   using TL = RcTile<BM, BN, BK>;
   using SA = RcStg<BM, BK, true>;
   using SB = RcStg<BN, BK, true>;
-  __shared__ __attribute__((aligned(16))) float smem[TL::SMEM];
-  __shared__ float cs[256];
-  __shared__ int last;
   float* As = smem;
   float* Bs = smem + BK * TL::AP;
   const int tid = threadIdx.x;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int n0 = k.bx * BN, m0 = k.by * BM;
   TL tl;
   tl.init(tid);
   SA sa;
@@ -261,7 +308,10 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
   unsigned oka = 0;
 #pragma unroll
   for (int i = 0; i < SB::PER; ++i) wrow[i] = (n0 + sb.row(i)) * a.T;
-  int ltap = 0, lc0 = 0;
+  // this workgroup's share of the T * Cin / BK stages (k.bz of nz)
+  const int nstage_all = a.T * (a.Cin / BK), sper = (nstage_all + a.nz - 1) / a.nz;
+  const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
+  int ltap = s_beg / (a.Cin / BK), lc0 = (s_beg % (a.Cin / BK)) * BK;
   bool newtap = true;
   auto load = [&]() {
     if (newtap) {
@@ -301,25 +351,26 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nstage = a.T * (a.Cin / BK);
-  load();
+  if (s_beg < s_end) load();
 #pragma unroll 1
-  for (int s = 0; s < nstage; ++s) {
+  for (int s = s_beg; s < s_end; ++s) {
     store();
     __syncthreads();
-    if (s + 1 < nstage) load();
+    if (s + 1 < s_end) load();
     tl.mma(As, Bs, acc);
     __syncthreads();
   }
   tl.spill(smem, acc);
   __syncthreads();
   const int col = tid % BN, rg = tid / BN, n = n0 + col;
-  float v[TL::NR], s = 0.f;
   const int cnt = min(BM, a.M - m0);
+  float v[TL::NR], s = 0.f;
+  if (!rc_tile_values<TL, BM, BN>(smem, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz,
+                                  (size_t)a.M * a.Cout, m0, n0, a.Cout, cnt, col, rg, v, lastp))
+    return;
 #pragma unroll
   for (int j = 0; j < TL::NR; ++j) {
     const int row = rg + j * TL::RG;
-    v[j] = TL::tile_at(smem, row, col);
     if (row < cnt) {
       a.y[(size_t)(m0 + row) * a.Cout + n] = v[j];
       s += v[j];
@@ -333,11 +384,38 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
     if (rg + j * TL::RG < cnt) q = fmaf(v[j] - mean_t, v[j] - mean_t, q);
   const float m2_t = rc_colsum<BN>(cs, q, col, rg);
   if (rg == 0) {
-    rc_st(a.bn.part + ((size_t)blockIdx.y * a.Cout + n) * 2, mean_t);
-    rc_st(a.bn.part + ((size_t)blockIdx.y * a.Cout + n) * 2 + 1, m2_t);
+    rc_st(a.bn.part + ((size_t)k.by * a.Cout + n) * 2, mean_t);
+    rc_st(a.bn.part + ((size_t)k.by * a.Cout + n) * 2 + 1, m2_t);
   }
-  if (!rc_last_workgroup(a.bn.counter + blockIdx.x, gridDim.y, &last)) return;
-  rc_bn_fwd_finalize<BN>(a.bn, reinterpret_cast<double*>(smem), gridDim.y, BM, a.M, a.Cout, n, col, rg);
+  const RcLevels lv(k.gy, k.by);
+  double* dl = reinterpret_cast<double*>(smem);
+  double o0, o1, o2;
+  const float* src_part = a.bn.part;
+  int np = lv.nrow, rows_per = BM;
+  if (lv.ngrp) {
+    if (!rc_last_workgroup(a.bn.counter + k.gx + k.bx * lv.ngrp + lv.grp, lv.g1 - lv.g0, lastp)) return;
+    rc_merge<BN, true>(a.bn.part, a.Cout, n, lv.g0, lv.g1, BM, a.M, dl, col, rg, o0, o1, o2);
+    float* l1 = lv.level1(a.bn.part, a.Cout);
+    if (rg == 0) {
+      rc_st(l1 + ((size_t)lv.grp * a.Cout + n) * 2, (float)o1);
+      rc_st(l1 + ((size_t)lv.grp * a.Cout + n) * 2 + 1, (float)o2);
+    }
+    src_part = l1;
+    np = lv.ngrp;
+    rows_per = BM * RC_GROUP;
+  }
+  if (!rc_last_workgroup(a.bn.counter + k.bx, np, lastp)) return;
+  rc_merge<BN, true>(src_part, a.Cout, n, 0, np, rows_per, a.M, dl, col, rg, o0, o1, o2);
+  if (rg == 0) rc_bn_fwd_finalize<BN>(a.bn, o1, o2, a.M, n);
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[RcTile<BM, BN, BK>::SMEM];
+  __shared__ float cs[256];
+  __shared__ int last;
+  rc_fwd_body<BM, BN, BK>(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs,
+                          &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -357,42 +435,50 @@ struct RcStat {           // a BatchNorm whose output gradient G the kernel hold
   int eval;
 };
 
+__device__ __forceinline__ void rc_stat_finalize(const RcStat& st, double s1, double s2, int M, int C, int n) {
+  if (st.dbeta) st.dbeta[n] = (float)((st.acc ? (double)st.dbeta[n] : 0.0) + s1);
+  if (st.dgamma) st.dgamma[n] = (float)((st.acc ? (double)st.dgamma[n] : 0.0) + s2);
+  const double rs = (double)st.rstd[n], p = (double)st.gamma[n] * rs;
+  double q = 0.0, r = 0.0;
+  if (!st.eval) {
+    q = -p * rs * (s2 / (double)M);
+    r = -p * (s1 / (double)M) - q * (double)st.mean[n];
+  }
+  st.pqr[n] = (float)p;
+  st.pqr[C + n] = (float)q;
+  st.pqr[2 * C + n] = (float)r;
+}
+
+// the hierarchical election + merge of the backward statistics of nstat BatchNorms (partials already stored)
 template <int BN>
-__device__ __forceinline__ void rc_stat_finalize(const RcStat& st, double* __restrict__ dl, int nparts, int M, int C, int n,
-                                                 int col, int rg) {
-  constexpr int RG = 256 / BN;
-  double s1 = 0.0, s2 = 0.0;
-  for (int p0 = rg; p0 < nparts; p0 += RG * 8) {
-    float v1[8], v2[8];
+__device__ __forceinline__ void rc_stat_tail(const RcStat* st, int nstat, int nrow, int by, int bx, int ncoltiles, int M,
+                                             int C, int n, double* dl, int col, int rg, int* last) {
+  const RcLevels lv(nrow, by);
+  double o0, o1, o2;
+  int np = lv.nrow;
+  bool l1 = false;
+  if (lv.ngrp) {
+    if (!rc_last_workgroup(st[0].counter + ncoltiles + bx * lv.ngrp + lv.grp, lv.g1 - lv.g0, last)) return;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = p0 + i * RG;
-      v1[i] = rc_ld(st.part + ((size_t)min(p, nparts - 1) * C + n) * 2);
-      v2[i] = rc_ld(st.part + ((size_t)min(p, nparts - 1) * C + n) * 2 + 1);
-    }
+    for (int t = 0; t < 2; ++t)
+      if (t < nstat) {
+        rc_merge<BN, false>(st[t].part, C, n, lv.g0, lv.g1, 0, 0, dl, col, rg, o0, o1, o2);
+        float* d = lv.level1(st[t].part, C);
+        if (rg == 0) {
+          rc_st(d + ((size_t)lv.grp * C + n) * 2, (float)o1);
+          rc_st(d + ((size_t)lv.grp * C + n) * 2 + 1, (float)o2);
+        }
+      }
+    np = lv.ngrp;
+    l1 = true;
+  }
+  if (!rc_last_workgroup(st[0].counter + bx, np, last)) return;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (p0 + i * RG < nparts) { s1 += (double)v1[i]; s2 += (double)v2[i]; }
-  }
-  __syncthreads();
-  dl[(rg * BN + col) * 2] = s1;
-  dl[(rg * BN + col) * 2 + 1] = s2;
-  __syncthreads();
-  if (rg == 0) {
-    s1 = 0.0; s2 = 0.0;
-    for (int g = 0; g < RG; ++g) { s1 += dl[(g * BN + col) * 2]; s2 += dl[(g * BN + col) * 2 + 1]; }
-    if (st.dbeta) st.dbeta[n] = (float)((st.acc ? (double)st.dbeta[n] : 0.0) + s1);
-    if (st.dgamma) st.dgamma[n] = (float)((st.acc ? (double)st.dgamma[n] : 0.0) + s2);
-    const double rs = (double)st.rstd[n], p = (double)st.gamma[n] * rs;
-    double q = 0.0, r = 0.0;
-    if (!st.eval) {
-      q = -p * rs * (s2 / (double)M);
-      r = -p * (s1 / (double)M) - q * (double)st.mean[n];
+  for (int t = 0; t < 2; ++t)
+    if (t < nstat) {
+      rc_merge<BN, false>(l1 ? lv.level1(st[t].part, C) : st[t].part, C, n, 0, np, 0, 0, dl, col, rg, o0, o1, o2);
+      if (rg == 0) rc_stat_finalize(st[t], o1, o2, M, C, n);
     }
-    st.pqr[n] = (float)p;
-    st.pqr[C + n] = (float)q;
-    st.pqr[2 * C + n] = (float)r;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -404,28 +490,29 @@ struct RcDgradArgs {
   const float* pqr;       // ... and (3, Cout): dY = G p + Y q + r.  NULL: dY = G
   const float* w;         // (Cout, T, Cin)
   const int* tbl;         // (T, Min): output row feeding (tap, input row), -1 = none; NULL: identity
-  const float* add;       // (Min, Cin) added before the mask (the shortcut's gradient) or NULL
+  const float* add;       // added before the mask (the shortcut's gradient) or NULL: (Min, Cin), or ...
+  const int* add_tbl;     // ... with add_tbl (Min): row add_tbl[m] of `add` (-1: nothing), a strided projection's gradient
   const float* mY;        // mask source (Min, Cin): RC_MASK_RAW mY > 0, RC_MASK_BN bn(mY) > 0
   const float* mmean;
   const float* msc;
   const float* mbeta;
   float* out;             // (Min, Cin)
-  int M, Min, Cin, Cout, T, mask, nstat;
+  float* ws;              // nz > 1: (nz, Min, Cin) partial outputs
+  unsigned* tile_ticket;
+  int M, Min, Cin, Cout, T, mask, nstat, nz;
   RcStat st[2];
 };
 
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
+__device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
+                                          int* __restrict__ lastp) {
   using TL = RcTile<BM, BN, BK>;
   using SA = RcStg<BM, BK, true>;
   using SB = RcStg<BN, BK, false>;
-  __shared__ __attribute__((aligned(16))) float smem[TL::SMEM];
-  __shared__ float cs[256];
-  __shared__ int last;
   float* As = smem;
   float* Bs = smem + BK * TL::AP;
   const int tid = threadIdx.x;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;     // n0: input-channel tile
+  const int n0 = k.bx * BN, m0 = k.by * BM;     // n0: input-channel tile
   TL tl;
   tl.init(tid);
   SA sa;
@@ -436,7 +523,9 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
   float rg_[SA::PER], ry[SA::PER], rb[SB::PER];
   float pp = 1.f, pq = 0.f, pr = 0.f;
   unsigned oka = 0;
-  int ltap = 0, lk0 = 0;
+  const int nstage_all = a.T * (a.Cout / BK), sper = (nstage_all + a.nz - 1) / a.nz;
+  const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
+  int ltap = s_beg / (a.Cout / BK), lk0 = (s_beg % (a.Cout / BK)) * BK;
   bool newtap = true;
   auto load = [&]() {
     if (newtap) {
@@ -477,13 +566,12 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nstage = a.T * (a.Cout / BK);
-  load();
+  if (s_beg < s_end) load();
 #pragma unroll 1
-  for (int s = 0; s < nstage; ++s) {
+  for (int s = s_beg; s < s_end; ++s) {
     store();
     __syncthreads();
-    if (s + 1 < nstage) load();
+    if (s + 1 < s_end) load();
     tl.mma(As, Bs, acc);
     __syncthreads();
   }
@@ -491,6 +579,10 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
   __syncthreads();
   const int col = tid % BN, rg = tid / BN, c = n0 + col;
   const int cnt = min(BM, a.Min - m0);
+  float v[TL::NR];
+  if (!rc_tile_values<TL, BM, BN>(smem, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz,
+                                  (size_t)a.Min * a.Cin, m0, n0, a.Cin, cnt, col, rg, v, lastp))
+    return;
   float mm = 0.f, ms = 1.f, mb = 0.f;
   if (a.mask == RC_MASK_BN) { mm = a.mmean[c]; ms = a.msc[c]; mb = a.mbeta[c]; }
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, tm[2] = {0.f, 0.f}, tr[2] = {0.f, 0.f};
@@ -502,8 +594,15 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
     const int row = rg + j * TL::RG;
     if (row < cnt) {
       const size_t o = (size_t)(m0 + row) * a.Cin + c;
-      float g = TL::tile_at(smem, row, col);
-      if (a.add) g += a.add[o];
+      float g = v[j];
+      if (a.add) {
+        if (a.add_tbl) {
+          const int r = a.add_tbl[m0 + row];
+          if (r >= 0) g += a.add[(size_t)r * a.Cin + c];
+        } else {
+          g += a.add[o];
+        }
+      }
       float my = 0.f;
       if (a.mask != RC_MASK_NONE) {
         my = a.mY[o];
@@ -526,20 +625,27 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
     if (t < a.nstat) {
       const float a1 = rc_colsum<BN>(cs, s1[t], col, rg), a2 = rc_colsum<BN>(cs, s2[t], col, rg);
       if (rg == 0) {
-        rc_st(a.st[t].part + ((size_t)blockIdx.y * a.Cin + c) * 2, a1);
-        rc_st(a.st[t].part + ((size_t)blockIdx.y * a.Cin + c) * 2 + 1, a2);
+        rc_st(a.st[t].part + ((size_t)k.by * a.Cin + c) * 2, a1);
+        rc_st(a.st[t].part + ((size_t)k.by * a.Cin + c) * 2 + 1, a2);
       }
     }
-  if (!rc_last_workgroup(a.st[0].counter + blockIdx.x, gridDim.y, &last)) return;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-    if (t < a.nstat) rc_stat_finalize<BN>(a.st[t], reinterpret_cast<double*>(smem), gridDim.y, a.Min, a.Cin, c, col, rg);
+  rc_stat_tail<BN>(a.st, a.nstat, k.gy, k.by, k.bx, k.gx, a.Min, a.Cin, c,
+                   reinterpret_cast<double*>(smem), col, rg, lastp);
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[RcTile<BM, BN, BK>::SMEM];
+  __shared__ float cs[256];
+  __shared__ int last;
+  rc_dgrad_body<BM, BN, BK>(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs,
+                          &last);
 }
 
 // stand-alone statistics of a BatchNorm backward whose G was produced elsewhere (pooling backward, tests):
 // grid (C / 64, row tiles of 64)
 __global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ G, RcStat st, int M, int C) {
-  __shared__ __attribute__((aligned(16))) float smem[64 * 4 * 2 * 2];
+  __shared__ __attribute__((aligned(16))) float smem[256 * 3 * 2];
   __shared__ float cs[256];
   __shared__ int last;
   const int tid = threadIdx.x, col = tid % 64, rg = tid / 64, c = blockIdx.x * 64 + col;
@@ -558,8 +664,8 @@ __global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ 
     rc_st(st.part + ((size_t)blockIdx.y * C + c) * 2, a1);
     rc_st(st.part + ((size_t)blockIdx.y * C + c) * 2 + 1, a2);
   }
-  if (!rc_last_workgroup(st.counter + blockIdx.x, gridDim.y, &last)) return;
-  rc_stat_finalize<64>(st, reinterpret_cast<double*>(smem), gridDim.y, M, C, c, col, rg);
+  rc_stat_tail<64>(&st, 1, gridDim.y, blockIdx.y, blockIdx.x, gridDim.x, M, C, c, reinterpret_cast<double*>(smem), col, rg,
+                   &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -581,17 +687,16 @@ struct RcWgradArgs {
 };
 
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a) {
+__device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
+                                          int* __restrict__ lastp) {
   using TL = RcTile<BM, BN, BK>;
   using SA = RcStg<BM, BK, false>;
   using SB = RcStg<BN, BK, false>;
-  __shared__ __attribute__((aligned(16))) float smem[TL::SMEM];
-  __shared__ int last;
   float* As = smem;
   float* Bs = smem + BK * TL::AP;
   const int tid = threadIdx.x;
-  const int c0 = blockIdx.x * BN, n0 = blockIdx.y * BM;
-  const int tap = blockIdx.z / a.nz, zi = blockIdx.z % a.nz;
+  const int c0 = k.bx * BN, n0 = k.by * BM;
+  const int tap = k.bz / a.nz, zi = k.bz % a.nz;
   const int kbeg = zi * a.kper, kend = min(a.M, kbeg + a.kper);
   TL tl;
   tl.init(tid);
@@ -672,12 +777,21 @@ __global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < TL::NR; ++j) rc_st(a.ws + (size_t)zi * numel + idx(j), v[j]);
-  unsigned* ticket = a.counter + ((size_t)tap * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  if (!rc_last_workgroup(ticket, (unsigned)a.nz, &last)) return;
+  unsigned* ticket = a.counter + ((size_t)tap * k.gy + k.by) * k.gx + k.bx;
+  if (!rc_last_workgroup(ticket, (unsigned)a.nz, lastp)) return;
 #pragma unroll
   for (int j = 0; j < TL::NR; ++j) {
     a.dw[idx(j)] = rc_sum_strided(a.ws + idx(j), numel, a.nz, a.acc ? a.dw[idx(j)] : 0.f);
   }
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[RcTile<BM, BN, BK>::SMEM];
+  __shared__ float cs[256];
+  __shared__ int last;
+  rc_wgrad_body<BM, BN, BK>(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs,
+                          &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -749,6 +863,60 @@ __global__ __launch_bounds__(256) void rc_tables_kernel(int* __restrict__ fwd, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// several independent jobs in ONE launch (a layer's data and weight gradient; a block's first convolution and its
+// projection shortcut): at batch 24 every job alone leaves most of the chip idle and costs a dependent launch
+// ---------------------------------------------------------------------------------------------------------------------
+#define RC_KIND_FWD 0
+#define RC_KIND_DGRAD 1
+#define RC_KIND_WGRAD 2
+#define RC_CFG_L32 0      // 64 x 64 tiles, 32-deep stages
+#define RC_CFG_S128 1     // 32 x 32 tiles, 4 waves split 128-deep stages
+#define RC_CFG_S64 2      // 32 x 32 tiles, 64-deep stages (64-channel reductions)
+struct RcPlan { int kind, cfg, gx, gy, gz; };
+struct RcGroup {
+  RcFwdArgs f[MMVAE_RC_MAX_JOBS];
+  RcDgradArgs d[MMVAE_RC_MAX_JOBS];
+  RcWgradArgs w[MMVAE_RC_MAX_JOBS];
+  RcPlan plan[MMVAE_RC_MAX_JOBS];
+  int blk0[MMVAE_RC_MAX_JOBS + 1];
+  int n;
+};
+
+template <int BM, int BN, int BK>
+__device__ __forceinline__ void rc_job(const RcGroup* __restrict__ g, int kind, int p, const RcBlk k, float* smem, float* cs,
+                                       int* lastp) {
+  if (kind == RC_KIND_FWD) {
+    const RcFwdArgs a = g->f[p];
+    rc_fwd_body<BM, BN, BK>(a, k, smem, cs, lastp);
+  } else if (kind == RC_KIND_DGRAD) {
+    const RcDgradArgs a = g->d[p];
+    rc_dgrad_body<BM, BN, BK>(a, k, smem, cs, lastp);
+  } else {
+    const RcWgradArgs a = g->w[p];
+    rc_wgrad_body<BM, BN, BK>(a, k, smem, cs, lastp);
+  }
+}
+
+// (the job table is read through the kernel-argument segment pointer: indexing the by-value parameter with the
+// workgroup's job number makes the compiler copy all 2.6 KB of it into scratch -- 2.5 KB per lane, 10 x the run time)
+__global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
+  __shared__ __attribute__((aligned(16))) float smem[RcTile<32, 32, 128>::SMEM];
+  __shared__ float cs[256];
+  __shared__ int last;
+  const RcGroup* __restrict__ g = (const RcGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < MMVAE_RC_MAX_JOBS; ++q)
+    if (q < g->n && (int)blockIdx.x >= g->blk0[q]) p = q;
+  const int local = blockIdx.x - g->blk0[p];
+  const RcPlan pl = g->plan[p];
+  const RcBlk k{local % pl.gx, (local / pl.gx) % pl.gy, local / (pl.gx * pl.gy), pl.gx, pl.gy};
+  if (pl.cfg == RC_CFG_L32) rc_job<64, 64, 32>(g, pl.kind, p, k, smem, cs, &last);
+  else if (pl.cfg == RC_CFG_S128) rc_job<32, 32, 128>(g, pl.kind, p, k, smem, cs, &last);
+  else rc_job<32, 32, 64>(g, pl.kind, p, k, smem, cs, &last);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
 static inline bool rc_small(long tiles64) { return tiles64 < 256; }
@@ -759,64 +927,28 @@ extern "C" int mmvae_rc_row_tile(int M, int N) {   // rows per statistics partia
   return rc_small(t64) ? 32 : 64;
 }
 
+// split of the reduction (taps x channels) of a forward / data-gradient GEMM with an (M, N) output over blockIdx.z: only
+// the 32 x 32 tiling (few tiles), >= 2 stages per split, enough workgroups for two per CU
+extern "C" int mmvae_rc_conv_splits(int M, int N, int K, int T) {
+  if (mmvae_rc_row_tile(M, N) == 64) return 1;
+  const long tiles = (long)((M + 31) / 32) * (N / 32);
+  const int nstage = T * (K / rc_bk_small(K));
+  long nz = (768 + tiles - 1) / tiles;
+  if (nz > (nstage + 1) / 2) nz = (nstage + 1) / 2;
+  if (nz > 16) nz = 16;
+  return (int)(nz < 1 ? 1 : nz);
+}
+extern "C" size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T) {
+  const int nz = mmvae_rc_conv_splits(M, N, K, T);
+  return nz > 1 ? (size_t)nz * M * N : 0;
+}
+
 extern "C" int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, int S, int P, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(fwd && bwd && B > 0 && H > 0 && W > 0 && K > 0 && S > 0);
   const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
   const long n = (long)B * (long)max(H * W, Ho * Wo) * K * K;
   hipLaunchKernelGGL(rc_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fwd, bwd, B, H,
                      W, Ho, Wo, K, S, P);
-  return mmvae_launch_status();
-}
-
-extern "C" int mmvae_rc_conv_fwd(const float* x, const float* w, const float* xmean, const float* xsc, const float* xbeta,
-                                 const int* tbl, float* y, int M, int Cin, int Cout, int T, int pre,
-                                 const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
-                                 float* rstd, float* sc, float* part, unsigned* counter, float eps, float momentum,
-                                 int eval, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(x && w && y && M > 0 && Cin % 64 == 0 && Cout % 64 == 0 && T >= 1);
-  MMVAE_CHECK_ARG(pre != RC_PRE_BN_RELU || (xmean && xsc && xbeta));
-  MMVAE_CHECK_ARG(!part || (gamma && beta && mean && rstd && sc && counter));
-  RcFwdArgs a{x, w, xmean, xsc, xbeta, tbl, y, M, Cin, Cout, T, pre,
-              {gamma, beta, run_mean, run_var, mean, rstd, sc, part, counter, eps, momentum, eval}};
-  hipStream_t st = (hipStream_t)stream;
-  if (mmvae_rc_row_tile(M, Cout) == 64) {
-    hipLaunchKernelGGL((rc_fwd_kernel<64, 64, 32>), dim3(Cout / 64, (M + 63) / 64), dim3(256), 0, st, a);
-  } else if (rc_bk_small(Cin) == 128) {
-    hipLaunchKernelGGL((rc_fwd_kernel<32, 32, 128>), dim3(Cout / 32, (M + 31) / 32), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((rc_fwd_kernel<32, 32, 64>), dim3(Cout / 32, (M + 31) / 32), dim3(256), 0, st, a);
-  }
-  return mmvae_launch_status();
-}
-
-extern "C" int mmvae_rc_conv_dgrad(const float* G, const float* Y, const float* pqr, const float* w, const int* tbl,
-                                   const float* add, int mask, const float* mY, const float* mmean, const float* msc,
-                                   const float* mbeta, float* out, int M, int Min, int Cin, int Cout, int T, int nstat,
-                                   const mmvae_rc_stat_t* st0, const mmvae_rc_stat_t* st1, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(G && w && out && M > 0 && Min > 0 && Cin % 64 == 0 && Cout % 64 == 0 && T >= 1);
-  MMVAE_CHECK_ARG((!pqr || Y) && nstat >= 0 && nstat <= 2 && (nstat < 1 || st0) && (nstat < 2 || st1));
-  MMVAE_CHECK_ARG(mask == RC_MASK_NONE || mY);
-  MMVAE_CHECK_ARG(mask != RC_MASK_BN || (mmean && msc && mbeta));
-  RcDgradArgs a{G, Y, pqr, w, tbl, add, mY, mmean, msc, mbeta, out, M, Min, Cin, Cout, T, mask, nstat, {}};
-  const mmvae_rc_stat_t* sts[2] = {st0, st1};
-  for (int t = 0; t < nstat; ++t)
-    a.st[t] = RcStat{sts[t]->Y, sts[t]->mean, sts[t]->rstd, sts[t]->gamma, sts[t]->pqr, sts[t]->dgamma, sts[t]->dbeta,
-                     sts[t]->part, sts[t]->counter, sts[t]->acc, sts[t]->eval};
-  hipStream_t s = (hipStream_t)stream;
-  if (mmvae_rc_row_tile(Min, Cin) == 64) {
-    hipLaunchKernelGGL((rc_dgrad_kernel<64, 64, 32>), dim3(Cin / 64, (Min + 63) / 64), dim3(256), 0, s, a);
-  } else if (rc_bk_small(Cout) == 128) {
-    hipLaunchKernelGGL((rc_dgrad_kernel<32, 32, 128>), dim3(Cin / 32, (Min + 31) / 32), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((rc_dgrad_kernel<32, 32, 64>), dim3(Cin / 32, (Min + 31) / 32), dim3(256), 0, s, a);
-  }
-  return mmvae_launch_status();
-}
-
-extern "C" int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(G && st && st->Y && st->pqr && st->part && st->counter && M > 0 && C % 64 == 0);
-  RcStat s{st->Y, st->mean, st->rstd, st->gamma, st->pqr, st->dgamma, st->dbeta, st->part, st->counter, st->acc, st->eval};
-  hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, s, M, C);
   return mmvae_launch_status();
 }
 
@@ -836,23 +968,97 @@ extern "C" size_t mmvae_rc_wgrad_ws_floats(int M, int Cin, int Cout, int T) {
 }
 extern "C" size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T) { return (size_t)(Cout / 32) * (Cin / 32) * T; }
 
-extern "C" int mmvae_rc_conv_wgrad(const float* G, const float* Y, const float* pqr, const float* x, const float* xmean,
-                                   const float* xsc, const float* xbeta, const int* tbl, float* dw, float* ws,
-                                   unsigned* counter, int M, int Cin, int Cout, int T, int pre, int accumulate,
-                                   mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(G && x && dw && M > 0 && Cin % 64 == 0 && Cout % 64 == 0 && T >= 1 && (!pqr || Y));
-  MMVAE_CHECK_ARG(pre != RC_PRE_BN_RELU || (xmean && xsc && xbeta));
-  const int nz = mmvae_rc_wgrad_splits(M, Cin, Cout, T);
-  MMVAE_CHECK_ARG(nz == 1 || (ws && counter));
-  const long t64 = (long)(Cout / 64) * (Cin / 64) * T;
-  const bool small = rc_small(t64);
+static RcStat rc_stat_of(const mmvae_rc_stat_t& s) {
+  return RcStat{s.Y, s.mean, s.rstd, s.gamma, s.pqr, s.dgamma, s.dbeta, s.part, s.counter, s.acc, s.eval};
+}
+
+static int rc_plan_fwd(const mmvae_rc_fwd_t& j, RcFwdArgs& a, RcPlan& pl) {
+  MMVAE_CHECK_ARG(j.x && j.w && j.y && j.M > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1);
+  MMVAE_CHECK_ARG(j.pre != RC_PRE_BN_RELU || (j.xmean && j.xsc && j.xbeta));
+  MMVAE_CHECK_ARG(!j.part || (j.gamma && j.beta && j.mean && j.rstd && j.sc && j.counter));
+  const int nz = mmvae_rc_conv_splits(j.M, j.Cout, j.Cin, j.T);
+  MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.tile_ticket));
+  a = RcFwdArgs{j.x, j.w, j.xmean, j.xsc, j.xbeta, j.tbl, j.y, j.ws, j.tile_ticket, j.M, j.Cin, j.Cout, j.T, j.pre, nz,
+                {j.gamma, j.beta, j.run_mean, j.run_var, j.mean, j.rstd, j.sc, j.part, j.counter, j.eps, j.momentum, j.eval}};
+  if (mmvae_rc_row_tile(j.M, j.Cout) == 64) pl = RcPlan{RC_KIND_FWD, RC_CFG_L32, j.Cout / 64, (j.M + 63) / 64, 1};
+  else pl = RcPlan{RC_KIND_FWD, rc_bk_small(j.Cin) == 128 ? RC_CFG_S128 : RC_CFG_S64, j.Cout / 32, (j.M + 31) / 32, nz};
+  return MMVAE_OK;
+}
+
+static int rc_plan_dgrad(const mmvae_rc_dgrad_t& j, RcDgradArgs& a, RcPlan& pl) {
+  MMVAE_CHECK_ARG(j.G && j.w && j.out && j.M > 0 && j.Min > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1);
+  MMVAE_CHECK_ARG((!j.pqr || j.Y) && j.nstat >= 0 && j.nstat <= 2);
+  MMVAE_CHECK_ARG(j.mask == RC_MASK_NONE || j.mY);
+  MMVAE_CHECK_ARG(j.mask != RC_MASK_BN || (j.mmean && j.msc && j.mbeta));
+  const int nz = mmvae_rc_conv_splits(j.Min, j.Cin, j.Cout, j.T);
+  MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.tile_ticket));
+  a = RcDgradArgs{j.G, j.Y, j.pqr, j.w, j.tbl, j.add, j.add_tbl, j.mY, j.mmean, j.msc, j.mbeta, j.out, j.ws, j.tile_ticket,
+                  j.M, j.Min, j.Cin, j.Cout, j.T, j.mask, j.nstat, nz, {}};
+  for (int t = 0; t < j.nstat; ++t) {
+    MMVAE_CHECK_ARG(j.st[t].Y && j.st[t].pqr && j.st[t].part && j.st[t].counter);
+    a.st[t] = rc_stat_of(j.st[t]);
+  }
+  if (mmvae_rc_row_tile(j.Min, j.Cin) == 64) pl = RcPlan{RC_KIND_DGRAD, RC_CFG_L32, j.Cin / 64, (j.Min + 63) / 64, 1};
+  else pl = RcPlan{RC_KIND_DGRAD, rc_bk_small(j.Cout) == 128 ? RC_CFG_S128 : RC_CFG_S64, j.Cin / 32, (j.Min + 31) / 32, nz};
+  return MMVAE_OK;
+}
+
+static int rc_plan_wgrad(const mmvae_rc_wgrad_t& j, RcWgradArgs& a, RcPlan& pl) {
+  MMVAE_CHECK_ARG(j.G && j.x && j.dw && j.M > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1 && (!j.pqr || j.Y));
+  MMVAE_CHECK_ARG(j.pre != RC_PRE_BN_RELU || (j.xmean && j.xsc && j.xbeta));
+  const int nz = mmvae_rc_wgrad_splits(j.M, j.Cin, j.Cout, j.T);
+  MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.counter));
+  const bool small = rc_small((long)(j.Cout / 64) * (j.Cin / 64) * j.T);
   const int bk = small ? 128 : 32;
-  int kper = (M + nz - 1) / nz;
+  int kper = (j.M + nz - 1) / nz;
   kper = (kper + bk - 1) / bk * bk;
-  RcWgradArgs a{G, Y, pqr, x, xmean, xsc, xbeta, tbl, dw, ws, counter, M, Cin, Cout, T, pre, accumulate ? 1 : 0, nz, kper};
-  hipStream_t s = (hipStream_t)stream;
-  if (!small) hipLaunchKernelGGL((rc_wgrad_kernel<64, 64, 32>), dim3(Cin / 64, Cout / 64, T * nz), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((rc_wgrad_kernel<32, 32, 128>), dim3(Cin / 32, Cout / 32, T * nz), dim3(256), 0, s, a);
+  a = RcWgradArgs{j.G, j.Y, j.pqr, j.x, j.xmean, j.xsc, j.xbeta, j.tbl, j.dw, j.ws, j.counter, j.M, j.Cin, j.Cout, j.T, j.pre,
+                  j.accumulate ? 1 : 0, nz, kper};
+  if (!small) pl = RcPlan{RC_KIND_WGRAD, RC_CFG_L32, j.Cin / 64, j.Cout / 64, j.T * nz};
+  else pl = RcPlan{RC_KIND_WGRAD, RC_CFG_S128, j.Cin / 32, j.Cout / 32, j.T * nz};
+  return MMVAE_OK;
+}
+
+template <class A, class KL, class KS128, class KS64>
+static void rc_launch_one(const A& a, const RcPlan& pl, hipStream_t st, KL kl, KS128 k128, KS64 k64) {
+  const dim3 grid(pl.gx, pl.gy, pl.gz);
+  if (pl.cfg == RC_CFG_L32) hipLaunchKernelGGL(kl, grid, dim3(256), 0, st, a);
+  else if (pl.cfg == RC_CFG_S128) hipLaunchKernelGGL(k128, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k64, grid, dim3(256), 0, st, a);
+}
+
+extern "C" int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(jobs && n >= 1 && n <= MMVAE_RC_MAX_JOBS);
+  hipStream_t st = (hipStream_t)stream;
+  static thread_local RcGroup g;     // ~2.5 KB of kernel arguments, assembled in place
+  g.n = n;
+  g.blk0[0] = 0;
+  for (int p = 0; p < n; ++p) {
+    int rc;
+    if (jobs[p].kind == RC_KIND_FWD) rc = rc_plan_fwd(jobs[p].f, g.f[p], g.plan[p]);
+    else if (jobs[p].kind == RC_KIND_DGRAD) rc = rc_plan_dgrad(jobs[p].d, g.d[p], g.plan[p]);
+    else if (jobs[p].kind == RC_KIND_WGRAD) rc = rc_plan_wgrad(jobs[p].w, g.w[p], g.plan[p]);
+    else return MMVAE_ERR_ARG;
+    if (rc != MMVAE_OK) return rc;
+    g.blk0[p + 1] = g.blk0[p] + g.plan[p].gx * g.plan[p].gy * g.plan[p].gz;
+  }
+  if (n == 1) {       // a job alone keeps its own kernel (and its name in a profile)
+    const RcPlan& pl = g.plan[0];
+    if (pl.kind == RC_KIND_FWD)
+      rc_launch_one(g.f[0], pl, st, rc_fwd_kernel<64, 64, 32>, rc_fwd_kernel<32, 32, 128>, rc_fwd_kernel<32, 32, 64>);
+    else if (pl.kind == RC_KIND_DGRAD)
+      rc_launch_one(g.d[0], pl, st, rc_dgrad_kernel<64, 64, 32>, rc_dgrad_kernel<32, 32, 128>, rc_dgrad_kernel<32, 32, 64>);
+    else
+      rc_launch_one(g.w[0], pl, st, rc_wgrad_kernel<64, 64, 32>, rc_wgrad_kernel<32, 32, 128>, rc_wgrad_kernel<32, 32, 64>);
+    return mmvae_launch_status();
+  }
+  hipLaunchKernelGGL(rc_group_kernel, dim3(g.blk0[n]), dim3(256), 0, st, g);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(G && st && st->Y && st->pqr && st->part && st->counter && M > 0 && C % 64 == 0);
+  hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, rc_stat_of(*st), M, C);
   return mmvae_launch_status();
 }
 

@@ -64,6 +64,32 @@ class RcStat(ctypes.Structure):      # mmvae_rc_stat_t: a BatchNorm whose backwa
                 ("part", c_p), ("counter", c_p), ("acc", c_i), ("eval", c_i)]
 
 
+class RcFwd(ctypes.Structure):       # mmvae_rc_fwd_t
+    _fields_ = [("x", c_p), ("w", c_p), ("xmean", c_p), ("xsc", c_p), ("xbeta", c_p), ("tbl", c_p), ("y", c_p), ("ws", c_p),
+                ("tile_ticket", c_p), ("M", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("pre", c_i), ("gamma", c_p),
+                ("beta", c_p), ("run_mean", c_p), ("run_var", c_p), ("mean", c_p), ("rstd", c_p), ("sc", c_p), ("part", c_p),
+                ("counter", c_p), ("eps", c_f), ("momentum", c_f), ("eval", c_i)]
+
+
+class RcDgrad(ctypes.Structure):     # mmvae_rc_dgrad_t
+    _fields_ = [("G", c_p), ("Y", c_p), ("pqr", c_p), ("w", c_p), ("tbl", c_p), ("add", c_p), ("add_tbl", c_p), ("mask", c_i),
+                ("mY", c_p), ("mmean", c_p), ("msc", c_p), ("mbeta", c_p), ("out", c_p), ("ws", c_p), ("tile_ticket", c_p),
+                ("M", c_i), ("Min", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("nstat", c_i), ("st", RcStat * 2)]
+
+
+class RcWgrad(ctypes.Structure):     # mmvae_rc_wgrad_t
+    _fields_ = [("G", c_p), ("Y", c_p), ("pqr", c_p), ("x", c_p), ("xmean", c_p), ("xsc", c_p), ("xbeta", c_p), ("tbl", c_p),
+                ("dw", c_p), ("ws", c_p), ("counter", c_p), ("M", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("pre", c_i),
+                ("accumulate", c_i)]
+
+
+RC_MAX_JOBS = 4
+
+
+class RcJob(ctypes.Structure):       # mmvae_rc_job_t
+    _fields_ = [("kind", c_i), ("f", RcFwd), ("d", RcDgrad), ("w", RcWgrad)]
+
+
 c_dp = ctypes.POINTER(Dropout)
 DROPOUT_SLOTS = 16
 
@@ -209,13 +235,13 @@ SIGNATURES = {
     "mmvae_avgpool_bwd": (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_rc_tables": (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
     "mmvae_rc_row_tile": (c_i, [c_i, c_i]),
-    "mmvae_rc_conv_fwd": (c_i, [c_p] * 7 + [c_i] * 5 + [c_p] * 9 + [c_f, c_f, c_i, c_p]),
-    "mmvae_rc_conv_dgrad": (c_i, [c_p] * 6 + [c_i] + [c_p] * 5 + [c_i] * 6 + [ctypes.POINTER(RcStat)] * 2 + [c_p]),
+    "mmvae_rc_conv_splits": (c_i, [c_i] * 4),
+    "mmvae_rc_conv_ws_floats": (c_sz, [c_i] * 4),
+    "mmvae_rc_launch": (c_i, [ctypes.POINTER(RcJob), c_i, c_p]),
     "mmvae_rc_bn_bwd_stats": (c_i, [c_p, ctypes.POINTER(RcStat), c_i, c_i, c_p]),
     "mmvae_rc_wgrad_splits": (c_i, [c_i] * 4),
     "mmvae_rc_wgrad_ws_floats": (c_sz, [c_i] * 4),
     "mmvae_rc_wgrad_tickets": (c_sz, [c_i] * 3),
-    "mmvae_rc_conv_wgrad": (c_i, [c_p] * 11 + [c_i] * 6 + [c_p]),
     "mmvae_rc_blockout": (c_i, [c_p] * 8 + [c_i, c_p, c_l, c_i, c_p]),
     "mmvae_rc_bn_apply": (c_i, [c_p] * 5 + [c_l, c_i, c_p]),
     "mmvae_dropout_advance": (c_i, [c_p, c_u, c_p]),

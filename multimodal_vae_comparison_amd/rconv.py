@@ -60,14 +60,35 @@ class Unit:
             C = self.bn.weight.shape[0]
             rt = H.lib().mmvae_rc_row_tile(M, C)
             f = lambda n: torch.empty(n, device=device)
+            R = (M + 31) // 32                       # row tiles at most (32-row tiling), + one level-1 pair per 16
             b = self._buf[M] = {"mean": f(C), "rstd": f(C), "sc": f(C), "pqr": f(3 * C),
-                                "part": f(((M + rt - 1) // rt + 1) * C * 2), "part_b": f(((M + 31) // 32 + 1) * C * 2),
-                                "counter": torch.zeros(C // 32 + 1, dtype=torch.int32, device=device)}
+                                "part": f((R + R // 16 + 2) * C * 2), "part_b": f((R + R // 16 + 2) * C * 2),
+                                "counter": torch.zeros((C // 32) * (2 + R // 16), dtype=torch.int32, device=device),
+                                "tile_tickets": torch.zeros(R * (C // 32), dtype=torch.int32, device=device)}
             w = self.conv.weight
             Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
             self._buf.setdefault("tickets", torch.zeros(H.lib().mmvae_rc_wgrad_tickets(Cin, Cout, T), dtype=torch.int32,
                                                         device=device))
         return b
+
+    def conv_ws(self, M, N, K, T, device):
+        """split-reduction workspace of a forward / data-gradient GEMM with an (M, N) output"""
+        n = H.lib().mmvae_rc_conv_ws_floats(M, N, K, T)
+        if n == 0:
+            return None
+        key = ("cws", M, N)
+        t = self._buf.get(key)
+        if t is None:
+            t = self._buf[key] = torch.empty(n, device=device)
+        return t
+
+    def dgrad_tickets(self, rows, device):
+        key = ("dt", rows)
+        t = self._buf.get(key)
+        if t is None:
+            t = self._buf[key] = torch.zeros((rows + 31) // 32 * (self.conv.weight.shape[1] // 32), dtype=torch.int32,
+                                             device=device)
+        return t
 
     def wgrad_ws(self, M, device):
         w = self.conv.weight
@@ -80,18 +101,43 @@ class Unit:
         return t
 
 
-def _fwd(u, x, Min, M, pre, xb, tbl, eval_mode):
-    """raw output (M, Cout) of unit u on pre(x); xb: the producer unit's buffers / beta for PRE_BN_RELU"""
+KIND_FWD, KIND_DGRAD, KIND_WGRAD = 0, 1, 2
+
+
+def launch(*jobs):
+    """independent jobs (H.RcJob) in ONE launch"""
+    arr = (H.RcJob * len(jobs))(*jobs)
+    ops._call("mmvae_rc_launch", arr, len(jobs), H.stream())
+
+
+def _p(t):
+    return H.ptr(t)
+
+
+def fwd_job(u, x, M, pre, xb, tbl, eval_mode):
+    """(job, raw output (M, Cout), buffers) of unit u on pre(x); xb = (producer buffers, producer beta) for PRE_BN_RELU"""
     w = u.conv.weight
     Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     b = u.buffers(M, x.device)
     y = torch.empty(M, Cout, device=x.device)
-    xm, xs, xbeta = (H.ptr(xb[0]["mean"]), H.ptr(xb[0]["sc"]), H.ptr(xb[1])) if pre == PRE_BN_RELU else (None, None, None)
     bn = u.bn
-    ops._call("mmvae_rc_conv_fwd", H.ptr(x), channels_last_ptr(w), xm, xs, xbeta, H.ptr(tbl), H.ptr(y), M, Cin, Cout, T, pre,
-              H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(bn.running_mean), H.ptr(bn.running_var), H.ptr(b["mean"]),
-              H.ptr(b["rstd"]), H.ptr(b["sc"]), H.ptr(b["part"]), H.ptr(b["counter"]), float(bn.eps), float(bn.momentum),
-              int(eval_mode), H.stream())
+    j = H.RcJob()
+    j.kind = KIND_FWD
+    f = j.f
+    f.x, f.w, f.tbl, f.y = _p(x), channels_last_ptr(w), _p(tbl), _p(y)
+    if pre == PRE_BN_RELU:
+        f.xmean, f.xsc, f.xbeta = _p(xb[0]["mean"]), _p(xb[0]["sc"]), _p(xb[1])
+    f.ws, f.tile_ticket = _p(u.conv_ws(M, Cout, Cin, T, x.device)), _p(b["tile_tickets"])
+    f.M, f.Cin, f.Cout, f.T, f.pre = M, Cin, Cout, T, pre
+    f.gamma, f.beta, f.run_mean, f.run_var = _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var)
+    f.mean, f.rstd, f.sc, f.part, f.counter = _p(b["mean"]), _p(b["rstd"]), _p(b["sc"]), _p(b["part"]), _p(b["counter"])
+    f.eps, f.momentum, f.eval = float(bn.eps), float(bn.momentum), int(eval_mode)
+    return j, y, b
+
+
+def _fwd(u, x, Min, M, pre, xb, tbl, eval_mode):
+    j, y, b = fwd_job(u, x, M, pre, xb, tbl, eval_mode)
+    launch(j)
     return y, b
 
 
@@ -100,32 +146,52 @@ def _stat(u, b, Y, eval_mode, grads):
     dg, ag = grads[u.bn.weight]
     db, ab = grads[u.bn.bias]
     assert ag == ab
-    return H.RcStat(H.ptr(Y), H.ptr(b["mean"]), H.ptr(b["rstd"]), H.ptr(u.bn.weight), H.ptr(b["pqr"]), H.ptr(dg), H.ptr(db),
-                    H.ptr(b["part_b"]), H.ptr(b["counter"]), int(ag), int(eval_mode))
+    return H.RcStat(_p(Y), _p(b["mean"]), _p(b["rstd"]), _p(u.bn.weight), _p(b["pqr"]), _p(dg), _p(db), _p(b["part_b"]),
+                    _p(b["counter"]), int(ag), int(eval_mode))
+
+
+def dgrad_job(u, b, G, Y, tbl, add, add_tbl, mask, mY, mb, out_rows, stats, with_pqr=True):
+    w = u.conv.weight
+    Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+    out = torch.empty(out_rows, Cin, device=G.device)
+    j = H.RcJob()
+    j.kind = KIND_DGRAD
+    d = j.d
+    d.G, d.Y, d.pqr, d.w, d.tbl = _p(G), _p(Y), _p(b["pqr"]) if with_pqr else None, channels_last_ptr(w), _p(tbl)
+    d.add, d.add_tbl, d.mask, d.mY = _p(add), _p(add_tbl), mask, _p(mY)
+    if mask == MASK_BN:
+        d.mmean, d.msc, d.mbeta = _p(mb[0]["mean"]), _p(mb[0]["sc"]), _p(mb[1])
+    d.out, d.ws, d.tile_ticket = _p(out), _p(u.conv_ws(out_rows, Cin, Cout, T, G.device)), _p(u.dgrad_tickets(out_rows, G.device))
+    d.M, d.Min, d.Cin, d.Cout, d.T, d.nstat = G.shape[0], out_rows, Cin, Cout, T, len(stats)
+    for i, st in enumerate(stats):
+        d.st[i] = st
+    return j, out
 
 
 def _dgrad(u, b, G, Y, tbl, add, mask, mY, mb, out_rows, stats, with_pqr=True):
-    w = u.conv.weight
-    Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-    M = G.shape[0]
-    out = torch.empty(out_rows, Cin, device=G.device)
-    mm, ms, mbeta = (H.ptr(mb[0]["mean"]), H.ptr(mb[0]["sc"]), H.ptr(mb[1])) if mask == MASK_BN else (None, None, None)
-    st = [ctypes.byref(s) for s in stats] + [None, None]
-    ops._call("mmvae_rc_conv_dgrad", H.ptr(G), H.ptr(Y), H.ptr(b["pqr"]) if with_pqr else None, channels_last_ptr(w),
-              H.ptr(tbl), H.ptr(add), mask, H.ptr(mY), mm, ms, mbeta, H.ptr(out), M, out_rows, Cin, Cout, T, len(stats),
-              st[0], st[1], H.stream())
+    j, out = dgrad_job(u, b, G, Y, tbl, add, None, mask, mY, mb, out_rows, stats, with_pqr)
+    launch(j)
     return out
 
 
-def _wgrad(u, b, G, Y, x, pre, xb, tbl, grads):
+def wgrad_job(u, b, G, Y, x, pre, xb, tbl, grads):
     w = u.conv.weight
     Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     M = G.shape[0]
     dw, acc = grads[w]
-    xm, xs, xbeta = (H.ptr(xb[0]["mean"]), H.ptr(xb[0]["sc"]), H.ptr(xb[1])) if pre == PRE_BN_RELU else (None, None, None)
-    ops._call("mmvae_rc_conv_wgrad", H.ptr(G), H.ptr(Y), H.ptr(b["pqr"]), H.ptr(x), xm, xs, xbeta, H.ptr(tbl),
-              channels_last_ptr(dw), H.ptr(u.wgrad_ws(M, G.device)), H.ptr(u._buf["tickets"]), M, Cin, Cout, T, pre,
-              int(acc), H.stream())
+    j = H.RcJob()
+    j.kind = KIND_WGRAD
+    g = j.w
+    g.G, g.Y, g.pqr, g.x, g.tbl = _p(G), _p(Y), _p(b["pqr"]), _p(x), _p(tbl)
+    if pre == PRE_BN_RELU:
+        g.xmean, g.xsc, g.xbeta = _p(xb[0]["mean"]), _p(xb[0]["sc"]), _p(xb[1])
+    g.dw, g.ws, g.counter = channels_last_ptr(dw), _p(u.wgrad_ws(M, G.device)), _p(u._buf["tickets"])
+    g.M, g.Cin, g.Cout, g.T, g.pre, g.accumulate = M, Cin, Cout, T, pre, int(acc)
+    return j
+
+
+def _wgrad(u, b, G, Y, x, pre, xb, tbl, grads):
+    launch(wgrad_job(u, b, G, Y, x, pre, xb, tbl, grads))
 
 
 class Block:
@@ -170,16 +236,18 @@ class BottleneckStack(Function):
             t3 = tables(dev, B, Hh, W, 3, S_, 1)
             t1 = tables(dev, B, Hh, W, 1, S_, 0) if S_ != 1 else (None, None)
             ev = not training
-            Y1, b1 = _fwd(blk.u1, s, Min, Min, pre1, None, None, ev)
+            j1, Y1, b1 = fwd_job(blk.u1, s, Min, pre1, None, None, ev)
+            Yd = bd = None
+            if blk.ud is not None:      # the projection shortcut reads the same input: one launch with conv1
+                jd, Yd, bd = fwd_job(blk.ud, s, M2, pre1, None, t1[0], ev)
+                launch(j1, jd)
+            else:
+                assert S_ == 1
+                launch(j1)
             _tap(blk.u1.bn, Y1, b1)
             Y2, b2 = _fwd(blk.u2, Y1, Min, M2, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], ev)
             _tap(blk.u2.bn, Y2, b2)
             Y3, b3 = _fwd(blk.u3, Y2, M2, M2, PRE_BN_RELU, (b2, blk.u2.bn.bias), None, ev)
-            Yd = bd = None
-            if blk.ud is not None:
-                Yd, bd = _fwd(blk.ud, s, Min, M2, pre1, None, t1[0], ev)
-            else:
-                assert S_ == 1
             out = torch.empty(M2, Y3.shape[1], device=dev)
             R = Yd if Yd is not None else s
             ops._call("mmvae_rc_blockout", H.ptr(Y3), H.ptr(b3["mean"]), H.ptr(b3["sc"]), H.ptr(blk.u3.bn.bias), H.ptr(R),
@@ -223,19 +291,28 @@ class BottleneckStack(Function):
                 if blk.ud:
                     std = _stat(blk.ud, bd, Yd, ev, grads)
                     ops._call("mmvae_rc_bn_bwd_stats", H.ptr(G), ctypes.byref(std), M2, Yd.shape[1], H.stream())
-            # conv3: data gradient -> gradient of bn2's output (ReLU mask from Y2) + bn2's statistics; weight gradient
-            G2 = _dgrad(blk.u3, b3, G, Y3, None, None, MASK_BN, Y2, (b2, blk.u2.bn.bias), M2, [_stat(blk.u2, b2, Y2, ev, grads)])
-            _wgrad(blk.u3, b3, G, Y3, Y2, PRE_BN_RELU, (b2, blk.u2.bn.bias), None, grads)
-            # conv2 (3x3, stride): rows of the block's input resolution
-            G1 = _dgrad(blk.u2, b2, G2, Y2, t3[1], None, MASK_BN, Y1, (b1, blk.u1.bn.bias), Min,
-                        [_stat(blk.u1, b1, Y1, ev, grads)])
-            _wgrad(blk.u2, b2, G2, Y2, Y1, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], grads)
-            # shortcut
+            # one launch: conv3's data gradient (-> gradient of bn2's output: ReLU mask from Y2, + bn2's statistics) and
+            # weight gradient, and the projection shortcut's data gradient (on ITS output rows; conv1's epilogue adds it
+            # through the stride table) and weight gradient -- all four only need G
+            jobs = []
+            j, G2 = dgrad_job(blk.u3, b3, G, Y3, None, None, None, MASK_BN, Y2, (b2, blk.u2.bn.bias), M2,
+                              [_stat(blk.u2, b2, Y2, ev, grads)])
+            jobs += [j, wgrad_job(blk.u3, b3, G, Y3, Y2, PRE_BN_RELU, (b2, blk.u2.bn.bias), None, grads)]
+            need_in = bi > 0 or ctx.needs_input_grad[0]
+            add = add_tbl = None
             if blk.ud:
-                add = _dgrad(blk.ud, bd, G, Yd, t1[1], None, MASK_NONE, None, None, Min, [])
-                _wgrad(blk.ud, bd, G, Yd, s, pre1, None, t1[0], grads)
+                if need_in:
+                    j, add = dgrad_job(blk.ud, bd, G, Yd, None, None, None, MASK_NONE, None, None, M2, [])
+                    add_tbl = t1[1][0] if S_ != 1 else None
+                    jobs.append(j)
+                jobs.append(wgrad_job(blk.ud, bd, G, Yd, s, pre1, None, t1[0], grads))
             else:
                 add = G
+            launch(*jobs)
+            # conv2 (3x3, stride): data gradient on the rows of the block's input resolution (+ bn1's statistics), weights
+            j, G1 = dgrad_job(blk.u2, b2, G2, Y2, t3[1], None, None, MASK_BN, Y1, (b1, blk.u1.bn.bias), Min,
+                              [_stat(blk.u1, b1, Y1, ev, grads)])
+            launch(j, wgrad_job(blk.u2, b2, G2, Y2, Y1, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], grads))
             # conv1: + shortcut, ReLU mask of the block input, and the statistics of the PREVIOUS block's last BatchNorms
             stats = []
             if bi > 0:
@@ -244,10 +321,12 @@ class BottleneckStack(Function):
                 stats.append(_stat(pb.u3, pb.u3.buffers(Min, dev), pY3, ev, grads))
                 if pb.ud:
                     stats.append(_stat(pb.ud, pb.ud.buffers(Min, dev), pYd, ev, grads))
-            need_in = bi > 0 or ctx.needs_input_grad[0]
+            jobs = [wgrad_job(blk.u1, b1, G1, Y1, s, pre1, None, None, grads)]
             if need_in:
-                G = _dgrad(blk.u1, b1, G1, Y1, None, add, MASK_RAW if act == H.ACT_RELU else MASK_NONE, s, None, Min, stats)
-            _wgrad(blk.u1, b1, G1, Y1, s, pre1, None, None, grads)
+                j, G = dgrad_job(blk.u1, b1, G1, Y1, None, add, add_tbl, MASK_RAW if act == H.ACT_RELU else MASK_NONE, s, None,
+                                 Min, stats)
+                jobs.insert(0, j)
+            launch(*jobs)
             ready = True
         ctx.saved = None
         return (G if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + \

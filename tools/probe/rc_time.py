@@ -49,7 +49,7 @@ SHAPES = [("l1.c1a", 16, 64, 64, 1, 1), ("l1.c1", 16, 256, 64, 1, 1), ("l1.c2", 
 
 tot = [0.0, 0.0, 0.0]
 print(f"B = {B}\n{'layer':8s} {'rows':>6s} {'Cin':>5s} {'Cout':>5s} k s | {'fwd us':>8s} {'TF/s':>6s} {'no-stat':>7s} | {'dgrad us':>8s} {'TF/s':>6s} | "
-      f"{'wgrad us':>8s} {'TF/s':>6s} nz")
+      f"{'wgrad us':>8s} {'TF/s':>6s} | {'d+w us':>7s} nz")
 for name, Hh, Cin, Cout, k, st in SHAPES:
     conv = ConvW(Cin, Cout, k, st, k // 2, channels_last=True).to(DEV)
     bn, bnp = BatchNorm2d(Cout).to(DEV), BatchNorm2d(Cin).to(DEV)
@@ -67,17 +67,22 @@ for name, Hh, Cin, Cout, k, st in SHAPES:
     H.check(H.lib().mmvae_rc_bn_bwd_stats(H.ptr(G), ctypes.byref(stt), M, Cout, H.stream()), "stats")
     t_f = timeit(lambda: rconv._fwd(u, x, Min, M, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, False))
     def fwd_nostat():
-        yy = torch.empty(M, Cout, device=DEV)
-        H.check(H.lib().mmvae_rc_conv_fwd(H.ptr(x), H.ptr(conv.weight), H.ptr(bp["mean"]), H.ptr(bp["sc"]), H.ptr(bnp.bias),
-                                          H.ptr(tf), H.ptr(yy), M, Cin, Cout, k * k, 2, None, None, None, None, None, None,
-                                          None, None, None, 1e-5, 0.1, 0, H.stream()), "fwd")
+        j, _, _ = rconv.fwd_job(u, x, M, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, False)
+        j.f.part = None
+        rconv.launch(j)
     t_n = timeit(fwd_nostat)
+
+    def pair():
+        jd, _ = rconv.dgrad_job(u, b, G, y, tb, None, None, rconv.MASK_BN, x, (bp, bnp.bias), Min, [rconv._stat(up, bp, x, False, grads)])
+        rconv.launch(jd, rconv.wgrad_job(u, b, G, y, x, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, grads))
+    t_p = timeit(pair)
     t_d = timeit(lambda: rconv._dgrad(u, b, G, y, tb, None, rconv.MASK_BN, x, (bp, bnp.bias), Min,
                                       [rconv._stat(up, bp, x, False, grads)]))
     t_w = timeit(lambda: rconv._wgrad(u, b, G, y, x, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, grads))
     fl = 2.0 * M * Cin * Cout * k * k
-    nz = H.lib().mmvae_rc_wgrad_splits(M, Cin, Cout, k * k)
+    nz = (H.lib().mmvae_rc_conv_splits(M, Cout, Cin, k * k), H.lib().mmvae_rc_conv_splits(Min, Cin, Cout, k * k),
+          H.lib().mmvae_rc_wgrad_splits(M, Cin, Cout, k * k))
     tot[0] += t_f; tot[1] += t_d; tot[2] += t_w
     print(f"{name:8s} {M:6d} {Cin:5d} {Cout:5d} {k} {st} | {t_f:8.1f} {fl / t_f * 1e-6:6.1f} {t_n:7.1f} | {t_d:8.1f} {fl / t_d * 1e-6:6.1f} | "
-          f"{t_w:8.1f} {fl / t_w * 1e-6:6.1f} {nz}")
+          f"{t_w:8.1f} {fl / t_w * 1e-6:6.1f} | {t_p:7.1f} {nz}")
 print(f"sum over the distinct shapes: fwd {tot[0]:.0f} us, dgrad {tot[1]:.0f} us, wgrad {tot[2]:.0f} us (graph replays of back-to-back launches)")
