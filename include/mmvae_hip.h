@@ -436,16 +436,15 @@ int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW,
  * autograd backward, models/encoders.py:108).  Weights are channels-last: (Cout, T = k*k taps, Cin) in memory behind the
  * (Cout, Cin, k, k) parameter view.  A convolution's output stays RAW (pre-BatchNorm); its consumers apply
  * bn(y) = fma(y - mean, sc, beta), sc = gamma * rstd, and the ReLU while staging their LDS tiles.  `pre`: how the input is
- * consumed -- 0 as it is, 1 relu(x), 2 relu(bn(x)) with (xmean, xsc, xbeta).  tbl: per-geometry source-row tables of
- * mmvae_rc_tables (NULL = 1x1 / stride 1).  All channel counts % 64 == 0. */
+ * consumed -- 0 as it is, 1 relu(x), 2 relu(bn(x)) with (xmean, xsc, xbeta).  All channel counts % 64 == 0. */
 /* fwd (T, B*Ho*Wo) and bwd (T, B*H*W) int32 tables of a K x K / stride S / padding P convolution (-1 = no source) */
 int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, int S, int P, mmvae_stream_t stream);
-/* rows per statistics partial the kernels use for an (M rows, N columns) output.  With R = ceil(M / that) row tiles a
- * `part` buffer holds (R + ceil(R / 16)) * N * 2 floats and a `counter` buffer (N / 32) * (1 + ceil(R / 16)) tickets
+/* rows per statistics partial the kernels use for an (M rows, N columns) output (64).  With R = ceil(M / 64) row tiles
+ * a `part` buffer holds (R + ceil(R / 16)) * N * 2 floats and a `counter` buffer (N / 64) * (1 + ceil(R / 16)) tickets
  * (zero once; the kernels re-arm them): more than 16 row tiles elect their finalizer in two levels. */
 int mmvae_rc_row_tile(int M, int N);
 /* forward / data-gradient GEMMs with few output tiles split their reduction (K channels x T taps) over workgroups:
- * ws = mmvae_rc_conv_ws_floats(M, N, K, T) floats and ceil(M / 32) * (N / 32) tile tickets (zero once) for an (M, N)
+ * ws = mmvae_rc_conv_ws_floats(M, N, K, T) floats and ceil(M / 64) * (N / 64) tile tickets (zero once) for an (M, N)
  * output (forward: N = Cout, K = Cin; data gradient: M = Min, N = Cin, K = Cout) */
 int mmvae_rc_conv_splits(int M, int N, int K, int T);
 size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T);
@@ -465,6 +464,11 @@ typedef struct {
   int acc;
   int eval;
 } mmvae_rc_stat_t;
+/* pixel geometry of a convolution: (B, H, W) input pixels -> (B, Ho, Wo) output pixels, KW columns of taps (T / KW rows),
+ * stride S, padding P; H, W < 16384 */
+typedef struct {
+  int H, W, Ho, Wo, KW, S, P;
+} mmvae_rc_geom_t;
 /* forward: y (M, Cout) = conv(pre(x)); with part != NULL also the BatchNorm that follows: batch mean / rstd /
  * sc = gamma rstd out, running statistics moved (eval != 0: mean / rstd / sc from the running statistics, nothing moved) */
 typedef struct {
@@ -473,11 +477,11 @@ typedef struct {
   const float* xmean;
   const float* xsc;
   const float* xbeta;
-  const int* tbl;
   float* y;
   float* ws;
   unsigned* tile_ticket;
   int M, Cin, Cout, T, pre;
+  mmvae_rc_geom_t g;
   const float* gamma;
   const float* beta;
   float* run_mean;
@@ -499,7 +503,6 @@ typedef struct {
   const float* Y;
   const float* pqr;
   const float* w;
-  const int* tbl;
   const float* add;
   const int* add_tbl;
   int mask;
@@ -511,9 +514,11 @@ typedef struct {
   float* ws;
   unsigned* tile_ticket;
   int M, Min, Cin, Cout, T, nstat;
+  mmvae_rc_geom_t g;
   mmvae_rc_stat_t st[2];
 } mmvae_rc_dgrad_t;
-/* weight gradient: dw (Cout, T, Cin) (+)= dY^T pre(x) per tap; ws / counter: mmvae_rc_wgrad_ws_floats / _tickets */
+/* weight gradient: dw (Cout, T, Cin) (+)= dY^T pre(x) per tap; tbl: the forward table of mmvae_rc_tables (NULL: 1x1,
+ * stride 1); ws / counter: mmvae_rc_wgrad_ws_floats / _tickets */
 typedef struct {
   const float* G;
   const float* Y;
@@ -528,9 +533,10 @@ typedef struct {
   unsigned* counter;
   int M, Cin, Cout, T, pre, accumulate;
 } mmvae_rc_wgrad_t;
-/* up to MMVAE_RC_MAX_JOBS independent jobs in ONE launch (a layer's data + weight gradient, a block's first convolution
- * + projection shortcut); kind: 0 forward (f), 1 data gradient (d), 2 weight gradient (w) */
-#define MMVAE_RC_MAX_JOBS 4
+/* up to MMVAE_RC_MAX_JOBS independent jobs in ONE launch (a block's first convolution + projection shortcut, the
+ * data gradients that only need one incoming gradient, batches of weight gradients beside the data-gradient chain);
+ * kind: 0 forward (f), 1 data gradient (d), 2 weight gradient (w) */
+#define MMVAE_RC_MAX_JOBS 8
 typedef struct {
   int kind;
   mmvae_rc_fwd_t f;

@@ -4,22 +4,51 @@
 // Activations are NHWC (rows = B*H*W, C) fp32 matrices; convolution weights are stored channels-last, (Cout, kh, kw, Cin)
 // in memory behind the (Cout, Cin, kh, kw) parameter view, so that for every filter tap the reduction runs over
 // contiguous input channels.  A k x k convolution is then a sum over its taps of 1x1 GEMMs whose A rows are shifted
-// pixels: the im2col matrix only ever exists as 32/64-row tiles in LDS (a per-geometry table gives, for a row and a tap,
-// the source pixel or -1 for the zero padding).
+// pixels: the im2col matrix only ever exists as 64-row tiles in LDS (the source pixel of a row and a tap is integer
+// arithmetic on the row's (b, h, w), zero for the padding).
 //
-// What is fused around the fp32 MFMA (v_mfma_f32_32x32x2_f32) tiles -- no BatchNorm or elementwise kernel is left
-// between two convolutions:
+// One tiling: workgroup = 4 wavefronts = a 64 x 64 output tile (2 x 2 waves of 32 x 32 on v_mfma_f32_32x32x2_f32), 32-deep
+// stages staged global -> registers -> LDS [k][row] (pitch 65), the next stage's loads in flight under the MFMAs.  Jobs
+// with few tiles split their reduction (taps x channels, or the pixel rows of a weight gradient) over blockIdx.z; the
+// partial accumulators go to a workspace in the MFMA register layout and the last workgroup of a tile sums them in a
+// fixed order (deterministic; no atomics on data) and runs the epilogue.
+//
+// What is fused around the tiles -- no BatchNorm, ReLU or im2col kernel is left between two convolutions:
 //   forward   A prologue: relu(bn(Y_prev)) = max(fma(y - mean, gamma rstd, beta), 0) of the producer's RAW output;
 //             epilogue: raw output + per-column (mean, M2) of the tile; the last workgroup of a column tile merges the
-//             row tiles' partials (Chan, double), emits mean / rstd / gamma rstd and moves the running statistics.
+//             row tiles' partials (double), emits mean / rstd / gamma rstd and moves the running statistics.
 //   dgrad     A prologue: the BatchNorm backward of the consumer side, dY = G p + Y q + r per channel (p, q, r from the
 //             statistics sum G, sum G xhat); epilogue: (+ shortcut gradient), ReLU mask recomputed from the producer's
 //             raw output, the statistics of THAT BatchNorm's backward, last workgroup: dgamma, dbeta, p, q, r.
-//   wgrad     A prologue as dgrad (transposed), B prologue as forward; split over the pixel rows with the partial tiles
-//             summed in a fixed order by the last workgroup of an output tile (deterministic, no atomics on data).
+//   wgrad     A prologue as dgrad (transposed), B prologue as forward.
 // Cross-workgroup hand-over inside a launch: agent-scope write-through stores, a relaxed agent-scope ticket,
-// agent-scope loads in the elected workgroup (latent.hip: poe_last_workgroup explains why not __threadfence()).
+// agent-scope loads in the elected workgroup (latent.hip: poe_last_workgroup explains why not __threadfence()).  Every
+// such step is a ~1.5 us round trip at device scope: loads of partials are issued 8+ at a time, and tickets with more
+// than 16 arrivals are split in two levels.
+#include <cstdlib>
+
 #include "common.hpp"
+
+// RC_PROBE build (tools/probe): wall-clock stamps (100 MHz) of thread 0 of every workgroup at fixed points of a job
+#ifdef RC_PROBE
+__device__ long long* rc_probe_ptr = nullptr;
+extern "C" int mmvae_rc_probe(long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(rc_probe_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : 3;
+}
+#define RC_STAMP(k_, i)                                                                                     \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && rc_probe_ptr)                                                                   \
+      rc_probe_ptr[((size_t)((k_).bz * (k_).gy + (k_).by) * (k_).gx + (k_).bx) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#define RC_STAMP_WAIT(k_, i)                                        \
+  do {                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+    RC_STAMP(k_, i);                                                \
+  } while (0)
+#else
+#define RC_STAMP(k_, i)
+#define RC_STAMP_WAIT(k_, i)
+#endif
 
 #define RC_PRE_NONE 0
 #define RC_PRE_RELU 1
@@ -27,29 +56,14 @@
 #define RC_MASK_NONE 0
 #define RC_MASK_RAW 1
 #define RC_MASK_BN 2
+#define RC_BM 64
+#define RC_BK 32
+#define RC_AP 65      // LDS row pitch of a staged operand ([k][row]; odd: conflict-free transposing stores and fragment reads)
 
 __device__ __forceinline__ float rc_bn(float y, float mean, float sc, float beta) { return fmaf(y - mean, sc, beta); }
 __device__ __forceinline__ void rc_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float rc_ld(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// sum of n values `stride` floats apart written by other workgroups of this launch, in index order, with the loads of
-// 8 values in flight together (a loop of dependent agent-scope loads costs a memory round trip per value)
-__device__ __forceinline__ float rc_sum_strided(const float* __restrict__ p, size_t stride, int n, float t) {
-  int z = 0;
-  for (; z + 8 <= n; z += 8) {
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = rc_ld(p + (size_t)(z + i) * stride);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += v[i];
-  }
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = rc_ld(p + (size_t)min(z + i, n - 1) * stride);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t += z + i < n ? v[i] : 0.f;
-  return t;
 }
 // `expected` workgroups take a ticket; the last one gets true (and re-arms the ticket for the next launch)
 __device__ __forceinline__ bool rc_last_workgroup(unsigned* __restrict__ ticket, unsigned expected, int* last_lds) {
@@ -68,75 +82,88 @@ __device__ __forceinline__ bool rc_last_workgroup(unsigned* __restrict__ ticket,
 // linear grid when several independent jobs share one launch: rc_group_kernel)
 struct RcBlk { int bx, by, bz, gx, gy; };
 
-// Staging of an R x BK operand tile into LDS as [k][r] (pitch R + 1, odd: conflict-free for both the transposing store
-// and the per-lane MFMA fragment reads).  KMAJOR: consecutive threads walk k (the source is k-contiguous), a thread's
-// slots are rows rl + i RSTEP; otherwise consecutive threads walk the rows and the slots are k = kl + i KSTEP.
-template <int R, int BK, bool KMAJOR>
-struct RcStg {
-  static constexpr int PER = R * BK / 256;
-  static constexpr int RSTEP = 256 / BK, KSTEP = 256 / R, RP = R + 1;
-  int rl, kl;
-  __device__ __forceinline__ void init(int tid) {
-    if (KMAJOR) { kl = tid % BK; rl = tid / BK; } else { rl = tid % R; kl = tid / R; }
-  }
-  __device__ __forceinline__ int row(int i) const { return KMAJOR ? rl + i * RSTEP : rl; }
-  __device__ __forceinline__ int kk(int i) const { return KMAJOR ? kl : kl + i * KSTEP; }
-  __device__ __forceinline__ void store(float* __restrict__ S, const float (&v)[PER]) const {
-    float* d = S + kl * RP + rl;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) d[KMAJOR ? i * RSTEP : i * KSTEP * RP] = v[i];
-  }
-};
+// pixel geometry of a convolution: (B, H, W) input pixels -> (B, Ho, Wo) output pixels, KW x (T / KW) taps, stride S,
+// padding P.  T == 1 && S == 1: rows map to themselves.
+struct RcGeom { int H, W, Ho, Wo, KW, S, P; };
 
-// 4 wavefronts over a BM x BN tile: WM x WN waves own 32 x 32 sub-tiles, the remaining factor WK splits every BK-deep
-// stage (64 x 64: 2 x 2 x 1; 32 x 32: 1 x 1 x 4 -- the layers with few output tiles and a deep reduction).
-template <int BM, int BN, int BK>
-struct RcTile {
-  static constexpr int WM = BM / 32, WN = BN / 32, WK = 4 / (WM * WN), KW = BK / WK;
-  static constexpr int AP = BM + 1, BP = BN + 1;
-  static constexpr int STAGE = BK * AP + BK * BP, OUT = WK * BM * BP;
-  static constexpr int SMEM = STAGE > OUT ? STAGE : OUT;
-  static constexpr int RG = 256 / BN, NR = BM / RG;   // epilogue: thread = (column, row group), NR rows each
-  int wm, wn, wk, li, lh;
+// wave / lane roles over the 64 x 64 tile: wave (wm, wn) owns rows [32 wm, +32) x columns [32 wn, +32); accumulator
+// register r of lane (li, lh) is element (row_of(r), col())
+struct RcWave {
+  int wm, wn, li, lh;
   __device__ __forceinline__ void init(int tid) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    wk = wave / (WM * WN);
-    wm = (wave % (WM * WN)) / WN;
-    wn = wave % WN;
+    wm = wave >> 1;
+    wn = wave & 1;
     li = lane & 31;
     lh = lane >> 5;
   }
+  __device__ __forceinline__ int row_of(int r) const { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; }
+  __device__ __forceinline__ int col() const { return wn * 32 + li; }
   __device__ __forceinline__ void mma(const float* __restrict__ As, const float* __restrict__ Bs, f32x16& acc) const {
-    const float* a = As + (wk * KW + lh) * AP + wm * 32 + li;
-    const float* b = Bs + (wk * KW + lh) * BP + wn * 32 + li;
+    const float* a = As + lh * RC_AP + wm * 32 + li;
+    const float* b = Bs + lh * RC_AP + wn * 32 + li;
 #pragma unroll
-    for (int kk = 0; kk < KW; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * AP], b[kk * BP], acc, 0, 0, 0);
-  }
-  // accumulators -> LDS tile(s) [wk][BM][BP]; the caller syncs before and after
-  __device__ __forceinline__ void spill(float* __restrict__ T, const f32x16& acc) const {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      T[(wk * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BP + wn * 32 + li] = acc[r];
-  }
-  __device__ __forceinline__ static float tile_at(const float* __restrict__ T, int row, int col) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < WK; ++w) t += T[(w * BM + row) * BP + col];
-    return t;
+    for (int kk = 0; kk < RC_BK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * RC_AP], b[kk * RC_AP], acc, 0, 0, 0);
   }
 };
 
-// sum over the RG row groups of a column (cs: 256 floats), every thread gets the total; fixed order
-template <int BN>
-__device__ __forceinline__ float rc_colsum(float* __restrict__ cs, float v, int col, int rg) {
-  constexpr int RG = 256 / BN;
-  __syncthreads();
-  cs[rg * BN + col] = v;
-  __syncthreads();
-  float t = 0.f;
+// Staging slots of a thread for a 64 x 32 operand tile: k-contiguous sources (KMAJOR) are walked with consecutive
+// threads along k (slot i = row rl + 8 i), row-contiguous ones along the rows (slot i = k kl + 4 i); 8 slots each.
+template <bool KMAJOR>
+struct RcStg {
+  int rl, kl;
+  __device__ __forceinline__ void init(int tid) {
+    if (KMAJOR) { kl = tid & 31; rl = tid >> 5; } else { rl = tid & 63; kl = tid >> 6; }
+  }
+  __device__ __forceinline__ int row(int i) const { return KMAJOR ? rl + i * 8 : rl; }
+  __device__ __forceinline__ int kk(int i) const { return KMAJOR ? kl : kl + i * 4; }
+  __device__ __forceinline__ void store(float* __restrict__ S, const float (&v)[8]) const {
+    float* d = S + kl * RC_AP + rl;
 #pragma unroll
-  for (int g = 0; g < RG; ++g) t += cs[g * BN + col];
-  return t;
+    for (int i = 0; i < 8; ++i) d[KMAJOR ? i * 8 : i * 4 * RC_AP] = v[i];
+  }
+};
+
+// column sums over the tile's 64 rows of per-lane partial sums (a lane: its 16 rows of column col()); cs: 128 floats
+__device__ __forceinline__ float rc_colsum(float* __restrict__ cs, float v, const RcWave& w) {
+  v += __shfl_xor(v, 32, 64);
+  __syncthreads();
+  if (w.lh == 0) cs[w.wm * 64 + w.col()] = v;
+  __syncthreads();
+  return cs[w.col()] + cs[64 + w.col()];
+}
+
+// The complete accumulators of this workgroup's tile.  nz == 1: its own.  nz > 1 (reduction split over blockIdx.z):
+// every split leaves its accumulators in ws [z][...] at (row, col) -> base + row * rstride + col; the last one to arrive
+// sums them in z order (16 x 4 loads in flight) and carries on alone -- false for the others.
+__device__ __forceinline__ bool rc_acc_reduce(f32x16& acc, float* __restrict__ ws, unsigned* __restrict__ ticket, int nz,
+                                              int zi, size_t zstride, size_t base, size_t rstride, int cnt,
+                                              const RcWave& w, int* last) {
+  if (nz == 1) return true;
+  float* mine = ws + (size_t)zi * zstride + base + w.col();
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (w.row_of(r) < cnt) rc_st(mine + (size_t)w.row_of(r) * rstride, acc[r]);
+  if (!rc_last_workgroup(ticket, (unsigned)nz, last)) return false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* all = ws + base + w.col();
+  for (int z0 = 0; z0 < nz; z0 += 4) {
+    float t[16][4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t[r][i] = rc_ld(all + (size_t)min(z0 + i, nz - 1) * zstride + (size_t)min(w.row_of(r), cnt - 1) * rstride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (z0 + i < nz) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += t[r][i];
+      }
+  }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -150,22 +177,22 @@ struct RcBnFwd {          // the BatchNorm that follows the convolution (statist
   float* mean;            // out (C): batch mean (eval: running mean)
   float* rstd;            // out (C)
   float* sc;              // out (C): gamma * rstd
-  float* part;            // (row tiles, C, 2)
-  unsigned* counter;      // (column tiles)
+  float* part;            // (row tiles [+ groups], C, 2)
+  unsigned* counter;      // (column tiles) final tickets, then (column tiles, groups)
   float eps, momentum;
   int eval;
 };
 struct RcFwdArgs {
-  const float* x;         // (Min, Cin)
+  const float* x;         // (B H W, Cin)
   const float* w;         // (Cout, T, Cin)
   const float* xmean;     // prologue of RC_PRE_BN_RELU: relu(fma(x - xmean, xsc, xbeta))
   const float* xsc;
   const float* xbeta;
-  const int* tbl;         // (T, M) source row of (tap, output row), -1 = padding; NULL: identity (T = 1, Min = M)
-  float* y;               // (M, Cout)
+  float* y;               // (M = B Ho Wo, Cout)
   float* ws;              // nz > 1: (nz, M, Cout) partial outputs
   unsigned* tile_ticket;  // nz > 1: one per output tile
   int M, Cin, Cout, T, pre, nz;
+  RcGeom g;
   RcBnFwd bn;             // bn.part == NULL: no statistics
 };
 
@@ -247,78 +274,56 @@ __device__ __forceinline__ void rc_bn_fwd_finalize(const RcBnFwd& bn, double mea
   bn.sc[n] = (float)((double)bn.gamma[n] * rs);
 }
 
-// The complete values of this workgroup's output tile.  nz == 1: the LDS tile.  nz > 1 (split of the reduction over
-// blockIdx.z, 32 x 32 tiles only): every split leaves its partial tile in ws [z][rows][N]; the last one to arrive sums
-// them in z order (NR x 8 loads in flight) and carries on alone -- false for the others.
-template <class TL, int BM, int BN>
-__device__ __forceinline__ bool rc_tile_values(const float* __restrict__ smem, float* __restrict__ ws,
-                                               unsigned* __restrict__ ticket, int nz, int zi, size_t zstride, int m0, int n0,
-                                               int N, int cnt, int col, int rg, float (&v)[TL::NR], int* last) {
-#pragma unroll
-  for (int j = 0; j < TL::NR; ++j) v[j] = TL::tile_at(smem, rg + j * TL::RG, col);
-  if (nz == 1) return true;
-  if constexpr (TL::NR <= 4) {
-#pragma unroll
-    for (int j = 0; j < TL::NR; ++j) {
-      const int row = rg + j * TL::RG;
-      if (row < cnt) rc_st(ws + (size_t)zi * zstride + (size_t)(m0 + row) * N + n0 + col, v[j]);
-    }
-    if (!rc_last_workgroup(ticket, (unsigned)nz, last)) return false;
-#pragma unroll
-    for (int j = 0; j < TL::NR; ++j) v[j] = 0.f;
-    for (int z0 = 0; z0 < nz; z0 += 8) {
-      float t[TL::NR][8];
-#pragma unroll
-      for (int j = 0; j < TL::NR; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          t[j][i] = rc_ld(ws + (size_t)min(z0 + i, nz - 1) * zstride + (size_t)(m0 + min(rg + j * TL::RG, cnt - 1)) * N +
-                          n0 + col);
-#pragma unroll
-      for (int j = 0; j < TL::NR; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (z0 + i < nz) v[j] += t[j][i];
-    }
-    return true;
-  } else {
-    return false;   // the dispatcher never splits the 64 x 64 tiling
-  }
-}
 
-template <int BM, int BN, int BK>
 __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
-                                          int* __restrict__ lastp) {
-  using TL = RcTile<BM, BN, BK>;
-  using SA = RcStg<BM, BK, true>;
-  using SB = RcStg<BN, BK, true>;
+                                            int* __restrict__ lastp) {
   float* As = smem;
-  float* Bs = smem + BK * TL::AP;
+  float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
-  const int n0 = k.bx * BN, m0 = k.by * BM;
-  TL tl;
-  tl.init(tid);
-  SA sa;
-  SB sb;
+  const int n0 = k.bx * 64, m0 = k.by * RC_BM;
+  RcWave wv;
+  wv.init(tid);
+  RcStg<true> sa, sb;
   sa.init(tid);
   sb.init(tid);
-  int src[SA::PER], wrow[SB::PER];
-  float ra[SA::PER], rb[SB::PER];
+  // geometry of this thread's 8 rows: pix = row of (b, oh S - P, ow S - P) (may lie outside), hw = (oh S - P, ow S - P)
+  const bool ident = a.T == 1 && a.g.S == 1;
+  int pix[8], hw[8], src[8], wrow[8];
+  float ra[8], rb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = m0 + sa.row(i);
+    wrow[i] = (n0 + sb.row(i)) * a.T;
+    if (ident) {
+      pix[i] = r < a.M ? r : -1;
+      hw[i] = 0;
+    } else {
+      const int hwo = a.g.Ho * a.g.Wo;
+      const int b = r / hwo, rem = r - b * hwo, oh = rem / a.g.Wo, ow = rem - oh * a.g.Wo;
+      const int h0 = oh * a.g.S - a.g.P, w0 = ow * a.g.S - a.g.P;
+      pix[i] = (b * a.g.H + h0) * a.g.W + w0;
+      hw[i] = r < a.M ? ((h0 + 0x4000) << 16 | (w0 + 0x4000)) : -1;
+    }
+  }
   float pm = 0.f, ps = 1.f, pb = 0.f;
   unsigned oka = 0;
-#pragma unroll
-  for (int i = 0; i < SB::PER; ++i) wrow[i] = (n0 + sb.row(i)) * a.T;
-  // this workgroup's share of the T * Cin / BK stages (k.bz of nz)
-  const int nstage_all = a.T * (a.Cin / BK), sper = (nstage_all + a.nz - 1) / a.nz;
+  // this workgroup's share of the T * Cin / 32 stages (blockIdx.z of nz)
+  const int spc = a.Cin / RC_BK, nstage_all = a.T * spc, sper = (nstage_all + a.nz - 1) / a.nz;
   const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
-  int ltap = s_beg / (a.Cin / BK), lc0 = (s_beg % (a.Cin / BK)) * BK;
+  int ltap = s_beg / spc, lc0 = (s_beg - ltap * spc) * RC_BK;
   bool newtap = true;
   auto load = [&]() {
     if (newtap) {
+      const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
 #pragma unroll
-      for (int i = 0; i < SA::PER; ++i) {
-        const int r = m0 + sa.row(i);
-        src[i] = r < a.M ? (a.tbl ? a.tbl[(size_t)ltap * a.M + r] : r) : -1;
+      for (int i = 0; i < 8; ++i) {
+        if (ident) {
+          src[i] = pix[i];
+        } else {
+          const int ih = (hw[i] >> 16) - 0x4000 + kh, iw = (hw[i] & 0xffff) - 0x4000 + kw;
+          const bool ok = hw[i] != -1 && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+          src[i] = ok ? pix[i] + kh * a.g.W + kw : -1;
+        }
       }
       newtap = false;
     }
@@ -326,20 +331,20 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     if (a.pre == RC_PRE_BN_RELU) { pm = a.xmean[c]; ps = a.xsc[c]; pb = a.xbeta[c]; }
     oka = 0;
 #pragma unroll
-    for (int i = 0; i < SA::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const bool ok = src[i] >= 0;
       oka |= (ok ? 1u : 0u) << i;
       ra[i] = a.x[ok ? (size_t)src[i] * a.Cin + c : 0];
     }
 #pragma unroll
-    for (int i = 0; i < SB::PER; ++i) rb[i] = a.w[(size_t)(wrow[i] + ltap) * a.Cin + lc0 + sb.kl];
-    lc0 += BK;
+    for (int i = 0; i < 8; ++i) rb[i] = a.w[(size_t)(wrow[i] + ltap) * a.Cin + lc0 + sb.kl];
+    lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
   auto store = [&]() {
-    float va[SA::PER];
+    float va[8];
 #pragma unroll
-    for (int i = 0; i < SA::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       float v = ra[i];
       if (a.pre == RC_PRE_BN_RELU) v = fmaxf(rc_bn(v, pm, ps, pb), 0.f);
       else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
@@ -357,65 +362,61 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     store();
     __syncthreads();
     if (s + 1 < s_end) load();
-    tl.mma(As, Bs, acc);
+    wv.mma(As, Bs, acc);
     __syncthreads();
   }
-  tl.spill(smem, acc);
-  __syncthreads();
-  const int col = tid % BN, rg = tid / BN, n = n0 + col;
-  const int cnt = min(BM, a.M - m0);
-  float v[TL::NR], s = 0.f;
-  if (!rc_tile_values<TL, BM, BN>(smem, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz,
-                                  (size_t)a.M * a.Cout, m0, n0, a.Cout, cnt, col, rg, v, lastp))
+  const int cnt = min(RC_BM, a.M - m0);
+  if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)a.M * a.Cout,
+                     (size_t)m0 * a.Cout + n0, a.Cout, cnt, wv, lastp))
     return;
+  const int n = n0 + wv.col();
+  float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < TL::NR; ++j) {
-    const int row = rg + j * TL::RG;
-    if (row < cnt) {
-      a.y[(size_t)(m0 + row) * a.Cout + n] = v[j];
-      s += v[j];
+  for (int r = 0; r < 16; ++r)
+    if (wv.row_of(r) < cnt) {
+      a.y[(size_t)(m0 + wv.row_of(r)) * a.Cout + n] = acc[r];
+      s += acc[r];
     }
-  }
   if (!a.bn.part) return;
-  const float mean_t = rc_colsum<BN>(cs, s, col, rg) / (float)cnt;
+  const float mean_t = rc_colsum(cs, s, wv) / (float)cnt;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < TL::NR; ++j)
-    if (rg + j * TL::RG < cnt) q = fmaf(v[j] - mean_t, v[j] - mean_t, q);
-  const float m2_t = rc_colsum<BN>(cs, q, col, rg);
-  if (rg == 0) {
+  for (int r = 0; r < 16; ++r)
+    if (wv.row_of(r) < cnt) q = fmaf(acc[r] - mean_t, acc[r] - mean_t, q);
+  const float m2_t = rc_colsum(cs, q, wv);
+  if (wv.wm == 0 && wv.lh == 0) {
     rc_st(a.bn.part + ((size_t)k.by * a.Cout + n) * 2, mean_t);
     rc_st(a.bn.part + ((size_t)k.by * a.Cout + n) * 2 + 1, m2_t);
   }
+  // election (two levels beyond RC_GROUP row tiles) and merge: thread = (column, one of 4 part groups)
+  const int col = tid & 63, rg = tid >> 6, nc = n0 + col;
   const RcLevels lv(k.gy, k.by);
   double* dl = reinterpret_cast<double*>(smem);
   double o0, o1, o2;
   const float* src_part = a.bn.part;
-  int np = lv.nrow, rows_per = BM;
+  int np = lv.nrow, rows_per = RC_BM;
   if (lv.ngrp) {
     if (!rc_last_workgroup(a.bn.counter + k.gx + k.bx * lv.ngrp + lv.grp, lv.g1 - lv.g0, lastp)) return;
-    rc_merge<BN, true>(a.bn.part, a.Cout, n, lv.g0, lv.g1, BM, a.M, dl, col, rg, o0, o1, o2);
+    rc_merge<64, true>(a.bn.part, a.Cout, nc, lv.g0, lv.g1, RC_BM, a.M, dl, col, rg, o0, o1, o2);
     float* l1 = lv.level1(a.bn.part, a.Cout);
     if (rg == 0) {
-      rc_st(l1 + ((size_t)lv.grp * a.Cout + n) * 2, (float)o1);
-      rc_st(l1 + ((size_t)lv.grp * a.Cout + n) * 2 + 1, (float)o2);
+      rc_st(l1 + ((size_t)lv.grp * a.Cout + nc) * 2, (float)o1);
+      rc_st(l1 + ((size_t)lv.grp * a.Cout + nc) * 2 + 1, (float)o2);
     }
     src_part = l1;
     np = lv.ngrp;
-    rows_per = BM * RC_GROUP;
+    rows_per = RC_BM * RC_GROUP;
   }
   if (!rc_last_workgroup(a.bn.counter + k.bx, np, lastp)) return;
-  rc_merge<BN, true>(src_part, a.Cout, n, 0, np, rows_per, a.M, dl, col, rg, o0, o1, o2);
-  if (rg == 0) rc_bn_fwd_finalize<BN>(a.bn, o1, o2, a.M, n);
+  rc_merge<64, true>(src_part, a.Cout, nc, 0, np, rows_per, a.M, dl, col, rg, o0, o1, o2);
+  if (rg == 0) rc_bn_fwd_finalize<64>(a.bn, o1, o2, a.M, nc);
 }
 
-template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[RcTile<BM, BN, BK>::SMEM];
-  __shared__ float cs[256];
+  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ float cs[128];
   __shared__ int last;
-  rc_fwd_body<BM, BN, BK>(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs,
-                          &last);
+  rc_fwd_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -429,8 +430,8 @@ struct RcStat {           // a BatchNorm whose output gradient G the kernel hold
   float* pqr;             // out (3, C): the input gradient is G p + Y q + r
   float* dgamma;
   float* dbeta;
-  float* part;            // (row tiles, C, 2)
-  unsigned* counter;      // (column tiles)
+  float* part;            // (row tiles [+ groups], C, 2)
+  unsigned* counter;      // as RcBnFwd
   int acc;                // add to dgamma / dbeta instead of overwriting
   int eval;
 };
@@ -481,6 +482,7 @@ __device__ __forceinline__ void rc_stat_tail(const RcStat* st, int nstat, int nr
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------------------------------
 // data gradient
 // ---------------------------------------------------------------------------------------------------------------------
@@ -489,7 +491,6 @@ struct RcDgradArgs {
   const float* Y;         // ... its raw input (this convolution's output) ...
   const float* pqr;       // ... and (3, Cout): dY = G p + Y q + r.  NULL: dY = G
   const float* w;         // (Cout, T, Cin)
-  const int* tbl;         // (T, Min): output row feeding (tap, input row), -1 = none; NULL: identity
   const float* add;       // added before the mask (the shortcut's gradient) or NULL: (Min, Cin), or ...
   const int* add_tbl;     // ... with add_tbl (Min): row add_tbl[m] of `add` (-1: nothing), a strided projection's gradient
   const float* mY;        // mask source (Min, Cin): RC_MASK_RAW mY > 0, RC_MASK_BN bn(mY) > 0
@@ -500,63 +501,93 @@ struct RcDgradArgs {
   float* ws;              // nz > 1: (nz, Min, Cin) partial outputs
   unsigned* tile_ticket;
   int M, Min, Cin, Cout, T, mask, nstat, nz;
+  RcGeom g;
   RcStat st[2];
 };
 
-template <int BM, int BN, int BK>
-__device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
-                                          int* __restrict__ lastp) {
-  using TL = RcTile<BM, BN, BK>;
-  using SA = RcStg<BM, BK, true>;
-  using SB = RcStg<BN, BK, false>;
+__device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk k, float* __restrict__ smem,
+                                              float* __restrict__ cs, int* __restrict__ lastp) {
   float* As = smem;
-  float* Bs = smem + BK * TL::AP;
+  float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
-  const int n0 = k.bx * BN, m0 = k.by * BM;     // n0: input-channel tile
-  TL tl;
-  tl.init(tid);
-  SA sa;
-  SB sb;
+  const int n0 = k.bx * 64, m0 = k.by * RC_BM;     // n0: input-channel tile
+  RC_STAMP(k, 0);
+  RcWave wv;
+  wv.init(tid);
+  RcStg<true> sa;
+  RcStg<false> sb;
   sa.init(tid);
   sb.init(tid);
-  int src[SA::PER];
-  float rg_[SA::PER], ry[SA::PER], rb[SB::PER];
+  // this thread's 8 input pixels: bh = (b, ih + P, iw + P) packed; the output pixel that reads pixel (ih, iw) through
+  // tap (kh, kw) is ((ih + P - kh) / S, (iw + P - kw) / S) when both divide and lie inside
+  const bool ident = a.T == 1 && a.g.S == 1;
+  int pb_[8], hw[8], src[8];
+  float rg_[8], ry[8], rb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = m0 + sa.row(i);
+    if (ident) {
+      pb_[i] = r < a.Min ? r : -1;
+      hw[i] = 0;
+    } else {
+      const int hwi = a.g.H * a.g.W;
+      const int b = r / hwi, rem = r - b * hwi, ih = rem / a.g.W, iw = rem - ih * a.g.W;
+      pb_[i] = b * a.g.Ho;
+      hw[i] = r < a.Min ? ((ih + a.g.P) << 16 | (iw + a.g.P)) : -1;
+    }
+  }
   float pp = 1.f, pq = 0.f, pr = 0.f;
   unsigned oka = 0;
-  const int nstage_all = a.T * (a.Cout / BK), sper = (nstage_all + a.nz - 1) / a.nz;
+  const int spc = a.Cout / RC_BK, nstage_all = a.T * spc, sper = (nstage_all + a.nz - 1) / a.nz;
   const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
-  int ltap = s_beg / (a.Cout / BK), lk0 = (s_beg % (a.Cout / BK)) * BK;
+  int ltap = s_beg / spc, lk0 = (s_beg - ltap * spc) * RC_BK;
   bool newtap = true;
   auto load = [&]() {
     if (newtap) {
+      const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
 #pragma unroll
-      for (int i = 0; i < SA::PER; ++i) {
-        const int r = m0 + sa.row(i);
-        src[i] = r < a.Min ? (a.tbl ? a.tbl[(size_t)ltap * a.Min + r] : r) : -1;
+      for (int i = 0; i < 8; ++i) {
+        if (ident) {
+          src[i] = pb_[i];
+        } else {
+          const int th = (hw[i] >> 16) - kh, tw = (hw[i] & 0xffff) - kw;
+          int oh = th, ow = tw;
+          bool ok = hw[i] != -1 && th >= 0 && tw >= 0;
+          if (a.g.S == 2) {
+            ok = ok && ((th | tw) & 1) == 0;
+            oh = th >> 1;
+            ow = tw >> 1;
+          } else if (a.g.S != 1) {
+            ok = ok && th % a.g.S == 0 && tw % a.g.S == 0;
+            oh = th / a.g.S;
+            ow = tw / a.g.S;
+          }
+          ok = ok && oh < a.g.Ho && ow < a.g.Wo;
+          src[i] = ok ? (pb_[i] + oh) * a.g.Wo + ow : -1;
+        }
       }
       newtap = false;
     }
-    const int k = lk0 + sa.kl;
-    if (a.pqr) { pp = a.pqr[k]; pq = a.pqr[a.Cout + k]; pr = a.pqr[2 * a.Cout + k]; }
+    const int kc = lk0 + sa.kl;
+    if (a.pqr) { pp = a.pqr[kc]; pq = a.pqr[a.Cout + kc]; pr = a.pqr[2 * a.Cout + kc]; }
     oka = 0;
 #pragma unroll
-    for (int i = 0; i < SA::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const bool ok = src[i] >= 0;
       oka |= (ok ? 1u : 0u) << i;
-      const size_t o = ok ? (size_t)src[i] * a.Cout + k : 0;
+      const size_t o = ok ? (size_t)src[i] * a.Cout + kc : 0;
       rg_[i] = a.G[o];
       ry[i] = a.pqr ? a.Y[o] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < SB::PER; ++i)
-      rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + ltap) * a.Cin + n0 + sb.rl];
-    lk0 += BK;
+    for (int i = 0; i < 8; ++i) rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + ltap) * a.Cin + n0 + sb.rl];
+    lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
   auto store = [&]() {
-    float va[SA::PER];
+    float va[8];
 #pragma unroll
-    for (int i = 0; i < SA::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
       va[i] = (oka >> i & 1u) ? v : 0.f;
     }
@@ -567,79 +598,93 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   if (s_beg < s_end) load();
+  RC_STAMP_WAIT(k, 1);
 #pragma unroll 1
   for (int s = s_beg; s < s_end; ++s) {
     store();
     __syncthreads();
     if (s + 1 < s_end) load();
-    tl.mma(As, Bs, acc);
+    wv.mma(As, Bs, acc);
     __syncthreads();
   }
-  tl.spill(smem, acc);
-  __syncthreads();
-  const int col = tid % BN, rg = tid / BN, c = n0 + col;
-  const int cnt = min(BM, a.Min - m0);
-  float v[TL::NR];
-  if (!rc_tile_values<TL, BM, BN>(smem, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz,
-                                  (size_t)a.Min * a.Cin, m0, n0, a.Cin, cnt, col, rg, v, lastp))
+  RC_STAMP(k, 2);
+  const int cnt = min(RC_BM, a.Min - m0);
+  if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)a.Min * a.Cin,
+                     (size_t)m0 * a.Cin + n0, a.Cin, cnt, wv, lastp))
     return;
+  RC_STAMP(k, 3);
+  const int c = n0 + wv.col();
   float mm = 0.f, ms = 1.f, mb = 0.f;
   if (a.mask == RC_MASK_BN) { mm = a.mmean[c]; ms = a.msc[c]; mb = a.mbeta[c]; }
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, tm[2] = {0.f, 0.f}, tr[2] = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 2; ++t)
     if (t < a.nstat) { tm[t] = a.st[t].mean[c]; tr[t] = a.st[t].rstd[c]; }
+  // the epilogue's operands first (all rows in flight), then the arithmetic.  st[0].Y is the mask source itself at the
+  // BatchNorm-mask call sites (one load serves both)
+  float vadd[16], vmy[16], vy0[16], vy1[16];
+  const bool st0_is_mask = a.nstat > 0 && a.mask != RC_MASK_NONE && a.st[0].Y == a.mY;
 #pragma unroll
-  for (int j = 0; j < TL::NR; ++j) {
-    const int row = rg + j * TL::RG;
-    if (row < cnt) {
-      const size_t o = (size_t)(m0 + row) * a.Cin + c;
-      float g = v[j];
-      if (a.add) {
-        if (a.add_tbl) {
-          const int r = a.add_tbl[m0 + row];
-          if (r >= 0) g += a.add[(size_t)r * a.Cin + c];
-        } else {
-          g += a.add[o];
-        }
+  for (int r = 0; r < 16; ++r) {
+    const int row = min(wv.row_of(r), cnt - 1);
+    const size_t o = (size_t)(m0 + row) * a.Cin + c;
+    vadd[r] = 0.f;
+    if (a.add) {
+      if (a.add_tbl) {
+        const int rr = a.add_tbl[m0 + row];
+        vadd[r] = a.add[rr >= 0 ? (size_t)rr * a.Cin + c : 0];
+        if (rr < 0) vadd[r] = 0.f;
+      } else {
+        vadd[r] = a.add[o];
       }
-      float my = 0.f;
+    }
+    vmy[r] = a.mask != RC_MASK_NONE ? a.mY[o] : 0.f;
+    vy0[r] = (a.nstat > 0 && !st0_is_mask) ? a.st[0].Y[o] : 0.f;
+    vy1[r] = a.nstat > 1 ? a.st[1].Y[o] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (wv.row_of(r) < cnt) {
+      const size_t o = (size_t)(m0 + wv.row_of(r)) * a.Cin + c;
+      float g = acc[r] + vadd[r];
       if (a.mask != RC_MASK_NONE) {
-        my = a.mY[o];
-        const float z = a.mask == RC_MASK_BN ? rc_bn(my, mm, ms, mb) : my;
+        const float z = a.mask == RC_MASK_BN ? rc_bn(vmy[r], mm, ms, mb) : vmy[r];
         g = z > 0.f ? g : 0.f;
       }
       a.out[o] = g;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (t < a.nstat) {
-          const float yv = (a.st[t].Y == a.mY && a.mask != RC_MASK_NONE) ? my : a.st[t].Y[o];
-          s1[t] += g;
-          s2[t] = fmaf(g, (yv - tm[t]) * tr[t], s2[t]);
-        }
+      if (a.nstat > 0) {
+        const float y0 = st0_is_mask ? vmy[r] : vy0[r];
+        s1[0] += g;
+        s2[0] = fmaf(g, (y0 - tm[0]) * tr[0], s2[0]);
+      }
+      if (a.nstat > 1) {
+        s1[1] += g;
+        s2[1] = fmaf(g, (vy1[r] - tm[1]) * tr[1], s2[1]);
+      }
     }
   }
+  RC_STAMP_WAIT(k, 4);
   if (a.nstat == 0) return;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
     if (t < a.nstat) {
-      const float a1 = rc_colsum<BN>(cs, s1[t], col, rg), a2 = rc_colsum<BN>(cs, s2[t], col, rg);
-      if (rg == 0) {
+      const float a1 = rc_colsum(cs, s1[t], wv), a2 = rc_colsum(cs, s2[t], wv);
+      if (wv.wm == 0 && wv.lh == 0) {
         rc_st(a.st[t].part + ((size_t)k.by * a.Cin + c) * 2, a1);
         rc_st(a.st[t].part + ((size_t)k.by * a.Cin + c) * 2 + 1, a2);
       }
     }
-  rc_stat_tail<BN>(a.st, a.nstat, k.gy, k.by, k.bx, k.gx, a.Min, a.Cin, c,
-                   reinterpret_cast<double*>(smem), col, rg, lastp);
+  RC_STAMP_WAIT(k, 5);
+  rc_stat_tail<64>(a.st, a.nstat, k.gy, k.by, k.bx, k.gx, a.Min, a.Cin, n0 + (tid & 63), reinterpret_cast<double*>(smem),
+                   tid & 63, tid >> 6, lastp);
+  RC_STAMP_WAIT(k, 6);
 }
 
-template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[RcTile<BM, BN, BK>::SMEM];
-  __shared__ float cs[256];
+  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ float cs[128];
   __shared__ int last;
-  rc_dgrad_body<BM, BN, BK>(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs,
-                          &last);
+  rc_dgrad_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
 }
 
 // stand-alone statistics of a BatchNorm backward whose G was produced elsewhere (pooling backward, tests):
@@ -659,7 +704,14 @@ __global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ 
     s1 += g;
     s2 = fmaf(g, (st.Y[o] - tm) * tr, s2);
   }
-  const float a1 = rc_colsum<64>(cs, s1, col, rg), a2 = rc_colsum<64>(cs, s2, col, rg);
+  __syncthreads();
+  cs[rg * 64 + col] = s1;
+  __syncthreads();
+  const float a1 = cs[col] + cs[64 + col] + cs[128 + col] + cs[192 + col];
+  __syncthreads();
+  cs[rg * 64 + col] = s2;
+  __syncthreads();
+  const float a2 = cs[col] + cs[64 + col] + cs[128 + col] + cs[192 + col];
   if (rg == 0) {
     rc_st(st.part + ((size_t)blockIdx.y * C + c) * 2, a1);
     rc_st(st.part + ((size_t)blockIdx.y * C + c) * 2 + 1, a2);
@@ -675,47 +727,50 @@ struct RcWgradArgs {
   const float* G;         // (M, Cout), Y, pqr: dY = G p + Y q + r (pqr NULL: dY = G)
   const float* Y;
   const float* pqr;
-  const float* x;         // (Min, Cin) raw input, consumed through `pre` as in the forward pass
+  const float* x;         // (B H W, Cin) raw input, consumed through `pre` as in the forward pass
   const float* xmean;
   const float* xsc;
   const float* xbeta;
-  const int* tbl;         // (T, M) as forward
+  const int* tbl;         // (T, M) source row of (tap, output row), -1 = padding; NULL: identity
   float* dw;              // (Cout, T, Cin)
   float* ws;              // nz > 1: (nz, Cout T Cin) partial tiles
   unsigned* counter;      // nz > 1: one ticket per output tile
   int M, Cin, Cout, T, pre, acc, nz, kper;
 };
 
-template <int BM, int BN, int BK>
-__device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
-                                          int* __restrict__ lastp) {
-  using TL = RcTile<BM, BN, BK>;
-  using SA = RcStg<BM, BK, false>;
-  using SB = RcStg<BN, BK, false>;
+__device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk k, float* __restrict__ smem,
+                                              float* __restrict__ cs, int* __restrict__ lastp) {
   float* As = smem;
-  float* Bs = smem + BK * TL::AP;
+  float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
-  const int c0 = k.bx * BN, n0 = k.by * BM;
-  const int tap = k.bz / a.nz, zi = k.bz % a.nz;
+  const int c0 = k.bx * 64, n0 = k.by * 64;
+  const int tap = k.bz / a.nz, zi = k.bz - tap * a.nz;
   const int kbeg = zi * a.kper, kend = min(a.M, kbeg + a.kper);
-  TL tl;
-  tl.init(tid);
-  SA sa;
-  SB sb;
+  RcWave wv;
+  wv.init(tid);
+  RcStg<false> sa, sb;
   sa.init(tid);
   sb.init(tid);
-  float rg_[SA::PER], ry[SA::PER], rb[SB::PER];
+  float rg_[8], ry[8], rb[8];
+  int sr[8];              // source rows of the stage being loaded next (one stage ahead of the data)
   unsigned oka = 0, okb = 0;
   const int n = n0 + sa.rl, c = c0 + sb.rl;
   float pp = 1.f, pq = 0.f, pr = 0.f, pm = 0.f, ps = 1.f, pb = 0.f;
   if (a.pqr) { pp = a.pqr[n]; pq = a.pqr[a.Cout + n]; pr = a.pqr[2 * a.Cout + n]; }
   if (a.pre == RC_PRE_BN_RELU) { pm = a.xmean[c]; ps = a.xsc[c]; pb = a.xbeta[c]; }
   const int* tb = a.tbl ? a.tbl + (size_t)tap * a.M : nullptr;
+  auto rows = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = k0 + sb.kk(i);
+      sr[i] = m < kend ? (tb ? tb[m] : m) : -1;
+    }
+  };
   auto load = [&](int k0) {
     oka = 0;
     okb = 0;
 #pragma unroll
-    for (int i = 0; i < SA::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int m = k0 + sa.kk(i);
       const bool ok = m < kend;
       oka |= (ok ? 1u : 0u) << i;
@@ -724,24 +779,22 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
       ry[i] = a.pqr ? a.Y[o] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < SB::PER; ++i) {
-      const int m = k0 + sb.kk(i);
-      int sr = -1;
-      if (m < kend) sr = tb ? tb[m] : m;
-      const bool ok = sr >= 0;
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = sr[i] >= 0;
       okb |= (ok ? 1u : 0u) << i;
-      rb[i] = a.x[ok ? (size_t)sr * a.Cin + c : 0];
+      rb[i] = a.x[ok ? (size_t)sr[i] * a.Cin + c : 0];
     }
+    if (k0 + RC_BK < kend) rows(k0 + RC_BK);      // the table entries of the stage after: not a dependent round trip then
   };
   auto store = [&]() {
-    float va[SA::PER], vb[SB::PER];
+    float va[8], vb[8];
 #pragma unroll
-    for (int i = 0; i < SA::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
       va[i] = (oka >> i & 1u) ? v : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < SB::PER; ++i) {
+    for (int i = 0; i < 8; ++i) {
       float v = rb[i];
       if (a.pre == RC_PRE_BN_RELU) v = fmaxf(rc_bn(v, pm, ps, pb), 0.f);
       else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
@@ -753,45 +806,35 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (kbeg < kend) load(kbeg);
+  if (kbeg < kend) {
+    rows(kbeg);
+    load(kbeg);
+  }
 #pragma unroll 1
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += RC_BK) {
     store();
     __syncthreads();
-    if (k0 + BK < kend) load(k0 + BK);
-    tl.mma(As, Bs, acc);
+    if (k0 + RC_BK < kend) load(k0 + RC_BK);
+    wv.mma(As, Bs, acc);
     __syncthreads();
   }
-  tl.spill(smem, acc);
-  __syncthreads();
-  const int col = tid % BN, rg = tid / BN;
-  const size_t numel = (size_t)a.Cout * a.T * a.Cin;
-  float v[TL::NR];
-#pragma unroll
-  for (int j = 0; j < TL::NR; ++j) v[j] = TL::tile_at(smem, rg + j * TL::RG, col);
-  auto idx = [&](int j) { return ((size_t)(n0 + rg + j * TL::RG) * a.T + tap) * a.Cin + c0 + col; };
-  if (a.nz == 1) {
-#pragma unroll
-    for (int j = 0; j < TL::NR; ++j) a.dw[idx(j)] = a.acc ? a.dw[idx(j)] + v[j] : v[j];
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < TL::NR; ++j) rc_st(a.ws + (size_t)zi * numel + idx(j), v[j]);
+  const size_t numel = (size_t)a.Cout * a.T * a.Cin, rstride = (size_t)a.T * a.Cin;
+  const size_t base = ((size_t)n0 * a.T + tap) * a.Cin + c0;
   unsigned* ticket = a.counter + ((size_t)tap * k.gy + k.by) * k.gx + k.bx;
-  if (!rc_last_workgroup(ticket, (unsigned)a.nz, lastp)) return;
+  if (!rc_acc_reduce(acc, a.ws, ticket, a.nz, zi, numel, base, rstride, 64, wv, lastp)) return;
+  float* d = a.dw + base + wv.col();
 #pragma unroll
-  for (int j = 0; j < TL::NR; ++j) {
-    a.dw[idx(j)] = rc_sum_strided(a.ws + idx(j), numel, a.nz, a.acc ? a.dw[idx(j)] : 0.f);
+  for (int r = 0; r < 16; ++r) {
+    float* p = d + (size_t)wv.row_of(r) * rstride;
+    *p = a.acc ? *p + acc[r] : acc[r];
   }
 }
 
-template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[RcTile<BM, BN, BK>::SMEM];
-  __shared__ float cs[256];
+  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ float cs[128];
   __shared__ int last;
-  rc_wgrad_body<BM, BN, BK>(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs,
-                          &last);
+  rc_wgrad_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -863,45 +906,31 @@ __global__ __launch_bounds__(256) void rc_tables_kernel(int* __restrict__ fwd, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// several independent jobs in ONE launch (a layer's data and weight gradient; a block's first convolution and its
-// projection shortcut): at batch 24 every job alone leaves most of the chip idle and costs a dependent launch
+// several independent jobs in ONE launch (a layer's data and weight gradient + the projection shortcut's; a block's first
+// convolution and its projection): at batch 24 every job alone leaves most of the chip idle and costs a dependent launch
 // ---------------------------------------------------------------------------------------------------------------------
 #define RC_KIND_FWD 0
 #define RC_KIND_DGRAD 1
 #define RC_KIND_WGRAD 2
-#define RC_CFG_L32 0      // 64 x 64 tiles, 32-deep stages
-#define RC_CFG_S128 1     // 32 x 32 tiles, 4 waves split 128-deep stages
-#define RC_CFG_S64 2      // 32 x 32 tiles, 64-deep stages (64-channel reductions)
-struct RcPlan { int kind, cfg, gx, gy, gz; };
-struct RcGroup {
-  RcFwdArgs f[MMVAE_RC_MAX_JOBS];
-  RcDgradArgs d[MMVAE_RC_MAX_JOBS];
-  RcWgradArgs w[MMVAE_RC_MAX_JOBS];
+struct RcPlan { int kind, gx, gy, gz; };
+union RcAny {
+  RcFwdArgs f;
+  RcDgradArgs d;
+  RcWgradArgs w;
+};
+struct RcGroup {            // kernel arguments: < 4 KB
+  RcAny job[MMVAE_RC_MAX_JOBS];
   RcPlan plan[MMVAE_RC_MAX_JOBS];
   int blk0[MMVAE_RC_MAX_JOBS + 1];
   int n;
 };
-
-template <int BM, int BN, int BK>
-__device__ __forceinline__ void rc_job(const RcGroup* __restrict__ g, int kind, int p, const RcBlk k, float* smem, float* cs,
-                                       int* lastp) {
-  if (kind == RC_KIND_FWD) {
-    const RcFwdArgs a = g->f[p];
-    rc_fwd_body<BM, BN, BK>(a, k, smem, cs, lastp);
-  } else if (kind == RC_KIND_DGRAD) {
-    const RcDgradArgs a = g->d[p];
-    rc_dgrad_body<BM, BN, BK>(a, k, smem, cs, lastp);
-  } else {
-    const RcWgradArgs a = g->w[p];
-    rc_wgrad_body<BM, BN, BK>(a, k, smem, cs, lastp);
-  }
-}
+static_assert(sizeof(RcGroup) <= 4000, "rc_group_kernel's arguments must fit the 4 KB kernel-argument segment");
 
 // (the job table is read through the kernel-argument segment pointer: indexing the by-value parameter with the
-// workgroup's job number makes the compiler copy all 2.6 KB of it into scratch -- 2.5 KB per lane, 10 x the run time)
+// workgroup's job number makes the compiler copy all of it into scratch -- 2.5 KB per lane, 10 x the run time)
 __global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
-  __shared__ __attribute__((aligned(16))) float smem[RcTile<32, 32, 128>::SMEM];
-  __shared__ float cs[256];
+  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ float cs[128];
   __shared__ int last;
   const RcGroup* __restrict__ g = (const RcGroup*)__builtin_amdgcn_kernarg_segment_ptr();
   int p = 0;
@@ -911,31 +940,37 @@ __global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
   const int local = blockIdx.x - g->blk0[p];
   const RcPlan pl = g->plan[p];
   const RcBlk k{local % pl.gx, (local / pl.gx) % pl.gy, local / (pl.gx * pl.gy), pl.gx, pl.gy};
-  if (pl.cfg == RC_CFG_L32) rc_job<64, 64, 32>(g, pl.kind, p, k, smem, cs, &last);
-  else if (pl.cfg == RC_CFG_S128) rc_job<32, 32, 128>(g, pl.kind, p, k, smem, cs, &last);
-  else rc_job<32, 32, 64>(g, pl.kind, p, k, smem, cs, &last);
+  if (pl.kind == RC_KIND_FWD) {
+    const RcFwdArgs a = g->job[p].f;
+    rc_fwd_body(a, k, smem, cs, &last);
+  } else if (pl.kind == RC_KIND_DGRAD) {
+    const RcDgradArgs a = g->job[p].d;
+    rc_dgrad_body(a, k, smem, cs, &last);
+  } else {
+    const RcWgradArgs a = g->job[p].w;
+    rc_wgrad_body(a, k, smem, cs, &last);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
-static inline bool rc_small(long tiles64) { return tiles64 < 256; }
-static inline int rc_bk_small(int K) { return K % 128 == 0 ? 128 : 64; }
-
-extern "C" int mmvae_rc_row_tile(int M, int N) {   // rows per statistics partial for an (M, N) output
-  const long t64 = (long)((M + 63) / 64) * (N / 64);
-  return rc_small(t64) ? 32 : 64;
+// workgroups a split job aims for (MMVAE_RC_TARGET_WGS: probe knob)
+static inline long rc_target() {
+  static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS"); return e ? atol(e) : 512L; }();
+  return t;
 }
 
-// split of the reduction (taps x channels) of a forward / data-gradient GEMM with an (M, N) output over blockIdx.z: only
-// the 32 x 32 tiling (few tiles), >= 2 stages per split, enough workgroups for two per CU
+extern "C" int mmvae_rc_row_tile(int M, int N) { return RC_BM; }   // rows per statistics partial
+
+// split of the reduction (T taps x K channels) of a forward / data-gradient GEMM with an (M, N) output over
+// blockIdx.z: >= 2 stages per split, enough workgroups for two per CU
 extern "C" int mmvae_rc_conv_splits(int M, int N, int K, int T) {
-  if (mmvae_rc_row_tile(M, N) == 64) return 1;
-  const long tiles = (long)((M + 31) / 32) * (N / 32);
-  const int nstage = T * (K / rc_bk_small(K));
-  long nz = (768 + tiles - 1) / tiles;
+  const long tiles = (long)((M + 63) / 64) * (N / 64);
+  const int nstage = T * (K / RC_BK);
+  long nz = (rc_target() + tiles - 1) / tiles;
   if (nz > (nstage + 1) / 2) nz = (nstage + 1) / 2;
-  if (nz > 16) nz = 16;
+  if (nz > 32) nz = 32;
   return (int)(nz < 1 ? 1 : nz);
 }
 extern "C" size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T) {
@@ -952,12 +987,11 @@ extern "C" int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, i
   return mmvae_launch_status();
 }
 
-// split of the pixel rows of a weight gradient: enough workgroups to fill the chip, >= 256 rows per split
+// split of the pixel rows of a weight gradient: enough workgroups to fill the chip, >= 128 rows per split
 extern "C" int mmvae_rc_wgrad_splits(int M, int Cin, int Cout, int T) {
-  const long t64 = (long)(Cout / 64) * (Cin / 64) * T;
-  const long tiles = rc_small(t64) ? t64 * 4 : t64;
-  long nz = (768 + tiles - 1) / tiles;
-  const long maxz = (M + 255) / 256;
+  const long tiles = (long)(Cout / 64) * (Cin / 64) * T;
+  long nz = (rc_target() + tiles - 1) / tiles;
+  const long maxz = (M + 127) / 128;
   if (nz > maxz) nz = maxz;
   if (nz > 64) nz = 64;
   return (int)(nz < 1 ? 1 : nz);
@@ -966,40 +1000,44 @@ extern "C" size_t mmvae_rc_wgrad_ws_floats(int M, int Cin, int Cout, int T) {
   const int nz = mmvae_rc_wgrad_splits(M, Cin, Cout, T);
   return nz > 1 ? (size_t)nz * Cout * T * Cin : 0;
 }
-extern "C" size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T) { return (size_t)(Cout / 32) * (Cin / 32) * T; }
+extern "C" size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T) { return (size_t)(Cout / 64) * (Cin / 64) * T; }
 
 static RcStat rc_stat_of(const mmvae_rc_stat_t& s) {
   return RcStat{s.Y, s.mean, s.rstd, s.gamma, s.pqr, s.dgamma, s.dbeta, s.part, s.counter, s.acc, s.eval};
 }
+static bool rc_geom_ok(const mmvae_rc_geom_t& g, int T) {
+  return g.KW >= 1 && T % g.KW == 0 && g.S >= 1 && g.H > 0 && g.W > 0 && g.Ho > 0 && g.Wo > 0 && g.H < 0x4000 && g.W < 0x4000;
+}
+static RcGeom rc_geom_of(const mmvae_rc_geom_t& g) { return RcGeom{g.H, g.W, g.Ho, g.Wo, g.KW, g.S, g.P}; }
 
 static int rc_plan_fwd(const mmvae_rc_fwd_t& j, RcFwdArgs& a, RcPlan& pl) {
-  MMVAE_CHECK_ARG(j.x && j.w && j.y && j.M > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1);
+  MMVAE_CHECK_ARG(j.x && j.w && j.y && j.M > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1 && rc_geom_ok(j.g, j.T));
   MMVAE_CHECK_ARG(j.pre != RC_PRE_BN_RELU || (j.xmean && j.xsc && j.xbeta));
   MMVAE_CHECK_ARG(!j.part || (j.gamma && j.beta && j.mean && j.rstd && j.sc && j.counter));
+  MMVAE_CHECK_ARG((long)j.M * j.Cout < (1L << 31) && (long)j.M * j.Cin * j.g.S * j.g.S < (1L << 31));
   const int nz = mmvae_rc_conv_splits(j.M, j.Cout, j.Cin, j.T);
   MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.tile_ticket));
-  a = RcFwdArgs{j.x, j.w, j.xmean, j.xsc, j.xbeta, j.tbl, j.y, j.ws, j.tile_ticket, j.M, j.Cin, j.Cout, j.T, j.pre, nz,
+  a = RcFwdArgs{j.x, j.w, j.xmean, j.xsc, j.xbeta, j.y, j.ws, j.tile_ticket, j.M, j.Cin, j.Cout, j.T, j.pre, nz, rc_geom_of(j.g),
                 {j.gamma, j.beta, j.run_mean, j.run_var, j.mean, j.rstd, j.sc, j.part, j.counter, j.eps, j.momentum, j.eval}};
-  if (mmvae_rc_row_tile(j.M, j.Cout) == 64) pl = RcPlan{RC_KIND_FWD, RC_CFG_L32, j.Cout / 64, (j.M + 63) / 64, 1};
-  else pl = RcPlan{RC_KIND_FWD, rc_bk_small(j.Cin) == 128 ? RC_CFG_S128 : RC_CFG_S64, j.Cout / 32, (j.M + 31) / 32, nz};
+  pl = RcPlan{RC_KIND_FWD, j.Cout / 64, (j.M + 63) / 64, nz};
   return MMVAE_OK;
 }
 
 static int rc_plan_dgrad(const mmvae_rc_dgrad_t& j, RcDgradArgs& a, RcPlan& pl) {
-  MMVAE_CHECK_ARG(j.G && j.w && j.out && j.M > 0 && j.Min > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1);
+  MMVAE_CHECK_ARG(j.G && j.w && j.out && j.M > 0 && j.Min > 0 && j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T >= 1 &&
+                  rc_geom_ok(j.g, j.T));
   MMVAE_CHECK_ARG((!j.pqr || j.Y) && j.nstat >= 0 && j.nstat <= 2);
   MMVAE_CHECK_ARG(j.mask == RC_MASK_NONE || j.mY);
   MMVAE_CHECK_ARG(j.mask != RC_MASK_BN || (j.mmean && j.msc && j.mbeta));
   const int nz = mmvae_rc_conv_splits(j.Min, j.Cin, j.Cout, j.T);
   MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.tile_ticket));
-  a = RcDgradArgs{j.G, j.Y, j.pqr, j.w, j.tbl, j.add, j.add_tbl, j.mY, j.mmean, j.msc, j.mbeta, j.out, j.ws, j.tile_ticket,
-                  j.M, j.Min, j.Cin, j.Cout, j.T, j.mask, j.nstat, nz, {}};
+  a = RcDgradArgs{j.G, j.Y, j.pqr, j.w, j.add, j.add_tbl, j.mY, j.mmean, j.msc, j.mbeta, j.out, j.ws, j.tile_ticket,
+                  j.M, j.Min, j.Cin, j.Cout, j.T, j.mask, j.nstat, nz, rc_geom_of(j.g), {}};
   for (int t = 0; t < j.nstat; ++t) {
     MMVAE_CHECK_ARG(j.st[t].Y && j.st[t].pqr && j.st[t].part && j.st[t].counter);
     a.st[t] = rc_stat_of(j.st[t]);
   }
-  if (mmvae_rc_row_tile(j.Min, j.Cin) == 64) pl = RcPlan{RC_KIND_DGRAD, RC_CFG_L32, j.Cin / 64, (j.Min + 63) / 64, 1};
-  else pl = RcPlan{RC_KIND_DGRAD, rc_bk_small(j.Cout) == 128 ? RC_CFG_S128 : RC_CFG_S64, j.Cin / 32, (j.Min + 31) / 32, nz};
+  pl = RcPlan{RC_KIND_DGRAD, j.Cin / 64, (j.Min + 63) / 64, nz};
   return MMVAE_OK;
 }
 
@@ -1008,48 +1046,35 @@ static int rc_plan_wgrad(const mmvae_rc_wgrad_t& j, RcWgradArgs& a, RcPlan& pl) 
   MMVAE_CHECK_ARG(j.pre != RC_PRE_BN_RELU || (j.xmean && j.xsc && j.xbeta));
   const int nz = mmvae_rc_wgrad_splits(j.M, j.Cin, j.Cout, j.T);
   MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.counter));
-  const bool small = rc_small((long)(j.Cout / 64) * (j.Cin / 64) * j.T);
-  const int bk = small ? 128 : 32;
   int kper = (j.M + nz - 1) / nz;
-  kper = (kper + bk - 1) / bk * bk;
+  kper = (kper + RC_BK - 1) / RC_BK * RC_BK;
   a = RcWgradArgs{j.G, j.Y, j.pqr, j.x, j.xmean, j.xsc, j.xbeta, j.tbl, j.dw, j.ws, j.counter, j.M, j.Cin, j.Cout, j.T, j.pre,
                   j.accumulate ? 1 : 0, nz, kper};
-  if (!small) pl = RcPlan{RC_KIND_WGRAD, RC_CFG_L32, j.Cin / 64, j.Cout / 64, j.T * nz};
-  else pl = RcPlan{RC_KIND_WGRAD, RC_CFG_S128, j.Cin / 32, j.Cout / 32, j.T * nz};
+  pl = RcPlan{RC_KIND_WGRAD, j.Cin / 64, j.Cout / 64, j.T * nz};
   return MMVAE_OK;
-}
-
-template <class A, class KL, class KS128, class KS64>
-static void rc_launch_one(const A& a, const RcPlan& pl, hipStream_t st, KL kl, KS128 k128, KS64 k64) {
-  const dim3 grid(pl.gx, pl.gy, pl.gz);
-  if (pl.cfg == RC_CFG_L32) hipLaunchKernelGGL(kl, grid, dim3(256), 0, st, a);
-  else if (pl.cfg == RC_CFG_S128) hipLaunchKernelGGL(k128, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k64, grid, dim3(256), 0, st, a);
 }
 
 extern "C" int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(jobs && n >= 1 && n <= MMVAE_RC_MAX_JOBS);
   hipStream_t st = (hipStream_t)stream;
-  static thread_local RcGroup g;     // ~2.5 KB of kernel arguments, assembled in place
+  static thread_local RcGroup g;     // < 4 KB of kernel arguments, assembled in place
   g.n = n;
   g.blk0[0] = 0;
   for (int p = 0; p < n; ++p) {
     int rc;
-    if (jobs[p].kind == RC_KIND_FWD) rc = rc_plan_fwd(jobs[p].f, g.f[p], g.plan[p]);
-    else if (jobs[p].kind == RC_KIND_DGRAD) rc = rc_plan_dgrad(jobs[p].d, g.d[p], g.plan[p]);
-    else if (jobs[p].kind == RC_KIND_WGRAD) rc = rc_plan_wgrad(jobs[p].w, g.w[p], g.plan[p]);
+    if (jobs[p].kind == RC_KIND_FWD) rc = rc_plan_fwd(jobs[p].f, g.job[p].f, g.plan[p]);
+    else if (jobs[p].kind == RC_KIND_DGRAD) rc = rc_plan_dgrad(jobs[p].d, g.job[p].d, g.plan[p]);
+    else if (jobs[p].kind == RC_KIND_WGRAD) rc = rc_plan_wgrad(jobs[p].w, g.job[p].w, g.plan[p]);
     else return MMVAE_ERR_ARG;
     if (rc != MMVAE_OK) return rc;
     g.blk0[p + 1] = g.blk0[p] + g.plan[p].gx * g.plan[p].gy * g.plan[p].gz;
   }
   if (n == 1) {       // a job alone keeps its own kernel (and its name in a profile)
     const RcPlan& pl = g.plan[0];
-    if (pl.kind == RC_KIND_FWD)
-      rc_launch_one(g.f[0], pl, st, rc_fwd_kernel<64, 64, 32>, rc_fwd_kernel<32, 32, 128>, rc_fwd_kernel<32, 32, 64>);
-    else if (pl.kind == RC_KIND_DGRAD)
-      rc_launch_one(g.d[0], pl, st, rc_dgrad_kernel<64, 64, 32>, rc_dgrad_kernel<32, 32, 128>, rc_dgrad_kernel<32, 32, 64>);
-    else
-      rc_launch_one(g.w[0], pl, st, rc_wgrad_kernel<64, 64, 32>, rc_wgrad_kernel<32, 32, 128>, rc_wgrad_kernel<32, 32, 64>);
+    const dim3 grid(pl.gx, pl.gy, pl.gz);
+    if (pl.kind == RC_KIND_FWD) hipLaunchKernelGGL(rc_fwd_kernel, grid, dim3(256), 0, st, g.job[0].f);
+    else if (pl.kind == RC_KIND_DGRAD) hipLaunchKernelGGL(rc_dgrad_kernel, grid, dim3(256), 0, st, g.job[0].d);
+    else hipLaunchKernelGGL(rc_wgrad_kernel, grid, dim3(256), 0, st, g.job[0].w);
     return mmvae_launch_status();
   }
   hipLaunchKernelGGL(rc_group_kernel, dim3(g.blk0[n]), dim3(256), 0, st, g);

@@ -64,17 +64,23 @@ class RcStat(ctypes.Structure):      # mmvae_rc_stat_t: a BatchNorm whose backwa
                 ("part", c_p), ("counter", c_p), ("acc", c_i), ("eval", c_i)]
 
 
+class RcGeom(ctypes.Structure):      # mmvae_rc_geom_t
+    _fields_ = [("H", c_i), ("W", c_i), ("Ho", c_i), ("Wo", c_i), ("KW", c_i), ("S", c_i), ("P", c_i)]
+
+
 class RcFwd(ctypes.Structure):       # mmvae_rc_fwd_t
-    _fields_ = [("x", c_p), ("w", c_p), ("xmean", c_p), ("xsc", c_p), ("xbeta", c_p), ("tbl", c_p), ("y", c_p), ("ws", c_p),
-                ("tile_ticket", c_p), ("M", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("pre", c_i), ("gamma", c_p),
+    _fields_ = [("x", c_p), ("w", c_p), ("xmean", c_p), ("xsc", c_p), ("xbeta", c_p), ("y", c_p), ("ws", c_p),
+                ("tile_ticket", c_p), ("M", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("pre", c_i), ("g", RcGeom),
+                ("gamma", c_p),
                 ("beta", c_p), ("run_mean", c_p), ("run_var", c_p), ("mean", c_p), ("rstd", c_p), ("sc", c_p), ("part", c_p),
                 ("counter", c_p), ("eps", c_f), ("momentum", c_f), ("eval", c_i)]
 
 
 class RcDgrad(ctypes.Structure):     # mmvae_rc_dgrad_t
-    _fields_ = [("G", c_p), ("Y", c_p), ("pqr", c_p), ("w", c_p), ("tbl", c_p), ("add", c_p), ("add_tbl", c_p), ("mask", c_i),
+    _fields_ = [("G", c_p), ("Y", c_p), ("pqr", c_p), ("w", c_p), ("add", c_p), ("add_tbl", c_p), ("mask", c_i),
                 ("mY", c_p), ("mmean", c_p), ("msc", c_p), ("mbeta", c_p), ("out", c_p), ("ws", c_p), ("tile_ticket", c_p),
-                ("M", c_i), ("Min", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("nstat", c_i), ("st", RcStat * 2)]
+                ("M", c_i), ("Min", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("nstat", c_i), ("g", RcGeom),
+                ("st", RcStat * 2)]
 
 
 class RcWgrad(ctypes.Structure):     # mmvae_rc_wgrad_t
@@ -83,7 +89,7 @@ class RcWgrad(ctypes.Structure):     # mmvae_rc_wgrad_t
                 ("accumulate", c_i)]
 
 
-RC_MAX_JOBS = 4
+RC_MAX_JOBS = 8
 
 
 class RcJob(ctypes.Structure):       # mmvae_rc_job_t

@@ -128,6 +128,14 @@ class GradReducer:
         cls._st(device)[1]["used"].add(stream)
 
     @classmethod
+    def ensure_flush(cls, device):
+        """queue the end-of-backward flush (side-stream join) even when no split partials were registered"""
+        _, st = cls._st(device)
+        if not st["armed"]:
+            st["armed"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: cls.flush(device))
+
+    @classmethod
     def queue(cls, device, launch, *keep):
         """postpone a weight-gradient launch (nothing but the final reduction reads its output) to the next batch
         point: one fork for many launches instead of one per launch"""

@@ -10,6 +10,7 @@ Launches per bottleneck: forward 3 convolutions (+1 projection) + 1 shortcut add
 3 (+1) weight gradients; the backward statistics of a block's last BatchNorm(s) come out of the NEXT block's first data
 gradient (stand-alone kernel only behind the pooling layer)."""
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -58,13 +59,12 @@ class Unit:
         b = self._buf.get(M)
         if b is None:
             C = self.bn.weight.shape[0]
-            rt = H.lib().mmvae_rc_row_tile(M, C)
             f = lambda n: torch.empty(n, device=device)
-            R = (M + 31) // 32                       # row tiles at most (32-row tiling), + one level-1 pair per 16
+            R = (M + 63) // 64                       # row tiles, + one level-1 pair per 16 of them
             b = self._buf[M] = {"mean": f(C), "rstd": f(C), "sc": f(C), "pqr": f(3 * C),
                                 "part": f((R + R // 16 + 2) * C * 2), "part_b": f((R + R // 16 + 2) * C * 2),
-                                "counter": torch.zeros((C // 32) * (2 + R // 16), dtype=torch.int32, device=device),
-                                "tile_tickets": torch.zeros(R * (C // 32), dtype=torch.int32, device=device)}
+                                "counter": torch.zeros((C // 64) * (2 + R // 16), dtype=torch.int32, device=device),
+                                "tile_tickets": torch.zeros(R * (C // 64), dtype=torch.int32, device=device)}
             w = self.conv.weight
             Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
             self._buf.setdefault("tickets", torch.zeros(H.lib().mmvae_rc_wgrad_tickets(Cin, Cout, T), dtype=torch.int32,
@@ -86,7 +86,7 @@ class Unit:
         key = ("dt", rows)
         t = self._buf.get(key)
         if t is None:
-            t = self._buf[key] = torch.zeros((rows + 31) // 32 * (self.conv.weight.shape[1] // 32), dtype=torch.int32,
+            t = self._buf[key] = torch.zeros((rows + 63) // 64 * (self.conv.weight.shape[1] // 64), dtype=torch.int32,
                                              device=device)
         return t
 
@@ -104,6 +104,14 @@ class Unit:
 KIND_FWD, KIND_DGRAD, KIND_WGRAD = 0, 1, 2
 
 
+def geom(Hh, W, K, S, P):
+    """mmvae_rc_geom_t of a K x K / stride S / padding P convolution over (H, W) maps"""
+    return H.RcGeom(Hh, W, (Hh + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1, K, S, P)
+
+
+IDENT = (1, 1, 1, 1, 0)     # (H, W, K, S, P) of a row-to-row (1x1, stride 1) job: the kernels skip the pixel arithmetic
+
+
 def launch(*jobs):
     """independent jobs (H.RcJob) in ONE launch"""
     arr = (H.RcJob * len(jobs))(*jobs)
@@ -114,8 +122,9 @@ def _p(t):
     return H.ptr(t)
 
 
-def fwd_job(u, x, M, pre, xb, tbl, eval_mode):
-    """(job, raw output (M, Cout), buffers) of unit u on pre(x); xb = (producer buffers, producer beta) for PRE_BN_RELU"""
+def fwd_job(u, x, M, pre, xb, g, eval_mode):
+    """(job, raw output (M, Cout), buffers) of unit u on pre(x); xb = (producer buffers, producer beta) for PRE_BN_RELU;
+    g: (H, W, K, S, P) of the input maps"""
     w = u.conv.weight
     Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     b = u.buffers(M, x.device)
@@ -124,7 +133,7 @@ def fwd_job(u, x, M, pre, xb, tbl, eval_mode):
     j = H.RcJob()
     j.kind = KIND_FWD
     f = j.f
-    f.x, f.w, f.tbl, f.y = _p(x), channels_last_ptr(w), _p(tbl), _p(y)
+    f.x, f.w, f.y, f.g = _p(x), channels_last_ptr(w), _p(y), geom(*g)
     if pre == PRE_BN_RELU:
         f.xmean, f.xsc, f.xbeta = _p(xb[0]["mean"]), _p(xb[0]["sc"]), _p(xb[1])
     f.ws, f.tile_ticket = _p(u.conv_ws(M, Cout, Cin, T, x.device)), _p(b["tile_tickets"])
@@ -135,8 +144,8 @@ def fwd_job(u, x, M, pre, xb, tbl, eval_mode):
     return j, y, b
 
 
-def _fwd(u, x, Min, M, pre, xb, tbl, eval_mode):
-    j, y, b = fwd_job(u, x, M, pre, xb, tbl, eval_mode)
+def _fwd(u, x, Min, M, pre, xb, g, eval_mode):
+    j, y, b = fwd_job(u, x, M, pre, xb, g, eval_mode)
     launch(j)
     return y, b
 
@@ -150,14 +159,14 @@ def _stat(u, b, Y, eval_mode, grads):
                     _p(b["counter"]), int(ag), int(eval_mode))
 
 
-def dgrad_job(u, b, G, Y, tbl, add, add_tbl, mask, mY, mb, out_rows, stats, with_pqr=True):
+def dgrad_job(u, b, G, Y, g, add, add_tbl, mask, mY, mb, out_rows, stats, with_pqr=True):
     w = u.conv.weight
     Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     out = torch.empty(out_rows, Cin, device=G.device)
     j = H.RcJob()
     j.kind = KIND_DGRAD
     d = j.d
-    d.G, d.Y, d.pqr, d.w, d.tbl = _p(G), _p(Y), _p(b["pqr"]) if with_pqr else None, channels_last_ptr(w), _p(tbl)
+    d.G, d.Y, d.pqr, d.w, d.g = _p(G), _p(Y), _p(b["pqr"]) if with_pqr else None, channels_last_ptr(w), geom(*g)
     d.add, d.add_tbl, d.mask, d.mY = _p(add), _p(add_tbl), mask, _p(mY)
     if mask == MASK_BN:
         d.mmean, d.msc, d.mbeta = _p(mb[0]["mean"]), _p(mb[0]["sc"]), _p(mb[1])
@@ -168,8 +177,8 @@ def dgrad_job(u, b, G, Y, tbl, add, add_tbl, mask, mY, mb, out_rows, stats, with
     return j, out
 
 
-def _dgrad(u, b, G, Y, tbl, add, mask, mY, mb, out_rows, stats, with_pqr=True):
-    j, out = dgrad_job(u, b, G, Y, tbl, add, None, mask, mY, mb, out_rows, stats, with_pqr)
+def _dgrad(u, b, G, Y, g, add, mask, mY, mb, out_rows, stats, with_pqr=True):
+    j, out = dgrad_job(u, b, G, Y, g, add, None, mask, mY, mb, out_rows, stats, with_pqr)
     launch(j)
     return out
 
@@ -233,21 +242,20 @@ class BottleneckStack(Function):
             Ho, Wo = (Hh - 1) // S_ + 1, (W - 1) // S_ + 1
             M2 = B * Ho * Wo
             pre1 = PRE_RELU if act == H.ACT_RELU else PRE_NONE
-            t3 = tables(dev, B, Hh, W, 3, S_, 1)
-            t1 = tables(dev, B, Hh, W, 1, S_, 0) if S_ != 1 else (None, None)
+            g3, g1 = (Hh, W, 3, S_, 1), (Hh, W, 1, S_, 0)
             ev = not training
-            j1, Y1, b1 = fwd_job(blk.u1, s, Min, pre1, None, None, ev)
+            j1, Y1, b1 = fwd_job(blk.u1, s, Min, pre1, None, IDENT, ev)
             Yd = bd = None
             if blk.ud is not None:      # the projection shortcut reads the same input: one launch with conv1
-                jd, Yd, bd = fwd_job(blk.ud, s, M2, pre1, None, t1[0], ev)
+                jd, Yd, bd = fwd_job(blk.ud, s, M2, pre1, None, g1, ev)
                 launch(j1, jd)
             else:
                 assert S_ == 1
                 launch(j1)
             _tap(blk.u1.bn, Y1, b1)
-            Y2, b2 = _fwd(blk.u2, Y1, Min, M2, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], ev)
+            Y2, b2 = _fwd(blk.u2, Y1, Min, M2, PRE_BN_RELU, (b1, blk.u1.bn.bias), g3, ev)
             _tap(blk.u2.bn, Y2, b2)
-            Y3, b3 = _fwd(blk.u3, Y2, M2, M2, PRE_BN_RELU, (b2, blk.u2.bn.bias), None, ev)
+            Y3, b3 = _fwd(blk.u3, Y2, M2, M2, PRE_BN_RELU, (b2, blk.u2.bn.bias), IDENT, ev)
             out = torch.empty(M2, Y3.shape[1], device=dev)
             R = Yd if Yd is not None else s
             ops._call("mmvae_rc_blockout", H.ptr(Y3), H.ptr(b3["mean"]), H.ptr(b3["sc"]), H.ptr(blk.u3.bn.bias), H.ptr(R),
@@ -274,6 +282,37 @@ class BottleneckStack(Function):
                 t = torch.empty_like(p)
                 grads[p] = (t, 0)
                 ret[p] = t
+        # Weight gradients ride in the launch of the data gradient that shares their inputs (default).  MMVAE_RC_WGRAD=side:
+        # queued and sent in batches of up to 8 jobs per launch on a side stream beside the chain of data gradients --
+        # measured SLOWER (4.55 against 4.2 ms/step at batch 24: the bulk workgroups take the CU slots the chain's short
+        # latency-bound kernels need; giving the chain's stream a higher priority made the graph 3x slower).
+        inline = os.environ.get("MMVAE_RC_WGRAD", "inline") != "side"
+        side = None
+        if not inline and ops.StreamPlan.enabled and ops.GradReducer.enabled:
+            side = ops.StreamPlan.get("rc_wgrad", dev)
+        cur = torch.cuda.current_stream(dev)
+        pending, held = [], []
+        nb = H.RC_MAX_JOBS
+
+        def take_wgrads():
+            """inline mode: the queued weight-gradient jobs join the next data-gradient launch"""
+            if not inline:
+                return []
+            out = pending[:]
+            del pending[:]
+            return out
+
+        def flush_wgrads(force=False):
+            while len(pending) >= nb or (force and pending):
+                batch = pending[:nb]
+                del pending[:nb]
+                if side is None:
+                    launch(*batch)
+                else:
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        launch(*batch)
+
         ready = False          # the statistics of this block's bn3 (/ projection bn) already came out of the next block
         for bi in range(len(blocks) - 1, -1, -1):
             blk = blocks[bi]
@@ -282,8 +321,9 @@ class BottleneckStack(Function):
             b1, b2, b3 = blk.u1.buffers(Min, dev), blk.u2.buffers(M2, dev), blk.u3.buffers(M2, dev)
             bd = blk.ud.buffers(M2, dev) if blk.ud else None
             S_ = blk.stride
-            t3 = tables(dev, B, Hh, W, 3, S_, 1)
+            t3 = tables(dev, B, Hh, W, 3, S_, 1)          # the weight gradients' row tables
             t1 = tables(dev, B, Hh, W, 1, S_, 0) if S_ != 1 else (None, None)
+            g3 = (Hh, W, 3, S_, 1)
             pre1 = PRE_RELU if act == H.ACT_RELU else PRE_NONE
             if not ready:
                 st3 = _stat(blk.u3, b3, Y3, ev, grads)
@@ -291,28 +331,28 @@ class BottleneckStack(Function):
                 if blk.ud:
                     std = _stat(blk.ud, bd, Yd, ev, grads)
                     ops._call("mmvae_rc_bn_bwd_stats", H.ptr(G), ctypes.byref(std), M2, Yd.shape[1], H.stream())
-            # one launch: conv3's data gradient (-> gradient of bn2's output: ReLU mask from Y2, + bn2's statistics) and
-            # weight gradient, and the projection shortcut's data gradient (on ITS output rows; conv1's epilogue adds it
-            # through the stride table) and weight gradient -- all four only need G
-            jobs = []
-            j, G2 = dgrad_job(blk.u3, b3, G, Y3, None, None, None, MASK_BN, Y2, (b2, blk.u2.bn.bias), M2,
-                              [_stat(blk.u2, b2, Y2, ev, grads)])
-            jobs += [j, wgrad_job(blk.u3, b3, G, Y3, Y2, PRE_BN_RELU, (b2, blk.u2.bn.bias), None, grads)]
             need_in = bi > 0 or ctx.needs_input_grad[0]
+            # conv3's data gradient (-> gradient of bn2's output: ReLU mask from Y2, + bn2's statistics) and the projection
+            # shortcut's (on ITS output rows; conv1's epilogue adds it through the stride table): both only need G
+            j, G2 = dgrad_job(blk.u3, b3, G, Y3, IDENT, None, None, MASK_BN, Y2, (b2, blk.u2.bn.bias), M2,
+                              [_stat(blk.u2, b2, Y2, ev, grads)])
+            jobs = [j]
+            pending.append(wgrad_job(blk.u3, b3, G, Y3, Y2, PRE_BN_RELU, (b2, blk.u2.bn.bias), None, grads))
             add = add_tbl = None
             if blk.ud:
                 if need_in:
-                    j, add = dgrad_job(blk.ud, bd, G, Yd, None, None, None, MASK_NONE, None, None, M2, [])
+                    j, add = dgrad_job(blk.ud, bd, G, Yd, IDENT, None, None, MASK_NONE, None, None, M2, [])
                     add_tbl = t1[1][0] if S_ != 1 else None
                     jobs.append(j)
-                jobs.append(wgrad_job(blk.ud, bd, G, Yd, s, pre1, None, t1[0], grads))
+                pending.append(wgrad_job(blk.ud, bd, G, Yd, s, pre1, None, t1[0], grads))
             else:
                 add = G
-            launch(*jobs)
-            # conv2 (3x3, stride): data gradient on the rows of the block's input resolution (+ bn1's statistics), weights
-            j, G1 = dgrad_job(blk.u2, b2, G2, Y2, t3[1], None, None, MASK_BN, Y1, (b1, blk.u1.bn.bias), Min,
+            launch(*jobs, *take_wgrads())
+            # conv2 (3x3, stride): data gradient on the rows of the block's input resolution (+ bn1's statistics)
+            j, G1 = dgrad_job(blk.u2, b2, G2, Y2, g3, None, None, MASK_BN, Y1, (b1, blk.u1.bn.bias), Min,
                               [_stat(blk.u1, b1, Y1, ev, grads)])
-            launch(j, wgrad_job(blk.u2, b2, G2, Y2, Y1, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], grads))
+            pending.append(wgrad_job(blk.u2, b2, G2, Y2, Y1, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], grads))
+            launch(j, *take_wgrads())
             # conv1: + shortcut, ReLU mask of the block input, and the statistics of the PREVIOUS block's last BatchNorms
             stats = []
             if bi > 0:
@@ -321,13 +361,23 @@ class BottleneckStack(Function):
                 stats.append(_stat(pb.u3, pb.u3.buffers(Min, dev), pY3, ev, grads))
                 if pb.ud:
                     stats.append(_stat(pb.ud, pb.ud.buffers(Min, dev), pYd, ev, grads))
-            jobs = [wgrad_job(blk.u1, b1, G1, Y1, s, pre1, None, None, grads)]
-            if need_in:
-                j, G = dgrad_job(blk.u1, b1, G1, Y1, None, add, add_tbl, MASK_RAW if act == H.ACT_RELU else MASK_NONE, s, None,
+            held += [G, G1, G2, add]
+            pending.append(wgrad_job(blk.u1, b1, G1, Y1, s, pre1, None, None, grads))   # (reads conv1's p, q, r: bn1's
+            if need_in:                                                                 # statistics came with conv2's dgrad)
+                j, G = dgrad_job(blk.u1, b1, G1, Y1, IDENT, add, add_tbl, MASK_RAW if act == H.ACT_RELU else MASK_NONE, s, None,
                                  Min, stats)
-                jobs.insert(0, j)
-            launch(*jobs)
+                launch(j, *take_wgrads())
+            flush_wgrads()
             ready = True
+        flush_wgrads(force=True)
+        if side is not None and ret:
+            cur.wait_stream(side)       # gradients handed back to autograd are read as soon as this function returns
+        elif side is not None:
+            # the side stream's kernels read the saved activations and the gradients of this pass: hold them, and have the
+            # end-of-backward fold join the stream (GradReducer.flush)
+            ops.GradReducer.note_stream(dev, side)
+            ops.GradReducer.keep(dev, *held, *[t for sv in saved for t in sv[:5]])
+            ops.GradReducer.ensure_flush(dev)
         ctx.saved = None
         return (G if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + \
             tuple(ret.get(p) for p in ctx.params)

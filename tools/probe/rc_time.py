@@ -57,26 +57,27 @@ for name, Hh, Cin, Cout, k, st in SHAPES:
     Ho = (Hh - 1) // st + 1
     Min, M = B * Hh * Hh, B * Ho * Ho
     tf, tb = (rconv.tables(DEV, B, Hh, Hh, k, st, k // 2) if (k > 1 or st > 1) else (None, None))
+    gm = (Hh, Hh, k, st, k // 2) if (k > 1 or st > 1) else rconv.IDENT
     x = torch.randn(Min, Cin, device=DEV)
     bp = up.buffers(Min, DEV)
     bp["mean"].zero_(); bp["sc"].fill_(1.0); bp["rstd"].fill_(1.0)
-    y, b = rconv._fwd(u, x, Min, M, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, False)
+    y, b = rconv._fwd(u, x, Min, M, rconv.PRE_BN_RELU, (bp, bnp.bias), gm, False)
     G = torch.randn(M, Cout, device=DEV)
     grads = {p: (torch.zeros_like(p), 1) for p in (conv.weight, bn.weight, bn.bias, bnp.weight, bnp.bias)}
     stt = rconv._stat(u, b, y, False, grads)
     H.check(H.lib().mmvae_rc_bn_bwd_stats(H.ptr(G), ctypes.byref(stt), M, Cout, H.stream()), "stats")
-    t_f = timeit(lambda: rconv._fwd(u, x, Min, M, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, False))
+    t_f = timeit(lambda: rconv._fwd(u, x, Min, M, rconv.PRE_BN_RELU, (bp, bnp.bias), gm, False))
     def fwd_nostat():
-        j, _, _ = rconv.fwd_job(u, x, M, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, False)
+        j, _, _ = rconv.fwd_job(u, x, M, rconv.PRE_BN_RELU, (bp, bnp.bias), gm, False)
         j.f.part = None
         rconv.launch(j)
     t_n = timeit(fwd_nostat)
 
     def pair():
-        jd, _ = rconv.dgrad_job(u, b, G, y, tb, None, None, rconv.MASK_BN, x, (bp, bnp.bias), Min, [rconv._stat(up, bp, x, False, grads)])
+        jd, _ = rconv.dgrad_job(u, b, G, y, gm, None, None, rconv.MASK_BN, x, (bp, bnp.bias), Min, [rconv._stat(up, bp, x, False, grads)])
         rconv.launch(jd, rconv.wgrad_job(u, b, G, y, x, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, grads))
     t_p = timeit(pair)
-    t_d = timeit(lambda: rconv._dgrad(u, b, G, y, tb, None, rconv.MASK_BN, x, (bp, bnp.bias), Min,
+    t_d = timeit(lambda: rconv._dgrad(u, b, G, y, gm, None, rconv.MASK_BN, x, (bp, bnp.bias), Min,
                                       [rconv._stat(up, bp, x, False, grads)]))
     t_w = timeit(lambda: rconv._wgrad(u, b, G, y, x, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, grads))
     fl = 2.0 * M * Cin * Cout * k * k
