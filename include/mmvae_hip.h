@@ -546,6 +546,10 @@ typedef struct {
 int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t stream);
 /* the same statistics for a gradient produced elsewhere (pooling backward) */
 int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream);
+/* ... and for the gradient of AdaptiveAvgPool2d(1) on relu(x) (torchvision resnet50.avgpool behind the last bottleneck),
+ * made in the same launch: G (B*HW, C) = dy[b, c] / HW * (x > 0) */
+int mmvae_rc_pool_bwd_stats(const float* dy, const float* x, float* G, const mmvae_rc_stat_t* st, int B, int HW, int C,
+                            mmvae_stream_t stream);
 int mmvae_rc_wgrad_splits(int M, int Cin, int Cout, int T);
 size_t mmvae_rc_wgrad_ws_floats(int M, int Cin, int Cout, int T);
 size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T);

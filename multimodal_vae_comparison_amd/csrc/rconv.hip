@@ -8,7 +8,7 @@
 // arithmetic on the row's (b, h, w), zero for the padding).
 //
 // One tiling: workgroup = 4 wavefronts = a 64 x 64 output tile (2 x 2 waves of 32 x 32 on v_mfma_f32_32x32x2_f32), 32-deep
-// stages staged global -> registers -> LDS [k][row] (pitch 65), the next stage's loads in flight under the MFMAs.  Jobs
+// stages (RC_BK) staged global -> registers -> LDS [k][row] (pitch 65), the next stage's loads in flight under the MFMAs.  Jobs
 // with few tiles split their reduction (taps x channels, or the pixel rows of a weight gradient) over blockIdx.z; the
 // partial accumulators go to a workspace in the MFMA register layout and the last workgroup of a tile sums them in a
 // fixed order (deterministic; no atomics on data) and runs the epilogue.
@@ -57,7 +57,11 @@ extern "C" int mmvae_rc_probe(long long* buf) {
 #define RC_MASK_RAW 1
 #define RC_MASK_BN 2
 #define RC_BM 64
+#ifndef RC_BK
 #define RC_BK 32
+#endif
+#define RC_NS (RC_BK / 4)      // staging slots of a thread per 64 x RC_BK operand tile
+#define RC_RSTEP (256 / RC_BK) // rows between a thread's slots when it walks a k-contiguous source
 #define RC_AP 65      // LDS row pitch of a staged operand ([k][row]; odd: conflict-free transposing stores and fragment reads)
 
 __device__ __forceinline__ float rc_bn(float y, float mean, float sc, float beta) { return fmaf(y - mean, sc, beta); }
@@ -114,14 +118,14 @@ template <bool KMAJOR>
 struct RcStg {
   int rl, kl;
   __device__ __forceinline__ void init(int tid) {
-    if (KMAJOR) { kl = tid & 31; rl = tid >> 5; } else { rl = tid & 63; kl = tid >> 6; }
+    if (KMAJOR) { kl = tid % RC_BK; rl = tid / RC_BK; } else { rl = tid & 63; kl = tid >> 6; }
   }
-  __device__ __forceinline__ int row(int i) const { return KMAJOR ? rl + i * 8 : rl; }
+  __device__ __forceinline__ int row(int i) const { return KMAJOR ? rl + i * RC_RSTEP : rl; }
   __device__ __forceinline__ int kk(int i) const { return KMAJOR ? kl : kl + i * 4; }
-  __device__ __forceinline__ void store(float* __restrict__ S, const float (&v)[8]) const {
+  __device__ __forceinline__ void store(float* __restrict__ S, const float (&v)[RC_NS]) const {
     float* d = S + kl * RC_AP + rl;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d[KMAJOR ? i * 8 : i * 4 * RC_AP] = v[i];
+    for (int i = 0; i < RC_NS; ++i) d[KMAJOR ? i * RC_RSTEP : i * 4 * RC_AP] = v[i];
   }
 };
 
@@ -288,10 +292,10 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   sb.init(tid);
   // geometry of this thread's 8 rows: pix = row of (b, oh S - P, ow S - P) (may lie outside), hw = (oh S - P, ow S - P)
   const bool ident = a.T == 1 && a.g.S == 1;
-  int pix[8], hw[8], src[8], wrow[8];
-  float ra[8], rb[8];
+  int pix[RC_NS], hw[RC_NS], src[RC_NS], wrow[RC_NS];
+  float ra[RC_NS], rb[RC_NS];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < RC_NS; ++i) {
     const int r = m0 + sa.row(i);
     wrow[i] = (n0 + sb.row(i)) * a.T;
     if (ident) {
@@ -316,7 +320,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     if (newtap) {
       const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < RC_NS; ++i) {
         if (ident) {
           src[i] = pix[i];
         } else {
@@ -331,20 +335,20 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     if (a.pre == RC_PRE_BN_RELU) { pm = a.xmean[c]; ps = a.xsc[c]; pb = a.xbeta[c]; }
     oka = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const bool ok = src[i] >= 0;
       oka |= (ok ? 1u : 0u) << i;
       ra[i] = a.x[ok ? (size_t)src[i] * a.Cin + c : 0];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = a.w[(size_t)(wrow[i] + ltap) * a.Cin + lc0 + sb.kl];
+    for (int i = 0; i < RC_NS; ++i) rb[i] = a.w[(size_t)(wrow[i] + ltap) * a.Cin + lc0 + sb.kl];
     lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
   auto store = [&]() {
-    float va[8];
+    float va[RC_NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       float v = ra[i];
       if (a.pre == RC_PRE_BN_RELU) v = fmaxf(rc_bn(v, pm, ps, pb), 0.f);
       else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
@@ -521,10 +525,10 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   // this thread's 8 input pixels: bh = (b, ih + P, iw + P) packed; the output pixel that reads pixel (ih, iw) through
   // tap (kh, kw) is ((ih + P - kh) / S, (iw + P - kw) / S) when both divide and lie inside
   const bool ident = a.T == 1 && a.g.S == 1;
-  int pb_[8], hw[8], src[8];
-  float rg_[8], ry[8], rb[8];
+  int pb_[RC_NS], hw[RC_NS], src[RC_NS];
+  float rg_[RC_NS], ry[RC_NS], rb[RC_NS];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < RC_NS; ++i) {
     const int r = m0 + sa.row(i);
     if (ident) {
       pb_[i] = r < a.Min ? r : -1;
@@ -546,7 +550,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
     if (newtap) {
       const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < RC_NS; ++i) {
         if (ident) {
           src[i] = pb_[i];
         } else {
@@ -572,7 +576,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
     if (a.pqr) { pp = a.pqr[kc]; pq = a.pqr[a.Cout + kc]; pr = a.pqr[2 * a.Cout + kc]; }
     oka = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const bool ok = src[i] >= 0;
       oka |= (ok ? 1u : 0u) << i;
       const size_t o = ok ? (size_t)src[i] * a.Cout + kc : 0;
@@ -580,14 +584,14 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       ry[i] = a.pqr ? a.Y[o] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + ltap) * a.Cin + n0 + sb.rl];
+    for (int i = 0; i < RC_NS; ++i) rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + ltap) * a.Cin + n0 + sb.rl];
     lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
   auto store = [&]() {
-    float va[8];
+    float va[RC_NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
       va[i] = (oka >> i & 1u) ? v : 0.f;
     }
@@ -689,7 +693,11 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
 
 // stand-alone statistics of a BatchNorm backward whose G was produced elsewhere (pooling backward, tests):
 // grid (C / 64, row tiles of 64)
-__global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ G, RcStat st, int M, int C) {
+// With dyp != NULL the gradient is made here as well: the backward of AdaptiveAvgPool2d(1) on relu(xs),
+// G[(b, hw), c] = dyp[b, c] / HW * (xs > 0), stored to Gout (the stack's last BatchNorm sits right under the pooling).
+__global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ G, RcStat st, int M, int C,
+                                                      const float* __restrict__ dyp, const float* __restrict__ xs,
+                                                      float* __restrict__ Gout, int HW) {
   __shared__ __attribute__((aligned(16))) float smem[256 * 3 * 2];
   __shared__ float cs[256];
   __shared__ int last;
@@ -700,7 +708,13 @@ __global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ 
 #pragma unroll 4
   for (int row = rg; row < cnt; row += 4) {
     const size_t o = (size_t)(m0 + row) * C + c;
-    const float g = G[o];
+    float g;
+    if (dyp) {
+      g = xs[o] > 0.f ? dyp[(size_t)((m0 + row) / HW) * C + c] * (1.0f / (float)HW) : 0.f;
+      Gout[o] = g;
+    } else {
+      g = G[o];
+    }
     s1 += g;
     s2 = fmaf(g, (st.Y[o] - tm) * tr, s2);
   }
@@ -751,8 +765,8 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   RcStg<false> sa, sb;
   sa.init(tid);
   sb.init(tid);
-  float rg_[8], ry[8], rb[8];
-  int sr[8];              // source rows of the stage being loaded next (one stage ahead of the data)
+  float rg_[RC_NS], ry[RC_NS], rb[RC_NS];
+  int sr[RC_NS];              // source rows of the stage being loaded next (one stage ahead of the data)
   unsigned oka = 0, okb = 0;
   const int n = n0 + sa.rl, c = c0 + sb.rl;
   float pp = 1.f, pq = 0.f, pr = 0.f, pm = 0.f, ps = 1.f, pb = 0.f;
@@ -761,7 +775,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   const int* tb = a.tbl ? a.tbl + (size_t)tap * a.M : nullptr;
   auto rows = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const int m = k0 + sb.kk(i);
       sr[i] = m < kend ? (tb ? tb[m] : m) : -1;
     }
@@ -770,7 +784,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
     oka = 0;
     okb = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const int m = k0 + sa.kk(i);
       const bool ok = m < kend;
       oka |= (ok ? 1u : 0u) << i;
@@ -779,7 +793,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
       ry[i] = a.pqr ? a.Y[o] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const bool ok = sr[i] >= 0;
       okb |= (ok ? 1u : 0u) << i;
       rb[i] = a.x[ok ? (size_t)sr[i] * a.Cin + c : 0];
@@ -787,14 +801,14 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
     if (k0 + RC_BK < kend) rows(k0 + RC_BK);      // the table entries of the stage after: not a dependent round trip then
   };
   auto store = [&]() {
-    float va[8], vb[8];
+    float va[RC_NS], vb[RC_NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
       va[i] = (oka >> i & 1u) ? v : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RC_NS; ++i) {
       float v = rb[i];
       if (a.pre == RC_PRE_BN_RELU) v = fmaxf(rc_bn(v, pm, ps, pb), 0.f);
       else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
@@ -955,9 +969,16 @@ __global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
 // ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
-// workgroups a split job aims for (MMVAE_RC_TARGET_WGS: probe knob)
+// workgroups a split job aims for (MMVAE_RC_TARGET_WGS / _W: probe knobs; measured on the shipped CdSprites+ config at
+// batch 24: 128 / 256 / 512 for the forward and data-gradient jobs 4.48 / 4.18 / 4.22 ms per step, 64 / 128 / 256 / 512+
+// for the weight gradients 4.69 / 4.30 / 4.20 / 4.18)
 static inline long rc_target() {
-  static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS"); return e ? atol(e) : 512L; }();
+  static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS"); return e ? atol(e) : 256L; }();
+  return t;
+}
+
+static inline long rc_target_w() {
+  static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS_W"); return e ? atol(e) : 512L; }();
   return t;
 }
 
@@ -990,7 +1011,7 @@ extern "C" int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, i
 // split of the pixel rows of a weight gradient: enough workgroups to fill the chip, >= 128 rows per split
 extern "C" int mmvae_rc_wgrad_splits(int M, int Cin, int Cout, int T) {
   const long tiles = (long)(Cout / 64) * (Cin / 64) * T;
-  long nz = (rc_target() + tiles - 1) / tiles;
+  long nz = (rc_target_w() + tiles - 1) / tiles;
   const long maxz = (M + 127) / 128;
   if (nz > maxz) nz = maxz;
   if (nz > 64) nz = 64;
@@ -1083,7 +1104,17 @@ extern "C" int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t
 
 extern "C" int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(G && st && st->Y && st->pqr && st->part && st->counter && M > 0 && C % 64 == 0);
-  hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, rc_stat_of(*st), M, C);
+  hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, rc_stat_of(*st), M, C,
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 1);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_rc_pool_bwd_stats(const float* dy, const float* x, float* G, const mmvae_rc_stat_t* st, int B, int HW,
+                                       int C, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && G && st && st->Y && st->pqr && st->part && st->counter && B > 0 && HW > 0 && C % 64 == 0);
+  const int M = B * HW;
+  hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                     rc_stat_of(*st), M, C, dy, x, G, HW);
   return mmvae_launch_status();
 }
 

@@ -245,6 +245,7 @@ SIGNATURES = {
     "mmvae_rc_conv_ws_floats": (c_sz, [c_i] * 4),
     "mmvae_rc_launch": (c_i, [ctypes.POINTER(RcJob), c_i, c_p]),
     "mmvae_rc_bn_bwd_stats": (c_i, [c_p, ctypes.POINTER(RcStat), c_i, c_i, c_p]),
+    "mmvae_rc_pool_bwd_stats": (c_i, [c_p, c_p, c_p, ctypes.POINTER(RcStat), c_i, c_i, c_i, c_p]),
     "mmvae_rc_wgrad_splits": (c_i, [c_i] * 4),
     "mmvae_rc_wgrad_ws_floats": (c_sz, [c_i] * 4),
     "mmvae_rc_wgrad_tickets": (c_sz, [c_i] * 3),

@@ -132,10 +132,8 @@ class ResNet50(nn.Module):
         Hh, W = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
         # the pooled values are already rectified (ACT_NONE); all 16 bottlenecks are one autograd node
         blocks = [blk for li in range(4) for blk in getattr(self, f"layer{li + 1}")]
-        h = rconv.bottleneck_stack(h, [blk.engine() for blk in blocks], B, Hh, W, H.ACT_NONE, self.training)
-        for blk in blocks:
-            Hh, W = (Hh - 1) // blk.conv2.stride + 1, (W - 1) // blk.conv2.stride + 1
-        h = ops.AvgPoolGlobal.apply(h, B, Hh * W, H.ACT_RELU)
+        # (with the global average pooling of relu(.) behind them: its backward shares a launch with the stack's)
+        h = rconv.bottleneck_stack(h, [blk.engine() for blk in blocks], B, Hh, W, H.ACT_NONE, self.training, pool=True)
         return self.fc(h)
 
 

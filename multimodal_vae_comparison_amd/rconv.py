@@ -230,7 +230,9 @@ class BottleneckStack(Function):
     """s_out = blocks(s_in): s_in (B*H*W, C) pre-activation consumed through `in_act` by the first block"""
 
     @staticmethod
-    def forward(ctx, s_in, blocks, B, Hh, W, in_act, training, *params):
+    def forward(ctx, s_in, blocks, B, Hh, W, in_act, training, pool, *params):
+        """pool: also apply AdaptiveAvgPool2d(1) to relu(s_out) -> (B, C) (resnet50.avgpool; its backward then rides in
+        the launch that makes the last BatchNorm's backward statistics)"""
         s = H.f32c(s_in)
         dev = s.device
         saved = []
@@ -267,6 +269,12 @@ class BottleneckStack(Function):
             s, Hh, W, act = out, Ho, Wo, H.ACT_RELU
         ctx.blocks, ctx.saved, ctx.training = blocks, saved, training
         ctx.params = params
+        ctx.pool = None
+        if pool:
+            y = torch.empty(B, s.shape[1], device=dev)
+            ops._call("mmvae_avgpool_fwd", H.ptr(s), H.ptr(y), B, Hh * W, s.shape[1], H.ACT_RELU, H.stream())
+            ctx.pool = (s, B, Hh * W)
+            return y
         return s
 
     @staticmethod
@@ -325,7 +333,18 @@ class BottleneckStack(Function):
             t1 = tables(dev, B, Hh, W, 1, S_, 0) if S_ != 1 else (None, None)
             g3 = (Hh, W, 3, S_, 1)
             pre1 = PRE_RELU if act == H.ACT_RELU else PRE_NONE
-            if not ready:
+            if not ready and ctx.pool is not None and not blk.ud:
+                s_out, pB, pHW = ctx.pool
+                dy, G = G, torch.empty_like(s_out)
+                st3 = _stat(blk.u3, b3, Y3, ev, grads)
+                ops._call("mmvae_rc_pool_bwd_stats", H.ptr(dy), H.ptr(s_out), H.ptr(G), ctypes.byref(st3), pB, pHW,
+                          Y3.shape[1], H.stream())
+            elif not ready:
+                if ctx.pool is not None:
+                    s_out, pB, pHW = ctx.pool
+                    dy, G = G, torch.empty_like(s_out)
+                    ops._call("mmvae_avgpool_bwd", H.ptr(dy), H.ptr(s_out), H.ptr(G), pB, pHW, s_out.shape[1], H.ACT_RELU,
+                              H.stream())
                 st3 = _stat(blk.u3, b3, Y3, ev, grads)
                 ops._call("mmvae_rc_bn_bwd_stats", H.ptr(G), ctypes.byref(st3), M2, Y3.shape[1], H.stream())
                 if blk.ud:
@@ -379,10 +398,10 @@ class BottleneckStack(Function):
             ops.GradReducer.keep(dev, *held, *[t for sv in saved for t in sv[:5]])
             ops.GradReducer.ensure_flush(dev)
         ctx.saved = None
-        return (G if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + \
+        return (G if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None) + \
             tuple(ret.get(p) for p in ctx.params)
 
 
-def bottleneck_stack(s_in, blocks, B, Hh, W, in_act, training):
+def bottleneck_stack(s_in, blocks, B, Hh, W, in_act, training, pool=False):
     params = [p for blk in blocks for p in blk.params()]
-    return BottleneckStack.apply(s_in, blocks, B, Hh, W, in_act, training, *params)
+    return BottleneckStack.apply(s_in, blocks, B, Hh, W, in_act, training, pool, *params)

@@ -1,0 +1,195 @@
+"""The fused convolution + BatchNorm engine of the ResNet-50 bottleneck stack (csrc/rconv.hip through the C ABI's
+mmvae_rc_launch, host side rconv.py) against torch in float64, one convolution + BatchNorm unit at a time: odd row counts
+(partial 64-row tiles), strides, reductions split over workgroups and not, several jobs in one launch, eval mode.
+(The bottleneck / tower level comparisons are tests/test_parity_e2e.py::test_resnet_*.)"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nhwc(t):
+    B, C, Hh, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * Hh * W, C).contiguous()
+
+
+def check(a, b, tol, what):
+    a = a.detach().double().cpu().numpy()
+    b = b.detach().double().cpu().numpy()
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol}"
+
+
+def _unit(Cin, Cout, k, s, seed):
+    from multimodal_vae_comparison_amd import rconv
+    from multimodal_vae_comparison_amd.models.resnet import BatchNorm2d, ConvW
+    torch.manual_seed(seed)
+    conv = ConvW(Cin, Cout, k, s, k // 2, channels_last=True).to(DEV)
+    bn, bnp = BatchNorm2d(Cout).to(DEV), BatchNorm2d(Cin).to(DEV)
+    with torch.no_grad():
+        for b in (bn, bnp):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.2)
+    return rconv.Unit(conv, bn), rconv.Unit(ConvW(64, Cin, 1, 1, 0).to(DEV), bnp), conv, bn, bnp
+
+
+SHAPES = [(3, 5, 64, 128, 3, 1), (2, 8, 128, 64, 3, 2), (5, 4, 256, 64, 1, 1), (2, 6, 64, 64, 1, 2), (6, 2, 512, 512, 3, 1),
+          (24, 8, 128, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("B,Hh,Cin,Cout,k,s", SHAPES)
+@pytest.mark.parametrize("training", [True, False])
+def test_unit_forward_backward_matches_torch(hip_lib, B, Hh, Cin, Cout, k, s, training):
+    """y = conv(relu(bn_prev(x))) with the statistics of the BatchNorm behind it; then, from a gradient G of that
+    BatchNorm's output: the input gradient through the ReLU mask, bn_prev's backward statistics (p, q, r, dgamma, dbeta)
+    and the weight gradient -- all against torch.autograd in float64"""
+    from multimodal_vae_comparison_amd import hipops as H, rconv
+    u, up, conv, bn, bnp = _unit(Cin, Cout, k, s, B + Cin + k)
+    g = torch.Generator().manual_seed(7 * B + Hh)
+    x = torch.randn(B, Cin, Hh, Hh, generator=g) * 1.5 + 0.3
+    Ho = (Hh - 1) // s + 1
+    Min, M = B * Hh * Hh, B * Ho * Ho
+    gm = (Hh, Hh, k, s, k // 2) if (k > 1 or s > 1) else rconv.IDENT
+    tf, _ = rconv.tables(torch.device(DEV), B, Hh, Hh, k, s, k // 2) if (k > 1 or s > 1) else (None, None)
+    # the producer side: x is the RAW output of a previous convolution whose BatchNorm (bnp) statistics are given
+    xr = x.double().requires_grad_(True)
+    P = {n: p.detach().double().cpu().requires_grad_(True) for n, p in
+         (("w", conv.weight), ("g", bn.weight), ("b", bn.bias), ("gp", bnp.weight), ("bp", bnp.bias))}
+    rm, rv = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    with torch.no_grad():
+        bn.running_mean.copy_(rm)
+        bn.running_var.copy_(rv)
+    mean_p = x.double().mean((0, 2, 3))
+    var_p = x.double().var((0, 2, 3), unbiased=False)
+    act = torch.relu(F.batch_norm(xr, None, None, P["gp"], P["bp"], training=True, eps=1e-5))
+    yr = F.conv2d(act, P["w"], None, stride=s, padding=k // 2)
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    out = F.batch_norm(yr, rm_r, rv_r, P["g"], P["b"], training=training, momentum=0.1, eps=1e-5)
+    G = torch.randn(out.shape, generator=g)
+    out.backward(G.double())
+    # engine: producer buffers filled by hand (mean, gamma rstd, rstd), then forward / stand-alone statistics / dgrad / wgrad
+    xg = _nhwc(x).to(DEV)
+    bp = up.buffers(Min, torch.device(DEV))
+    rstd_p = 1.0 / torch.sqrt(var_p + 1e-5)
+    bp["mean"].copy_(mean_p.float())
+    bp["rstd"].copy_(rstd_p.float())
+    bp["sc"].copy_((bnp.weight.detach().double().cpu() * rstd_p).float())
+    bn.train(training)
+    y, b = rconv._fwd(u, xg, Min, M, rconv.PRE_BN_RELU, (bp, bnp.bias), gm, not training)
+    torch.cuda.synchronize()
+    check(y, _nhwc(yr), 2e-5, "raw output")
+    if training:
+        check(b["mean"], yr.mean((0, 2, 3)), 2e-5, "batch mean")
+        check(b["rstd"], 1.0 / torch.sqrt(yr.var((0, 2, 3), unbiased=False) + 1e-5), 2e-5, "rstd")
+        check(bn.running_mean, rm_r, 1e-5, "running_mean")
+        check(bn.running_var, rv_r, 1e-5, "running_var")
+    else:
+        check(b["mean"], rm, 1e-6, "eval mean")
+        check(bn.running_var, rv, 0, "running_var untouched")
+    Gg = _nhwc(G).to(DEV)
+    grads = {p: (torch.zeros_like(p), 0) for p in (conv.weight, bn.weight, bn.bias, bnp.weight, bnp.bias)}
+    st = rconv._stat(u, b, y, not training, grads)
+    H.check(H.lib().mmvae_rc_bn_bwd_stats(H.ptr(Gg), ctypes.byref(st), M, Cout, H.stream()), "stats")
+    dx = rconv._dgrad(u, b, Gg, y, gm, None, rconv.MASK_BN, xg, (bp, bnp.bias), Min, [rconv._stat(up, bp, xg, False, grads)])
+    rconv._wgrad(u, b, Gg, y, xg, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, grads)
+    torch.cuda.synchronize()
+    check(grads[bn.weight][0], P["g"].grad, 5e-5, "dgamma")
+    check(grads[bn.bias][0], P["b"].grad, 5e-5, "dbeta")
+    check(grads[conv.weight][0], P["w"].grad, 5e-5, "dw")
+    check(grads[bnp.weight][0], P["gp"].grad, 1e-4, "dgamma of the producer's BatchNorm")
+    check(grads[bnp.bias][0], P["bp"].grad, 1e-4, "dbeta of the producer's BatchNorm")
+    # the gradient of the producer's raw output = bn_prev backward applied to dx: G p + Y q + r with the emitted vectors
+    p_, q_, r_ = bp["pqr"].view(3, Cin)
+    check(dx * p_ + xg * q_ + r_, _nhwc(xr.grad), 1e-4, "gradient of the producer's raw output")
+
+
+def test_jobs_in_one_launch_equal_their_own_launches(hip_lib):
+    """mmvae_rc_launch with several jobs (a data gradient, a weight gradient, a forward of another unit) is bit-identical
+    to launching each alone"""
+    from multimodal_vae_comparison_amd import hipops as H, rconv
+    B, Hh = 4, 8
+    dev = torch.device(DEV)
+    u, up, conv, bn, bnp = _unit(128, 128, 3, 1, 1)
+    u2, up2, conv2, bn2, bnp2 = _unit(128, 256, 1, 1, 2)
+    g = torch.Generator().manual_seed(3)
+    M = B * Hh * Hh
+    x = torch.randn(M, 128, generator=g).to(DEV)
+    G = torch.randn(M, 128, generator=g).to(DEV)
+    bp = up.buffers(M, dev)
+    bp["mean"].normal_(0, 0.1); bp["sc"].uniform_(0.5, 1.5); bp["rstd"].uniform_(0.5, 1.5)
+    gm = (Hh, Hh, 3, 1, 1)
+    tf, _ = rconv.tables(dev, B, Hh, Hh, 3, 1, 1)
+    y, b = rconv._fwd(u, x, M, M, rconv.PRE_BN_RELU, (bp, bnp.bias), gm, False)
+    grads = {p: (torch.zeros_like(p), 0) for p in (conv.weight, bn.weight, bn.bias, bnp.weight, bnp.bias)}
+    H.check(H.lib().mmvae_rc_bn_bwd_stats(H.ptr(G), ctypes.byref(rconv._stat(u, b, y, False, grads)), M, 128, H.stream()), "stats")
+
+    def jobs():
+        gr = {p: (torch.zeros_like(p), 0) for p in grads}
+        jd, dx = rconv.dgrad_job(u, b, G, y, gm, None, None, rconv.MASK_BN, x, (bp, bnp.bias), M, [rconv._stat(up, bp, x, False, gr)])
+        jw = rconv.wgrad_job(u, b, G, y, x, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, gr)
+        jf, y2, b2 = rconv.fwd_job(u2, x, M, rconv.PRE_RELU, None, rconv.IDENT, False)
+        return (jd, jw, jf), (dx, gr[conv.weight][0], y2, b2, gr[bnp.weight][0])
+
+    js, (dx1, dw1, y21, b21, dg1) = jobs()
+    for j in js:
+        rconv.launch(j)
+    torch.cuda.synchronize()
+    mean1 = b21["mean"].clone()
+    pqr1 = bp["pqr"].clone()
+    js, (dx2, dw2, y22, b22, dg2) = jobs()
+    rconv.launch(*js)
+    torch.cuda.synchronize()
+    for a_, b_, nm in ((dx1, dx2, "dx"), (dw1, dw2, "dw"), (y21, y22, "y"), (mean1, b22["mean"], "mean"), (pqr1, bp["pqr"], "pqr"),
+                       (dg1, dg2, "dgamma")):
+        assert torch.equal(a_, b_), nm
+
+
+def test_row_tables_match_the_definition(hip_lib):
+    from multimodal_vae_comparison_amd import rconv
+    B, Hh, W, K, S, P = 2, 5, 7, 3, 2, 1
+    fwd, bwd = rconv.tables(torch.device(DEV), B, Hh, W, K, S, P)
+    Ho, Wo = (Hh + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
+    f = -np.ones((K * K, B * Ho * Wo), dtype=np.int32)
+    r = -np.ones((K * K, B * Hh * W), dtype=np.int32)
+    for b in range(B):
+        for oh in range(Ho):
+            for ow in range(Wo):
+                for kh in range(K):
+                    for kw in range(K):
+                        ih, iw = oh * S - P + kh, ow * S - P + kw
+                        if 0 <= ih < Hh and 0 <= iw < W:
+                            f[kh * K + kw, (b * Ho + oh) * Wo + ow] = (b * Hh + ih) * W + iw
+                            r[kh * K + kw, (b * Hh + ih) * W + iw] = (b * Ho + oh) * Wo + ow
+    assert np.array_equal(fwd.cpu().numpy(), f) and np.array_equal(bwd.cpu().numpy(), r)
+
+
+def test_channels_last_weights_keep_their_state_dict_values(hip_lib):
+    """the k x k weights live channels-last in the flat parameter / gradient / Adam buffers; what state_dict() and the
+    optimiser state hand out are the reference's (Cout, Cin, k, k) tensors"""
+    from multimodal_vae_comparison_amd.flat import FlatAdam, FlatParams
+    from multimodal_vae_comparison_amd.models.resnet import Bottleneck
+    torch.manual_seed(0)
+    blk = Bottleneck(64, 64, 1, True).to(DEV)
+    w0 = blk.conv2.weight.detach().clone()
+    assert tuple(w0.shape) == (64, 64, 3, 3) and not blk.conv2.weight.is_contiguous()
+    flat = FlatParams(blk)
+    opt = FlatAdam(flat)
+    w = blk.conv2.weight
+    assert torch.equal(w.detach(), w0) and torch.equal(blk.state_dict()["conv2.weight"], w0)
+    o = flat.offset_of[id(w)]
+    assert torch.equal(flat.data[o:o + w.numel()].view(64, 3, 3, 64), w0.permute(0, 2, 3, 1))
+    w.grad.copy_(torch.arange(w.numel(), device=DEV, dtype=torch.float32).view(64, 64, 3, 3) * 1e-6)
+    opt.step()
+    sd = opt.state_dict()
+    i = [id(p) for p in flat.params_in_model_order].index(id(w))
+    assert tuple(sd["state"][i]["exp_avg"].shape) == (64, 64, 3, 3)
+    check(sd["state"][i]["exp_avg"], 0.1 * torch.arange(w.numel(), dtype=torch.float64).view(64, 64, 3, 3) * 1e-6, 1e-5, "exp_avg")
+    opt2 = FlatAdam(FlatParams(Bottleneck(64, 64, 1, True).to(DEV)))
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
