@@ -396,36 +396,9 @@ int mmvae_moe_elbo_bwd(const float* g, const float* out, const float* W_host, fl
 
 /* ------------------------------------------------------------------------------------------------
  * ResNet-50 image tower (`encoder: CNN`, models/encoders.py:86-127: torchvision resnet50 -> SiLU -> heads).  Inside the
- * tower activations are NHWC (rows = B*H*W, C): 1x1 convolutions are mmvae_linear_* GEMMs, k x k convolutions are
- * im2col + the same GEMMs (columns ordered (c, kh, kw) = the native (Cout, Cin, k, k) weight layout), and these are the
- * HBM-bound helpers around them.  Layers emit pre-activations; `in_act` (NONE / RELU) is applied while reading.
+ * tower activations are NHWC (rows = B*H*W, C) matrices; layers emit pre-activations, `in_act` (NONE / RELU) is applied
+ * while reading.
  * ---------------------------------------------------------------------------------------------- */
-/* cols[(b,oh,ow), c*K*K + kh*K + kw] = act(x[b, oh*S-P+kh, ow*S-P+kw, c]) (0 outside); x NHWC, or NCHW when nchw != 0 */
-int mmvae_im2col(const float* x, float* cols, int B, int H, int W, int C, int K, int S, int P, int in_act, int nchw,
-                 mmvae_stream_t stream);
-/* dx[b,h,w,c] = act'(x) * sum of the dcols entries that read this pixel (NHWC); x may be NULL when in_act = NONE */
-int mmvae_col2im(const float* dcols, const float* x, float* dx, int B, int H, int W, int C, int K, int S, int P,
-                 int in_act, mmvae_stream_t stream);
-/* torch.nn.BatchNorm2d, training mode, on an (M, C) NHWC matrix: y = (x - mean) rstd gamma + beta [+ res | relu(res)];
- * save_mean / save_rstd (C) for the backward pass; run_mean / run_var (C, or NULL) updated with `momentum` (unbiased
- * variance).  eval_mode != 0: the running statistics normalise (model.eval()) and are not updated.
- * ws: mmvae_bn_ws_floats(M, C) floats.
- * bwd: dx, dres (or NULL), dgamma / dbeta (+)= per `accumulate`; MMVAE_ACC_DEFER leaves mmvae_bn_row_blocks(M) rows of
- * [sum dy xhat ... | sum dy ...] (2*C floats each: dbeta partials first, dgamma partials at +C) in ws for the
- * caller's fold. */
-size_t mmvae_bn_ws_floats(int M, int C);
-int mmvae_bn_row_blocks(int M);
-int mmvae_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y,
-                       float* save_mean, float* save_rstd, float* run_mean, float* run_var, float* ws, int M, int C,
-                       float eps, float momentum, int res_relu, int eval_mode, mmvae_stream_t stream);
-int mmvae_bn_train_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean,
-                       const float* save_rstd, const float* res, float* dx, float* dres, float* dgamma, float* dbeta,
-                       float* ws, int M, int C, int res_relu, int accumulate, int eval_mode, mmvae_stream_t stream);
-/* MaxPool2d(3, 2, 1) on act(x), NHWC; idx (int32, output shape) = h*W + w of the first maximum of each window */
-int mmvae_maxpool3x3s2_fwd(const float* x, float* y, int* idx, int B, int H, int W, int C, int in_act,
-                           mmvae_stream_t stream);
-int mmvae_maxpool3x3s2_bwd(const float* dy, const int* idx, const float* x, float* dx, int B, int H, int W, int C,
-                           int in_act, mmvae_stream_t stream);
 /* AdaptiveAvgPool2d(1) on act(x): (B, HW, C) -> (B, C) */
 int mmvae_avgpool_fwd(const float* x, float* y, int B, int HW, int C, int in_act, mmvae_stream_t stream);
 int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW, int C, int in_act,
@@ -553,6 +526,26 @@ int mmvae_rc_pool_bwd_stats(const float* dy, const float* x, float* G, const mmv
 int mmvae_rc_wgrad_splits(int M, int Cin, int Cout, int T);
 size_t mmvae_rc_wgrad_ws_floats(int M, int Cin, int Cout, int T);
 size_t mmvae_rc_wgrad_tickets(int Cin, int Cout, int T);
+/* the stem (torchvision resnet50.conv1 / bn1 / relu / maxpool): y (M, Cout) = conv(img) of the NCHW image batch
+ * (B, Cimg, H, W) with the channels-last weight (Cout, T, Cimg), BatchNorm statistics as in the forward jobs; max pooling
+ * (3, 2, 1) of relu(bn(y)) with the index of each window's first maximum; its backward made in the launch that sums the
+ * BatchNorm's backward statistics, G (B*H*W, C) = (bn(Y) > 0) * scattered dy (st->Y = y, st->mean with sc / beta
+ * normalise); and the weight gradient, dY = G p + Y q + r, tbl (2, M): per output pixel b Cimg H W + h0 W + w0 and
+ * (h0 + 16384) << 16 | (w0 + 16384) of its window origin (h0, w0) = (oh S - P, ow S - P). */
+int mmvae_rc_stem_fwd(const float* img, const float* w, float* y, int M, int Cimg, int Cout, int T,
+                      const mmvae_rc_geom_t* g, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                      float* mean, float* rstd, float* sc, float* part, unsigned* counter, float eps, float momentum,
+                      int eval, mmvae_stream_t stream);
+int mmvae_rc_maxpool_fwd(const float* y, const float* mean, const float* sc, const float* beta, float* out, int* idx, int B,
+                         int H, int W, int C, mmvae_stream_t stream);
+int mmvae_rc_maxpool_bwd_stats(const float* dy, const int* idx, float* G, const float* sc, const float* beta,
+                               const mmvae_rc_stat_t* st, int B, int H, int W, int C, mmvae_stream_t stream);
+int mmvae_rc_stem_wgrad_splits(int M, int Cimg, int Cout, int T);
+size_t mmvae_rc_stem_wgrad_ws_floats(int M, int Cimg, int Cout, int T);
+/* ws: mmvae_rc_stem_wgrad_ws_floats floats; counter: (Cout / 64) * ceil(T Cimg / 64) tickets (zero once) */
+int mmvae_rc_stem_wgrad(const float* G, const float* Y, const float* pqr, const float* img, const int* tbl, float* dw,
+                        float* ws, unsigned* counter, int M, int Cimg, int Cout, int T, const mmvae_rc_geom_t* g,
+                        int accumulate, mmvae_stream_t stream);
 /* end of a bottleneck: out = bn3(Y3) + (bn_d(R) when mr != NULL, else relu?(R)) */
 int mmvae_rc_blockout(const float* Y3, const float* m3, const float* sc3, const float* b3, const float* R,
                       const float* mr, const float* scr, const float* br, int res_relu, float* out, long rows, int C,

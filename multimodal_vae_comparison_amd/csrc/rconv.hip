@@ -279,6 +279,54 @@ __device__ __forceinline__ void rc_bn_fwd_finalize(const RcBnFwd& bn, double mea
 }
 
 
+// store of a finished tile + the statistics of the BatchNorm behind it (partials, election, merge, finalize)
+__device__ __forceinline__ void rc_fwd_tail(const f32x16& acc, float* __restrict__ y, int M, int Cout, const RcBnFwd& bn,
+                                            const RcBlk k, int m0, int n0, int cnt, const RcWave& wv,
+                                            float* __restrict__ smem, float* __restrict__ cs, int* __restrict__ lastp) {
+  const int tid = threadIdx.x;
+  const int n = n0 + wv.col();
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (wv.row_of(r) < cnt) {
+      y[(size_t)(m0 + wv.row_of(r)) * Cout + n] = acc[r];
+      s += acc[r];
+    }
+  if (!bn.part) return;
+  const float mean_t = rc_colsum(cs, s, wv) / (float)cnt;
+  float q = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (wv.row_of(r) < cnt) q = fmaf(acc[r] - mean_t, acc[r] - mean_t, q);
+  const float m2_t = rc_colsum(cs, q, wv);
+  if (wv.wm == 0 && wv.lh == 0) {
+    rc_st(bn.part + ((size_t)k.by * Cout + n) * 2, mean_t);
+    rc_st(bn.part + ((size_t)k.by * Cout + n) * 2 + 1, m2_t);
+  }
+  // election (two levels beyond RC_GROUP row tiles) and merge: thread = (column, one of 4 part groups)
+  const int col = tid & 63, rg = tid >> 6, nc = n0 + col;
+  const RcLevels lv(k.gy, k.by);
+  double* dl = reinterpret_cast<double*>(smem);
+  double o0, o1, o2;
+  const float* src_part = bn.part;
+  int np = lv.nrow, rows_per = RC_BM;
+  if (lv.ngrp) {
+    if (!rc_last_workgroup(bn.counter + k.gx + k.bx * lv.ngrp + lv.grp, lv.g1 - lv.g0, lastp)) return;
+    rc_merge<64, true>(bn.part, Cout, nc, lv.g0, lv.g1, RC_BM, M, dl, col, rg, o0, o1, o2);
+    float* l1 = lv.level1(bn.part, Cout);
+    if (rg == 0) {
+      rc_st(l1 + ((size_t)lv.grp * Cout + nc) * 2, (float)o1);
+      rc_st(l1 + ((size_t)lv.grp * Cout + nc) * 2 + 1, (float)o2);
+    }
+    src_part = l1;
+    np = lv.ngrp;
+    rows_per = RC_BM * RC_GROUP;
+  }
+  if (!rc_last_workgroup(bn.counter + k.bx, np, lastp)) return;
+  rc_merge<64, true>(src_part, Cout, nc, 0, np, rows_per, M, dl, col, rg, o0, o1, o2);
+  if (rg == 0) rc_bn_fwd_finalize<64>(bn, o1, o2, M, nc);
+}
+
 __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
                                             int* __restrict__ lastp) {
   float* As = smem;
@@ -373,47 +421,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)a.M * a.Cout,
                      (size_t)m0 * a.Cout + n0, a.Cout, cnt, wv, lastp))
     return;
-  const int n = n0 + wv.col();
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (wv.row_of(r) < cnt) {
-      a.y[(size_t)(m0 + wv.row_of(r)) * a.Cout + n] = acc[r];
-      s += acc[r];
-    }
-  if (!a.bn.part) return;
-  const float mean_t = rc_colsum(cs, s, wv) / (float)cnt;
-  float q = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (wv.row_of(r) < cnt) q = fmaf(acc[r] - mean_t, acc[r] - mean_t, q);
-  const float m2_t = rc_colsum(cs, q, wv);
-  if (wv.wm == 0 && wv.lh == 0) {
-    rc_st(a.bn.part + ((size_t)k.by * a.Cout + n) * 2, mean_t);
-    rc_st(a.bn.part + ((size_t)k.by * a.Cout + n) * 2 + 1, m2_t);
-  }
-  // election (two levels beyond RC_GROUP row tiles) and merge: thread = (column, one of 4 part groups)
-  const int col = tid & 63, rg = tid >> 6, nc = n0 + col;
-  const RcLevels lv(k.gy, k.by);
-  double* dl = reinterpret_cast<double*>(smem);
-  double o0, o1, o2;
-  const float* src_part = a.bn.part;
-  int np = lv.nrow, rows_per = RC_BM;
-  if (lv.ngrp) {
-    if (!rc_last_workgroup(a.bn.counter + k.gx + k.bx * lv.ngrp + lv.grp, lv.g1 - lv.g0, lastp)) return;
-    rc_merge<64, true>(a.bn.part, a.Cout, nc, lv.g0, lv.g1, RC_BM, a.M, dl, col, rg, o0, o1, o2);
-    float* l1 = lv.level1(a.bn.part, a.Cout);
-    if (rg == 0) {
-      rc_st(l1 + ((size_t)lv.grp * a.Cout + nc) * 2, (float)o1);
-      rc_st(l1 + ((size_t)lv.grp * a.Cout + nc) * 2 + 1, (float)o2);
-    }
-    src_part = l1;
-    np = lv.ngrp;
-    rows_per = RC_BM * RC_GROUP;
-  }
-  if (!rc_last_workgroup(a.bn.counter + k.bx, np, lastp)) return;
-  rc_merge<64, true>(src_part, a.Cout, nc, 0, np, rows_per, a.M, dl, col, rg, o0, o1, o2);
-  if (rg == 0) rc_bn_fwd_finalize<64>(a.bn, o1, o2, a.M, nc);
+  rc_fwd_tail(acc, a.y, a.M, a.Cout, a.bn, k, m0, n0, cnt, wv, smem, cs, lastp);
 }
 
 __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
@@ -695,9 +703,13 @@ __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
 // grid (C / 64, row tiles of 64)
 // With dyp != NULL the gradient is made here as well: the backward of AdaptiveAvgPool2d(1) on relu(xs),
 // G[(b, hw), c] = dyp[b, c] / HW * (xs > 0), stored to Gout (the stack's last BatchNorm sits right under the pooling).
+// With idx != NULL: the backward of the stem's MaxPool2d(3, 2, 1) on relu(bn(Y)): G[(b,h,w), c] = (bn(Y) > 0) * sum of the
+// dyp entries of the <= 4 windows around (h, w) whose recorded maximum is this pixel; (msc, mbeta) with st.mean normalise.
 __global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ G, RcStat st, int M, int C,
                                                       const float* __restrict__ dyp, const float* __restrict__ xs,
-                                                      float* __restrict__ Gout, int HW) {
+                                                      float* __restrict__ Gout, int HW, const int* __restrict__ idx,
+                                                      const float* __restrict__ msc, const float* __restrict__ mbeta,
+                                                      int H, int W, int Ho, int Wo) {
   __shared__ __attribute__((aligned(16))) float smem[256 * 3 * 2];
   __shared__ float cs[256];
   __shared__ int last;
@@ -709,7 +721,20 @@ __global__ __launch_bounds__(256) void rc_stat_kernel(const float* __restrict__ 
   for (int row = rg; row < cnt; row += 4) {
     const size_t o = (size_t)(m0 + row) * C + c;
     float g;
-    if (dyp) {
+    if (idx) {
+      const int r = m0 + row, b = r / (H * W), me = r - b * (H * W), h = me / W, w = me - h * W;
+      g = 0.f;
+      for (int oh = h / 2; oh <= (h + 1) / 2; ++oh) {
+        if (oh >= Ho) continue;
+        for (int ow = w / 2; ow <= (w + 1) / 2; ++ow) {
+          if (ow >= Wo) continue;
+          const size_t oo = (((size_t)b * Ho + oh) * Wo + ow) * C + c;
+          if (idx[oo] == me) g += dyp[oo];
+        }
+      }
+      if (!(rc_bn(st.Y[o], tm, msc[c], mbeta[c]) > 0.f)) g = 0.f;
+      Gout[o] = g;
+    } else if (dyp) {
       g = xs[o] > 0.f ? dyp[(size_t)((m0 + row) / HW) * C + c] * (1.0f / (float)HW) : 0.f;
       Gout[o] = g;
     } else {
@@ -849,6 +874,223 @@ __global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a) {
   __shared__ float cs[128];
   __shared__ int last;
   rc_wgrad_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the stem: conv1 (7x7 / 2, 3 -> 64 channels) straight from the NCHW image batch, its BatchNorm statistics in the epilogue;
+// max pooling that normalises + rectifies while it reads; and the weight gradient.  The reduction index is k = tap * Cimg
+// + c (the channels-last weight row), walked 32 at a time: K = 147 is 5 stages, the last one partial.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RcStemFwdArgs {
+  const float* img;       // (B, Cimg, H, W)
+  const float* w;         // (Cout, T, Cimg)
+  float* y;               // (M = B Ho Wo, Cout)
+  int M, Cimg, Cout, T;
+  RcGeom g;
+  RcBnFwd bn;
+};
+
+__global__ __launch_bounds__(256) void rc_stem_fwd_kernel(RcStemFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ float cs[128];
+  __shared__ int last;
+  float* As = smem;
+  float* Bs = smem + RC_BK * RC_AP;
+  const RcBlk k{(int)blockIdx.x, (int)blockIdx.y, 0, (int)gridDim.x, (int)gridDim.y};
+  const int tid = threadIdx.x;
+  const int n0 = k.bx * 64, m0 = k.by * RC_BM;
+  RcWave wv;
+  wv.init(tid);
+  RcStg<true> sa, sb;
+  sa.init(tid);
+  sb.init(tid);
+  const int K = a.T * a.Cimg, hwi = a.g.H * a.g.W;
+  int pix[RC_NS], hw[RC_NS];
+  float ra[RC_NS], rb[RC_NS];
+#pragma unroll
+  for (int i = 0; i < RC_NS; ++i) {
+    const int r = m0 + sa.row(i);
+    const int hwo = a.g.Ho * a.g.Wo;
+    const int b = r / hwo, rem = r - b * hwo, oh = rem / a.g.Wo, ow = rem - oh * a.g.Wo;
+    const int h0 = oh * a.g.S - a.g.P, w0 = ow * a.g.S - a.g.P;
+    pix[i] = b * a.Cimg * hwi + h0 * a.g.W + w0;
+    hw[i] = r < a.M ? ((h0 + 0x4000) << 16 | (w0 + 0x4000)) : -1;
+  }
+  unsigned oka = 0;
+  auto load = [&](int k0) {
+    const int kk = k0 + sa.kl;
+    const int tap = kk / a.Cimg, c = kk - tap * a.Cimg, kh = tap / a.g.KW, kw = tap - kh * a.g.KW;
+    const int koff = c * hwi + kh * a.g.W + kw;
+    oka = 0;
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) {
+      const int ih = (hw[i] >> 16) - 0x4000 + kh, iw = (hw[i] & 0xffff) - 0x4000 + kw;
+      const bool ok = kk < K && hw[i] != -1 && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+      oka |= (ok ? 1u : 0u) << i;
+      ra[i] = a.img[ok ? pix[i] + koff : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) {
+      const float t = a.w[(size_t)(n0 + sb.row(i)) * K + min(k0 + sb.kl, K - 1)];
+      rb[i] = k0 + sb.kl < K ? t : 0.f;
+    }
+  };
+  auto store = [&]() {
+    float va[RC_NS];
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) va[i] = (oka >> i & 1u) ? ra[i] : 0.f;
+    sa.store(As, va);
+    sb.store(Bs, rb);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  load(0);
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += RC_BK) {
+    store();
+    __syncthreads();
+    if (k0 + RC_BK < K) load(k0 + RC_BK);
+    wv.mma(As, Bs, acc);
+    __syncthreads();
+  }
+  rc_fwd_tail(acc, a.y, a.M, a.Cout, a.bn, k, m0, n0, min(RC_BM, a.M - m0), wv, smem, cs, &last);
+}
+
+// dw (Cout, K = T Cimg) (+)= dY^T patches(img), dY = G p + Y q + r; tbl (2, M): per output pixel the image offset of its
+// window origin (b Cimg H W + h0 W + w0) and (h0, w0) packed as in the forward kernel.  grid (ceil(K / 64), Cout / 64, nz)
+struct RcStemWgradArgs {
+  const float* G;
+  const float* Y;
+  const float* pqr;
+  const float* img;
+  const int* tbl;
+  float* dw;
+  float* ws;              // nz > 1: (nz, Cout, Kpad = 64 gridDim.x)
+  unsigned* counter;
+  int M, Cimg, Cout, T, acc, nz, kper;
+  RcGeom g;
+};
+
+__global__ __launch_bounds__(256) void rc_stem_wgrad_kernel(RcStemWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ int last;
+  float* As = smem;
+  float* Bs = smem + RC_BK * RC_AP;
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * 64, n0 = blockIdx.y * 64, zi = blockIdx.z;
+  const int kbeg = zi * a.kper, kend = min(a.M, kbeg + a.kper);
+  const int K = a.T * a.Cimg, Kpad = 64 * gridDim.x, hwi = a.g.H * a.g.W;
+  RcWave wv;
+  wv.init(tid);
+  RcStg<false> sa, sb;
+  sa.init(tid);
+  sb.init(tid);
+  float rg_[RC_NS], ry[RC_NS], rb[RC_NS];
+  int tp[RC_NS], th[RC_NS];
+  unsigned oka = 0, okb = 0;
+  const int n = n0 + sa.rl, j = c0 + sb.rl;
+  const int tap = j / a.Cimg, c = j - tap * a.Cimg, kh = tap / a.g.KW, kw = tap - kh * a.g.KW;
+  const int koff = c * hwi + kh * a.g.W + kw;
+  float pp = 1.f, pq = 0.f, pr = 0.f;
+  if (a.pqr) { pp = a.pqr[n]; pq = a.pqr[a.Cout + n]; pr = a.pqr[2 * a.Cout + n]; }
+  auto rows = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) {
+      const int m = k0 + sb.kk(i);
+      tp[i] = a.tbl[min(m, a.M - 1)];
+      th[i] = m < kend ? a.tbl[a.M + min(m, a.M - 1)] : -1;
+    }
+  };
+  auto load = [&](int k0) {
+    oka = 0;
+    okb = 0;
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) {
+      const int m = k0 + sa.kk(i);
+      const bool ok = m < kend;
+      oka |= (ok ? 1u : 0u) << i;
+      const size_t o = ok ? (size_t)m * a.Cout + n : 0;
+      rg_[i] = a.G[o];
+      ry[i] = a.pqr ? a.Y[o] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) {
+      const int ih = (th[i] >> 16) - 0x4000 + kh, iw = (th[i] & 0xffff) - 0x4000 + kw;
+      const bool ok = j < K && th[i] != -1 && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+      okb |= (ok ? 1u : 0u) << i;
+      rb[i] = a.img[ok ? tp[i] + koff : 0];
+    }
+    if (k0 + RC_BK < kend) rows(k0 + RC_BK);
+  };
+  auto store = [&]() {
+    float va[RC_NS], vb[RC_NS];
+#pragma unroll
+    for (int i = 0; i < RC_NS; ++i) {
+      const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
+      va[i] = (oka >> i & 1u) ? v : 0.f;
+      vb[i] = (okb >> i & 1u) ? rb[i] : 0.f;
+    }
+    sa.store(As, va);
+    sb.store(Bs, vb);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (kbeg < kend) {
+    rows(kbeg);
+    load(kbeg);
+  }
+#pragma unroll 1
+  for (int k0 = kbeg; k0 < kend; k0 += RC_BK) {
+    store();
+    __syncthreads();
+    if (k0 + RC_BK < kend) load(k0 + RC_BK);
+    wv.mma(As, Bs, acc);
+    __syncthreads();
+  }
+  unsigned* ticket = a.counter + blockIdx.y * gridDim.x + blockIdx.x;
+  if (!rc_acc_reduce(acc, a.ws, ticket, a.nz, zi, (size_t)a.Cout * Kpad, (size_t)n0 * Kpad + c0, Kpad, 64, wv, &last)) return;
+  const int jj = c0 + wv.col();
+  if (jj < K) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* p = a.dw + (size_t)(n0 + wv.row_of(r)) * K + jj;
+      *p = a.acc ? *p + acc[r] : acc[r];
+    }
+  }
+}
+
+// MaxPool2d(3, 2, 1) on relu(bn(y)) of the raw stem output y (B H W, C): out (B Ho Wo, C), idx = h W + w of the first
+// maximum (torch: strict '>')
+__global__ __launch_bounds__(256) void rc_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ sc, const float* __restrict__ beta,
+                                                             float* __restrict__ out, int* __restrict__ idx, int B, int H,
+                                                             int W, int C, int Ho, int Wo) {
+  const long total = (long)B * Ho * Wo * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long r = e / C;
+    const int ow = (int)(r % Wo), oh = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
+    const float m = mean[c], s = sc[c], bt = beta[c];
+    float best = -INFINITY;
+    int bi = -1;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = 2 * oh - 1 + kh;
+      if (ih < 0 || ih >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = 2 * ow - 1 + kw;
+        if (iw < 0 || iw >= W) continue;
+        const float v = fmaxf(rc_bn(y[(((size_t)b * H + ih) * W + iw) * C + c], m, s, bt), 0.f);
+        if (v > best || bi < 0) {
+          best = v;
+          bi = ih * W + iw;
+        }
+      }
+    }
+    out[e] = best;
+    idx[e] = bi;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1105,7 +1347,8 @@ extern "C" int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t
 extern "C" int mmvae_rc_bn_bwd_stats(const float* G, const mmvae_rc_stat_t* st, int M, int C, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(G && st && st->Y && st->pqr && st->part && st->counter && M > 0 && C % 64 == 0);
   hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, rc_stat_of(*st), M, C,
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 1);
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 1, (const int*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, 1, 1, 1, 1);
   return mmvae_launch_status();
 }
 
@@ -1114,7 +1357,65 @@ extern "C" int mmvae_rc_pool_bwd_stats(const float* dy, const float* x, float* G
   MMVAE_CHECK_ARG(dy && x && G && st && st->Y && st->pqr && st->part && st->counter && B > 0 && HW > 0 && C % 64 == 0);
   const int M = B * HW;
   hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
-                     rc_stat_of(*st), M, C, dy, x, G, HW);
+                     rc_stat_of(*st), M, C, dy, x, G, HW, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, 1, 1, 1,
+                     1);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_rc_maxpool_fwd(const float* y, const float* mean, const float* sc, const float* beta, float* out,
+                                    int* idx, int B, int H, int W, int C, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(y && mean && sc && beta && out && idx && B > 0 && H > 1 && W > 1 && C > 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long n = (long)B * Ho * Wo * C;
+  hipLaunchKernelGGL(rc_maxpool_fwd_kernel, dim3((unsigned)min((n + 255) / 256, 65535L * 16)), dim3(256), 0,
+                     (hipStream_t)stream, y, mean, sc, beta, out, idx, B, H, W, C, Ho, Wo);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_rc_maxpool_bwd_stats(const float* dy, const int* idx, float* G, const float* sc, const float* beta,
+                                          const mmvae_rc_stat_t* st, int B, int H, int W, int C, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && idx && G && sc && beta && st && st->Y && st->mean && st->pqr && st->part && st->counter && B > 0 &&
+                  H > 1 && W > 1 && C % 64 == 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, M = B * H * W;
+  hipLaunchKernelGGL(rc_stat_kernel, dim3(C / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                     rc_stat_of(*st), M, C, dy, (const float*)nullptr, G, 1, idx, sc, beta, H, W, Ho, Wo);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_rc_stem_fwd(const float* img, const float* w, float* y, int M, int Cimg, int Cout, int T,
+                                 const mmvae_rc_geom_t* g, const float* gamma, const float* beta, float* run_mean,
+                                 float* run_var, float* mean, float* rstd, float* sc, float* part, unsigned* counter,
+                                 float eps, float momentum, int eval, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(img && w && y && g && M > 0 && Cimg > 0 && Cout % 64 == 0 && T >= 1 && rc_geom_ok(*g, T));
+  MMVAE_CHECK_ARG(part && gamma && beta && mean && rstd && sc && counter);
+  RcStemFwdArgs a{img, w, y, M, Cimg, Cout, T, rc_geom_of(*g),
+                  {gamma, beta, run_mean, run_var, mean, rstd, sc, part, counter, eps, momentum, eval}};
+  hipLaunchKernelGGL(rc_stem_fwd_kernel, dim3(Cout / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+  return mmvae_launch_status();
+}
+
+extern "C" int mmvae_rc_stem_wgrad_splits(int M, int Cimg, int Cout, int T) {
+  const long tiles = (long)(Cout / 64) * ((T * Cimg + 63) / 64);
+  long nz = (rc_target_w() + tiles - 1) / tiles;
+  const long maxz = (M + 127) / 128;
+  if (nz > maxz) nz = maxz;
+  if (nz > 128) nz = 128;
+  return (int)(nz < 1 ? 1 : nz);
+}
+extern "C" size_t mmvae_rc_stem_wgrad_ws_floats(int M, int Cimg, int Cout, int T) {
+  return (size_t)mmvae_rc_stem_wgrad_splits(M, Cimg, Cout, T) * Cout * (((size_t)T * Cimg + 63) / 64 * 64);
+}
+
+extern "C" int mmvae_rc_stem_wgrad(const float* G, const float* Y, const float* pqr, const float* img, const int* tbl,
+                                   float* dw, float* ws, unsigned* counter, int M, int Cimg, int Cout, int T,
+                                   const mmvae_rc_geom_t* g, int accumulate, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(G && img && tbl && dw && ws && counter && g && M > 0 && Cimg > 0 && Cout % 64 == 0 && T >= 1 && (!pqr || Y) &&
+                  rc_geom_ok(*g, T));
+  const int nz = mmvae_rc_stem_wgrad_splits(M, Cimg, Cout, T);
+  int kper = (M + nz - 1) / nz;
+  kper = (kper + RC_BK - 1) / RC_BK * RC_BK;
+  RcStemWgradArgs a{G, Y, pqr, img, tbl, dw, ws, counter, M, Cimg, Cout, T, accumulate ? 1 : 0, nz, kper, rc_geom_of(*g)};
+  hipLaunchKernelGGL(rc_stem_wgrad_kernel, dim3((T * Cimg + 63) / 64, Cout / 64, nz), dim3(256), 0, (hipStream_t)stream, a);
   return mmvae_launch_status();
 }
 

@@ -229,14 +229,6 @@ SIGNATURES = {
     "mmvae_laplace_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_laplace_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_rand_laplace": (c_i, [c_p, c_l, c_p, c_p]),
-    "mmvae_im2col": (c_i, [c_p, c_p] + [c_i] * 9 + [c_p]),
-    "mmvae_col2im": (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
-    "mmvae_bn_ws_floats": (c_sz, [c_i, c_i]),
-    "mmvae_bn_row_blocks": (c_i, [c_i]),
-    "mmvae_bn_train_fwd": (c_i, [c_p] * 10 + [c_i, c_i, c_f, c_f, c_i, c_i, c_p]),
-    "mmvae_bn_train_bwd": (c_i, [c_p] * 11 + [c_i, c_i, c_i, c_i, c_i, c_p]),
-    "mmvae_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 5 + [c_p]),
-    "mmvae_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p]),
     "mmvae_avgpool_fwd": (c_i, [c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_avgpool_bwd": (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p]),
     "mmvae_rc_tables": (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
@@ -246,6 +238,12 @@ SIGNATURES = {
     "mmvae_rc_launch": (c_i, [ctypes.POINTER(RcJob), c_i, c_p]),
     "mmvae_rc_bn_bwd_stats": (c_i, [c_p, ctypes.POINTER(RcStat), c_i, c_i, c_p]),
     "mmvae_rc_pool_bwd_stats": (c_i, [c_p, c_p, c_p, ctypes.POINTER(RcStat), c_i, c_i, c_i, c_p]),
+    "mmvae_rc_stem_fwd": (c_i, [c_p] * 3 + [c_i] * 4 + [ctypes.POINTER(RcGeom)] + [c_p] * 9 + [c_f, c_f, c_i, c_p]),
+    "mmvae_rc_maxpool_fwd": (c_i, [c_p] * 6 + [c_i] * 4 + [c_p]),
+    "mmvae_rc_maxpool_bwd_stats": (c_i, [c_p] * 5 + [ctypes.POINTER(RcStat)] + [c_i] * 4 + [c_p]),
+    "mmvae_rc_stem_wgrad_splits": (c_i, [c_i] * 4),
+    "mmvae_rc_stem_wgrad_ws_floats": (c_sz, [c_i] * 4),
+    "mmvae_rc_stem_wgrad": (c_i, [c_p] * 8 + [c_i] * 4 + [ctypes.POINTER(RcGeom), c_i, c_p]),
     "mmvae_rc_wgrad_splits": (c_i, [c_i] * 4),
     "mmvae_rc_wgrad_ws_floats": (c_sz, [c_i] * 4),
     "mmvae_rc_wgrad_tickets": (c_sz, [c_i] * 3),

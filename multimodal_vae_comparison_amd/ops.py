@@ -845,127 +845,8 @@ class LinearKN(Function):
 
 
 # ----------------------------------------------------------------------------------------------
-# ResNet-50 tower pieces (csrc/resnet.hip): NHWC activations as (rows, C) matrices
+# ResNet-50 tower: global average pooling (csrc/resnet.hip); the rest of the tower is rconv.py / csrc/rconv.hip
 # ----------------------------------------------------------------------------------------------
-class Im2col(Function):
-    """cols (B*Ho*Wo, C*K*K) of act(x); x NHWC (B,H,W,C) or -- nchw -- the image batch (B,C,H,W)"""
-
-    @staticmethod
-    def forward(ctx, x, B, Hh, W, C, K, S, P, in_act, nchw):
-        x = H.f32c(x)
-        Ho, Wo = (Hh + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
-        cols = torch.empty(B * Ho * Wo, C * K * K, device=x.device)
-        _call("mmvae_im2col", H.ptr(x), H.ptr(cols), B, Hh, W, C, K, S, P, in_act, int(nchw), H.stream())
-        ctx.save_for_backward(x if in_act != H.ACT_NONE else None)
-        ctx.cfg = (B, Hh, W, C, K, S, P, in_act, nchw, tuple(x.shape))
-        return cols
-
-    @staticmethod
-    def backward(ctx, dcols):
-        (x,) = ctx.saved_tensors
-        B, Hh, W, C, K, S, P, in_act, nchw, shape = ctx.cfg
-        if not ctx.needs_input_grad[0]:
-            return (None,) * 10
-        assert not nchw, "the NCHW form is the image input (no gradient)"
-        dcols = H.f32c(dcols)
-        dx = torch.empty(shape, device=dcols.device)
-        _call("mmvae_col2im", H.ptr(dcols), H.ptr(x), H.ptr(dx), B, Hh, W, C, K, S, P, in_act, H.stream())
-        return (dx,) + (None,) * 9
-
-
-def conv_nhwc(x, B, Hh, W, w, stride, pad, in_act=H.ACT_NONE, gw=None, nchw=False):
-    """nn.Conv2d(bias=False) on act(x) with NHWC activations: x (B*H*W, Cin) [or the NCHW image batch] ->
-    (B*Ho*Wo, Cout).  1x1 / stride 1 is one GEMM; everything else im2col + GEMM (weight used in its stored layout)."""
-    Cout, Cin, K, _ = w.shape
-    wv = w.view(Cout, Cin * K * K)
-    gv = gw.view(Cout, Cin * K * K) if gw is not None else None
-    if K == 1 and stride == 1 and pad == 0 and not nchw:
-        return Linear.apply(x, wv, None, in_act, gv, None)
-    cols = Im2col.apply(x, B, Hh, W, Cin, K, stride, pad, in_act, nchw)
-    return Linear.apply(cols, wv, None, H.ACT_NONE, gv, None)
-
-
-class BatchNorm(Function):
-    """torch.nn.BatchNorm2d on an (M, C) NHWC matrix, y = bn(x) [+ res | relu(res)]; training: batch statistics and the
-    running-statistics update in the same launch; eval: the running statistics."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, res, res_relu, run_mean, run_var, training, momentum, eps, gg, gb):
-        x = H.f32c(x)
-        M, C = x.shape
-        y = torch.empty_like(x)
-        mean, rstd = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
-        # (a private buffer, not the shared workspace: towers on different streams run BatchNorms concurrently)
-        ws = torch.empty(H.lib().mmvae_bn_ws_floats(M, C), device=x.device)
-        if res is not None:
-            res = H.f32c(res)
-        _call("mmvae_bn_train_fwd", H.ptr(x), H.ptr(gamma), H.ptr(beta), H.ptr(res), H.ptr(y), H.ptr(mean), H.ptr(rstd),
-              H.ptr(run_mean), H.ptr(run_var), H.ptr(ws), M, C, float(eps), float(momentum), int(bool(res_relu)),
-              int(not training), H.stream())
-        ctx.save_for_backward(x, gamma, mean, rstd, res if res_relu else None)
-        ctx.cfg = (bool(res_relu), res is not None, not training, gg, gb)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, gamma, mean, rstd, res = ctx.saved_tensors
-        res_relu, has_res, eval_mode, gg, gb = ctx.cfg
-        dy = H.f32c(dy)
-        M, C = x.shape
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
-        lib = H.lib()
-        defer = _defer(gg, gb)
-        nws = lib.mmvae_bn_ws_floats(M, C)
-        ret_g = ret_b = None
-        if defer:
-            ws = GradReducer.alloc(nws, x.device)
-            _call("mmvae_bn_train_bwd", H.ptr(dy), H.ptr(x), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(res), H.ptr(dx),
-                  H.ptr(dres), None, None, H.ptr(ws), M, C, int(res_relu), H.ACC_DEFER, int(eval_mode), H.stream())
-            nb = lib.mmvae_bn_row_blocks(M)
-            GradReducer.add(ws.data_ptr(), gb, nb, C, 2 * C)                  # sum dy
-            GradReducer.add(ws.data_ptr() + 4 * C, gg, nb, C, 2 * C)          # sum dy xhat
-        else:
-            ws = torch.empty(nws, device=x.device)
-            if gg is not None:
-                dg, db, acc = gg, gb, 1
-            else:
-                dg, db, acc = torch.empty(C, device=x.device), torch.empty(C, device=x.device), 0
-                ret_g, ret_b = dg, db
-            _call("mmvae_bn_train_bwd", H.ptr(dy), H.ptr(x), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(res), H.ptr(dx),
-                  H.ptr(dres), H.ptr(dg), H.ptr(db), H.ptr(ws), M, C, int(res_relu), acc, int(eval_mode), H.stream())
-        return dx, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
-
-
-def batch_norm(x, gamma, beta, run_mean, run_var, training, res=None, res_relu=False, momentum=0.1, eps=1e-5):
-    return BatchNorm.apply(x, gamma, beta, res, res_relu, run_mean, run_var, training, momentum, eps, gamma.grad,
-                           beta.grad)
-
-
-class MaxPool3x3S2(Function):
-    """nn.MaxPool2d(3, 2, 1) on relu(x), NHWC: x (B*H*W, C) -> (B*Ho*Wo, C)"""
-
-    @staticmethod
-    def forward(ctx, x, B, Hh, W, in_act):
-        x = H.f32c(x)
-        C = x.shape[-1]
-        Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty(B * Ho * Wo, C, device=x.device)
-        idx = torch.empty(B * Ho * Wo, C, device=x.device, dtype=torch.int32)
-        _call("mmvae_maxpool3x3s2_fwd", H.ptr(x), H.ptr(y), H.ptr(idx), B, Hh, W, C, in_act, H.stream())
-        ctx.save_for_backward(x, idx)
-        ctx.cfg = (B, Hh, W, C, in_act)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, idx = ctx.saved_tensors
-        B, Hh, W, C, in_act = ctx.cfg
-        dx = torch.empty_like(x)
-        _call("mmvae_maxpool3x3s2_bwd", H.ptr(H.f32c(dy)), H.ptr(idx), H.ptr(x), H.ptr(dx), B, Hh, W, C, in_act, H.stream())
-        return dx, None, None, None, None
-
-
 class AvgPoolGlobal(Function):
     """nn.AdaptiveAvgPool2d(1) on relu(x): (B*HW, C) -> (B, C)"""
 

@@ -402,6 +402,91 @@ class BottleneckStack(Function):
             tuple(ret.get(p) for p in ctx.params)
 
 
+_stem_tables = {}
+
+
+def stem_table(device, B, C, Hh, W, K, S, P):
+    """(2, B*Ho*Wo) int32: per output pixel the image offset of its window origin and the origin's (h0, w0) packed as the
+    stem kernels expect them (mmvae_rc_stem_wgrad)"""
+    key = (device.index, B, C, Hh, W, K, S, P)
+    t = _stem_tables.get(key)
+    if t is None:
+        Ho, Wo = (Hh + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
+        b = torch.arange(B).view(B, 1, 1)
+        h0 = (torch.arange(Ho) * S - P).view(1, Ho, 1)
+        w0 = (torch.arange(Wo) * S - P).view(1, 1, Wo)
+        base = (b * (C * Hh * W) + h0 * W + w0).reshape(-1)
+        hw = (((h0 + 0x4000) << 16) | (w0 + 0x4000)).expand(B, Ho, Wo).reshape(-1)
+        t = _stem_tables[key] = torch.stack([base, hw]).to(torch.int32).to(device).contiguous()
+    return t
+
+
+class Stem(Function):
+    """resnet50.conv1 -> bn1 -> relu -> maxpool on the NCHW image batch: (B, 3, H, W) -> (B*Hp*Wp, 64) pooled (rectified)
+    values; one convolution launch (BatchNorm statistics in its epilogue), one pooling launch; backward: the pooling
+    backward + bn1's backward statistics in one launch, the weight gradient in another."""
+
+    @staticmethod
+    def forward(ctx, x, unit, training, w, gamma, beta):
+        x = H.f32c(x)
+        dev = x.device
+        B, C, Hh, W = x.shape
+        K, S, P = unit.conv.k, unit.conv.stride, unit.conv.pad
+        g = geom(Hh, W, K, S, P)
+        M, Cout = B * g.Ho * g.Wo, w.shape[0]
+        b = unit.buffers(M, dev)
+        y = torch.empty(M, Cout, device=dev)
+        bn = unit.bn
+        ops._call("mmvae_rc_stem_fwd", H.ptr(x), channels_last_ptr(w), H.ptr(y), M, C, Cout, K * K, ctypes.byref(g),
+                  H.ptr(gamma), H.ptr(beta), H.ptr(bn.running_mean), H.ptr(bn.running_var), H.ptr(b["mean"]), H.ptr(b["rstd"]),
+                  H.ptr(b["sc"]), H.ptr(b["part"]), H.ptr(b["counter"]), float(bn.eps), float(bn.momentum), int(not training),
+                  H.stream())
+        _tap(bn, y, b)
+        Hp, Wp = (g.Ho - 1) // 2 + 1, (g.Wo - 1) // 2 + 1
+        out = torch.empty(B * Hp * Wp, Cout, device=dev)
+        idx = torch.empty(B * Hp * Wp, Cout, device=dev, dtype=torch.int32)
+        ops._call("mmvae_rc_maxpool_fwd", H.ptr(y), H.ptr(b["mean"]), H.ptr(b["sc"]), H.ptr(beta), H.ptr(out), H.ptr(idx), B,
+                  g.Ho, g.Wo, Cout, H.stream())
+        ctx.saved = (x, y, idx, w, gamma, beta)
+        ctx.cfg = (unit, training, (B, C, Hh, W, K, S, P))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, idx, w, gamma, beta = ctx.saved
+        unit, training, (B, C, Hh, W, K, S, P) = ctx.cfg
+        dev = x.device
+        g = geom(Hh, W, K, S, P)
+        M, Cout = y.shape
+        b = unit.buffers(M, dev)
+        grads, ret = {}, {}
+        for p in (w, gamma, beta):
+            if p.grad is not None:
+                grads[p] = (p.grad, 1)
+            else:
+                grads[p] = (torch.empty_like(p), 0)
+                ret[p] = grads[p][0]
+        G = torch.empty_like(y)
+        st = _stat(unit, b, y, not training, grads)
+        ops._call("mmvae_rc_maxpool_bwd_stats", H.ptr(H.f32c(dy)), H.ptr(idx), H.ptr(G), H.ptr(b["sc"]), H.ptr(beta),
+                  ctypes.byref(st), B, g.Ho, g.Wo, Cout, H.stream())
+        lib = H.lib()
+        key = ("stem_ws", M)
+        ws = unit._buf.get(key)
+        if ws is None:
+            ws = unit._buf[key] = (torch.empty(lib.mmvae_rc_stem_wgrad_ws_floats(M, C, Cout, K * K), device=dev),
+                                   torch.zeros((Cout // 64) * ((K * K * C + 63) // 64), dtype=torch.int32, device=dev))
+        dw, acc = grads[w]
+        ops._call("mmvae_rc_stem_wgrad", H.ptr(G), H.ptr(y), H.ptr(b["pqr"]), H.ptr(x), H.ptr(stem_table(dev, B, C, Hh, W, K, S, P)),
+                  channels_last_ptr(dw), H.ptr(ws[0]), H.ptr(ws[1]), M, C, Cout, K * K, ctypes.byref(g), int(acc), H.stream())
+        ctx.saved = None
+        return None, None, None, ret.get(w), ret.get(gamma), ret.get(beta)
+
+
+def stem(x, unit, training):
+    return Stem.apply(x, unit, training, unit.conv.weight, unit.bn.weight, unit.bn.bias)
+
+
 def bottleneck_stack(s_in, blocks, B, Hh, W, in_act, training, pool=False):
     params = [p for blk in blocks for p in blk.params()]
     return BottleneckStack.apply(s_in, blocks, B, Hh, W, in_act, training, pool, *params)

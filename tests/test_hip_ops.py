@@ -869,85 +869,17 @@ def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
 
 
 # ---------------------------------------------------------------------------------------------
-# ResNet-50 tower pieces (csrc/resnet.hip): NHWC activations
+# ResNet-50 tower: global average pooling (csrc/resnet.hip)
 # ---------------------------------------------------------------------------------------------
 def _nhwc(t):        # (B,C,H,W) -> (B*H*W, C)
     B, C, Hh, W = t.shape
     return t.permute(0, 2, 3, 1).reshape(B * Hh * W, C).contiguous()
 
 
-@pytest.mark.parametrize("B,Cin,Cout,Hh,K,S,P,act,nchw", [(3, 3, 64, 64, 7, 2, 3, 0, True), (5, 64, 64, 16, 3, 1, 1, 2, False),
-                                                          (4, 128, 128, 16, 3, 2, 1, 2, False), (6, 256, 512, 8, 1, 2, 0, 2, False),
-                                                          (7, 64, 256, 16, 1, 1, 0, 0, False), (2, 512, 512, 2, 3, 1, 1, 2, False)])
-def test_conv_nhwc_matches_conv2d(ops, B, Cin, Cout, Hh, K, S, P, act, nchw):
-    """im2col + MFMA GEMM (weight in its stored (Cout, Cin, k, k) layout) == F.conv2d(act(x)), forward and backward"""
-    g = torch.Generator().manual_seed(Cin + Cout + K)
-    x = torch.randn(B, Cin, Hh, Hh, generator=g)
-    w = torch.randn(Cout, Cin, K, K, generator=g) / math.sqrt(Cin * K * K)
-    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
-    ref = F.conv2d(_act(xr, act), wr, None, stride=S, padding=P)
-    dy = torch.randn(ref.shape, generator=g)
-    ref.backward(dy.double())
-    xin = (x if nchw else _nhwc(x)).to(DEV).requires_grad_(not nchw)
-    wg = w.to(DEV).requires_grad_(True)
-    out = ops.conv_nhwc(xin, B, Hh, Hh, wg, S, P, act, None, nchw)
-    out.backward(_nhwc(dy).to(DEV))
-    check(out, _nhwc(ref), 2e-5, "y")
-    check(wg.grad, wr.grad, 5e-5, "dw")
-    if not nchw:
-        check(xin.grad, _nhwc(xr.grad), 5e-5, "dx")
-
-
-@pytest.mark.parametrize("M,C,training,res_mode", [(4096, 64, True, 0), (300, 256, True, 2), (16, 2048, True, 1),
-                                                    (520, 128, False, 2), (70000, 64, True, 0),
-                                                    # scalar fallback (C % 4 != 0); register-resident row blocks of 96
-                                                    # rows; the looping 16-byte form in eval mode
-                                                    (100, 6, True, 1), (24576, 64, True, 2), (40000, 128, False, 1)])
-def test_batch_norm_matches_torch(ops, M, C, training, res_mode):
-    """nn.BatchNorm2d on an (M, C) matrix: batch statistics + running update (train) / running statistics (eval),
-    optional residual (1: plain, 2: through a ReLU), forward and backward"""
-    g = torch.Generator().manual_seed(M + C)
-    x = torch.randn(M, C, generator=g) * 2.0 + 0.7
-    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
-    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
-    res = torch.randn(M, C, generator=g) if res_mode else None
-    dy = torch.randn(M, C, generator=g)
-    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
-    rr = res.double().requires_grad_(True) if res_mode else None
-    rm_r, rv_r = rm.double().clone(), rv.double().clone()
-    ref = F.batch_norm(xr, rm_r, rv_r, gr, br, training=training, momentum=0.1, eps=1e-5)
-    if res_mode:
-        ref = ref + (torch.relu(rr) if res_mode == 2 else rr)
-    ref.backward(dy.double())
-    xg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, gamma, beta))
-    rg = res.to(DEV).requires_grad_(True) if res_mode else None
-    rmd, rvd = rm.to(DEV), rv.to(DEV)
-    out = ops.BatchNorm.apply(xg, gg, bg, rg, res_mode == 2, rmd, rvd, training, 0.1, 1e-5, None, None)
-    out.backward(dy.to(DEV))
-    check(out, ref, 2e-5, "y")
-    check(xg.grad, xr.grad, 1e-4, "dx")
-    check(gg.grad, gr.grad, 5e-5, "dgamma")
-    check(bg.grad, br.grad, 5e-5, "dbeta")
-    if res_mode:
-        check(rg.grad, rr.grad, 1e-6, "dres")
-    check(rmd, rm_r, 1e-5, "running_mean")
-    check(rvd, rv_r, 1e-5, "running_var")
-
-
-def test_maxpool_and_avgpool_match_torch(ops):
+def test_avgpool_matches_torch(ops):
+    """(the tower's other pieces -- stem, bottlenecks, BatchNorms, max pooling -- are tests/test_rconv_gpu.py)"""
     g = torch.Generator().manual_seed(3)
-    B, C, Hh = 5, 64, 32
-    x = torch.randn(B, C, Hh, Hh, generator=g)
-    x[:, :, ::3, ::2] = -0.5          # rectified to exact zeros: windows with ties (the first maximum wins, as torch)
-    xr = x.double().requires_grad_(True)
-    ref = F.max_pool2d(torch.relu(xr), 3, 2, 1)
-    dy = torch.randn(ref.shape, generator=g)
-    ref.backward(dy.double())
-    xg = _nhwc(x).to(DEV).requires_grad_(True)
-    out = ops.MaxPool3x3S2.apply(xg, B, Hh, Hh, 2)
-    out.backward(_nhwc(dy).to(DEV))
-    check(out, _nhwc(ref), 1e-7, "maxpool")
-    check(xg.grad, _nhwc(xr.grad), 1e-7, "maxpool dx")
+    B = 5
     x2 = torch.randn(B, 2048, 2, 2, generator=g)
     x2r = x2.double().requires_grad_(True)
     ref2 = F.adaptive_avg_pool2d(torch.relu(x2r), 1).flatten(1)

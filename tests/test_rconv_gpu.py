@@ -193,3 +193,37 @@ def test_channels_last_weights_keep_their_state_dict_values(hip_lib):
     opt2 = FlatAdam(FlatParams(Bottleneck(64, 64, 1, True).to(DEV)))
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+
+
+@pytest.mark.parametrize("B,Hh,training", [(3, 64, True), (2, 32, True), (5, 20, True), (2, 64, False)])
+def test_stem_matches_torch(hip_lib, B, Hh, training):
+    """conv1 (7x7 / 2 from the NCHW image) -> bn1 -> relu -> maxpool(3, 2, 1), forward and backward, against torch float64"""
+    from multimodal_vae_comparison_amd import rconv
+    from multimodal_vae_comparison_amd.models.resnet import BatchNorm2d, ConvW
+    torch.manual_seed(B + Hh)
+    conv = ConvW(3, 64, 7, 2, 3, channels_last=True).to(DEV)
+    bn = BatchNorm2d(64).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.train(training)
+    g = torch.Generator().manual_seed(Hh)
+    x = torch.rand(B, 3, Hh, Hh, generator=g)
+    P = {n: p.detach().double().cpu().requires_grad_(True) for n, p in (("w", conv.weight), ("g", bn.weight), ("b", bn.bias))}
+    rm, rv = bn.running_mean.double().cpu().clone(), bn.running_var.double().cpu().clone()
+    y = F.conv2d(x.double(), P["w"], None, stride=2, padding=3)
+    ref = F.max_pool2d(torch.relu(F.batch_norm(y, rm, rv, P["g"], P["b"], training=training, momentum=0.1, eps=1e-5)), 3, 2, 1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    out = rconv.stem(x.to(DEV), rconv.Unit(conv, bn), training)
+    out.backward(_nhwc(dy).to(DEV))
+    torch.cuda.synchronize()
+    check(out, _nhwc(ref), 2e-5, "pooled output")
+    check(conv.weight.grad, P["w"].grad, 1e-4, "dw")
+    check(bn.weight.grad, P["g"].grad, 1e-4, "dgamma")
+    check(bn.bias.grad, P["b"].grad, 1e-4, "dbeta")
+    if training:
+        check(bn.running_mean, rm, 1e-5, "running_mean")
+        check(bn.running_var, rv, 1e-5, "running_var")
