@@ -228,6 +228,26 @@ def dominant_kernel_roofline(meta, device):
     from multimodal_vae_comparison_amd import ops
     from multimodal_vae_comparison_amd import hipops as H
     B = meta["B"]
+    if meta["mods"][0]["enc"] == "CNN":
+        # ResNet-50 tower: the 3x3 convolution of a layer2 bottleneck (128 -> 128 channels on 8x8 maps of a 64x64 input)
+        # with its BatchNorm statistics, on the fused engine (rconv.py): 2 * B*64 * 128 * 128*9 FLOP per launch
+        from multimodal_vae_comparison_amd import rconv
+        from multimodal_vae_comparison_amd.models.resnet import BatchNorm2d, ConvW
+        conv, bn, bnp = ConvW(128, 128, 3, 1, 1, channels_last=True).to(device), BatchNorm2d(128).to(device), BatchNorm2d(128).to(device)
+        u, up = rconv.Unit(conv, bn), rconv.Unit(ConvW(64, 128, 1, 1, 0).to(device), bnp)
+        M = B * 64
+        x = torch.randn(M, 128, device=device)
+        bp = up.buffers(M, device)
+        bp["mean"].zero_(); bp["sc"].fill_(1.0); bp["rstd"].fill_(1.0)
+        us = _event_time_us(lambda: rconv._fwd(u, x, M, M, rconv.PRE_BN_RELU, (bp, bnp.bias), (8, 8, 3, 1, 1), False), reps=30)
+        flops = 2.0 * M * 128 * 128 * 9
+        ach = flops / (us * 1e-6) / 1e12
+        return {"bound": "mfma", "kernel": f"rc_fwd_kernel (layer2 3x3 convolution + BatchNorm statistics, {M} x 128 <- 1152)",
+                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_us": round(us, 2), "traffic": None,
+                "traffic_unit": "bytes/launch", "traffic_source": None,
+                "note": "eager launches back to back (includes the host launch gap when the kernel is shorter); at batch 24 "
+                        "the launch is a chain of hand-over steps, not arithmetic (DESIGN 5c)"}
     if meta["mods"][0]["enc"] == "MNIST":
         N = B * len(meta["mods"]) * meta.get("K", 1) if meta.get("obj") == "dreg" else B
         x = torch.randn(N, 64, 8, 8, device=device)

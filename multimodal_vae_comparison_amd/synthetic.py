@@ -89,7 +89,8 @@ WORKLOADS = {
              "mopoe", CD_MODS + [{"enc": "Transformer", "dec": "Transformer", "data_dim": [100, 4, 1],
                                   "ltype": "optimal_sigma"}], 32, 128, 32, {}),
     "cdsprites_shipped": ("the shipped configs/config_cdspritesplus.yml: MoE elbo, `encoder: CNN` = ResNet-50 image "
-                          "tower + Dec_CNN, TxtTransformer text towers, n_latents=24, batch=24, T=32",
+                          "tower (random init; parity pinned to the oracle's restatement, UNPINNED vs torchvision) + "
+                          "Dec_CNN, TxtTransformer text towers, n_latents=24, batch=24, T=32",
                           "moe", [dict(CD_MODS[0], enc="CNN"), CD_MODS[1]], 24, 24, 32, {}),
     "mnistsvhn": ("the shipped configs/config_mnistsvhn.yml: MoE, obj dreg, K=30, prior laplace, llik_scaling auto, "
                   "n_latents=20, batch=128", "moe", [dict(m, llik_scaling="auto") for m in MS_MODS], 20, 128, 0,
