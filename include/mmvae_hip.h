@@ -417,7 +417,7 @@ int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, int S, int P
  * (zero once; the kernels re-arm them): more than 16 row tiles elect their finalizer in two levels. */
 int mmvae_rc_row_tile(int M, int N);
 /* forward / data-gradient GEMMs with few output tiles split their reduction (K channels x T taps) over workgroups:
- * ws = mmvae_rc_conv_ws_floats(M, N, K, T) floats and ceil(M / 64) * (N / 64) tile tickets (zero once) for an (M, N)
+ * ws = mmvae_rc_conv_ws_floats(M, N, K, T) floats and (ceil(M / 64) + 4) * (N / 64) tile tickets (zero once) for an (M, N)
  * output (forward: N = Cout, K = Cin; data gradient: M = Min, N = Cin, K = Cout) */
 int mmvae_rc_conv_splits(int M, int N, int K, int T);
 size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T);
@@ -486,6 +486,10 @@ typedef struct {
   float* out;
   float* ws;
   unsigned* tile_ticket;
+  const int* row_map; /* stride 2, even H and W: the Min input pixels ordered by the parity class (ih % 2, iw % 2), classes
+                         (0,0) (0,1) (1,0) (1,1), raster order inside a class -- a tile then only runs its class's taps
+                         (9 / 4 instead of 9 passes per pixel for 3 x 3); statistics buffers sized for 4 * ceil(Min / 256)
+                         row tiles.  NULL: raster order */
   int M, Min, Cin, Cout, T, nstat;
   mmvae_rc_geom_t g;
   mmvae_rc_stat_t st[2];

@@ -512,7 +512,8 @@ struct RcDgradArgs {
   float* out;             // (Min, Cin)
   float* ws;              // nz > 1: (nz, Min, Cin) partial outputs
   unsigned* tile_ticket;
-  int M, Min, Cin, Cout, T, mask, nstat, nz;
+  const int* row_map;     // stride 2, even H and W: the input pixels ordered by parity class (4 x Min / 4 rows), see below
+  int M, Min, Cin, Cout, T, mask, nstat, nz, cls_tiles;
   RcGeom g;
   RcStat st[2];
 };
@@ -522,7 +523,17 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   float* As = smem;
   float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
-  const int n0 = k.bx * 64, m0 = k.by * RC_BM;     // n0: input-channel tile
+  // Stride 2 (row_map): an input pixel (ih, iw) is read through tap (kh, kw) only when ih + P - kh and iw + P - kw are
+  // even, i.e. through 1, 2, 2 or 4 of a 3 x 3 filter's taps depending on the parities of (ih, iw).  Walking the pixels in
+  // raster order makes every 64-row tile run all 9 taps with three quarters of its (row, tap) pairs zero; so the rows are
+  // walked class by class (row tile -> class k.by / cls_tiles, rows row_map[class * Min / 4 + ...]) and a tile only runs
+  // its class's taps: 9 / 4 instead of 9 tap passes per pixel.
+  const bool cls = a.row_map != nullptr;
+  const int pcl = cls ? k.by / a.cls_tiles : 0, rows_c = cls ? a.Min / 4 : a.Min;
+  const int n0 = k.bx * 64, m0 = (cls ? k.by - pcl * a.cls_tiles : k.by) * RC_BM;     // n0: input-channel tile
+  const int* rmap = cls ? a.row_map + (size_t)pcl * rows_c : nullptr;
+  const int kh0 = cls ? ((pcl >> 1) + a.g.P) & 1 : 0, kw0 = cls ? ((pcl & 1) + a.g.P) & 1 : 0;
+  const int KH = a.T / a.g.KW, nkw = cls ? (a.g.KW - kw0 + 1) / 2 : a.g.KW, ntap = cls ? ((KH - kh0 + 1) / 2) * nkw : a.T;
   RC_STAMP(k, 0);
   RcWave wv;
   wv.init(tid);
@@ -537,7 +548,8 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   float rg_[RC_NS], ry[RC_NS], rb[RC_NS];
 #pragma unroll
   for (int i = 0; i < RC_NS; ++i) {
-    const int r = m0 + sa.row(i);
+    const int rr = m0 + sa.row(i);
+    const int r = cls ? rmap[min(rr, rows_c - 1)] : rr;
     if (ident) {
       pb_[i] = r < a.Min ? r : -1;
       hw[i] = 0;
@@ -545,18 +557,21 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       const int hwi = a.g.H * a.g.W;
       const int b = r / hwi, rem = r - b * hwi, ih = rem / a.g.W, iw = rem - ih * a.g.W;
       pb_[i] = b * a.g.Ho;
-      hw[i] = r < a.Min ? ((ih + a.g.P) << 16 | (iw + a.g.P)) : -1;
+      hw[i] = rr < rows_c ? ((ih + a.g.P) << 16 | (iw + a.g.P)) : -1;
     }
   }
   float pp = 1.f, pq = 0.f, pr = 0.f;
   unsigned oka = 0;
-  const int spc = a.Cout / RC_BK, nstage_all = a.T * spc, sper = (nstage_all + a.nz - 1) / a.nz;
+  int wtap = 0;           // the filter tap (kh KW + kw) of the stage being loaded
+  const int spc = a.Cout / RC_BK, nstage_all = ntap * spc, sper = (nstage_all + a.nz - 1) / a.nz;
   const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
   int ltap = s_beg / spc, lk0 = (s_beg - ltap * spc) * RC_BK;
   bool newtap = true;
   auto load = [&]() {
     if (newtap) {
-      const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
+      const int ta = ltap / nkw, tb = ltap - ta * nkw;
+      const int kh = cls ? kh0 + 2 * ta : ta, kw = cls ? kw0 + 2 * tb : tb;
+      wtap = kh * a.g.KW + kw;
 #pragma unroll
       for (int i = 0; i < RC_NS; ++i) {
         if (ident) {
@@ -592,7 +607,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       ry[i] = a.pqr ? a.Y[o] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + ltap) * a.Cin + n0 + sb.rl];
+    for (int i = 0; i < RC_NS; ++i) rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + wtap) * a.Cin + n0 + sb.rl];
     lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
@@ -620,9 +635,10 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
     __syncthreads();
   }
   RC_STAMP(k, 2);
-  const int cnt = min(RC_BM, a.Min - m0);
-  if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)a.Min * a.Cin,
-                     (size_t)m0 * a.Cin + n0, a.Cin, cnt, wv, lastp))
+  const int cnt = min(RC_BM, rows_c - m0);
+  // (workspace rows by row tile, not by pixel: in class order the tiles of different classes share local row numbers)
+  if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)k.gy * RC_BM * a.Cin,
+                     (size_t)k.by * RC_BM * a.Cin + n0, a.Cin, cnt, wv, lastp))
     return;
   RC_STAMP(k, 3);
   const int c = n0 + wv.col();
@@ -632,46 +648,56 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
     if (t < a.nstat) { tm[t] = a.st[t].mean[c]; tr[t] = a.st[t].rstd[c]; }
-  // the epilogue's operands first (all rows in flight), then the arithmetic.  st[0].Y is the mask source itself at the
-  // BatchNorm-mask call sites (one load serves both)
-  float vadd[16], vmy[16], vy0[16], vy1[16];
+  // the epilogue in two halves of 8 accumulator rows: the operands of a half first (all in flight), then its arithmetic.
+  // st[0].Y is the mask source itself at the BatchNorm-mask call sites (one load serves both)
   const bool st0_is_mask = a.nstat > 0 && a.mask != RC_MASK_NONE && a.st[0].Y == a.mY;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = min(wv.row_of(r), cnt - 1);
-    const size_t o = (size_t)(m0 + row) * a.Cin + c;
-    vadd[r] = 0.f;
-    if (a.add) {
-      if (a.add_tbl) {
-        const int rr = a.add_tbl[m0 + row];
-        vadd[r] = a.add[rr >= 0 ? (size_t)rr * a.Cin + c : 0];
-        if (rr < 0) vadd[r] = 0.f;
-      } else {
-        vadd[r] = a.add[o];
-      }
-    }
-    vmy[r] = a.mask != RC_MASK_NONE ? a.mY[o] : 0.f;
-    vy0[r] = (a.nstat > 0 && !st0_is_mask) ? a.st[0].Y[o] : 0.f;
-    vy1[r] = a.nstat > 1 ? a.st[1].Y[o] : 0.f;
-  }
+  for (int h = 0; h < 2; ++h) {
+    int arow[8];            // the output rows of this half's accumulator registers
+    float vadd[8], vmy[8], vy0[8], vy1[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    if (wv.row_of(r) < cnt) {
-      const size_t o = (size_t)(m0 + wv.row_of(r)) * a.Cin + c;
-      float g = acc[r] + vadd[r];
-      if (a.mask != RC_MASK_NONE) {
-        const float z = a.mask == RC_MASK_BN ? rc_bn(vmy[r], mm, ms, mb) : vmy[r];
-        g = z > 0.f ? g : 0.f;
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * h + q;
+      const int rr = m0 + min(wv.row_of(r), cnt - 1);
+      arow[q] = cls ? rmap[rr] : rr;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const size_t o = (size_t)arow[q] * a.Cin + c;
+      vadd[q] = 0.f;
+      if (a.add) {
+        if (a.add_tbl) {
+          const int rr = a.add_tbl[arow[q]];
+          vadd[q] = a.add[rr >= 0 ? (size_t)rr * a.Cin + c : 0];
+          if (rr < 0) vadd[q] = 0.f;
+        } else {
+          vadd[q] = a.add[o];
+        }
       }
-      a.out[o] = g;
-      if (a.nstat > 0) {
-        const float y0 = st0_is_mask ? vmy[r] : vy0[r];
-        s1[0] += g;
-        s2[0] = fmaf(g, (y0 - tm[0]) * tr[0], s2[0]);
-      }
-      if (a.nstat > 1) {
-        s1[1] += g;
-        s2[1] = fmaf(g, (vy1[r] - tm[1]) * tr[1], s2[1]);
+      vmy[q] = a.mask != RC_MASK_NONE ? a.mY[o] : 0.f;
+      vy0[q] = (a.nstat > 0 && !st0_is_mask) ? a.st[0].Y[o] : 0.f;
+      vy1[q] = a.nstat > 1 ? a.st[1].Y[o] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * h + q;
+      if (wv.row_of(r) < cnt) {
+        const size_t o = (size_t)arow[q] * a.Cin + c;
+        float g = acc[r] + vadd[q];
+        if (a.mask != RC_MASK_NONE) {
+          const float z = a.mask == RC_MASK_BN ? rc_bn(vmy[q], mm, ms, mb) : vmy[q];
+          g = z > 0.f ? g : 0.f;
+        }
+        a.out[o] = g;
+        if (a.nstat > 0) {
+          const float y0 = st0_is_mask ? vmy[q] : vy0[q];
+          s1[0] += g;
+          s2[0] = fmaf(g, (y0 - tm[0]) * tr[0], s2[0]);
+        }
+        if (a.nstat > 1) {
+          s1[1] += g;
+          s2[1] = fmaf(g, (vy1[q] - tm[1]) * tr[1], s2[1]);
+        }
       }
     }
   }
@@ -1236,9 +1262,9 @@ extern "C" int mmvae_rc_conv_splits(int M, int N, int K, int T) {
   if (nz > 32) nz = 32;
   return (int)(nz < 1 ? 1 : nz);
 }
-extern "C" size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T) {
-  const int nz = mmvae_rc_conv_splits(M, N, K, T);
-  return nz > 1 ? (size_t)nz * M * N : 0;
+extern "C" size_t mmvae_rc_conv_ws_floats(int M, int N, int K, int T) {      // rows by 64-row tile, + 4 tiles for the
+  const int nz = mmvae_rc_conv_splits(M, N, K, T);                             // parity-class order of stride-2 gradients
+  return nz > 1 ? (size_t)nz * ((size_t)(M + 63) / 64 * 64 + 256) * N : 0;
 }
 
 extern "C" int mmvae_rc_tables(int* fwd, int* bwd, int B, int H, int W, int K, int S, int P, mmvae_stream_t stream) {
@@ -1292,15 +1318,21 @@ static int rc_plan_dgrad(const mmvae_rc_dgrad_t& j, RcDgradArgs& a, RcPlan& pl) 
   MMVAE_CHECK_ARG((!j.pqr || j.Y) && j.nstat >= 0 && j.nstat <= 2);
   MMVAE_CHECK_ARG(j.mask == RC_MASK_NONE || j.mY);
   MMVAE_CHECK_ARG(j.mask != RC_MASK_BN || (j.mmean && j.msc && j.mbeta));
-  const int nz = mmvae_rc_conv_splits(j.Min, j.Cin, j.Cout, j.T);
+  int nz = mmvae_rc_conv_splits(j.Min, j.Cin, j.Cout, j.T), cls_tiles = 0, row_tiles = (j.Min + 63) / 64;
+  if (j.row_map) {      // parity-class order of a stride-2 data gradient: 4 x Min / 4 rows; the one-tap class has
+    MMVAE_CHECK_ARG(j.g.S == 2 && j.T > 1 && j.g.H % 2 == 0 && j.g.W % 2 == 0 && j.Min % 4 == 0);   // Cout / 32 stages
+    if (nz > j.Cout / RC_BK) nz = j.Cout / RC_BK;
+    cls_tiles = (j.Min / 4 + 63) / 64;
+    row_tiles = 4 * cls_tiles;
+  }
   MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.tile_ticket));
-  a = RcDgradArgs{j.G, j.Y, j.pqr, j.w, j.add, j.add_tbl, j.mY, j.mmean, j.msc, j.mbeta, j.out, j.ws, j.tile_ticket,
-                  j.M, j.Min, j.Cin, j.Cout, j.T, j.mask, j.nstat, nz, rc_geom_of(j.g), {}};
+  a = RcDgradArgs{j.G, j.Y, j.pqr, j.w, j.add, j.add_tbl, j.mY, j.mmean, j.msc, j.mbeta, j.out, j.ws, j.tile_ticket, j.row_map,
+                  j.M, j.Min, j.Cin, j.Cout, j.T, j.mask, j.nstat, nz, cls_tiles, rc_geom_of(j.g), {}};
   for (int t = 0; t < j.nstat; ++t) {
     MMVAE_CHECK_ARG(j.st[t].Y && j.st[t].pqr && j.st[t].part && j.st[t].counter);
     a.st[t] = rc_stat_of(j.st[t]);
   }
-  pl = RcPlan{RC_KIND_DGRAD, j.Cin / 64, (j.Min + 63) / 64, nz};
+  pl = RcPlan{RC_KIND_DGRAD, j.Cin / 64, row_tiles, nz};
   return MMVAE_OK;
 }
 

@@ -79,7 +79,7 @@ class RcFwd(ctypes.Structure):       # mmvae_rc_fwd_t
 class RcDgrad(ctypes.Structure):     # mmvae_rc_dgrad_t
     _fields_ = [("G", c_p), ("Y", c_p), ("pqr", c_p), ("w", c_p), ("add", c_p), ("add_tbl", c_p), ("mask", c_i),
                 ("mY", c_p), ("mmean", c_p), ("msc", c_p), ("mbeta", c_p), ("out", c_p), ("ws", c_p), ("tile_ticket", c_p),
-                ("M", c_i), ("Min", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("nstat", c_i), ("g", RcGeom),
+                ("row_map", c_p), ("M", c_i), ("Min", c_i), ("Cin", c_i), ("Cout", c_i), ("T", c_i), ("nstat", c_i), ("g", RcGeom),
                 ("st", RcStat * 2)]
 
 

@@ -37,6 +37,23 @@ def tables(device, B, Hh, W, K, S, P):
     return t
 
 
+_row_maps = {}
+
+
+def parity_row_map(device, B, Hh, W):
+    """the B*H*W input pixels of a stride-2 convolution ordered by the parity class (ih % 2, iw % 2) -- classes (0,0), (0,1),
+    (1,0), (1,1), raster order inside a class (mmvae_rc_dgrad_t.row_map); None when H or W is odd"""
+    if Hh % 2 or W % 2:
+        return None
+    key = (device.index, B, Hh, W)
+    t = _row_maps.get(key)
+    if t is None:
+        rows = torch.arange(B * Hh * W, dtype=torch.int32).view(B, Hh, W)
+        t = torch.cat([rows[:, ph::2, pw::2].reshape(-1) for ph in (0, 1) for pw in (0, 1)]).to(device).contiguous()
+        _row_maps[key] = t
+    return t
+
+
 def channels_last_ptr(w):
     """device pointer of a (Cout, Cin, k, k) weight whose memory is (Cout, k, k, Cin)"""
     if w.dim() == 4 and w.shape[2] * w.shape[3] > 1:
@@ -62,8 +79,9 @@ class Unit:
             f = lambda n: torch.empty(n, device=device)
             R = (M + 63) // 64                       # row tiles, + one level-1 pair per 16 of them
             b = self._buf[M] = {"mean": f(C), "rstd": f(C), "sc": f(C), "pqr": f(3 * C),
-                                "part": f((R + R // 16 + 2) * C * 2), "part_b": f((R + R // 16 + 2) * C * 2),
-                                "counter": torch.zeros((C // 64) * (2 + R // 16), dtype=torch.int32, device=device),
+                                # (+ slack: a stride-2 data gradient walks its rows in 4 parity classes, up to 3 more tiles)
+                                "part": f((R + R // 16 + 8) * C * 2), "part_b": f((R + R // 16 + 8) * C * 2),
+                                "counter": torch.zeros((C // 64) * (4 + R // 16), dtype=torch.int32, device=device),
                                 "tile_tickets": torch.zeros(R * (C // 64), dtype=torch.int32, device=device)}
             w = self.conv.weight
             Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
@@ -86,7 +104,7 @@ class Unit:
         key = ("dt", rows)
         t = self._buf.get(key)
         if t is None:
-            t = self._buf[key] = torch.zeros((rows + 63) // 64 * (self.conv.weight.shape[1] // 64), dtype=torch.int32,
+            t = self._buf[key] = torch.zeros(((rows + 63) // 64 + 4) * (self.conv.weight.shape[1] // 64), dtype=torch.int32,
                                              device=device)
         return t
 
@@ -159,7 +177,7 @@ def _stat(u, b, Y, eval_mode, grads):
                     _p(b["counter"]), int(ag), int(eval_mode))
 
 
-def dgrad_job(u, b, G, Y, g, add, add_tbl, mask, mY, mb, out_rows, stats, with_pqr=True):
+def dgrad_job(u, b, G, Y, g, add, add_tbl, mask, mY, mb, out_rows, stats, with_pqr=True, row_map=None):
     w = u.conv.weight
     Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     out = torch.empty(out_rows, Cin, device=G.device)
@@ -167,7 +185,7 @@ def dgrad_job(u, b, G, Y, g, add, add_tbl, mask, mY, mb, out_rows, stats, with_p
     j.kind = KIND_DGRAD
     d = j.d
     d.G, d.Y, d.pqr, d.w, d.g = _p(G), _p(Y), _p(b["pqr"]) if with_pqr else None, channels_last_ptr(w), geom(*g)
-    d.add, d.add_tbl, d.mask, d.mY = _p(add), _p(add_tbl), mask, _p(mY)
+    d.add, d.add_tbl, d.mask, d.mY, d.row_map = _p(add), _p(add_tbl), mask, _p(mY), _p(row_map)
     if mask == MASK_BN:
         d.mmean, d.msc, d.mbeta = _p(mb[0]["mean"]), _p(mb[0]["sc"]), _p(mb[1])
     d.out, d.ws, d.tile_ticket = _p(out), _p(u.conv_ws(out_rows, Cin, Cout, T, G.device)), _p(u.dgrad_tickets(out_rows, G.device))
@@ -369,7 +387,8 @@ class BottleneckStack(Function):
             launch(*jobs, *take_wgrads())
             # conv2 (3x3, stride): data gradient on the rows of the block's input resolution (+ bn1's statistics)
             j, G1 = dgrad_job(blk.u2, b2, G2, Y2, g3, None, None, MASK_BN, Y1, (b1, blk.u1.bn.bias), Min,
-                              [_stat(blk.u1, b1, Y1, ev, grads)])
+                              [_stat(blk.u1, b1, Y1, ev, grads)],
+                              row_map=parity_row_map(dev, B, Hh, W) if S_ == 2 else None)
             pending.append(wgrad_job(blk.u2, b2, G2, Y2, Y1, PRE_BN_RELU, (b1, blk.u1.bn.bias), t3[0], grads))
             launch(j, *take_wgrads())
             # conv1: + shortcut, ReLU mask of the block input, and the statistics of the PREVIOUS block's last BatchNorms

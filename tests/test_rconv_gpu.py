@@ -40,7 +40,7 @@ def _unit(Cin, Cout, k, s, seed):
 
 
 SHAPES = [(3, 5, 64, 128, 3, 1), (2, 8, 128, 64, 3, 2), (5, 4, 256, 64, 1, 1), (2, 6, 64, 64, 1, 2), (6, 2, 512, 512, 3, 1),
-          (24, 8, 128, 128, 3, 1)]
+          (24, 8, 128, 128, 3, 1), (3, 16, 128, 128, 3, 2), (5, 6, 64, 64, 3, 2), (2, 7, 64, 64, 3, 2)]
 
 
 @pytest.mark.parametrize("B,Hh,Cin,Cout,k,s", SHAPES)
@@ -96,7 +96,10 @@ def test_unit_forward_backward_matches_torch(hip_lib, B, Hh, Cin, Cout, k, s, tr
     grads = {p: (torch.zeros_like(p), 0) for p in (conv.weight, bn.weight, bn.bias, bnp.weight, bnp.bias)}
     st = rconv._stat(u, b, y, not training, grads)
     H.check(H.lib().mmvae_rc_bn_bwd_stats(H.ptr(Gg), ctypes.byref(st), M, Cout, H.stream()), "stats")
-    dx = rconv._dgrad(u, b, Gg, y, gm, None, rconv.MASK_BN, xg, (bp, bnp.bias), Min, [rconv._stat(up, bp, xg, False, grads)])
+    rmap = rconv.parity_row_map(torch.device(DEV), B, Hh, Hh) if (s == 2 and k > 1) else None     # stride 2: class order
+    jd, dx = rconv.dgrad_job(u, b, Gg, y, gm, None, None, rconv.MASK_BN, xg, (bp, bnp.bias), Min,
+                             [rconv._stat(up, bp, xg, False, grads)], row_map=rmap)
+    rconv.launch(jd)
     rconv._wgrad(u, b, Gg, y, xg, rconv.PRE_BN_RELU, (bp, bnp.bias), tf, grads)
     torch.cuda.synchronize()
     check(grads[bn.weight][0], P["g"].grad, 5e-5, "dgamma")
