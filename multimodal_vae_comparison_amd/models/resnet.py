@@ -18,7 +18,8 @@ stem (7x7 convolution straight from the NCHW image, BatchNorm statistics in its 
 while it reads) and the global average pooling ride on the same engine: no im2col / col2im / BatchNorm kernel is left
 on the tower's path.
 Parity: pinned against an oracle restatement of the same published topology with synthetic weights
-(oracle/mmvae_oracle.py: enc_cnn_resnet50); UNPINNED against torchvision itself, which is absent in this image."""
+(oracle/mmvae_oracle.py: enc_cnn_resnet50), which is pinned against transformers' independent ResNet v1.5
+(tests/test_oracle_resnet_independent.py); UNPINNED against torchvision itself, which is absent in this image."""
 import math
 import os
 

@@ -89,7 +89,7 @@ WORKLOADS = {
              "mopoe", CD_MODS + [{"enc": "Transformer", "dec": "Transformer", "data_dim": [100, 4, 1],
                                   "ltype": "optimal_sigma"}], 32, 128, 32, {}),
     "cdsprites_shipped": ("the shipped configs/config_cdspritesplus.yml: MoE elbo, `encoder: CNN` = ResNet-50 image "
-                          "tower (random init; parity pinned to the oracle's restatement, UNPINNED vs torchvision) + "
+                          "tower (random init; parity pinned to the oracle's restatement and through it to transformers' independent ResNet v1.5, UNPINNED vs torchvision itself) + "
                           "Dec_CNN, TxtTransformer text towers, n_latents=24, batch=24, T=32",
                           "moe", [dict(CD_MODS[0], enc="CNN"), CD_MODS[1]], 24, 24, 32, {}),
     "mnistsvhn": ("the shipped configs/config_mnistsvhn.yml: MoE, obj dreg, K=30, prior laplace, llik_scaling auto, "

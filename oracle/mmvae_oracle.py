@@ -272,14 +272,16 @@ def enc_cnn2(p, pre, x):
                           p[f"{pre}.enc.logvar_layer.weight"], p[f"{pre}.enc.logvar_layer.bias"])
 
 
-def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
-    """Enc_CNN.forward, models/encoders.py:116-127: silu(resnet50(x)) -> heads.  resnet50 is NOT vendored by the
-    reference (torchvision, absent in this image; parity with torchvision itself is UNPINNED): the published topology is
-    restated here -- conv 7x7/2 (no bias), BatchNorm, ReLU, maxpool 3x3/2, [3, 4, 6, 3] bottlenecks (1x1, 3x3 with the
-    stride, 1x1 x4; 1x1 projection shortcut on the first block of a stage), global average pool, Linear(2048, 1000).
+def resnet50_logits(p, r, x, train=False, stats=None, taps=None):
+    """torchvision resnet50(x) -> (B, 1000) with parameters p[f"{r}.<torchvision name>"].  resnet50 is NOT vendored by
+    the reference (torchvision, absent in this image; parity with torchvision itself is UNPINNED): the published topology
+    is restated here -- conv 7x7/2 (no bias), BatchNorm, ReLU, maxpool 3x3/2, [3, 4, 6, 3] bottlenecks (1x1, 3x3 with the
+    stride, 1x1 x4; 1x1 projection shortcut on the first block of a stage), global average pool, Linear(2048, 1000) --
+    and PINNED against an independent implementation of the same published architecture, Hugging Face transformers'
+    ResNetForImageClassification (v1.5 bottlenecks, 320 state entries like torchvision's), with the same weights in
+    float64: tests/test_oracle_resnet_independent.py (logits and every parameter gradient, train and eval mode).
     BatchNorm: batch statistics when `train` (a reference model in .train()), else the running statistics `stats`
     ({key.running_mean / key.running_var}; default 0 / 1 = a freshly constructed module in .eval())."""
-    r = f"{pre}.enc.resnet"
 
     def bn(h, key):
         c = h.shape[1]
@@ -305,7 +307,12 @@ def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
                 h.retain_grad()
                 taps.append((k, h))
     h = F.adaptive_avg_pool2d(h, 1).flatten(1)
-    h = F.silu(F.linear(h, p[f"{r}.fc.weight"], p[f"{r}.fc.bias"]))
+    return F.linear(h, p[f"{r}.fc.weight"], p[f"{r}.fc.bias"])
+
+
+def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
+    """Enc_CNN.forward, models/encoders.py:116-127: silu(resnet50(x)) -> heads (resnet50: resnet50_logits above)"""
+    h = F.silu(resnet50_logits(p, f"{pre}.enc.resnet", x, train, stats, taps))
     return process_output(h, p[f"{pre}.enc.mu_layer.weight"], p[f"{pre}.enc.mu_layer.bias"],
                           p[f"{pre}.enc.logvar_layer.weight"], p[f"{pre}.enc.logvar_layer.bias"])
 
