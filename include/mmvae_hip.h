@@ -857,6 +857,13 @@ int mmvae_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, mmvae_
 int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
                             float beta2, float eps, int step, int* step_dev, float grad_scale,
                             int zero_grad, mmvae_stream_t stream);
+/* `optimizer: adabelief` (models/trainer.py:82-86: adabelief_pytorch.AdaBelief(lr, eps=1e-16, betas=(0.9, 0.999),
+ * weight_decouple=True, rectify=False), weight_decay 0): m = b1 m + (1-b1) g; s = b2 s + (1-b2)(g-m)^2 + eps;
+ * p -= lr/bc1 * m / (sqrt(s)/sqrt(bc2) + eps).  The package is not vendored by the reference and absent here: restated
+ * from Zhuang et al. 2020 (Algorithm 2) and the package's update order, parity unpinned.  step / step_dev / grad_scale /
+ * zero_grad as mmvae_adam_amsgrad_flat. */
+int mmvae_adabelief_flat(float* p, float* g, float* m, float* s, long n, float lr, double beta1, double beta2, float eps,
+                         int step, int* step_dev, float grad_scale, int zero_grad, mmvae_stream_t stream);
 int mmvae_step_inc(int* step_dev, mmvae_stream_t stream);
 /* dst[i] (+)= sum_r src[r*stride + i],  i < len */
 int mmvae_reduce_rows(const float* src, float* dst, int n_rows, long len, long stride, int accumulate,

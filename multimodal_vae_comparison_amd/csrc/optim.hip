@@ -127,6 +127,90 @@ extern "C" int mmvae_adam_amsgrad_flat(float* p, float* g, float* m, float* v, f
   return mmvae_launch_status();
 }
 
+// AdaBelief (Zhuang et al., NeurIPS 2020, Algorithm 2) as the reference configures it: `optimizer: adabelief` ->
+// adabelief_pytorch.AdaBelief(lr, eps=1e-16, betas=(0.9, 0.999), weight_decouple=True, rectify=False) (reference
+// models/trainer.py:82-86; the package is a dependency the reference does not vendor and this image does not have:
+// PARITY UNPINNED, restated from the paper and the package's update order, weight_decay = 0 = its default):
+//   m = b1 m + (1-b1) g ; s = b2 s + (1-b2) (g - m)^2 + eps   (the package adds eps to the stored s, as the paper does)
+//   p -= (lr / bc1) * m / (sqrt(s) / sqrt(bc2) + eps)
+// (1 - beta) comes from the host in double -> float, as torch hands `value=1 - beta2` to its kernels: 1.0f - 0.999f is
+// 1.3e-5 off 0.001)
+__device__ __forceinline__ void adabelief_update1(float& P, const float G, float& M, float& S, const float b1, const float b2,
+                                                  const float omb1, const float omb2, const float eps, const float gscale,
+                                                  const float lr_bc1, const float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+  const float gr = G * gscale;
+  M = fmaf(b1, M, omb1 * gr);
+  const float d = gr - M;
+  S = fmaf(b2, S, (omb2 * d) * d) + eps;
+  const float den = fmaf(sqrtf(S), inv_sqrt_bc2, eps);
+  P = P - (lr_bc1 * M) / den;
+}
+
+// same step-count protocol as adam_amsgrad_kernel (step < 0: device block {count, ticket, beta1^count, beta2^count})
+__global__ __launch_bounds__(256) void adabelief_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ sv, long n, float lr, int step,
+                                                        int* __restrict__ step_dev, float b1, float b2, float omb1,
+                                                        float omb2, float eps, float gscale, int zero_grad) {
+  __shared__ float bc[2];
+  __shared__ double pw[2];
+  if (threadIdx.x == 0) {
+    const int st = step_dev ? step_dev[0] + (step < 0 ? 1 : 0) : step;
+    double p1, p2;
+    if (step_dev && step < 0) {
+      const double* run = reinterpret_cast<const double*>(step_dev + 2);
+      const double r1 = run[0], r2 = run[1];
+      p1 = st == 1 ? (double)b1 : (r1 > 0.0 ? r1 * (double)b1 : pow((double)b1, (double)st));
+      p2 = st == 1 ? (double)b2 : (r2 > 0.0 ? r2 * (double)b2 : pow((double)b2, (double)st));
+      pw[0] = p1;
+      pw[1] = p2;
+    } else {
+      p1 = pow((double)b1, (double)st);
+      p2 = pow((double)b2, (double)st);
+    }
+    bc[0] = (float)((double)lr / (1.0 - p1));
+    bc[1] = (float)(1.0 / sqrt(1.0 - p2));
+  }
+  __syncthreads();
+  const float lr_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float pi = p[i], mi = m[i], si = sv[i];
+    adabelief_update1(pi, g[i], mi, si, b1, b2, omb1, omb2, eps, gscale, lr_bc1, inv_sqrt_bc2);
+    p[i] = pi;
+    m[i] = mi;
+    sv[i] = si;
+    if (zero_grad) g[i] = 0.f;
+  }
+  if (step_dev && step < 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int ticket = atomicAdd(step_dev + 1, 1);
+      if (ticket == (int)gridDim.x - 1) {
+        step_dev[1] = 0;
+        step_dev[0] += 1;
+        double* run = reinterpret_cast<double*>(step_dev + 2);
+        run[0] = pw[0];
+        run[1] = pw[1];
+      }
+    }
+  }
+}
+
+extern "C" int mmvae_adabelief_flat(float* p, float* g, float* m, float* s, long n, float lr, double beta1, double beta2,
+                                    float eps, int step, int* step_dev, float grad_scale, int zero_grad,
+                                    mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(p && g && m && s && n > 0 && (step > 0 || step_dev));
+  if (step < 0 && (((uintptr_t)step_dev) & 7) != 0) return MMVAE_ERR_ARG;
+  long blocks = (n + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adabelief_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, s, n, lr, step,
+                     step_dev, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, grad_scale,
+                     zero_grad);
+  return mmvae_launch_status();
+}
+
 // dst[i] (+)= sum_r src[r*stride + i].  Block = 64 columns x 4 row slices; every thread keeps 8 independent
 // loads in flight (a serial "a += src[r]" chain costs one memory latency per row: 26 us for 64 rows).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,

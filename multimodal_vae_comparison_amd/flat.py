@@ -93,6 +93,8 @@ class FlatAdam(torch.optim.Optimizer):
     as one kernel over the flat buffer.  The step count lives on the device so that a captured hipGraph
     replays with the correct bias correction."""
 
+    supports_fold = True       # FlatAdam.step() can take the end-of-backward fold (GradReducer.deferred) into its launch
+
     def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps, amsgrad=True))
         self.flat = flat
@@ -192,6 +194,73 @@ class FlatAdam(torch.optim.Optimizer):
             steps.add(int(float(st["step"])))
         assert len(steps) <= 1, f"per-parameter step counts differ: {steps}"
         self.step_dev.zero_()                     # the running beta powers are rebuilt by the kernel (pow()) once
+        if steps:
+            self.step_dev[0] = steps.pop()
+        g = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = g["lr"]
+        self.param_groups[0]["betas"] = tuple(g["betas"])
+        self.param_groups[0]["eps"] = g["eps"]
+
+
+class FlatAdaBelief(FlatAdam):
+    """adabelief_pytorch.AdaBelief(lr, eps=1e-16, betas=(0.9, 0.999), weight_decouple=True, rectify=False) -- what the
+    reference's `optimizer: adabelief` builds (models/trainer.py:82-86) -- as one kernel over the flat buffers.  The package
+    is not vendored by the reference and absent in this image: the update is restated from the paper (Zhuang et al. 2020,
+    Algorithm 2) and the package's update order (csrc/optim.hip: adabelief_update1), PARITY UNPINNED.  State names as the
+    package's: exp_avg, exp_avg_var."""
+
+    supports_fold = False      # the end-of-backward fold is fused into the Adam launch only
+
+    def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.999), eps=1e-16, grad_scale=1.0):
+        super().__init__(flat, lr=lr, betas=betas, eps=eps, grad_scale=grad_scale)
+        self.param_groups[0]["amsgrad"] = False
+        self.vmax = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if self._steps_since_check == 0:
+            self.check_grad_views()
+        self._steps_since_check = (self._steps_since_check + 1) & 255
+        assert ops.GradReducer.deferred is None, "FlatAdaBelief does not take a deferred fold"
+        g = self.param_groups[0]
+        ops.adabelief_flat(self.flat.data, self.flat.grad, self.m, self.v, float(g["lr"]), g["betas"][0], g["betas"][1],
+                           g["eps"], -1, self.step_dev, self.grad_scale, True)
+        return loss
+
+    def state_dict(self):
+        step = int(self.step_dev[0].item())
+        state = {}
+        for i, p in enumerate(self.flat.params_in_model_order):
+            o = self.flat.offset_of[id(p)]
+            state[i] = {"step": step, "exp_avg": FlatParams.view_of(self.m, o, p).clone(),
+                        "exp_avg_var": FlatParams.view_of(self.v, o, p).clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "buffer": [[None, None, None] for _ in range(10)], "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        params = self.flat.params_in_model_order
+        listed = sd["param_groups"][0].get("params")
+        if listed is not None and len(listed) != len(params):
+            raise RuntimeError(f"optimizer param group lists {len(listed)} parameters, the model has {len(params)}")
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for i, p in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            if st["exp_avg"].numel() != p.numel():
+                raise RuntimeError(f"optimizer state {i}: exp_avg has {st['exp_avg'].numel()} elements, parameter has {p.numel()}")
+            o = self.flat.offset_of[id(p)]
+            sl = slice(o, o + p.numel())
+            self.m[sl].copy_(FlatParams.flatten_like(st["exp_avg"].reshape(p.shape), p))
+            self.v[sl].copy_(FlatParams.flatten_like(st["exp_avg_var"].reshape(p.shape), p))
+            steps.add(int(float(st["step"])))
+        assert len(steps) <= 1, f"per-parameter step counts differ: {steps}"
+        self.step_dev.zero_()
         if steps:
             self.step_dev[0] = steps.pop()
         g = sd["param_groups"][0]

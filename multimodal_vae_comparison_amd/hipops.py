@@ -194,6 +194,7 @@ SIGNATURES = {
     "mmvae_permute_mask_fwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
     "mmvae_permute_mask_bwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
     "mmvae_adam_amsgrad_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_i, c_p, c_f, c_i, c_p]),
+    "mmvae_adabelief_flat": (c_i, [c_p] * 4 + [c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_i, c_p, c_f, c_i, c_p]),
     "mmvae_step_inc": (c_i, [c_p, c_p]),
     "mmvae_reduce_rows": (c_i, [c_p, c_p, c_i, c_l, c_l, c_i, c_p]),
     "mmvae_fill": (c_i, [c_p, c_l, c_f, c_p]),

@@ -66,16 +66,17 @@ class MultimodalVAE(nn.Module):
         return self.model
 
     def configure_optimizers(self):
-        """models/trainer.py:75-89: Adam(lr, amsgrad=True) over the trainable parameters.  `optimizer: adabelief`
-        (:82-86) imports the third-party adabelief_pytorch package, which the reference does not vendor: not on this
-        path, refused loudly (as any other name is by the reference's own NotImplementedError)."""
+        """models/trainer.py:75-89: Adam(lr, amsgrad=True) over the trainable parameters, or `optimizer: adabelief`
+        (:82-86: adabelief_pytorch.AdaBelief(lr, eps=1e-16, betas=(0.9, 0.999), weight_decouple=True, rectify=False) -- a
+        package the reference does not vendor and this image does not have: its published update restated as one flat
+        kernel, parity unpinned, flat.FlatAdaBelief); any other name raises NotImplementedError as in the reference."""
         name = self.config.optimizer.lower()
         if name == "adabelief":
-            raise NotImplementedError("optimizer: adabelief needs the un-vendored adabelief_pytorch package "
-                                      "(reference models/trainer.py:82-86); the MI355X path implements adam (amsgrad)")
-        if name != "adam":
+            self.optimizer = flatmod.FlatAdaBelief(self.flat, lr=float(self.config.lr))
+        elif name == "adam":
+            self.optimizer = flatmod.FlatAdam(self.flat, lr=float(self.config.lr))
+        else:
             raise NotImplementedError(self.config.optimizer)
-        self.optimizer = flatmod.FlatAdam(self.flat, lr=float(self.config.lr))
         return self.optimizer
 
     def log(self, name, value, batch_size=None, **kw):
@@ -255,7 +256,8 @@ class MultimodalVAE(nn.Module):
                         ring.done = False
                         ops.GradReducer.side_tail = ops.GradReducer.pre_join = ring.pull_next
                     # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
-                    ops.GradReducer.defer_next = self._adam_in_graph and os.environ.get("MMVAE_ADAM_FOLD", "1") == "1"
+                    ops.GradReducer.defer_next = (self._adam_in_graph and self.optimizer.supports_fold and
+                                                  os.environ.get("MMVAE_ADAM_FOLD", "1") == "1")
                     res = self._fwd_bwd(batch)
                     ops.GradReducer.defer_next = False
                     ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
@@ -306,7 +308,8 @@ class MultimodalVAE(nn.Module):
         good, else the reason; every rank reaches the same verdict (the failure flag is reduced with MAX)."""
         dist = torch.distributed
         opt = self.optimizer
-        keep = [t.clone() for t in (self.flat.data, opt.m, opt.v, opt.vmax, opt.step_dev)]
+        state = tuple(t for t in (self.flat.data, opt.m, opt.v, opt.vmax, opt.step_dev) if t is not None)
+        keep = [t.clone() for t in state]
         bad, why = 0.0, None
         try:
             self._graph.replay()
@@ -320,7 +323,7 @@ class MultimodalVAE(nn.Module):
         flag = torch.tensor([bad + float(not bool(torch.isfinite(cs).all())) + float(lo.item() != hi.item())],
                             device=cs.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        for t, k in zip((self.flat.data, opt.m, opt.v, opt.vmax, opt.step_dev), keep):
+        for t, k in zip(state, keep):
             t.copy_(k)
         self.flat.zero_grad()
         torch.cuda.synchronize()

@@ -2356,6 +2356,11 @@ def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=No
           eps, int(step), H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())
 
 
+def adabelief_flat(p, g, m, s, lr, beta1, beta2, eps, step, step_dev=None, grad_scale=1.0, zero_grad=True):
+    _call("mmvae_adabelief_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(s), p.numel(), lr, beta1, beta2, eps, int(step),
+          H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())
+
+
 def adam_fold_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step_dev, grad_scale, zero_grad, deferred):
     """GradReducer.deferred + Adam(amsgrad) in one launch (mmvae_adam_fold_flat)"""
     tail = deferred["tail"]

@@ -1208,6 +1208,24 @@ OBJECTIVES = {"vae": vae_objective, "mopoe": mopoe_objective, "poe": poe_objecti
 # ----------------------------------------------------------------------------------------------
 # optimiser
 # ----------------------------------------------------------------------------------------------
+def adabelief_step(params, grads, state, lr, step, b1=0.9, b2=0.999, eps=1e-16):
+    """`optimizer: adabelief` (models/trainer.py:82-86): adabelief_pytorch.AdaBelief(lr, eps=1e-16, betas=(0.9, 0.999),
+    weight_decouple=True, rectify=False), weight_decay 0 (the package's default: the decoupled decay is a no-op).  The
+    package is NOT vendored by the reference and absent in this image (environment.yml lists it without a version):
+    PARITY UNPINNED -- restated from Zhuang et al., "AdaBelief Optimizer", NeurIPS 2020, Algorithm 2 and the package's
+    (0.2.x) update order, including its in-place `exp_avg_var.add_(eps)` (the eps of the paper's s_t update stays in the
+    state).  `step` is 1-based.  state: dict name -> (exp_avg, exp_avg_var), updated in place; params updated in place."""
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    for k, g in grads.items():
+        m, s_ = state[k]
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        r = g - m
+        s_.mul_(b2).addcmul_(r, r, value=1 - b2)
+        denom = (s_.add_(eps).sqrt() / math.sqrt(bc2)).add_(eps)
+        params[k].data.addcdiv_(m, denom, value=-lr / bc1)
+
+
 def adam_amsgrad_step(params, grads, state, lr, step, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam(amsgrad=True) single-tensor update (models/trainer.py:79-81); `step` is 1-based.
     state: dict name -> (m, v, vmax) updated in place; params updated in place."""

@@ -174,7 +174,7 @@ def test_lightning_steps_log_what_the_reference_logs(hip_lib, mixing):
 
 def test_pre_trained_warm_start_and_adabelief(hip_lib, tmp_path):
     """`pre_trained:` (models/trainer.py:95-97) loads the checkpoint into the model the config describes -- and fails
-    loudly when it cannot; `optimizer: adabelief` (:82-86) is refused with the reason"""
+    loudly when it cannot; an unknown optimizer name raises NotImplementedError as in the reference (:87-88)"""
     from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
     from multimodal_vae_comparison_amd.synthetic import cdsprites_config
     tr, batch = _trainer()
@@ -189,6 +189,61 @@ def test_pre_trained_warm_start_and_adabelief(hip_lib, tmp_path):
         MultimodalVAE(dict(cdsprites_config("mopoe", 8), pre_trained=str(tmp_path / "missing.ckpt")), device=DEV)
     with pytest.raises(RuntimeError, match="size mismatch"):
         MultimodalVAE(dict(cdsprites_config("mopoe", 16), pre_trained=path), device=DEV)
-    ab = MultimodalVAE(dict(cdsprites_config("mopoe", 8), optimizer="adabelief"), device=DEV)
-    with pytest.raises(NotImplementedError, match="adabelief_pytorch"):
-        ab.configure_optimizers()
+    other = MultimodalVAE(dict(cdsprites_config("mopoe", 8), optimizer="sgd"), device=DEV)
+    with pytest.raises(NotImplementedError):
+        other.configure_optimizers()
+
+
+def test_adabelief_matches_the_restated_update(hip_lib):
+    """`optimizer: adabelief` (models/trainer.py:82-86): the flat kernel against the oracle's restatement of the published
+    update (parity unpinned: the adabelief_pytorch package is absent), over several steps of one model's real gradients --
+    eagerly, through a checkpoint round trip, and inside the captured step"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import mmvae_oracle as orc
+    from multimodal_vae_comparison_amd.flat import FlatAdaBelief
+    from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
+    from multimodal_vae_comparison_amd.synthetic import cdsprites_batch, cdsprites_config
+    torch.manual_seed(0)
+    tr = MultimodalVAE(dict(cdsprites_config("mopoe", 8, batch_size=6), optimizer="adabelief", lr=1e-3), device=DEV)
+    opt = tr.configure_optimizers()
+    assert isinstance(opt, FlatAdaBelief) and opt.param_groups[0]["eps"] == 1e-16
+    tr.model.train()
+    batch = cdsprites_batch(6, 32, device=DEV, seed=1)
+    ref_p = {k: v.detach().double().cpu().clone() for k, v in tr.model.named_parameters()}
+    ref_s = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref_p.items()}
+    holder = {k: torch.nn.Parameter(v) for k, v in ref_p.items()}
+    losses = []
+    for step in range(1, 4):
+        out = tr.model.objective(batch)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        grads = {k: (p.grad.detach().double().cpu().clone() if p.grad is not None else torch.zeros_like(ref_p[k]))
+                 for k, p in tr.model.named_parameters()}
+        opt.step()
+        torch.cuda.synchronize()
+        orc.adabelief_step(holder, grads, ref_s, 1e-3, step)
+        losses.append(float(out["loss"]))
+        for k, p in tr.model.named_parameters():
+            err = float((p.detach().double().cpu() - holder[k].data).abs().max())
+            assert err <= 2e-6 * max(1.0, float(holder[k].data.abs().max())), (step, k, err)
+    assert losses[-1] < losses[0]
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_var"} and sd["state"][0]["step"] == 3
+    by_id = {id(p): k for k, p in tr.model.named_parameters()}
+    names = [by_id[id(p)] for p in tr.flat.params_in_model_order]      # the order optimizer state entries are numbered in
+    for i, k in enumerate(names):
+        assert float((sd["state"][i]["exp_avg_var"].double().cpu() - ref_s[k][1]).abs().max()) <= \
+            1e-5 * max(float(ref_s[k][1].abs().max()), 1e-12), k
+    opt2 = FlatAdaBelief(tr.flat, lr=1e-3)
+    opt2.load_state_dict(sd)
+    sd2 = opt2.state_dict()         # (the flat buffers' alignment gaps are not state: compare what the state dict carries)
+    assert int(opt2.step_dev[0]) == 3 and all(torch.equal(sd2["state"][i][f], sd["state"][i][f])
+                                                 for i in sd["state"] for f in ("exp_avg", "exp_avg_var"))
+    # the captured step takes the same optimiser (no deferred fold: the fold rides on Adam launches only)
+    tr.capture(batch)
+    l0 = float(tr.fused_step()["loss"])
+    for _ in range(5):
+        l1 = float(tr.fused_step()["loss"])
+    assert l1 < l0
