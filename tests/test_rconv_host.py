@@ -1,0 +1,55 @@
+"""Host-side pieces of the ResNet engine (rconv.py) that need no GPU: the parity-class row order of stride-2 data
+gradients and the stem's window-origin table against their definitions; the channels-last parameter views of flat.py."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multimodal_vae_comparison_amd import rconv        # noqa: E402
+from multimodal_vae_comparison_amd.flat import FlatParams  # noqa: E402
+from multimodal_vae_comparison_amd.models.resnet import Bottleneck  # noqa: E402
+
+CPU = torch.device("cpu")
+
+
+def test_parity_row_map_orders_pixels_by_class():
+    B, Hh, W = 3, 6, 4
+    m = rconv.parity_row_map(CPU, B, Hh, W)
+    assert sorted(m.tolist()) == list(range(B * Hh * W))           # a permutation
+    n = B * Hh * W // 4
+    for cls, (ph, pw) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        rows = m[cls * n:(cls + 1) * n]
+        ih, iw = (rows // W) % Hh, rows % W
+        assert bool(((ih % 2) == ph).all()) and bool(((iw % 2) == pw).all())
+        assert rows.tolist() == sorted(rows.tolist())               # raster order inside a class
+    assert rconv.parity_row_map(CPU, 2, 7, 4) is None              # odd maps: raster order, all taps
+
+
+def test_stem_table_is_the_window_origin():
+    B, C, Hh, W, K, S, P = 2, 3, 10, 12, 7, 2, 3
+    t = rconv.stem_table(CPU, B, C, Hh, W, K, S, P)
+    Ho, Wo = (Hh + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
+    assert tuple(t.shape) == (2, B * Ho * Wo)
+    for b in range(B):
+        for oh in range(Ho):
+            for ow in range(Wo):
+                r = (b * Ho + oh) * Wo + ow
+                h0, w0 = oh * S - P, ow * S - P
+                assert int(t[0, r]) == b * C * Hh * W + h0 * W + w0
+                assert int(t[1, r]) == ((h0 + 0x4000) << 16) | (w0 + 0x4000)
+
+
+def test_flat_buffers_hold_kxk_weights_channels_last():
+    torch.manual_seed(0)
+    blk = Bottleneck(64, 64, 2, True)
+    w0 = blk.conv2.weight.detach().clone()
+    flat = FlatParams(blk)
+    w = blk.conv2.weight
+    o = flat.offset_of[id(w)]
+    assert torch.equal(w.detach(), w0) and tuple(w.stride()) == (576, 1, 192, 64)
+    assert torch.equal(flat.data[o:o + w.numel()].view(64, 3, 3, 64), w0.permute(0, 2, 3, 1))
+    assert w.grad.data_ptr() == flat.grad.data_ptr() + 4 * o and tuple(w.grad.stride()) == tuple(w.stride())
+    w1 = blk.conv1.weight                                   # 1x1: plain contiguous
+    assert w1.is_contiguous() and torch.equal(FlatParams.flatten_like(w1.detach(), w1), w1.detach().reshape(-1))
