@@ -86,6 +86,25 @@ __device__ __forceinline__ bool rc_last_workgroup(unsigned* __restrict__ ticket,
 // linear grid when several independent jobs share one launch: rc_group_kernel)
 struct RcBlk { int bx, by, bz, gx, gy; };
 
+// Linear workgroup number of a job -> its coordinates.  Workgroup i of a launch runs on XCD i % 8 (tools/probe/
+// xcd_scope.hip: without exception), and every XCD has its own L2: with `xcd` the row tile `by` always lands on XCD
+// by % 8, in every launch, so that the rows one launch wrote through an XCD's L2 are read on that XCD by the next (the
+// plain order puts row tile `by` wherever gx happens to send it).  `local` must be congruent to the hardware workgroup
+// number mod 8; the job's grid is padded to 8 * ceil(gy / 8) * gx * gz workgroups, the surplus leaves at once (false).
+__device__ __forceinline__ bool rc_blk_of(int local, int gx, int gy, int gz, int xcd, RcBlk& k) {
+  if (!xcd) {
+    if (local >= gx * gy * gz) return false;
+    k = RcBlk{local % gx, (local / gx) % gy, local / (gx * gy), gx, gy};
+    return true;
+  }
+  const int x = local & 7, q = local >> 3, per = gx * gz;
+  const int ny = (gy - x + 7) >> 3;            // row tiles x, x + 8, ... of this XCD
+  if (q >= ny * per) return false;
+  const int i = q / per, rem = q - i * per;
+  k = RcBlk{rem % gx, x + 8 * i, rem / gx, gx, gy};
+  return true;
+}
+
 // pixel geometry of a convolution: (B, H, W) input pixels -> (B, Ho, Wo) output pixels, KW x (T / KW) taps, stride S,
 // padding P.  T == 1 && S == 1: rows map to themselves.
 struct RcGeom { int H, W, Ho, Wo, KW, S, P; };
@@ -424,11 +443,13 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   rc_fwd_tail(acc, a.y, a.M, a.Cout, a.bn, k, m0, n0, cnt, wv, smem, cs, lastp);
 }
 
-__global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
+__global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a, int gx, int gy, int gz, int xcd) {
   __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
-  rc_fwd_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
+  RcBlk k;
+  if (!rc_blk_of((int)blockIdx.x, gx, gy, gz, xcd, k)) return;
+  rc_fwd_body(a, k, smem, cs, &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -718,11 +739,13 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   RC_STAMP_WAIT(k, 6);
 }
 
-__global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a) {
+__global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a, int gx, int gy, int gz, int xcd) {
   __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
-  rc_dgrad_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
+  RcBlk k;
+  if (!rc_blk_of((int)blockIdx.x, gx, gy, gz, xcd, k)) return;
+  rc_dgrad_body(a, k, smem, cs, &last);
 }
 
 // stand-alone statistics of a BatchNorm backward whose G was produced elsewhere (pooling backward, tests):
@@ -895,11 +918,13 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   }
 }
 
-__global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a) {
+__global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a, int gx, int gy, int gz, int xcd) {
   __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
-  rc_wgrad_body(a, RcBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, cs, &last);
+  RcBlk k;
+  if (!rc_blk_of((int)blockIdx.x, gx, gy, gz, xcd, k)) return;
+  rc_wgrad_body(a, k, smem, cs, &last);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1194,7 +1219,7 @@ __global__ __launch_bounds__(256) void rc_tables_kernel(int* __restrict__ fwd, i
 #define RC_KIND_FWD 0
 #define RC_KIND_DGRAD 1
 #define RC_KIND_WGRAD 2
-struct RcPlan { int kind, gx, gy, gz; };
+struct RcPlan { int kind, gx, gy, gz, xcd; };
 union RcAny {
   RcFwdArgs f;
   RcDgradArgs d;
@@ -1219,9 +1244,10 @@ __global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
 #pragma unroll
   for (int q = 1; q < MMVAE_RC_MAX_JOBS; ++q)
     if (q < g->n && (int)blockIdx.x >= g->blk0[q]) p = q;
-  const int local = blockIdx.x - g->blk0[p];
+  const int local = blockIdx.x - g->blk0[p];          // (blk0 are multiples of 8)
   const RcPlan pl = g->plan[p];
-  const RcBlk k{local % pl.gx, (local / pl.gx) % pl.gy, local / (pl.gx * pl.gy), pl.gx, pl.gy};
+  RcBlk k;
+  if (!rc_blk_of(local, pl.gx, pl.gy, pl.gz, pl.xcd, k)) return;
   if (pl.kind == RC_KIND_FWD) {
     const RcFwdArgs a = g->job[p].f;
     rc_fwd_body(a, k, smem, cs, &last);
@@ -1245,6 +1271,19 @@ static inline long rc_target() {
   return t;
 }
 
+// row tile -> XCD placement of the forward / data-gradient jobs (MMVAE_RC_XCD=1; default off).  MEASURED, no gain: the
+// shipped CdSprites+ step 8.95 against 8.95 ms at batch 128 (every layer has >= 8 row tiles there) -- what one launch
+// leaves in an XCD's L2 is not what the next launch's misses are about (L2 hit rate 0.55 either way: weights and the
+// other tiles' rows) -- and 4.57 against 4.16 ms at batch 24, where layers 3 and 4 have 6 and 2 row tiles and the
+// placement leaves most XCDs idle.
+static inline int rc_xcd() {
+  static const int v = [] { const char* e = getenv("MMVAE_RC_XCD"); return e ? atoi(e) : 0; }();
+  return v;
+}
+static inline int rc_plan_blocks(const RcPlan& pl) {
+  const int n = pl.xcd ? 8 * ((pl.gy + 7) / 8) * pl.gx * pl.gz : pl.gx * pl.gy * pl.gz;
+  return (n + 7) / 8 * 8;
+}
 static inline long rc_target_w() {
   static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS_W"); return e ? atol(e) : 512L; }();
   return t;
@@ -1308,7 +1347,7 @@ static int rc_plan_fwd(const mmvae_rc_fwd_t& j, RcFwdArgs& a, RcPlan& pl) {
   MMVAE_CHECK_ARG(nz == 1 || (j.ws && j.tile_ticket));
   a = RcFwdArgs{j.x, j.w, j.xmean, j.xsc, j.xbeta, j.y, j.ws, j.tile_ticket, j.M, j.Cin, j.Cout, j.T, j.pre, nz, rc_geom_of(j.g),
                 {j.gamma, j.beta, j.run_mean, j.run_var, j.mean, j.rstd, j.sc, j.part, j.counter, j.eps, j.momentum, j.eval}};
-  pl = RcPlan{RC_KIND_FWD, j.Cout / 64, (j.M + 63) / 64, nz};
+  pl = RcPlan{RC_KIND_FWD, j.Cout / 64, (j.M + 63) / 64, nz, rc_xcd()};
   return MMVAE_OK;
 }
 
@@ -1332,7 +1371,7 @@ static int rc_plan_dgrad(const mmvae_rc_dgrad_t& j, RcDgradArgs& a, RcPlan& pl) 
     MMVAE_CHECK_ARG(j.st[t].Y && j.st[t].pqr && j.st[t].part && j.st[t].counter);
     a.st[t] = rc_stat_of(j.st[t]);
   }
-  pl = RcPlan{RC_KIND_DGRAD, j.Cin / 64, row_tiles, nz};
+  pl = RcPlan{RC_KIND_DGRAD, j.Cin / 64, row_tiles, nz, rc_xcd()};
   return MMVAE_OK;
 }
 
@@ -1345,7 +1384,7 @@ static int rc_plan_wgrad(const mmvae_rc_wgrad_t& j, RcWgradArgs& a, RcPlan& pl) 
   kper = (kper + RC_BK - 1) / RC_BK * RC_BK;
   a = RcWgradArgs{j.G, j.Y, j.pqr, j.x, j.xmean, j.xsc, j.xbeta, j.tbl, j.dw, j.ws, j.counter, j.M, j.Cin, j.Cout, j.T, j.pre,
                   j.accumulate ? 1 : 0, nz, kper};
-  pl = RcPlan{RC_KIND_WGRAD, j.Cin / 64, j.Cout / 64, j.T * nz};
+  pl = RcPlan{RC_KIND_WGRAD, j.Cin / 64, j.Cout / 64, j.T * nz, 0};
   return MMVAE_OK;
 }
 
@@ -1362,14 +1401,16 @@ extern "C" int mmvae_rc_launch(const mmvae_rc_job_t* jobs, int n, mmvae_stream_t
     else if (jobs[p].kind == RC_KIND_WGRAD) rc = rc_plan_wgrad(jobs[p].w, g.job[p].w, g.plan[p]);
     else return MMVAE_ERR_ARG;
     if (rc != MMVAE_OK) return rc;
-    g.blk0[p + 1] = g.blk0[p] + g.plan[p].gx * g.plan[p].gy * g.plan[p].gz;
+    g.blk0[p + 1] = g.blk0[p] + rc_plan_blocks(g.plan[p]);
   }
   if (n == 1) {       // a job alone keeps its own kernel (and its name in a profile)
     const RcPlan& pl = g.plan[0];
-    const dim3 grid(pl.gx, pl.gy, pl.gz);
-    if (pl.kind == RC_KIND_FWD) hipLaunchKernelGGL(rc_fwd_kernel, grid, dim3(256), 0, st, g.job[0].f);
-    else if (pl.kind == RC_KIND_DGRAD) hipLaunchKernelGGL(rc_dgrad_kernel, grid, dim3(256), 0, st, g.job[0].d);
-    else hipLaunchKernelGGL(rc_wgrad_kernel, grid, dim3(256), 0, st, g.job[0].w);
+    const dim3 grid(rc_plan_blocks(pl));
+    if (pl.kind == RC_KIND_FWD)
+      hipLaunchKernelGGL(rc_fwd_kernel, grid, dim3(256), 0, st, g.job[0].f, pl.gx, pl.gy, pl.gz, pl.xcd);
+    else if (pl.kind == RC_KIND_DGRAD)
+      hipLaunchKernelGGL(rc_dgrad_kernel, grid, dim3(256), 0, st, g.job[0].d, pl.gx, pl.gy, pl.gz, pl.xcd);
+    else hipLaunchKernelGGL(rc_wgrad_kernel, grid, dim3(256), 0, st, g.job[0].w, pl.gx, pl.gy, pl.gz, pl.xcd);
     return mmvae_launch_status();
   }
   hipLaunchKernelGGL(rc_group_kernel, dim3(g.blk0[n]), dim3(256), 0, st, g);
