@@ -412,7 +412,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
-  auto store = [&]() {
+  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
     float va[RC_NS];
 #pragma unroll
     for (int i = 0; i < RC_NS; ++i) {
@@ -421,20 +421,28 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
       va[i] = (oka >> i & 1u) ? v : 0.f;
     }
-    sa.store(As, va);
-    sb.store(Bs, rb);
+    sa.store(As_, va);
+    sb.store(Bs_, rb);
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (s_beg < s_end) load();
+  // two LDS stage buffers: the next stage is stored while the other waves still read the current one -- one barrier
+  // per stage, and a wave's staging arithmetic and LDS writes run under its own issued MFMAs
+  if (s_beg < s_end) {
+    load();
+    store(As, Bs);
+  }
+  __syncthreads();
+  int cur = 0;
 #pragma unroll 1
   for (int s = s_beg; s < s_end; ++s) {
-    store();
-    __syncthreads();
+    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
     if (s + 1 < s_end) load();
-    wv.mma(As, Bs, acc);
+    wv.mma(As + o, Bs + o, acc);
+    if (s + 1 < s_end) store(As + on, Bs + on);
     __syncthreads();
+    cur ^= 1;
   }
   const int cnt = min(RC_BM, a.M - m0);
   if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)a.M * a.Cout,
@@ -444,7 +452,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
 }
 
 __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a, int gx, int gy, int gz, int xcd) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
   RcBlk k;
@@ -632,28 +640,34 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
     lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
-  auto store = [&]() {
+  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
     float va[RC_NS];
 #pragma unroll
     for (int i = 0; i < RC_NS; ++i) {
       const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
       va[i] = (oka >> i & 1u) ? v : 0.f;
     }
-    sa.store(As, va);
-    sb.store(Bs, rb);
+    sa.store(As_, va);
+    sb.store(Bs_, rb);
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (s_beg < s_end) load();
-  RC_STAMP_WAIT(k, 1);
+  if (s_beg < s_end) {
+    load();
+    RC_STAMP_WAIT(k, 1);
+    store(As, Bs);
+  }
+  __syncthreads();
+  int cur = 0;
 #pragma unroll 1
   for (int s = s_beg; s < s_end; ++s) {
-    store();
-    __syncthreads();
+    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
     if (s + 1 < s_end) load();
-    wv.mma(As, Bs, acc);
+    wv.mma(As + o, Bs + o, acc);
+    if (s + 1 < s_end) store(As + on, Bs + on);
     __syncthreads();
+    cur ^= 1;
   }
   RC_STAMP(k, 2);
   const int cnt = min(RC_BM, rows_c - m0);
@@ -740,7 +754,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
 }
 
 __global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a, int gx, int gy, int gz, int xcd) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
   RcBlk k;
@@ -874,7 +888,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
     }
     if (k0 + RC_BK < kend) rows(k0 + RC_BK);      // the table entries of the stage after: not a dependent round trip then
   };
-  auto store = [&]() {
+  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
     float va[RC_NS], vb[RC_NS];
 #pragma unroll
     for (int i = 0; i < RC_NS; ++i) {
@@ -888,8 +902,8 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
       else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
       vb[i] = (okb >> i & 1u) ? v : 0.f;
     }
-    sa.store(As, va);
-    sb.store(Bs, vb);
+    sa.store(As_, va);
+    sb.store(Bs_, vb);
   };
   f32x16 acc;
 #pragma unroll
@@ -898,13 +912,17 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
     rows(kbeg);
     load(kbeg);
   }
+  if (kbeg < kend) store(As, Bs);
+  __syncthreads();
+  int cur = 0;
 #pragma unroll 1
   for (int k0 = kbeg; k0 < kend; k0 += RC_BK) {
-    store();
-    __syncthreads();
+    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
     if (k0 + RC_BK < kend) load(k0 + RC_BK);
-    wv.mma(As, Bs, acc);
+    wv.mma(As + o, Bs + o, acc);
+    if (k0 + RC_BK < kend) store(As + on, Bs + on);
     __syncthreads();
+    cur ^= 1;
   }
   const size_t numel = (size_t)a.Cout * a.T * a.Cin, rstride = (size_t)a.T * a.Cin;
   const size_t base = ((size_t)n0 * a.T + tap) * a.Cin + c0;
@@ -919,7 +937,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
 }
 
 __global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a, int gx, int gy, int gz, int xcd) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
   RcBlk k;
@@ -942,7 +960,7 @@ struct RcStemFwdArgs {
 };
 
 __global__ __launch_bounds__(256) void rc_stem_fwd_kernel(RcStemFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
   float* As = smem;
@@ -986,24 +1004,28 @@ __global__ __launch_bounds__(256) void rc_stem_fwd_kernel(RcStemFwdArgs a) {
       rb[i] = k0 + sb.kl < K ? t : 0.f;
     }
   };
-  auto store = [&]() {
+  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
     float va[RC_NS];
 #pragma unroll
     for (int i = 0; i < RC_NS; ++i) va[i] = (oka >> i & 1u) ? ra[i] : 0.f;
-    sa.store(As, va);
-    sb.store(Bs, rb);
+    sa.store(As_, va);
+    sb.store(Bs_, rb);
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   load(0);
+  store(As, Bs);
+  __syncthreads();
+  int cur = 0;
 #pragma unroll 1
   for (int k0 = 0; k0 < K; k0 += RC_BK) {
-    store();
-    __syncthreads();
+    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
     if (k0 + RC_BK < K) load(k0 + RC_BK);
-    wv.mma(As, Bs, acc);
+    wv.mma(As + o, Bs + o, acc);
+    if (k0 + RC_BK < K) store(As + on, Bs + on);
     __syncthreads();
+    cur ^= 1;
   }
   rc_fwd_tail(acc, a.y, a.M, a.Cout, a.bn, k, m0, n0, min(RC_BM, a.M - m0), wv, smem, cs, &last);
 }
@@ -1024,7 +1046,7 @@ struct RcStemWgradArgs {
 };
 
 __global__ __launch_bounds__(256) void rc_stem_wgrad_kernel(RcStemWgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ int last;
   float* As = smem;
   float* Bs = smem + RC_BK * RC_AP;
@@ -1074,7 +1096,7 @@ __global__ __launch_bounds__(256) void rc_stem_wgrad_kernel(RcStemWgradArgs a) {
     }
     if (k0 + RC_BK < kend) rows(k0 + RC_BK);
   };
-  auto store = [&]() {
+  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
     float va[RC_NS], vb[RC_NS];
 #pragma unroll
     for (int i = 0; i < RC_NS; ++i) {
@@ -1082,8 +1104,8 @@ __global__ __launch_bounds__(256) void rc_stem_wgrad_kernel(RcStemWgradArgs a) {
       va[i] = (oka >> i & 1u) ? v : 0.f;
       vb[i] = (okb >> i & 1u) ? rb[i] : 0.f;
     }
-    sa.store(As, va);
-    sb.store(Bs, vb);
+    sa.store(As_, va);
+    sb.store(Bs_, vb);
   };
   f32x16 acc;
 #pragma unroll
@@ -1092,13 +1114,17 @@ __global__ __launch_bounds__(256) void rc_stem_wgrad_kernel(RcStemWgradArgs a) {
     rows(kbeg);
     load(kbeg);
   }
+  if (kbeg < kend) store(As, Bs);
+  __syncthreads();
+  int cur = 0;
 #pragma unroll 1
   for (int k0 = kbeg; k0 < kend; k0 += RC_BK) {
-    store();
-    __syncthreads();
+    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
     if (k0 + RC_BK < kend) load(k0 + RC_BK);
-    wv.mma(As, Bs, acc);
+    wv.mma(As + o, Bs + o, acc);
+    if (k0 + RC_BK < kend) store(As + on, Bs + on);
     __syncthreads();
+    cur ^= 1;
   }
   unsigned* ticket = a.counter + blockIdx.y * gridDim.x + blockIdx.x;
   if (!rc_acc_reduce(acc, a.ws, ticket, a.nz, zi, (size_t)a.Cout * Kpad, (size_t)n0 * Kpad + c0, Kpad, 64, wv, &last)) return;
@@ -1236,7 +1262,7 @@ static_assert(sizeof(RcGroup) <= 4000, "rc_group_kernel's arguments must fit the
 // (the job table is read through the kernel-argument segment pointer: indexing the by-value parameter with the
 // workgroup's job number makes the compiler copy all of it into scratch -- 2.5 KB per lane, 10 x the run time)
 __global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * RC_BK * RC_AP];
+  __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
   const RcGroup* __restrict__ g = (const RcGroup*)__builtin_amdgcn_kernarg_segment_ptr();
