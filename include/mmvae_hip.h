@@ -196,6 +196,19 @@ typedef struct {
   int M, N, K; long ldx; int x_act, accumulate;
 } mmvae_wgrad_job_t;
 int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int n_jobs, mmvae_stream_t stream);
+/* All weight gradients behind one fused text layer in ONE launch (csrc/twgrad.hip; round 4): dW_j = dy_j^T x_j and
+ * db_j = colsum(dy_j) of torch.nn.TransformerEncoderLayer / TransformerDecoderLayer's linears
+ * (models/encoders.py:828-837, models/decoders.py:708-723), each operand row fetched once.  Every job writes
+ * mmvae_txt_wgrad_splits(M, N, K) partial rows to ws: [nz][N * K] then [nz][N], to be folded by
+ * mmvae_reduce_segments / mmvae_adam_fold_flat.  N (K) must be even when > 32. */
+typedef struct {
+  const float* dy; const float* x; float* ws;
+  int M, N, K;
+} mmvae_txt_wgrad_job_t;
+int mmvae_txt_wgrad(const mmvae_txt_wgrad_job_t* jobs, int n_jobs, mmvae_stream_t stream);
+int mmvae_txt_wgrad_splits(int M, int N, int K);
+size_t mmvae_txt_wgrad_ws_floats(int M, int N, int K);
+int mmvae_txt_wgrad_supported(int M, int N, int K);
 /* both of the above in one grouped launch: dx = ep(dy W), dW (+)= dy^T act(x), db (+)= colsum(dy) */
 int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const float* aux, float* dx, float* dw,
                      float* db, float* ws, int M, int N, int K, long ldx, int x_act, int ep_mode, int accumulate,

@@ -124,6 +124,10 @@ SIGNATURES = {
     "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_linear_bwd_weight_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_linear_bwd_weight_batch": (c_i, [c_p, c_i, c_p]),
+    "mmvae_txt_wgrad": (c_i, [c_p, c_i, c_p]),
+    "mmvae_txt_wgrad_splits": (c_i, [c_i] * 3),
+    "mmvae_txt_wgrad_ws_floats": (c_sz, [c_i] * 3),
+    "mmvae_txt_wgrad_supported": (c_i, [c_i] * 3),
     "mmvae_input_pipe_create": (c_i, [c_p, c_p, c_sz]),
     "mmvae_input_pipe_destroy": (c_i, [c_p]),
     "mmvae_input_pipe_prefetch": (c_i, [c_p, c_p]),
@@ -291,6 +295,13 @@ DROPOUT_ADVANCE_MAX = 16
 class WgradJob(ctypes.Structure):
     _fields_ = [("dy", c_p), ("x", c_p), ("dw", c_p), ("db", c_p), ("ws", c_p), ("M", c_i), ("N", c_i), ("K", c_i),
                 ("ldx", c_l), ("x_act", c_i), ("accumulate", c_i)]
+
+
+class TxtWgradJob(ctypes.Structure):      # mmvae_txt_wgrad_job_t
+    _fields_ = [("dy", c_p), ("x", c_p), ("ws", c_p), ("M", c_i), ("N", c_i), ("K", c_i)]
+
+
+TXT_WGRAD_MAX = 8
 
 
 class TxtLayerW(ctypes.Structure):

@@ -1825,6 +1825,36 @@ def _linear_wgrad_many(jobs):
     return [(None, None)] * len(jobs)
 
 
+# Round 4: ONE launch per fused text layer for all of its weight gradients on a kernel built for tall-skinny reductions
+# (csrc/twgrad.hip: every operand row fetched once, 64 x 64 output units in registers, row slices over waves).
+TXT_WGRAD = os.environ.get("MMVAE_TXT_WGRAD", "1") != "0"
+
+
+def _txt_wgrad(jobs):
+    """the weight half of every Linear behind a fused text layer: jobs (dy2, x2, w, b, gw, gb) as _linear_wgrad_many"""
+    lib = H.lib()
+    ok = TXT_WGRAD and 1 <= len(jobs) <= H.TXT_WGRAD_MAX and all(
+        b is not None and _defer(gw, gb) and dy2.is_contiguous() and x2.is_contiguous() and
+        lib.mmvae_txt_wgrad_supported(dy2.shape[0], dy2.shape[1], x2.shape[1]) for (dy2, x2, _, b, gw, gb) in jobs)
+    if not ok:
+        return _linear_wgrad_many(jobs)
+    arr = (H.TxtWgradJob * len(jobs))()
+    segs = []
+    for i, (dy2, x2, w, b, gw, gb) in enumerate(jobs):
+        M, N = dy2.shape
+        K = x2.shape[1]
+        nz = lib.mmvae_txt_wgrad_splits(M, N, K)
+        ws = GradReducer.alloc(lib.mmvae_txt_wgrad_ws_floats(M, N, K), dy2.device)
+        j = arr[i]
+        j.dy, j.x, j.ws, j.M, j.N, j.K = H.ptr(dy2), H.ptr(x2), H.ptr(ws), M, N, K
+        segs.append((ws, nz, gw, gb, N, K))
+    _call("mmvae_txt_wgrad", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
+    for ws, nz, gw, gb, N, K in segs:
+        GradReducer.add(ws.data_ptr(), gw, nz, N * K, N * K)
+        GradReducer.add(ws.data_ptr() + 4 * nz * N * K, gb, nz, N, N)
+    return [(None, None)] * len(jobs)
+
+
 class TxtLayerMeta:
     """static description of one fused transformer layer call (shapes + the DropSpecs of its dropout sites)"""
 
@@ -1978,7 +2008,7 @@ class TxtLayer(Function):
                 gw = gw[wsl] if gw is not None else None
                 gb = gb[wsl] if gb is not None else None
             jobs.append((dyt, xt, wt, bt, gw, gb))
-        for (dyt, xt, wn, bn, wsl), (rw, rb) in zip(specs, _linear_wgrad_many(jobs)):
+        for (dyt, xt, wn, bn, wsl), (rw, rb) in zip(specs, _txt_wgrad(jobs)):
             if wsl is None:
                 ret[wn], ret[bn] = rw, rb
             elif rw is not None:      # no preset gradient views: embed the slice gradient in a full-size zero tensor

@@ -938,6 +938,45 @@ def test_linear_bwd_weight_batch_is_the_separate_calls(hip_lib, rows, D, FF, sma
         check(got_b, ref_b, 5e-5, f"db {M, N, K}")
 
 
+@pytest.mark.parametrize("rows,D,FF,small", [(4096, 32, 128, 128), (4096, 54, 128, 0), (1536, 16, 128, 48), (300, 24, 40, 7),
+                                             (32000, 54, 128, 1000), (37, 54, 128, 3), (1, 32, 128, 1)])
+def test_txt_wgrad_matches_float64(hip_lib, rows, D, FF, small):
+    """mmvae_txt_wgrad (csrc/twgrad.hip): the weight and bias gradients behind one fused text layer in one launch; the
+    sum of every job's partial rows against float64 (ragged row counts, widths that are no multiple of 32 or 64,
+    the cross-attention value job over the batch rows only), and nothing written outside a job's workspace."""
+    import ctypes
+    from multimodal_vae_comparison_amd import hipops as H
+    lib = H.lib()
+    g = torch.Generator().manual_seed(rows + D)
+    shapes = [(rows, 3 * D, D), (rows, D, D), (rows, FF, D), (rows, D, FF)]
+    if small:
+        shapes += [(rows, D, D), (small, D, D)]
+    prob = [(torch.randn(M, N, generator=g).to(DEV), torch.randn(M, K, generator=g).to(DEV)) for M, N, K in shapes]
+    st = torch.cuda.current_stream().cuda_stream
+    arr = (H.TxtWgradJob * len(shapes))()
+    wss = []
+    for j, (dy, x), (M, N, K) in zip(arr, prob, shapes):
+        assert lib.mmvae_txt_wgrad_supported(M, N, K) == 1
+        nz = lib.mmvae_txt_wgrad_splits(M, N, K)
+        nws = lib.mmvae_txt_wgrad_ws_floats(M, N, K)
+        assert nws == nz * (N * K + N)
+        ws = torch.full((nws + 64,), float("nan"), device=DEV)
+        ws[nws:] = 7.0
+        wss.append((ws, nz, nws))
+        j.dy, j.x, j.ws, j.M, j.N, j.K = dy.data_ptr(), x.data_ptr(), ws.data_ptr(), M, N, K
+    assert lib.mmvae_txt_wgrad(ctypes.cast(arr, ctypes.c_void_p), len(shapes), st) == 0
+    torch.cuda.synchronize()
+    for (dy, x), (ws, nz, nws), (M, N, K) in zip(prob, wss, shapes):
+        assert bool(torch.isfinite(ws[:nws]).all()), (M, N, K)      # every partial row written
+        assert bool((ws[nws:] == 7.0).all()), (M, N, K)
+        ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+        got_w = ws[:nz * N * K].view(nz, N, K).double().sum(0)
+        got_b = ws[nz * N * K:nws].view(nz, N).double().sum(0)
+        check(got_w, ref_w, 5e-5, f"dw {M, N, K}")
+        check(got_b, ref_b, 5e-5, f"db {M, N, K}")
+    assert lib.mmvae_txt_wgrad_supported(64, 35, 32) == 0 and lib.mmvae_txt_wgrad_supported(64, 31, 33) == 0
+
+
 def test_dropout_advance_many(ops, hip_lib):
     """mmvae_dropout_advance_many == mmvae_dropout_advance(state, 0) on every state; duplicates are refused"""
     import ctypes
