@@ -831,6 +831,17 @@ static inline bool txt_layer_visit(int D, int FF, int NH, int dec, F&& f) {
   return false;
 }
 
+// csrc/txtwave.hip: the same layer as one wave per sequence, activations chained through registers (round 4, default).
+// MMVAE_TXT_WAVE=0 keeps the workgroup-per-sequence kernels of this file (same saved tensors, same masks).
+int txt_wave_fwd_dispatch(const float* x, const uint8_t* valid, const float* mem, float* y, const mmvae_txt_layer_w_t& wv,
+                          const mmvae_txt_layer_saved_t& sv, const mmvae_txt_layer_drop_t& d, int L, int N, int D, int FF,
+                          int NH, int dec, int time_mean, const float* head_w, const float* head_b, float* heads, int HN,
+                          hipStream_t stream);
+static inline int txt_wave_mode() {
+  static const int m = getenv("MMVAE_TXT_WAVE") ? atoi(getenv("MMVAE_TXT_WAVE")) : 3;    // bit 0: forward, bit 1: backward
+  return m;
+}
+
 extern "C" int mmvae_txt_layer_supported(int L, int D, int FF, int NH, int dec) {
   if (L < 1 || L > tl::T) return 0;
   return txt_layer_visit(D, FF, NH, dec, [](auto) {}) ? 1 : 0;
@@ -854,6 +865,9 @@ extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const f
   }
   const mmvae_txt_layer_w_t wv = *w;
   const mmvae_txt_layer_saved_t sv = *saved;
+  if ((txt_wave_mode() & 1) && !sv.probs)      // (the wave kernel does not export the attention weights)
+    return txt_wave_fwd_dispatch(x, valid, mem, y, wv, sv, d, L, N, D, FF, NH, dec, time_mean, head_w, head_b, heads, HN,
+                                 (hipStream_t)stream);
   if (!txt_layer_visit(D, FF, NH, dec, [&](auto g) {
         using G = decltype(g);
         hipLaunchKernelGGL((txt_layer_fwd_kernel<G>), dim3(N), dim3(256), 0, (hipStream_t)stream, x, valid, mem, y, wv, sv,
