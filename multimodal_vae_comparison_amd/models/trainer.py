@@ -130,8 +130,9 @@ class MultimodalVAE(nn.Module):
                 "hyper_parameters": {"cfg": self.config, "feature_dims": self.feature_dims}}
         if self.optimizer is not None:
             for st in ckpt["optimizer_states"][0]["state"].values():
-                for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
-                    st[k] = st[k].cpu()
+                for k, v in list(st.items()):        # Adam(amsgrad): exp_avg / exp_avg_sq / max_exp_avg_sq; AdaBelief:
+                    if torch.is_tensor(v):            # exp_avg / exp_avg_var -- whatever the optimiser keeps
+                        st[k] = v.cpu()
         torch.save(ckpt, path)
 
     def load_checkpoint(self, path_or_ckpt, strict=True):
@@ -274,13 +275,19 @@ class MultimodalVAE(nn.Module):
                 self.abi_calls_in_graph = ops.CALLS[0] - calls0      # C-ABI calls of one captured step (~ graph kernel nodes)
                 return res
             if self._collective_in_graph:
+                # EVERY rank reaches the verdict all-reduce (a rank whose capture raised used to skip it and
+                # leave the others hanging in it), and a failed capture leaves no hook set on GradReducer
+                captured = None
                 try:
                     out = record(True)
-                    why = self._validate_graph_collective()
-                    if self._input_ring is not None:
-                        self._input_ring.reprime()      # the validation replay consumed a slot
                 except RuntimeError as e:          # the runtime refused to capture the collective
-                    why = f"all-reduce not capturable here ({e})"
+                    captured = f"all-reduce not capturable here ({e})"
+                finally:
+                    ops.GradReducer.defer_next = False
+                    ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
+                why = self._validate_graph_collective(captured)
+                if why is None and self._input_ring is not None:
+                    self._input_ring.reprime()      # the validation replay consumed a slot
                 if why is not None:                # launch it after the graph instead (the round-1 step structure)
                     import warnings
                     warnings.warn(f"{why}; using the post-graph tail")
@@ -299,7 +306,7 @@ class MultimodalVAE(nn.Module):
         self.flat.zero_grad()
         return out
 
-    def _validate_graph_collective(self):
+    def _validate_graph_collective(self, capture_error=None):
         """A captured RCCL all-reduce has to prove itself before the step relies on it (the path had only ever
         run on a one-rank group): ONE replay of the freshly captured graph -- backward, in-graph all-reduce, Adam --
         and then the replicas must still hold bit-identical parameters (min == max of a checksum over the ranks, the
@@ -308,14 +315,21 @@ class MultimodalVAE(nn.Module):
         good, else the reason; every rank reaches the same verdict (the failure flag is reduced with MAX)."""
         dist = torch.distributed
         opt = self.optimizer
-        state = tuple(t for t in (self.flat.data, opt.m, opt.v, opt.vmax, opt.step_dev) if t is not None)
+        # every tensor the replay advances: parameters, optimiser state and step count, and the model's buffers -- noise
+        # and dropout counters (`_rng_state`, DropoutState.state), BatchNorm running statistics / num_batches_tracked of a
+        # ResNet tower (ADVICE r3: those were left advanced, so the first batch was counted twice)
+        state = tuple(t for t in (self.flat.data, opt.m, opt.v, getattr(opt, "vmax", None), opt.step_dev) if t is not None)
+        state += tuple(b for b in self.model.buffers() if b.is_cuda)
         keep = [t.clone() for t in state]
         bad, why = 0.0, None
-        try:
-            self._graph.replay()
-            torch.cuda.synchronize()
-        except RuntimeError as e:
-            bad, why = 1.0, f"replay of the graph with the captured all-reduce failed ({e})"
+        if capture_error is not None:       # this rank has no graph to replay: it only votes
+            bad, why = 1.0, capture_error
+        else:
+            try:
+                self._graph.replay()
+                torch.cuda.synchronize()
+            except RuntimeError as e:
+                bad, why = 1.0, f"replay of the graph with the captured all-reduce failed ({e})"
         cs = self.flat.data.double().sum().reshape(1)
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -603,7 +617,7 @@ class InputPipe:
         assert 0 < len(mods) <= H.INPUT_MAX_MODS
         self._mods = (H.InputMod * len(mods))(*mods)
         self._sig = _packed_signature(packed)   # every later batch must have exactly this layout
-        self._checked = set()
+        self._checked = {}
         self._keep = trainer._static_batch      # the raw pointers above point into these tensors
         h = ctypes.c_void_p()
         rc = H.lib().mmvae_input_pipe_create(ctypes.byref(h), self.staging.data_ptr(), self.bytes)
@@ -614,12 +628,14 @@ class InputPipe:
     def _ptr(self, packed):
         buf = packed["_packed"]
         ptr = buf.data_ptr()
-        if ptr not in self._checked:        # (a ring of pinned batches: each buffer's layout is checked once)
+        # (a ring of pinned batches: each buffer's layout is checked once -- and the checked buffer is HELD, so that its
+        # address cannot come back as another allocation with other offsets: ADVICE r3)
+        if self._checked.get(ptr) is not buf:
             assert buf.numel() == self.bytes and buf.is_pinned()
             if _packed_signature(packed) != self._sig:
                 raise ValueError("InputPipe: this packed batch has another layout (offsets / shapes / dtypes) than the "
                                  "one the pipe was created for")
-            self._checked.add(ptr)
+            self._checked[ptr] = buf
         return ptr
 
     def prefetch(self, packed):

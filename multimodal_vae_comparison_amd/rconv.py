@@ -71,6 +71,21 @@ class Unit:
     def __init__(self, conv, bn):
         self.conv, self.bn = conv, bn
         self._buf = {}
+        self._gen = {}
+
+    def stamp(self, M):
+        """a forward pass over M rows is about to overwrite this unit's per-step vectors (mean / rstd / sc / pqr are kept
+        per unit and row count, not per call): returns the generation the matching backward must still find"""
+        g = self._gen[M] = self._gen.get(M, 0) + 1
+        return g
+
+    def check(self, M, gen):
+        """a second forward with the same row count before this backward (two micro-batches, or an eval
+        forward in between) has overwritten the statistics and ReLU masks this backward is about to apply"""
+        if self._gen.get(M) != gen:
+            raise RuntimeError("ResNet tower: the forward pass this backward belongs to is no longer the unit's latest "
+                               f"one over {M} rows (generation {gen} vs {self._gen.get(M)}): its BatchNorm statistics were "
+                               "overwritten; run backward before the next forward of the same shape")
 
     def buffers(self, M, device):
         b = self._buf.get(M)
@@ -146,6 +161,7 @@ def fwd_job(u, x, M, pre, xb, g, eval_mode):
     w = u.conv.weight
     Cout, Cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
     b = u.buffers(M, x.device)
+    b["gen"] = u.stamp(M)
     y = torch.empty(M, Cout, device=x.device)
     bn = u.bn
     j = H.RcJob()
@@ -283,7 +299,8 @@ class BottleneckStack(Function):
                       H.ptr(blk.ud.bn.bias) if bd else None, int(act == H.ACT_RELU), H.ptr(out), M2, Y3.shape[1], H.stream())
             if blk.u3.bn._forward_hooks:
                 blk.u3.bn(out, tap=True)
-            saved.append((s, Y1, Y2, Y3, Yd, act, (B, Hh, W, Ho, Wo)))
+            saved.append((s, Y1, Y2, Y3, Yd, act, (B, Hh, W, Ho, Wo),
+                          (b1["gen"], b2["gen"], b3["gen"], bd["gen"] if bd else None)))
             s, Hh, W, act = out, Ho, Wo, H.ACT_RELU
         ctx.blocks, ctx.saved, ctx.training = blocks, saved, training
         ctx.params = params
@@ -342,10 +359,13 @@ class BottleneckStack(Function):
         ready = False          # the statistics of this block's bn3 (/ projection bn) already came out of the next block
         for bi in range(len(blocks) - 1, -1, -1):
             blk = blocks[bi]
-            s, Y1, Y2, Y3, Yd, act, (B, Hh, W, Ho, Wo) = saved[bi]
+            s, Y1, Y2, Y3, Yd, act, (B, Hh, W, Ho, Wo), gens = saved[bi]
             Min, M2 = B * Hh * W, B * Ho * Wo
             b1, b2, b3 = blk.u1.buffers(Min, dev), blk.u2.buffers(M2, dev), blk.u3.buffers(M2, dev)
             bd = blk.ud.buffers(M2, dev) if blk.ud else None
+            blk.u1.check(Min, gens[0]); blk.u2.check(M2, gens[1]); blk.u3.check(M2, gens[2])
+            if blk.ud:
+                blk.ud.check(M2, gens[3])
             S_ = blk.stride
             t3 = tables(dev, B, Hh, W, 3, S_, 1)          # the weight gradients' row tables
             t1 = tables(dev, B, Hh, W, 1, S_, 0) if S_ != 1 else (None, None)
@@ -454,6 +474,7 @@ class Stem(Function):
         g = geom(Hh, W, K, S, P)
         M, Cout = B * g.Ho * g.Wo, w.shape[0]
         b = unit.buffers(M, dev)
+        ctx.gen = unit.stamp(M)
         y = torch.empty(M, Cout, device=dev)
         bn = unit.bn
         ops._call("mmvae_rc_stem_fwd", H.ptr(x), channels_last_ptr(w), H.ptr(y), M, C, Cout, K * K, ctypes.byref(g),
@@ -478,6 +499,7 @@ class Stem(Function):
         g = geom(Hh, W, K, S, P)
         M, Cout = y.shape
         b = unit.buffers(M, dev)
+        unit.check(M, ctx.gen)
         grads, ret = {}, {}
         for p in (w, gamma, beta):
             if p.grad is not None:

@@ -241,6 +241,22 @@ def test_adabelief_matches_the_restated_update(hip_lib):
     sd2 = opt2.state_dict()         # (the flat buffers' alignment gaps are not state: compare what the state dict carries)
     assert int(opt2.step_dev[0]) == 3 and all(torch.equal(sd2["state"][i][f], sd["state"][i][f])
                                                  for i in sd["state"] for f in ("exp_avg", "exp_avg_var"))
+    # the trainer's own checkpoint carries that state too (save_checkpoint indexed Adam's field names)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "adabelief.ckpt")
+        tr.save_checkpoint(path, epoch=1, global_step=3)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        st0 = ck["optimizer_states"][0]["state"][0]
+        assert set(st0) == {"step", "exp_avg", "exp_avg_var"} and not st0["exp_avg"].is_cuda
+        tr2 = MultimodalVAE(dict(cdsprites_config("mopoe", 8, batch_size=6), optimizer="adabelief", lr=1e-3), device=DEV)
+        tr2.configure_optimizers()
+        tr2.load_checkpoint(path)
+        sd3 = tr2.optimizer.state_dict()
+        assert all(torch.equal(sd3["state"][i][f].cpu(), sd["state"][i][f].cpu())
+                   for i in sd["state"] for f in ("exp_avg", "exp_avg_var"))
+        for (k, a), (_, b) in zip(tr.model.named_parameters(), tr2.model.named_parameters()):
+            assert torch.equal(a, b), k
     # the captured step takes the same optimiser (no deferred fold: the fold rides on Adam launches only)
     tr.capture(batch)
     l0 = float(tr.fused_step()["loss"])

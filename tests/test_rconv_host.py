@@ -53,3 +53,22 @@ def test_flat_buffers_hold_kxk_weights_channels_last():
     assert w.grad.data_ptr() == flat.grad.data_ptr() + 4 * o and tuple(w.grad.stride()) == tuple(w.stride())
     w1 = blk.conv1.weight                                   # 1x1: plain contiguous
     assert w1.is_contiguous() and torch.equal(FlatParams.flatten_like(w1.detach(), w1), w1.detach().reshape(-1))
+
+
+def test_unit_generation_guard():
+    """a unit's per-step vectors live per (unit, row count); a backward whose forward is no longer the latest
+    one over that row count must refuse instead of applying another pass's statistics"""
+    import pytest
+    torch.manual_seed(0)
+    blk = Bottleneck(64, 64, 1, True)
+    u = rconv.Unit(blk.conv1, blk.bn1)
+    g1 = u.stamp(128)
+    u.check(128, g1)
+    g_other = u.stamp(64)            # another row count does not disturb it
+    u.check(128, g1)
+    u.check(64, g_other)
+    g2 = u.stamp(128)                # a second forward over the same rows does
+    assert g2 == g1 + 1
+    u.check(128, g2)
+    with pytest.raises(RuntimeError, match="no longer the unit's latest"):
+        u.check(128, g1)
