@@ -204,6 +204,60 @@ def _pmc_traffic(kernel_prefix):
     return int((2 * fetch + write) * 1024), os.path.relpath(path, ROOT)
 
 
+def _kernel_flops(name, B, T=32):
+    """algorithmic FLOPs of one launch of a cfg2-step kernel at per-GPU batch B (None: not a matrix kernel / unknown):
+    the FLOP model behind `roofline.dominant_by_time.frac`"""
+    import re
+    conv2 = 2.0 * B * 16 * 16 * 32 * 512                     # conv2 / convT(16) shape: one pass (fwd, dgrad or wgrad)
+    m = re.search(r"tl::Geom<(\d+), (\d+), (\d+), (true|false)>|tv::Geom<(\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        g = [x for x in m.groups() if x is not None]
+        D, FF, NH, dec = int(g[0]), int(g[1]), int(g[2]), g[3] == "true"
+        fwd = T * D * 3 * D + 2 * T * T * D + T * D * D + 2 * T * D * FF + (T * D * D + D * D if dec else 0)   # MAC / sequence
+        bwd = fwd + 2 * T * T * D                             # data-gradient chain + the recomputed scores
+        return 2.0 * B * (bwd if "bwd" in name else fwd)
+    if "conv2d_bwd_fused_kernel<ScatterGeom<4," in name or "convT_bwd_fused_kernel<GatherGeom<32, 5," in name:
+        return 2 * conv2
+    if "conv_gather_kernel<GatherGeom<32, 5," in name or "conv_scatter_kernel<ScatterGeom<4," in name:
+        return conv2
+    if "txt_wgrad_kernel" in name:                            # both layers' launches averaged: (enc + dec) / 2
+        M = T * B
+        enc = 2.0 * M * (162 * 54 + 54 * 54 + 128 * 54 + 54 * 128)
+        dec = 2.0 * M * (96 * 32 + 32 * 32 + 128 * 32 + 32 * 128 + 32 * 32)
+        return (enc + dec) / 2
+    if "rgemm_kernel<16, false, false>" in name:              # (round 3: a text layer's (T*B, 162) x (T*B, 54) weight gradient)
+        return 2.0 * T * B * 162 * 54
+    if "rgemm_grouped_kernel<64, 16, true>" in name:          # Linear(512, 512) backward: dX + dW
+        return 2 * 2.0 * B * 512 * 512
+    if "rgemm16_kernel<64, true, true>" in name:
+        return 2.0 * B * 512 * 512
+    return None
+
+
+def _dominant_by_time(B):
+    """the kernel with the largest share of GPU time in the newest committed rocprofv3 kernel-stats file of this workload
+    (profiles/r*_cfg2_b<B>_kernel_stats.csv, made by tools/gpu_evidence_r04.sh from `rocprofv3 --kernel-trace --stats --
+    python3 bench.py ...`), and its fraction of the fp32 MFMA peak from the FLOP model above -- the conv2-forward entry of
+    `roofline` is the best-tuned kernel, not the one the step spends most of its time in"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg2_b{B}_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = [r for r in csv.DictReader(open(files[-1])) if "at::native" not in r["Name"] and "rocclr" not in r["Name"]]
+    if not rows:
+        return None
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    fl = _kernel_flops(top["Name"], B)
+    avg_us = float(top["AverageNs"]) / 1e3
+    ach = fl / (avg_us * 1e-6) / 1e12 if fl else None
+    return {"kernel": top["Name"].replace("void ", "")[:96], "share": round(float(top["TotalDurationNs"]) / tot, 4),
+            "avg_us": round(avg_us, 2), "achieved": round(ach, 2) if ach else None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def _event_time_us(fn, reps=50):
     with torch.no_grad():
         for _ in range(5):
@@ -279,11 +333,14 @@ def dominant_kernel_roofline(meta, device):
         if B != 128:
             traffic = None
     ach = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_us": round(us, 2),
-            "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": (f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
-                               f"16-B/lane correction); algorithmic 21.0e6 at B=128") if src else None}
+    out = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_us": round(us, 2),
+           "traffic": traffic, "traffic_unit": "bytes/launch",
+           "traffic_source": (f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
+                              f"16-B/lane correction); algorithmic 21.0e6 at B=128") if src else None}
+    if meta["mixing"] == "mopoe" and len(meta["mods"]) == 2 and meta["mods"][1]["enc"] == "TxtTransformer":    # cfg2
+        out["dominant_by_time"] = _dominant_by_time(B)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------

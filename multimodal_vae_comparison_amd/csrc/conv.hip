@@ -41,10 +41,13 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
 // chunks win, 0.4162 vs 0.4231 ms/step over three pairs: half as many weight-gradient workgroups beside the data-gradient
 // ones and the text tower's; with longer splits -- batch 256: 1.27 vs 1.33 ms -- the 8-channel chunks keep the
 // weight-gradient body from becoming the launch's long pole.)
+// (Round 4: with the text tower's forward on the wave-per-sequence kernels -- no LDS, 128 SIMDs -- and its weight
+// gradients in one launch per layer, the 8-channel chunks win at batch 128 too: 0.4110 -> 0.4050 and 0.4110 -> 0.4047
+// ms/step, two same-box rounds; the short-split exception is gone.)
 static inline bool wgrad_qc8(int nsplit, int n_macro) {
   static const int forced = getenv("MMVAE_WGRAD_QC") ? atoi(getenv("MMVAE_WGRAD_QC")) : 0;
   if (forced) return forced == 8;
-  if (n_macro <= 8 * nsplit) return false;
+  (void)n_macro;
   return nsplit * 2 < 256;
 }
 

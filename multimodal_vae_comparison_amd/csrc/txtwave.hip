@@ -447,6 +447,7 @@ __global__ __launch_bounds__(64) void txt_wave_fwd_kernel(const float* __restric
                                                           const int time_mean, const float* __restrict__ head_w,
                                                           const float* __restrict__ head_b, float* __restrict__ heads,
                                                           const int HN, float* __restrict__ trash) {
+  MMVAE_TRACE_STAMP(16 + (G::DEC ? 1 : 0));
   using P = FwdPlan<G>;
   constexpr int D = G::D, FF = G::FF, NH = G::NH, HD = G::HD, DT = G::DT, FT = G::FT, AT = G::AT, AV = G::AV;
   constexpr bool DEC = G::DEC, PACK = G::PACK;
@@ -872,3 +873,5 @@ int txt_wave_fwd_dispatch(const float* x, const uint8_t* valid, const float* mem
     return MMVAE_ERR_UNSUPPORTED;
   return mmvae_launch_status();
 }
+
+MMVAE_TRACE_SETTER(txtwave)

@@ -30,7 +30,7 @@ tr.configure_optimizers()
 batch = cdsprites_batch(B, 32, seed=1, device=dev)
 table = torch.zeros(64, dtype=torch.int64, device=dev)
 L = ctypes.CDLL(os.environ["MMVAE_HIP_LIB"])
-for m in ("conv", "txtlayer", "optim", "latent"):
+for m in ("conv", "txtlayer", "txtwave", "optim", "latent"):
     fn = getattr(L, f"mmvae_trace_set_{m}")
     fn.argtypes = [ctypes.c_void_p]
     assert fn(table.data_ptr()) == 0
