@@ -722,6 +722,12 @@ typedef struct {
   mmvae_dropout_t attn, drop1, xattn, drop2, ffn, drop3; /* encoder: attn, drop1, ffn, drop2 */
 } mmvae_txt_layer_drop_t;
 int mmvae_txt_layer_supported(int L, int D, int FF, int NH, int dec);
+/* Round 4: two kernel families serve these entry points -- one workgroup per sequence (csrc/txtlayer.hip) and one WAVE
+ * per sequence with the activations chained through registers (csrc/txtwave.hip; forward always, backward from 384
+ * sequences).  Same arithmetic, saved tensors and masks; this sets the choice (-1 keeps a value): forward on the wave
+ * kernels, backward on them from bwd_min_n sequences (d > 32 layers) / bwd_min_n_dec (d <= 32 decoder layers).
+ * Defaults from MMVAE_TXT_WAVE / MMVAE_TXT_WAVE_BWD_MIN_N[_DEC]. */
+int mmvae_txt_layer_plan(int fwd_wave, int bwd_min_n, int bwd_min_n_dec);
 size_t mmvae_txt_layer_lnws_floats(int N, int D, int dec);
 /* time_mean != 0: y / dy are (N, D), the mean of the layer output over the L frames and its gradient -- the pooling
  * `x.mean(0)` that follows the last encoder layer (models/encoders.py:552), folded into the layer's launch */

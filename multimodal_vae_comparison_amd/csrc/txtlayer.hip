@@ -837,9 +837,27 @@ int txt_wave_fwd_dispatch(const float* x, const uint8_t* valid, const float* mem
                           const mmvae_txt_layer_saved_t& sv, const mmvae_txt_layer_drop_t& d, int L, int N, int D, int FF,
                           int NH, int dec, int time_mean, const float* head_w, const float* head_b, float* heads, int HN,
                           hipStream_t stream);
-static inline int txt_wave_mode() {
-  static const int m = getenv("MMVAE_TXT_WAVE") ? atoi(getenv("MMVAE_TXT_WAVE")) : 3;    // bit 0: forward, bit 1: backward
-  return m;
+int txt_wave_bwd_dispatch(const float* dy, const uint8_t* valid, float* dx, float* dmem, const mmvae_txt_layer_w_t& wv,
+                          const mmvae_txt_layer_saved_t& sv, const mmvae_txt_layer_grads_t& gv,
+                          const mmvae_txt_layer_drop_t& d, int L, int N, int D, int FF, int NH, int dec, int time_mean,
+                          hipStream_t stream);
+// which kernels serve a layer: { forward on the wave kernels, backward on them from this many sequences (encoder-width
+// layers, d <= 32 decoder layers) }.  Environment defaults, or mmvae_txt_layer_plan() (tests run both forms in one process).
+static int g_txt_plan[3] = {-1, -1, -1};
+static inline void txt_plan_init() {
+  if (g_txt_plan[0] >= 0) return;
+  const int m = getenv("MMVAE_TXT_WAVE") ? atoi(getenv("MMVAE_TXT_WAVE")) : 3;    // bit 0: forward, bit 1: backward
+  g_txt_plan[0] = m & 1;
+  const int never = 1 << 30;
+  g_txt_plan[1] = !(m & 2) ? never : getenv("MMVAE_TXT_WAVE_BWD_MIN_N") ? atoi(getenv("MMVAE_TXT_WAVE_BWD_MIN_N")) : 384;
+  g_txt_plan[2] = !(m & 2) ? never : getenv("MMVAE_TXT_WAVE_BWD_MIN_N_DEC") ? atoi(getenv("MMVAE_TXT_WAVE_BWD_MIN_N_DEC")) : 384;
+}
+extern "C" int mmvae_txt_layer_plan(int fwd_wave, int bwd_min_n, int bwd_min_n_dec) {
+  txt_plan_init();
+  if (fwd_wave >= 0) g_txt_plan[0] = fwd_wave ? 1 : 0;
+  if (bwd_min_n >= 0) g_txt_plan[1] = bwd_min_n;
+  if (bwd_min_n_dec >= 0) g_txt_plan[2] = bwd_min_n_dec;
+  return MMVAE_OK;
 }
 
 extern "C" int mmvae_txt_layer_supported(int L, int D, int FF, int NH, int dec) {
@@ -865,7 +883,8 @@ extern "C" int mmvae_txt_layer_fwd(const float* x, const uint8_t* valid, const f
   }
   const mmvae_txt_layer_w_t wv = *w;
   const mmvae_txt_layer_saved_t sv = *saved;
-  if ((txt_wave_mode() & 1) && !sv.probs)      // (the wave kernel does not export the attention weights)
+  txt_plan_init();
+  if (g_txt_plan[0] && !sv.probs)      // (the wave kernel does not export the attention weights)
     return txt_wave_fwd_dispatch(x, valid, mem, y, wv, sv, d, L, N, D, FF, NH, dec, time_mean, head_w, head_b, heads, HN,
                                  (hipStream_t)stream);
   if (!txt_layer_visit(D, FF, NH, dec, [&](auto g) {
@@ -893,6 +912,12 @@ extern "C" int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float*
   const mmvae_txt_layer_w_t wv = *w;
   const mmvae_txt_layer_saved_t sv = *saved;
   const mmvae_txt_layer_grads_t gv = *grads;
+  // the wave-per-sequence backward (csrc/txtwave.hip) wins once the sequences outnumber the CUs' 4-wave slots; below
+  // that, the 54-wide encoder layer's chain is longer on one SIMD than spread over four (measured in the step: batch
+  // 128 0.405 vs 0.415 ms with it, batch 512 1.108 vs 1.089, batch 1000 1.950 vs 1.865): from 384 sequences (MMVAE_TXT_WAVE_BWD_MIN_N[_DEC])
+  txt_plan_init();
+  if (N >= ((dec && D <= 32) ? g_txt_plan[2] : g_txt_plan[1]))
+    return txt_wave_bwd_dispatch(dy, valid, dx, dmem, wv, sv, gv, d, L, N, D, FF, NH, dec, time_mean, (hipStream_t)stream);
   if (!txt_layer_visit(D, FF, NH, dec, [&](auto g) {
         using G = decltype(g);
         hipLaunchKernelGGL((txt_layer_bwd_kernel<G>), dim3(N), dim3(256), 0, (hipStream_t)stream, dy, valid, dx, dmem, wv,

@@ -356,6 +356,7 @@ __device__ __forceinline__ T* bptr(T* base, const uint32_t byte_off) {      // u
 enum { WS_IN = 0, WS_OUT, WS_XOUT, WS_L1, WS_L2 };
 struct UD {
   int ws, ldw, nbase, kbase, nvalid, kvalid, swap;
+  int kc = 1;      // W[n][k] (k contiguous); 0: W[k][n]
 };
 struct BD {
   int start, len;
@@ -830,6 +831,499 @@ __global__ __launch_bounds__(64) void txt_wave_fwd_kernel(const float* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// backward (data-gradient chain); same outputs as txt_layer_bwd_kernel: dx, dmem, the output gradient of every GEMM
+// (d_f, d_h1, d_ca, d_v, d_a, d_qkv) for the weight-gradient launch, LayerNorm parameter partials lnws[n][k][2][D]
+// ------------------------------------------------------------------------------------------------------------
+namespace tv {
+
+// All data-gradient GEMMs read the weights "the other way": dX = dY W, i.e. W[k][n] with the OUTPUT column contiguous
+// (kc = 0).  Program order: the feed-forward block interleaved like the forward (d gelu tile i + 1 and the linear1
+// data-gradient units of tile i - 1 in front of tile i's GELU' / dropout), [cross out_proj,] out_proj per attention
+// tile, in_proj per (attention tile, Q | K | V).
+template <typename G>
+struct BwdPlan {
+  static constexpr int D = G::D, DT = G::DT, FT = G::FT, AT = G::AT;
+  static constexpr int NF = 2 * FT * DT, NC = G::DEC ? DT * DT : 0, NB = AT * DT, NX = AT * 3 * DT;
+  static constexpr int F0 = 0, C0 = NF, B0 = C0 + NC, X0 = B0 + NB, NU = X0 + NX;
+  __host__ __device__ static constexpr int posG(int i, int j) { return F0 + (i < 2 ? i * DT : 2 * DT + (i - 2) * 2 * DT) + j; }
+  __host__ __device__ static constexpr int posH(int i, int jj) {      // linear1 data gradient (output tile i, hidden tile jj)
+    int p = F0 + 2 * DT;
+    for (int g = 0; g < jj; ++g) p += ((g + 2 < FT) ? DT : 0) + DT;
+    return p + ((jj + 2 < FT) ? DT : 0) + i;
+  }
+  __host__ __device__ static constexpr int posC(int i, int j) { return C0 + i * DT + j; }
+  __host__ __device__ static constexpr int posB(int a, int j) { return B0 + a * DT + j; }
+  __host__ __device__ static constexpr int posX(int a, int part, int i) { return X0 + (a * 3 + part) * DT + i; }
+  static constexpr int NBAT = 2 + FT + (G::DEC ? 1 : 0) + AT + 3 * AT;
+  __host__ __device__ static constexpr int batG(int i) { return i; }                                    // i = 0, 1
+  __host__ __device__ static constexpr int batF(int jj) { return 2 + jj; }
+  __host__ __device__ static constexpr int batC() { return 2 + FT; }
+  __host__ __device__ static constexpr int batB(int a) { return 2 + FT + (G::DEC ? 1 : 0) + a; }
+  __host__ __device__ static constexpr int batX(int a, int part) { return 2 + FT + (G::DEC ? 1 : 0) + AT + 3 * a + part; }
+  struct Table {
+    UD u[NU];
+    BD b[NBAT + 1];
+    int bat_of[NU];
+  };
+};
+template <typename G>
+__host__ __device__ constexpr typename BwdPlan<G>::Table make_bwd_table() {
+  using P = BwdPlan<G>;
+  typename P::Table t{};
+  for (int i = 0; i < G::FT; ++i)
+    for (int j = 0; j < G::DT; ++j) t.u[P::posG(i, j)] = UD{WS_L2, G::FF, 32 * i, 32 * j, 32, G::dvalid(j), 0, 0};
+  for (int i = 0; i < G::DT; ++i)
+    for (int jj = 0; jj < G::FT; ++jj) t.u[P::posH(i, jj)] = UD{WS_L1, G::D, 32 * i, 32 * jj, G::dvalid(i), 32, 0, 0};
+  t.b[P::batG(0)] = BD{P::posG(0, 0), G::DT};
+  t.b[P::batG(1)] = BD{P::posG(1, 0), G::DT};
+  for (int jj = 0; jj < G::FT; ++jj) {
+    const bool l1 = jj + 2 < G::FT;
+    t.b[P::batF(jj)] = BD{l1 ? P::posG(jj + 2, 0) : P::posH(0, jj), (l1 ? G::DT : 0) + G::DT};
+  }
+  if (G::DEC) {
+    t.b[P::batC()] = BD{P::posC(0, 0), G::DT * G::DT};
+    for (int i = 0; i < G::DT; ++i)
+      for (int j = 0; j < G::DT; ++j)
+        t.u[P::posC(i, j)] = UD{WS_XOUT, G::D, 32 * i, 32 * j, G::dvalid(i), G::dvalid(j), 0, 0};
+  }
+  for (int a = 0; a < G::AT; ++a) {
+    t.b[P::batB(a)] = BD{P::posB(a, 0), G::DT};
+    for (int j = 0; j < G::DT; ++j) t.u[P::posB(a, j)] = UD{WS_OUT, G::D, G::abase(a), 32 * j, G::AV, G::dvalid(j), 0, 0};
+    for (int part = 0; part < 3; ++part) {
+      t.b[P::batX(a, part)] = BD{P::posX(a, part, 0), G::DT};
+      for (int i = 0; i < G::DT; ++i)
+        t.u[P::posX(a, part, i)] = UD{WS_IN, G::D, 32 * i, part * G::D + G::abase(a), G::dvalid(i), G::AV, 0, 0};
+    }
+  }
+  t.b[P::NBAT] = BD{P::NU, 0};
+  for (int b = 0; b < P::NBAT; ++b)
+    for (int k = 0; k < t.b[b].len; ++k) t.bat_of[t.b[b].start + k] = b;
+  return t;
+}
+template <typename G>
+inline constexpr typename BwdPlan<G>::Table bwd_table = make_bwd_table<G>();
+
+// LayerNorm backward over the D columns of TL tiles: dr = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma
+template <typename G>
+__device__ __forceinline__ void ln_bwd_tl(const f32x16 (&dyv)[G::DT], const f32x16 (&xh)[G::DT], const float* __restrict__ gamma,
+                                          const float rstd, const Ctx& c, f32x16 (&dr)[G::DT]) {
+  constexpr int D = G::D;
+  f32x16 gg[G::DT];
+  float s1 = 0.f, s2 = 0.f;
+  static_for<G::DT>([&](auto i) {
+    const f32x16 gm = vec_load<G::dvalid(i)>(gamma + 32 * i + 4 * c.lh, c);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gg[i][r] = dyv[i][r] * gm[r];
+      s1 += gg[i][r];
+      s2 += gg[i][r] * xh[i][r];
+    }
+  });
+  s1 = half_sum(s1);
+  s2 = half_sum(s2);
+  const float m1 = s1 / (float)D, m2 = s2 / (float)D;
+  static_for<G::DT>([&](auto i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dr[i][r] = col_ok<G::dvalid(i)>(r, c) ? rstd * (gg[i][r] - m1 - xh[i][r] * m2) : 0.f;
+  });
+}
+
+// 32 x 32 register tile (lane (i, half), register r <-> column tcol(r) + 4 half) -> its transpose, through a
+// [32][33] LDS scratch of this wave
+__device__ __forceinline__ f32x16 tile_transpose(float* __restrict__ tp, const f32x16& v, const Ctx& c) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tp[c.li * 33 + tcol(r) + 4 * c.lh] = v[r];
+  __syncthreads();
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = tp[(tcol(r) + 4 * c.lh) * 33 + c.li];
+  __syncthreads();
+  return o;
+}
+
+}  // namespace tv
+
+template <typename G, bool FULL>
+__global__ __launch_bounds__(64) void txt_wave_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ valid,
+                                                          float* __restrict__ dx, float* __restrict__ dmem,
+                                                          const mmvae_txt_layer_w_t w, const mmvae_txt_layer_saved_t sv,
+                                                          const mmvae_txt_layer_grads_t gr, const mmvae_txt_layer_drop_t dr_,
+                                                          const int L, const int N, const int time_mean,
+                                                          float* __restrict__ trash) {
+  MMVAE_TRACE_STAMP(18 + (G::DEC ? 1 : 0));
+  using P = BwdPlan<G>;
+  constexpr int D = G::D, FF = G::FF, NH = G::NH, HD = G::HD, DT = G::DT, FT = G::FT, AT = G::AT, AV = G::AV;
+  constexpr bool DEC = G::DEC, PACK = G::PACK;
+  constexpr int HPT = PACK ? NH : 1, NLN = DEC ? 3 : 2;
+  constexpr int PP = D | 1;
+  __shared__ float cs[32 * PP];          // column sums over the tokens
+  __shared__ float tp[32 * 33];          // tile transposes
+  __shared__ float vec[64];              // decoder: d v broadcast
+  Ctx c;
+  c.lane = threadIdx.x;
+  c.li = c.lane & 31;
+  c.lh = c.lane >> 5;
+  c.n = blockIdx.x;
+  c.N = N;
+  c.L = L;
+  c.trash = trash + 4 * c.lane;
+  c.zero = reinterpret_cast<const float*>(tv_zero);
+  const int tok = c.li;
+  const bool tok_ok = FULL || tok < L;
+  const uint32_t row = (uint32_t)(tok_ok ? tok : 0) * N + c.n;
+  const uint32_t rD = row * (D * 4) + 16 * c.lh, rF = row * (FF * 4) + 16 * c.lh, rQ = row * (3 * D * 4) + 16 * c.lh;
+
+  float wb[2][4][16];
+  auto batch_load = [&](auto b_) {
+    constexpr int b = b_;
+    if constexpr (b < P::NBAT) {
+      constexpr BD bd = bwd_table<G>.b[b];
+      static_for<bd.len>([&](auto k) {
+        constexpr UD d = bwd_table<G>.u[bd.start + k];
+        const float* W = d.ws == WS_IN ? w.in_w : d.ws == WS_OUT ? w.out_w : d.ws == WS_XOUT ? w.x_out_w
+                       : d.ws == WS_L1 ? w.l1_w : w.l2_w;
+        wload<false, d.nvalid, d.kvalid>(wb[b & 1][k], W, d.ldw, d.nbase, d.kbase, c);
+      });
+    }
+  };
+  auto begin = [&](auto b_) {
+    constexpr int b = b_;
+    batch_load(IC<b + 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](auto u_, f32x16& acc, const f32x16& xop) {
+    constexpr int u = u_;
+    constexpr UD d = bwd_table<G>.u[u];
+    constexpr int b = bwd_table<G>.bat_of[u];
+    mma_unit<d.kvalid, false>(acc, wb[b & 1][u - bwd_table<G>.b[b].start], xop);
+  };
+  // column sums over the tokens of a TL activation: lane col < D returns sum_t v[t][col]
+  auto col_sum = [&](const f32x16 (&v)[DT]) {
+    static_for<DT>([&](auto i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = 32 * i + tcol(r) + 4 * c.lh;
+        if (col < D) cs[tok * PP + col] = v[i][r];
+      }
+    });
+    __syncthreads();
+    float a = 0.f;
+    const int col = c.lane < D ? c.lane : 0;
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) a += cs[t * PP + col];
+    __syncthreads();
+    return a;
+  };
+  // LayerNorm weight / bias gradient partials of this sequence: lnws[n][k][0] = sum_t dy xhat, [1] = sum_t dy
+  auto ln_partials = [&](const f32x16 (&dyv)[DT], const f32x16 (&xh)[DT], const int k) {
+    f32x16 pr[DT];
+    static_for<DT>([&](auto i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[i][r] = dyv[i][r] * xh[i][r];
+    });
+    const float sg = col_sum(pr), sb = col_sum(dyv);
+    float* o = gr.lnws + (((size_t)c.n * NLN + k) * 2) * D;
+    gstore(c.lane < D ? o + c.lane : c.trash, sg);
+    gstore(c.lane < D ? o + D + c.lane : c.trash, sb);
+  };
+  TV_STAMP(1, 0);
+  batch_load(IC<0>{});
+
+  // ---- incoming gradient (rows t >= L are zero) and the last LayerNorm ----
+  f32x16 g[DT], xh[DT], dr[DT];
+  static_for<DT>([&](auto i) {
+    if (time_mean) {   // dy (N, D) is the gradient of the mean over frames: every row gets dy / L
+      const f32x16 v = vec_load<G::dvalid(i)>(dy + (size_t)c.n * D + 32 * i + 4 * c.lh, c);
+      const float sc = tok_ok ? 1.0f / (float)L : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[i][r] = v[r] * sc;
+    } else {
+      g[i] = tl_load<G::dvalid(i)>(bptr(dy, rD + 128 * i), dy, tok_ok, c);
+    }
+    xh[i] = tl_load<G::dvalid(i)>(bptr(sv.xhatf, rD + 128 * i), sv.xhatf, tok_ok, c);
+  });
+  ln_partials(g, xh, NLN - 1);
+  ln_bwd_tl<G>(g, xh, DEC ? w.n3_g : w.n2_g, gload(tok_ok ? sv.rstdf + row : c.zero), c, dr);
+
+  TV_STAMP(1, 1);
+  // ================= feed-forward block =================
+  f32x16 dyn[DT];        // gradient of the FFN block's input (LayerNorm2 output for the decoder, LayerNorm1 for the encoder)
+  {
+    f32x16 df[DT];
+    {
+      const DropKey dk = drop_key_nb(DEC ? dr_.drop3 : dr_.drop2);
+      static_for<DT>([&](auto i) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          float m[4];
+          drop4_even(dk, (rD >> 2) + 32 * i + 8 * gq, m);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) df[i][4 * gq + bb] = dr[i][4 * gq + bb] * m[bb];
+        }
+        tl_store<G::dvalid(i)>(bptr(gr.d_f, rD + 128 * i), df[i], tok_ok, c);      // gradient of linear2's output
+      });
+    }
+    const DropKey dk = drop_key_nb(dr_.ffn);
+    f32x16 dh[FT], xacc[DT], gacc[2], hv[2];
+    static_for<DT>([&](auto i) { xacc[i] = zero16(); });
+    auto ling = [&](auto i_) {          // d(gelu output) tile i = df W2[:, tile i] -> gacc[i & 1]
+      constexpr int i = i_;
+      gacc[i & 1] = zero16();
+      static_for<DT>([&](auto j) { mma(IC<P::posG(i, j)>{}, gacc[i & 1], df[j]); });
+    };
+    auto epig = [&](auto i_) {          // through the dropout and GELU': d h1 tile i
+      constexpr int i = i_;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float m[4];
+        drop4_even(dk, (rF >> 2) + 32 * i + 8 * gq, m);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int r = 4 * gq + bb;
+          dh[i][r] = tok_ok ? gacc[i & 1][r] * m[bb] * gelu_grad(hv[i & 1][r]) : 0.f;
+        }
+      }
+      tl_store<32>(bptr(gr.d_h1, rF + 128 * i), dh[i], tok_ok, c);                 // gradient of linear1's output
+    };
+    hv[0] = tl_load<32>(bptr(sv.h1, rF), sv.h1, tok_ok, c);
+    begin(IC<P::batG(0)>{});
+    ling(IC<0>{});
+    hv[1] = tl_load<32>(bptr(sv.h1, rF + 128), sv.h1, tok_ok, c);
+    begin(IC<P::batG(1)>{});
+    ling(IC<1>{});
+    epig(IC<0>{});
+    static_for<FT>([&](auto jj_) {
+      constexpr int jj = jj_;
+      if constexpr (jj + 2 < FT) hv[jj & 1] = tl_load<32>(bptr(sv.h1, rF + 128 * (jj + 2)), sv.h1, tok_ok, c);
+      begin(IC<P::batF(jj)>{});
+      if constexpr (jj + 2 < FT) ling(IC<jj + 2>{});
+      static_for<DT>([&](auto i) { mma(IC<P::posH(i, jj)>{}, xacc[i], dh[jj]); });
+      if constexpr (jj + 1 < FT) epig(IC<jj + 1>{});
+    });
+    static_for<DT>([&](auto i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dyn[i][r] = dr[i][r] + xacc[i][r];
+    });
+  }
+
+  TV_STAMP(1, 2);
+  if constexpr (DEC) {
+    // ================= cross-attention block (value path over the length-1 memory) =================
+    static_for<DT>([&](auto i) { xh[i] = tl_load<G::dvalid(i)>(bptr(sv.xhat2, rD + 128 * i), sv.xhat2, tok_ok, c); });
+    ln_partials(dyn, xh, 1);
+    ln_bwd_tl<G>(dyn, xh, w.n2_g, gload(tok_ok ? sv.rstd2 + row : c.zero), c, dr);
+    f32x16 dca[DT], dvb[DT];
+    {
+      const DropKey dk = drop_key_nb(dr_.drop2);
+      static_for<DT>([&](auto i) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          float m[4];
+          drop4_even(dk, (rD >> 2) + 32 * i + 8 * gq, m);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) dca[i][4 * gq + bb] = dr[i][4 * gq + bb] * m[bb];
+        }
+        tl_store<G::dvalid(i)>(bptr(gr.d_ca, rD + 128 * i), dca[i], tok_ok, c);    // gradient of the cross out_proj's output
+      });
+    }
+    begin(IC<P::batC()>{});
+    static_for<DT>([&](auto i) {
+      dvb[i] = zero16();
+      static_for<DT>([&](auto j) { mma(IC<P::posC(i, j)>{}, dvb[i], dca[j]); });
+    });
+    {   // d v[c] = sum_t mask(t, h(c)) d vb[t][c]
+      const DropKey dk = drop_key_nb(dr_.xattn);
+      float hm[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) hm[h] = tok_ok ? drop1_nb(dk, ((uint32_t)c.n * NH + h) * L + tok) : 0.f;
+      static_for<DT>([&](auto i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c0 = 32 * i + tcol(r);
+          const float m0 = hm[(c0 < D ? c0 : 0) / HD], m1 = hm[(c0 + 4 < D ? c0 + 4 : 0) / HD];
+          dvb[i][r] *= c.lh ? m1 : m0;
+        }
+      });
+      const float dv = col_sum(dvb);
+      gstore(c.lane < D ? gr.d_v + (size_t)c.n * D + c.lane : c.trash, dv);      // gradient of the value projection (N, D)
+      if (c.lane < D) vec[c.lane] = dv;
+      __syncthreads();
+      float a = 0.f;                                                           // d mem = d v W_v
+      const int k = c.lane < D ? c.lane : 0;
+#pragma unroll 8
+      for (int cc = 0; cc < D; ++cc) a += vec[cc] * w.x_in_w[(size_t)cc * D + k];
+      gstore(c.lane < D ? dmem + (size_t)c.n * D + c.lane : c.trash, a);
+      __syncthreads();
+    }
+    static_for<DT>([&](auto i) { dyn[i] = dr[i]; });      // the residual path: gradient of LayerNorm1's output
+  }
+
+  TV_STAMP(1, 3);
+  // ================= self-attention block =================
+  static_for<DT>([&](auto i) { xh[i] = tl_load<G::dvalid(i)>(bptr(sv.xhat1, rD + 128 * i), sv.xhat1, tok_ok, c); });
+  ln_partials(dyn, xh, 0);
+  ln_bwd_tl<G>(dyn, xh, w.n1_g, gload(tok_ok ? sv.rstd1 + row : c.zero), c, dr);
+  f32x16 da[DT];
+  {
+    const DropKey dk = drop_key_nb(dr_.drop1);
+    static_for<DT>([&](auto i) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float m[4];
+        drop4_even(dk, (rD >> 2) + 32 * i + 8 * gq, m);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) da[i][4 * gq + bb] = dr[i][4 * gq + bb] * m[bb];
+      }
+      tl_store<G::dvalid(i)>(bptr(gr.d_a, rD + 128 * i), da[i], tok_ok, c);        // gradient of out_proj's output
+    });
+  }
+  TV_STAMP(1, 4);
+  const unsigned long long vb64 = __ballot(tok_ok && valid[(size_t)c.n * L + (tok_ok ? tok : 0)] != 0);
+  const uint32_t key_bits = (uint32_t)vb64;
+  f32x16 dao[AT], xacc[DT];
+  static_for<DT>([&](auto i) { xacc[i] = zero16(); });
+  static_for<AT>([&](auto a) {
+    dao[a] = zero16();
+    begin(IC<P::batB(a)>{});
+    static_for<DT>([&](auto j) { mma(IC<P::posB(a, j)>{}, dao[a], da[j]); });      // d(attention output), tile a
+  });
+  TV_STAMP(1, 5);
+  {
+    const DropKey dk = drop_key_nb(dr_.attn);
+    const uint32_t vstride = (uint32_t)N * (3 * D * 4);
+    const uint32_t voff = ((uint32_t)(4 * c.lh) * N + c.n) * (3 * D * 4) + 4 * c.li;   // column layout: token 4 half, column li
+    const bool dl_ok = c.li < AV;
+    static_for<AT>([&](auto a_) {
+      constexpr int a = a_;
+      // operands of this attention tile: Q, K, V in token layout now; Q, K in column layout (lane = dd, registers = tokens)
+      // and d O in column layout only when the products that consume them start (register pressure)
+      const f32x16 qt = tl_load<AV>(bptr(sv.qkv, rQ + 4 * G::abase(a)), sv.qkv, tok_ok, c);
+      const f32x16 kt = tl_load<AV>(bptr(sv.qkv, rQ + 4 * (D + G::abase(a))), sv.qkv, tok_ok, c);
+      const f32x16 vt = tl_load<AV>(bptr(sv.qkv, rQ + 4 * (2 * D + G::abase(a))), sv.qkv, tok_ok, c);
+      f32x16 ds[HPT], pd[HPT];
+      static_for<HPT>([&](auto hh) {
+        constexpr int h = PACK ? (int)hh : a;
+        constexpr int c0 = PACK ? h * HD : 0;
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (tcol(r) >= c0 && tcol(r) < c0 + HD) {
+            s = mfma(kt[r], qt[r], s);                 // S^T[key][query]
+            dp = mfma(vt[r], dao[a][r], dp);           // d P^T[key][query] = sum_dv V[key][dv] dO[query][dv]
+          }
+        const float scale = 1.0f / sqrtf((float)HD);
+        float p[16], mk[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = tcol(r) + 4 * c.lh;
+          float sc = s[r] * scale;
+          if ((!FULL && key >= L) || !((key_bits >> key) & 1u)) sc = -INFINITY;
+          p[r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+        mx = half_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[r] = __expf(p[r] - mx);
+          sum += p[r];
+        }
+        sum = half_sum(sum);
+        const float inv = 1.0f / sum;
+        const uint32_t prow = (((uint32_t)c.n * NH + h) * L + tok) * L;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          float m[4];
+          if constexpr (FULL) drop4_even(dk, prow + 8 * gq + 4 * c.lh, m);
+          else drop4_any(dk, prow + 8 * gq + 4 * c.lh, m);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) mk[4 * gq + bb] = m[bb];
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[r] *= inv;
+          dp[r] *= mk[r];                              // through the dropout
+          dot += dp[r] * p[r];
+        }
+        dot = half_sum(dot);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = tcol(r) + 4 * c.lh;
+          float v = p[r] * (dp[r] - dot) * scale;
+          if (!(v == v) || (!FULL && (key >= L || tok >= L))) v = 0.f;   // masked / padded entries (and no NaN from 0 * inf)
+          ds[hh][r] = v;
+          pd[hh][r] = (!FULL && tok >= L) ? 0.f : p[r] * mk[r];
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);        // (Q, K, V in token layout are dead from here on)
+      f32x16 dq = zero16(), dkk = zero16(), dvv = zero16();
+      {
+        f32x16 kd;                               // K in column layout
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = dl_ok && (FULL || tcol(r) + 4 * c.lh < L);
+          kd[r] = gload(ok ? bptr(sv.qkv, voff + 4 * (D + G::abase(a)) + tcol(r) * vstride) : c.zero);
+        }
+        static_for<HPT>([&](auto hh) {
+          constexpr int c0 = PACK ? (int)hh * HD : 0;
+          const bool mine = !PACK || (c.li >= c0 && c.li < c0 + HD);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq = mfma(mine ? kd[r] : 0.f, ds[hh][r], dq);    // d Q^T[dd][query]
+        });
+      }
+      {
+        f32x16 qd;                               // Q in column layout
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = dl_ok && (FULL || tcol(r) + 4 * c.lh < L);
+          qd[r] = gload(ok ? bptr(sv.qkv, voff + 4 * G::abase(a) + tcol(r) * vstride) : c.zero);
+        }
+        static_for<HPT>([&](auto hh) {
+          constexpr int c0 = PACK ? (int)hh * HD : 0;
+          const bool mine = !PACK || (c.li >= c0 && c.li < c0 + HD);
+          const f32x16 dsT = tile_transpose(tp, ds[hh], c);                            // lane = key, registers = queries
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dkk = mfma(mine ? qd[r] : 0.f, dsT[r], dkk);    // d K^T[dd][key]
+        });
+      }
+      {
+        const f32x16 dod = tile_transpose(tp, dao[a], c);     // d O in column layout (lane = dv, registers = queries)
+        static_for<HPT>([&](auto hh) {
+          constexpr int c0 = PACK ? (int)hh * HD : 0;
+          const bool mine = !PACK || (c.li >= c0 && c.li < c0 + HD);
+          const f32x16 pdT = tile_transpose(tp, pd[hh], c);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dvv = mfma(mine ? dod[r] : 0.f, pdT[r], dvv);   // d V^T[dv][key]
+        });
+      }
+      tl_store<AV>(bptr(gr.d_qkv, rQ + 4 * G::abase(a)), dq, tok_ok, c);
+      tl_store<AV>(bptr(gr.d_qkv, rQ + 4 * (D + G::abase(a))), dkk, tok_ok, c);
+      tl_store<AV>(bptr(gr.d_qkv, rQ + 4 * (2 * D + G::abase(a))), dvv, tok_ok, c);
+      // d x += d qkv W_in, this tile's rows of the in_proj
+      TV_STAMP(1, 10 + 2 * a);
+      begin(IC<P::batX(a, 0)>{});
+      static_for<DT>([&](auto i) { mma(IC<P::posX(a, 0, i)>{}, xacc[i], dq); });
+      begin(IC<P::batX(a, 1)>{});
+      static_for<DT>([&](auto i) { mma(IC<P::posX(a, 1, i)>{}, xacc[i], dkk); });
+      begin(IC<P::batX(a, 2)>{});
+      static_for<DT>([&](auto i) { mma(IC<P::posX(a, 2, i)>{}, xacc[i], dvv); });
+      TV_STAMP(1, 11 + 2 * a);
+    });
+  }
+  static_for<DT>([&](auto i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xacc[i][r] += dr[i][r];
+    tl_store<G::dvalid(i)>(bptr(dx, rD + 128 * i), xacc[i], tok_ok, c);
+  });
+  TV_STAMP(1, 7);
+}
+
+
 #ifdef TV_PROBE
 extern "C" int mmvae_txt_wave_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(tv::tv_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
@@ -869,6 +1363,24 @@ int txt_wave_fwd_dispatch(const float* x, const uint8_t* valid, const float* mem
         else
           hipLaunchKernelGGL((txt_wave_fwd_kernel<G, false>), dim3(N), dim3(64), 0, stream, x, valid, mem, y, wv, sv, d, L,
                              N, time_mean, head_w, head_b, heads, HN, tv_trash_ptr());
+      }))
+    return MMVAE_ERR_UNSUPPORTED;
+  return mmvae_launch_status();
+}
+
+int txt_wave_bwd_dispatch(const float* dy, const uint8_t* valid, float* dx, float* dmem, const mmvae_txt_layer_w_t& wv,
+                          const mmvae_txt_layer_saved_t& sv, const mmvae_txt_layer_grads_t& gv,
+                          const mmvae_txt_layer_drop_t& d, int L, int N, int D, int FF, int NH, int dec, int time_mean,
+                          hipStream_t stream) {
+  if (!tv_trash_ptr()) return MMVAE_ERR_LAUNCH;
+  if (!txt_wave_visit(D, FF, NH, dec, [&](auto g) {
+        using G = decltype(g);
+        if (L == 32)
+          hipLaunchKernelGGL((txt_wave_bwd_kernel<G, true>), dim3(N), dim3(64), 0, stream, dy, valid, dx, dmem, wv, sv, gv, d,
+                             L, N, time_mean, tv_trash_ptr());
+        else
+          hipLaunchKernelGGL((txt_wave_bwd_kernel<G, false>), dim3(N), dim3(64), 0, stream, dy, valid, dx, dmem, wv, sv, gv, d,
+                             L, N, time_mean, tv_trash_ptr());
       }))
     return MMVAE_ERR_UNSUPPORTED;
   return mmvae_launch_status();

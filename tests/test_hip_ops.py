@@ -822,9 +822,12 @@ def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
                                              (False, 6, 5, 32, True), (True, 6, 5, 54, True),
                                              (False, 32, 128, 54, "mean"), (False, 7, 6, 54, "mean"),
                                              (True, 8, 32, 16, True), (True, 5, 3, 16, False)])
-def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
-    """csrc/txtlayer.hip (one launch per layer and direction) against the op-by-op kernels (each checked against
-    torch above): outputs, input gradients and every parameter gradient, with identical dropout masks."""
+@pytest.mark.parametrize("family", ["wave", "wave_fwd", "workgroup"])
+def test_txt_layer_fused_matches_op_by_op(ops, hip_lib, family, dec, L, N, d, train):
+    """csrc/txtlayer.hip / csrc/txtwave.hip (one launch per layer and direction; family: wave-per-sequence kernels in
+    both directions | forward only | the workgroup-per-sequence kernels) against the op-by-op kernels (each checked
+    against torch above): outputs, input gradients and every parameter gradient, with identical dropout masks."""
+    hip_lib.mmvae_txt_layer_plan(*{"wave": (1, 0, 0), "wave_fwd": (1, 1 << 30, 1 << 30), "workgroup": (0, 1 << 30, 1 << 30)}[family])
     from multimodal_vae_comparison_amd.models import decoders, encoders
     from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
     pooled = train == "mean"      # encoder layer with the time pooling folded in (train mode)
@@ -859,6 +862,7 @@ def test_txt_layer_fused_matches_op_by_op(ops, dec, L, N, d, train):
         yu, dxu, dmu, gu = run(False)
     finally:
         encoders.FUSED_TXT_LAYERS = True
+        hip_lib.mmvae_txt_layer_plan(1, 384, 384)
     check(yf, yu, 2e-5, "layer out")
     check(dxf, dxu, 5e-5, "layer dx")
     if dec:
