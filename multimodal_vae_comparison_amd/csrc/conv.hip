@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
 }
 
 // 32-channel weight gradients: 8-channel chunks (4 x splits workgroups) when 16-channel chunks would leave the chip
-// half empty.  MMVAE_WGRAD_QC = 16 | 8 forces one (tuning knob).
+// half empty.
 // (Round 2, in the step: with at most 8 macro tiles per split -- batch <= 128 on the 32-wide maps -- the 16-channel
 // chunks win, 0.4162 vs 0.4231 ms/step over three pairs: half as many weight-gradient workgroups beside the data-gradient
 // ones and the text tower's; with longer splits -- batch 256: 1.27 vs 1.33 ms -- the 8-channel chunks keep the
@@ -45,8 +45,6 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
 // gradients in one launch per layer, the 8-channel chunks win at batch 128 too: 0.4110 -> 0.4050 and 0.4110 -> 0.4047
 // ms/step, two same-box rounds; the short-split exception is gone.)
 static inline bool wgrad_qc8(int nsplit, int n_macro) {
-  static const int forced = getenv("MMVAE_WGRAD_QC") ? atoi(getenv("MMVAE_WGRAD_QC")) : 0;
-  if (forced) return forced == 8;
   (void)n_macro;
   return nsplit * 2 < 256;
 }

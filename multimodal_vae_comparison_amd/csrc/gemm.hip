@@ -469,10 +469,7 @@ static inline bool rgemm_aligned(const float* p, long row_stride, int K) {
   return ((uintptr_t)p & 15) == 0 && (row_stride & 3) == 0 && (K & 3) == 0 && K >= 4;
 }
 static inline int rgemm_depth(int K) { return K >= 384 ? 64 : 16; }
-static bool rgemm_enabled() {
-  static const int v = [] { const char* e = getenv("MMVAE_RGEMM"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
+static bool rgemm_enabled() { return true; }
 
 
 // ------------------------------------------------------------------------------------------------
@@ -680,12 +677,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g) {
   }
 }
 
-// shapes the large-tile kernel takes: big enough to fill the chip with 128-row tiles, float4-loadable operands
 // shapes the large-tile kernel takes: enough 128-row tiles to put >= 2 workgroups on every CU, float4-loadable
-// operands.  Returns the N tile (128 | 64) or 0; -64: the 64 x 64 tiles (mid-size M, see gemm_big_kernel).
+// operands.  Returns the N tile (128 | 64) or 0.
 static inline int gemm_big_bn(const GemmArgs& g, int nz, bool ak, bool bk_major) {
-  static const int on = [] { const char* e = getenv("MMVAE_GEMM_BIG"); return e ? atoi(e) : 1; }();
-  if (!on) return 0;
   if (g.K < 16 || g.N < 32 || g.M < 128) return 0;
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   if (!al16(g.A) || !al16(g.B)) return 0;
@@ -696,18 +690,12 @@ static inline int gemm_big_bn(const GemmArgs& g, int nz, bool ak, bool bk_major)
   const long rows = (g.M + 127) / 128;
   if (rows * ((g.N + 127) / 128) * nz >= 512 && g.N > 64) return 128;
   if (rows * ((g.N + 63) / 64) * nz >= 384) return 64;
-  // mid-size problems past the register-operand regime (M <= 256 rows): 64 x 64 tiles once they give >= 64 workgroups.
-  // MEASURED AND OFF BY DEFAULT (round 3, profiles/r03_b_b1000_kernel_stats.csv): 1000 x 512 x 512 takes 34 us on these
-  // tiles against 17.7 us on the register-operand kernel -- 128 workgroups, one per CU, with 8 MFMAs per wave between two
-  // barriers: a 16-deep stage hides 0.23 us of the ~1.5 us global-load latency; the register-operand kernel keeps a
-  // 64-deep slice of loads in flight per wave on 512 workgroups.  MMVAE_GEMM_BIG64=1 selects it (tests cover it).
-  static const int on64 = [] { const char* e = getenv("MMVAE_GEMM_BIG64"); return e ? atoi(e) : 0; }();
-  if (on64 && g.M > 256 && g.N >= 64 && g.K >= 64 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * nz >= 64) return -64;
+  // (A 64 x 64-tile variant for mid-size problems past the register-operand regime was measured in round 3 and removed in
+  // round 4: 1000 x 512 x 512 took 34 us on it against 17.7 us on the register-operand kernel.)
   return 0;
 }
 static void gemm_big_launch(const GemmArgs& g, int bn, int nz, bool ak, bool bk_major, hipStream_t st) {
-  const int bm = bn < 0 ? 64 : 128;
-  if (bn < 0) bn = -bn;
+  constexpr int bm = 128;
   const dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, nz);
 #define GB_LAUNCH(BM, BN)                                                                                   \
   do {                                                                                                      \
@@ -716,8 +704,7 @@ static void gemm_big_launch(const GemmArgs& g, int bn, int nz, bool ak, bool bk_
     else if (!bk_major) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, g); \
     else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, g);                 \
   } while (0)
-  if (bm == 64) GB_LAUNCH(64, 64);
-  else if (bn == 128) GB_LAUNCH(128, 128);
+  if (bn == 128) GB_LAUNCH(128, 128);
   else GB_LAUNCH(128, 64);
 #undef GB_LAUNCH
 }
@@ -786,7 +773,7 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   }
   // split reduction over workgroups with few output tiles (the text towers' (L*N)-row weight gradients: 162 x 54
   // outputs, 4096 rows): same kper / partial layout as the staged kernel, register-operand body
-  static const bool rsplit = !(getenv("MMVAE_RGEMM_SPLIT") && atoi(getenv("MMVAE_RGEMM_SPLIT")) == 0);
+  const bool rsplit = true;
   if (rgemm_enabled() && rsplit && nz > 1 && tiles32 <= 64 && kper <= 1024 && !ak && !bk_major) {
     const dim3 rgrid(ntn, (M + 31) / 32, nz);
     if (rgemm_depth(kper) == 64) hipLaunchKernelGGL((rgemm_kernel<64, false, false>), rgrid, dim3(512), 0, st, g);
@@ -955,7 +942,7 @@ static bool wgrad_batch_plan(const mmvae_wgrad_job_t& j, GemmArgs& g, int& nx, i
   if (gemm_big_bn(g, nz, false, false)) return false;
   nx = (g.N + 31) / 32; ny = (g.M + 31) / 32;
   const long tiles32 = (long)nx * ny;
-  static const bool rsplit = !(getenv("MMVAE_RGEMM_SPLIT") && atoi(getenv("MMVAE_RGEMM_SPLIT")) == 0);
+  const bool rsplit = true;
   if (!rgemm_enabled()) return false;
   if (nz > 1) {
     if (!(rsplit && tiles32 <= 64 && kper <= 1024 && j.accumulate == MMVAE_ACC_DEFER)) return false;

@@ -625,8 +625,7 @@ __global__ __launch_bounds__(256) void poe_bwd_fast_kernel(mmvae_poe_bwd_args a,
 // (E, n_z) -> instantiation; false when the generic kernels have to run
 template <typename F>
 static inline bool poe_fast_visit(int E, int n_z, int D, F&& f) {
-  static const bool off = getenv("MMVAE_POE_FAST") && atoi(getenv("MMVAE_POE_FAST")) == 0;
-  if (off || D > 64 || E < 1 || E > 3 || n_z < 0 || n_z > 3) return false;
+  if (D > 64 || E < 1 || E > 3 || n_z < 0 || n_z > 3) return false;
 #define POE_CASE(EE, ZZ) if (E == EE && n_z == ZZ) { f(std::integral_constant<int, EE>{}, std::integral_constant<int, ZZ>{}); return true; }
   POE_CASE(1, 0) POE_CASE(1, 1) POE_CASE(1, 2) POE_CASE(1, 3)
   POE_CASE(2, 0) POE_CASE(2, 1) POE_CASE(2, 2) POE_CASE(2, 3)

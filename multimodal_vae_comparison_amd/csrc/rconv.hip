@@ -1289,31 +1289,22 @@ __global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
 // ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
-// workgroups a split job aims for (MMVAE_RC_TARGET_WGS / _W: probe knobs; measured on the shipped CdSprites+ config at
+// workgroups a split job aims for (measured on the shipped CdSprites+ config at
 // batch 24: 128 / 256 / 512 for the forward and data-gradient jobs 4.48 / 4.18 / 4.22 ms per step, 64 / 128 / 256 / 512+
 // for the weight gradients 4.69 / 4.30 / 4.20 / 4.18)
-static inline long rc_target() {
-  static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS"); return e ? atol(e) : 256L; }();
-  return t;
-}
+static inline long rc_target() { return 256L; }
 
-// row tile -> XCD placement of the forward / data-gradient jobs (MMVAE_RC_XCD=1; default off).  MEASURED, no gain: the
+// row tile -> XCD placement of the forward / data-gradient jobs (kept in the launch plumbing, off).  MEASURED in round 3, no gain: the
 // shipped CdSprites+ step 8.95 against 8.95 ms at batch 128 (every layer has >= 8 row tiles there) -- what one launch
 // leaves in an XCD's L2 is not what the next launch's misses are about (L2 hit rate 0.55 either way: weights and the
 // other tiles' rows) -- and 4.57 against 4.16 ms at batch 24, where layers 3 and 4 have 6 and 2 row tiles and the
 // placement leaves most XCDs idle.
-static inline int rc_xcd() {
-  static const int v = [] { const char* e = getenv("MMVAE_RC_XCD"); return e ? atoi(e) : 0; }();
-  return v;
-}
+static inline int rc_xcd() { return 0; }
 static inline int rc_plan_blocks(const RcPlan& pl) {
   const int n = pl.xcd ? 8 * ((pl.gy + 7) / 8) * pl.gx * pl.gz : pl.gx * pl.gy * pl.gz;
   return (n + 7) / 8 * 8;
 }
-static inline long rc_target_w() {
-  static const long t = [] { const char* e = getenv("MMVAE_RC_TARGET_WGS_W"); return e ? atol(e) : 512L; }();
-  return t;
-}
+static inline long rc_target_w() { return 512L; }
 
 extern "C" int mmvae_rc_row_tile(int M, int N) { return RC_BM; }   // rows per statistics partial
 
@@ -1534,5 +1525,52 @@ extern "C" int mmvae_rc_bn_apply(const float* Y, const float* mean, const float*
   const long n = rows * C;
   hipLaunchKernelGGL(rc_bn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Y, mean, sc,
                      beta, out, n, C);
+  return mmvae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Global average pooling of the tower (torchvision resnet50.avgpool on relu(x)), the two kernels of the tower that are not
+// GEMM-shaped (folded in from csrc/resnet.hip in round 4)
+// ---------------------------------------------------------------------------------------------------------------------
+static inline unsigned rc_ew_blocks(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdaptiveAvgPool2d(1) on relu(x): (B, HW, C) -> (B, C), and its backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                          int HW, int C, int act) {
+  const long total = (long)B * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C), b = (int)(e / C);
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += apply_in_act(x[((size_t)b * HW + p) * C + c], act);
+    y[e] = s / (float)HW;
+  }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dx, int B, int HW, int C, int act) {
+  const long total = (long)B * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C), b = (int)(e / ((long)HW * C));
+    float g = dy[(size_t)b * C + c] * inv;
+    if (act == MMVAE_ACT_RELU && !(x[e] > 0.f)) g = 0.f;
+    dx[e] = g;
+  }
+}
+extern "C" int mmvae_avgpool_fwd(const float* x, float* y, int B, int HW, int C, int in_act, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && y && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(rc_ew_blocks((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, HW, C,
+                     in_act);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_avgpool_bwd(const float* dy, const float* x, float* dx, int B, int HW, int C, int in_act,
+                                 mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && x && dx && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(rc_ew_blocks((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx,
+                     B, HW, C, in_act);
   return mmvae_launch_status();
 }

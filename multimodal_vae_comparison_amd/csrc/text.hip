@@ -647,8 +647,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
   }
 }
 static inline bool attn_use_mfma(int L, int S, int hd) {
-  static const int on = [] { const char* e = getenv("MMVAE_ATTN_MFMA"); return e ? atoi(e) : 1; }();
-  return on && hd <= AT_HD && (L > 64 || S > 64) && L <= 128 && S <= 128;
+  return hd <= AT_HD && (L > 64 || S > 64) && L <= 128 && S <= 128;
 }
 
 extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out,

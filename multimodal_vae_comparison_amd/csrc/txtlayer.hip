@@ -850,7 +850,7 @@ static inline void txt_plan_init() {
   g_txt_plan[0] = m & 1;
   const int never = 1 << 30;
   g_txt_plan[1] = !(m & 2) ? never : getenv("MMVAE_TXT_WAVE_BWD_MIN_N") ? atoi(getenv("MMVAE_TXT_WAVE_BWD_MIN_N")) : 384;
-  g_txt_plan[2] = !(m & 2) ? never : getenv("MMVAE_TXT_WAVE_BWD_MIN_N_DEC") ? atoi(getenv("MMVAE_TXT_WAVE_BWD_MIN_N_DEC")) : 384;
+  g_txt_plan[2] = g_txt_plan[1];
 }
 extern "C" int mmvae_txt_layer_plan(int fwd_wave, int bwd_min_n, int bwd_min_n_dec) {
   txt_plan_init();
@@ -914,7 +914,7 @@ extern "C" int mmvae_txt_layer_bwd(const float* dy, const uint8_t* valid, float*
   const mmvae_txt_layer_grads_t gv = *grads;
   // the wave-per-sequence backward (csrc/txtwave.hip) wins once the sequences outnumber the CUs' 4-wave slots; below
   // that, the 54-wide encoder layer's chain is longer on one SIMD than spread over four (measured in the step: batch
-  // 128 0.405 vs 0.415 ms with it, batch 512 1.108 vs 1.089, batch 1000 1.950 vs 1.865): from 384 sequences (MMVAE_TXT_WAVE_BWD_MIN_N[_DEC])
+  // 128 0.405 vs 0.415 ms with it, batch 512 1.108 vs 1.089, batch 1000 1.950 vs 1.865): from 384 sequences (MMVAE_TXT_WAVE_BWD_MIN_N)
   txt_plan_init();
   if (N >= ((dec && D <= 32) ? g_txt_plan[2] : g_txt_plan[1]))
     return txt_wave_bwd_dispatch(dy, valid, dx, dmem, wv, sv, gv, d, L, N, D, FF, NH, dec, time_mean, (hipStream_t)stream);

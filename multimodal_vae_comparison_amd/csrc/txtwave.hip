@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64) void txt_wave_fwd_kernel(const float* __restric
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[r] = __expf(p[r] - mx);
+          p[r] = expf(p[r] - mx);
           sum += p[r];
         }
         sum = half_sum(sum);
@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(64) void txt_wave_bwd_kernel(const float* __restric
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[r] = __expf(p[r] - mx);
+          p[r] = expf(p[r] - mx);
           sum += p[r];
         }
         sum = half_sum(sum);

@@ -275,9 +275,9 @@ class Enc_TxtRNN(VaeEncoder):
         return self.finish_heads(self.o2p(out))                             # [mu | logvar head] = o2p's two halves
 
 
-FUSED_TXT_LAYERS = os.environ.get("MMVAE_FUSED_TXT", "1") != "0"
-FUSED_HEADS = os.environ.get("MMVAE_FUSED_HEADS", "1") != "0"     # text encoder: heads inside the last layer's launch
-FUSED_FFN = os.environ.get("MMVAE_FUSED_FFN", "1") != "0"         # d_model-32 layers outside the fused-layer shapes
+FUSED_TXT_LAYERS = True      # module switches (tests compare both forms)
+FUSED_HEADS = True     # text encoder: heads inside the last layer's launch
+FUSED_FFN = True         # d_model-32 layers outside the fused-layer shapes
 
 
 class HipTransformerEncoderLayer(nn.Module):

@@ -14,7 +14,7 @@ from .output_storage import VAEOutput
 
 # the decoders' first dropout-counter advance rides on the first encoder's launch (DropoutState.link;
 # MMVAE_DROPOUT_LINK=0: one one-thread launch at the head of every tower's chain)
-LINK_DROPOUT_ADVANCE = os.environ.get("MMVAE_DROPOUT_LINK", "1") == "1"
+LINK_DROPOUT_ADVANCE = True
 
 
 def normal(loc, scale):
@@ -133,20 +133,7 @@ class TorchMMVAE(nn.Module):
         # ONE side stream however many towers there are: a captured step with three parallel branches (image, text,
         # actions on their own streams) crashes ROCm 7.2's hipGraphInstantiate (segmentation fault inside capture_end;
         # two branches and the eager three-stream path are fine) -- the towers beyond the first two share a stream
-        max_side = int(os.environ.get("MMVAE_MAX_SIDE_STREAMS", "1"))
-        explicit = os.environ.get("MMVAE_TOWER_STREAMS")         # tuning knob, e.g. "0,0,1": stream index per tower
-        if explicit:
-            idx = [int(t) for t in explicit.split(",")]
-            assert len(idx) == len(names) and all(0 <= t <= max_side for t in idx)
-            out = []
-            for t in idx:
-                if t == 0:
-                    out.append(None)
-                else:
-                    s = ops.StreamPlan.get(f"tower{t}", device)
-                    ops.GradReducer.note_stream(device, s)
-                    out.append(s)
-            return out
+        max_side = 1
         if len(names) >= 3 and max_side == 1:
             # two streams for three or more towers: the tower with the longest launch chain (number of sub-modules as the
             # proxy: the 8 + 4-layer action Transformers, a ResNet-50) gets the side stream to itself, the others share

@@ -79,7 +79,7 @@ class MoPOE(TorchMMVAE):
         dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
         # (which tower keeps the capture stream, and the capture order of the towers, decide how hipGraph partitions the
         # step into queues: measured, see DESIGN.md section 5 -- tower 0 on the capture stream, captured first)
-        main_tower = int(os.environ.get("MMVAE_MAIN_TOWER", "0"))
+        main_tower = 0
         streams = self._tower_streams(dev, main_tower)
         cur = torch.cuda.current_stream(dev)
         real = [cur if st is None else st for st in streams]
@@ -87,14 +87,12 @@ class MoPOE(TorchMMVAE):
         B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
         W = self._elbo_weights(B)
         # the M rsamples (:363-369): drawn by the fusion kernel itself unless the noise is replayed (`eps_override`)
-        eps_mode = os.environ.get("MMVAE_EPS", "fused")
+        eps_mode = "fused"
         if self.eps_override is not None and eps_mode == "fused":
             eps_mode = "after"
         eps = self._draw_many(M, B, D, dev) if eps_mode == "first" else None
         enc = [None] * M
         enc_order = list(enumerate(zip(names, streams)))
-        if os.environ.get("MMVAE_ENC_ORDER", "fwd") == "rev":
-            enc_order = enc_order[::-1]
         for i, (n, st) in enc_order:
             with torch.cuda.stream(st):
                 tower = self.vaes[n].enc
@@ -109,7 +107,7 @@ class MoPOE(TorchMMVAE):
                     # one rsample per modality (:363-369), behind tower 0's encoder: that stream idles until the
                     # fusion anyway
                     eps = self._draw_many(M, B, D, dev)
-        rotate = os.environ.get("MMVAE_ROTATE", "1") == "1"
+        rotate = True      # the fusion runs on the last tower's stream, the decoders rotate by one stream
         fuse = real[-1] if rotate else real[0]
         for st in real:
             if st != fuse:
@@ -132,8 +130,6 @@ class MoPOE(TorchMMVAE):
                 st.wait_stream(fuse)
         recs = [None] * M
         order = [(i, names[i], real[(i + M - 1) % M] if rotate else real[i]) for i in range(M)]
-        if os.environ.get("MMVAE_DEC_ORDER", "fwd") == "rev":
-            order = order[::-1]
         for i, n, st in order:
             vae = self.vaes[n]
             _uses(z[i], st)
@@ -181,25 +177,15 @@ class MoPOE(TorchMMVAE):
             self._seeds.append(torch.tensor(W[0][M:], device=dev).reshape(-1, 1).expand(M + 1, B).contiguous())
             self._seed_key = key
         recs, kl, W, streams, dev = self._elbo_terms(mods, self._seeds)
-        cur = torch.cuda.current_stream(dev)
-        side = next((st for st in streams[::-1] if st is not None), None)
-        mode = os.environ.get("MMVAE_LOSS_SIDE", "0")
-
         def assemble(stream):
             with torch.cuda.stream(stream), torch.no_grad():
                 return ops.lincomb_rows([r.detach() for r in recs] + [kl.detach()], W)
 
         out = None
-        tail = None
-        if mode == "0" and os.environ.get("MMVAE_LOSS_TAIL", "1") == "1":
-            # the logged values ride on the end-of-backward fold launch (one extra workgroup): the forward's row sums
-            # are long finished by then, and a launch of their own would sit between the fold and the optimiser
-            tail = ops.GradReducer.tail = ops.lincomb_rows_args(recs + [kl], W)
-        if mode == "2" and side is not None:
-            # the logged values are assembled on the fusion stream between its decoder's forward and backward: that
-            # stream has slack until the fusion backward (the other decoder's backward is the longer one)
-            side.wait_stream(cur)
-            out = assemble(side)
+        # the logged values ride on the end-of-backward fold launch (one extra workgroup): the forward's row sums are long
+        # finished by then, and a launch of their own would sit between the fold and the optimiser (assembling them on a
+        # side stream instead cost +20 us: DESIGN section 5)
+        tail = ops.GradReducer.tail = ops.lincomb_rows_args(recs + [kl], W)
         if cut:
             # decoders + fusion only: the gradients of the towers' head outputs come back instead of flowing on
             self._cut = (list(self._fusion_inputs), torch.autograd.grad(recs + [kl], self._fusion_inputs, self._seeds),
@@ -209,9 +195,6 @@ class MoPOE(TorchMMVAE):
         ops.GradReducer.tail = None
         if tail is not None and tail["done"]:
             out = tail["args"][2].unbind(0)
-        if out is None and mode == "1" and side is not None:
-            side.wait_stream(cur)
-            out = assemble(side)
         if out is None:
             self._join(streams, dev)
             out = assemble(None)

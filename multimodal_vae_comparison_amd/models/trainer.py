@@ -228,7 +228,7 @@ class MultimodalVAE(nn.Module):
         # second graph launch, the second collective and the second fold cost 75 us per step (0.458 -> 0.532 ms), more
         # than a 2 MB ring all-reduce over xGMI takes -- it needs a cheaper cut before it pays.
         overlap = (world_size > 1 and hasattr(self.model, "backward_encoders") and 0 < self.flat.split < self.flat.grad.numel()
-                   and os.environ.get("MMVAE_DP_OVERLAP", "0") == "1" and os.environ.get("MMVAE_SPLIT_BACKWARD", "1") == "1")
+                   and os.environ.get("MMVAE_DP_OVERLAP", "0") == "1")
         if overlap:
             with torch.cuda.stream(s):                # one warm-up of the two-phase path
                 self.model.objective_backward(batch, cut=True)
@@ -257,8 +257,7 @@ class MultimodalVAE(nn.Module):
                         ring.done = False
                         ops.GradReducer.side_tail = ops.GradReducer.pre_join = ring.pull_next
                     # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
-                    ops.GradReducer.defer_next = (self._adam_in_graph and self.optimizer.supports_fold and
-                                                  os.environ.get("MMVAE_ADAM_FOLD", "1") == "1")
+                    ops.GradReducer.defer_next = self._adam_in_graph and self.optimizer.supports_fold
                     res = self._fwd_bwd(batch)
                     ops.GradReducer.defer_next = False
                     ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
@@ -348,7 +347,7 @@ class MultimodalVAE(nn.Module):
     def _fwd_bwd(self, batch):
         """forward + backward of the objective; mixers whose loss is linear in per-tower terms provide
         `objective_backward`, which seeds every tower's backward without joining the towers first"""
-        if hasattr(self.model, "objective_backward") and os.environ.get("MMVAE_SPLIT_BACKWARD", "1") == "1":
+        if hasattr(self.model, "objective_backward"):
             return self.model.objective_backward(batch)
         out = self.model.objective(batch)
         out["loss"].backward(self._one)

@@ -279,9 +279,7 @@ class StreamPlan:
 
     @classmethod
     def other_stream(cls, device):
-        """the step's stream that is NOT the current one (None outside a two-stream step or when switched off)"""
-        if os.environ.get("MMVAE_WGRAD_OTHER_STREAM", "1") != "1":
-            return None
+        """the step's stream that is NOT the current one (None outside a two-stream step)"""
         key = device.index if device.index is not None else torch.cuda.current_device()
         pr = cls.pair.get(key)
         if not pr:
@@ -845,7 +843,7 @@ class LinearKN(Function):
 
 
 # ----------------------------------------------------------------------------------------------
-# ResNet-50 tower: global average pooling (csrc/resnet.hip); the rest of the tower is rconv.py / csrc/rconv.hip
+# ResNet-50 tower: global average pooling (csrc/rconv.hip); the rest of the tower is rconv.py / csrc/rconv.hip
 # ----------------------------------------------------------------------------------------------
 class AvgPoolGlobal(Function):
     """nn.AdaptiveAvgPool2d(1) on relu(x): (B*HW, C) -> (B, C)"""
@@ -1784,60 +1782,21 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
     return ret_w, ret_b
 
 
-# One launch for the weight gradients behind a fused text layer (mmvae_linear_bwd_weight_batch): 8 graph nodes fewer
-# per cfg2 step.  Below batch ~100 the step is bound by the host's graph launch (~4.8 us per node), and fewer nodes is
-# what pays: B=16 0.331 -> 0.286 ms, B=32 0.336 -> 0.291, B=64 0.355 -> 0.330, B=96 0.385 -> 0.378.  At B=128 the GPU is
-# the limit and the six (four) small launches trickle through beside the image tower's conv backward better than one
-# 350-workgroup burst (0.414 -> 0.417 ms, 3 same-box pairs).  MMVAE_WGRAD_BATCH = auto (default: batch when a layer has
-# at most WGRAD_BATCH_ROWS rows) | 1 | 0.
-_WGRAD_BATCH_ENV = os.environ.get("MMVAE_WGRAD_BATCH", "auto")
-WGRAD_BATCH = True if _WGRAD_BATCH_ENV == "1" else False if _WGRAD_BATCH_ENV == "0" else None      # None: by size
-WGRAD_BATCH_ROWS = 3072
-
-
-def _linear_wgrad_many(jobs):
-    """[_linear_wgrad(*job) for job in jobs]; when batching applies (WGRAD_BATCH above) ONE launch for all of them
-    (mmvae_linear_bwd_weight_batch: same tiling, split plan and partial layout per job, bit-identical results) when
-    every job accumulates into preset gradient views under the deferred reduction.  jobs: (dy2, x2, w, b, gw, gb)."""
-    batch = WGRAD_BATCH if WGRAD_BATCH is not None else max(j[0].shape[0] for j in jobs) <= WGRAD_BATCH_ROWS
-    if not batch or len(jobs) < 2 or len(jobs) > H.WGRAD_BATCH_MAX or not all(
-            _defer(gw, gb if b is not None else gw) for (_, _, _, b, gw, gb) in jobs):
-        return [_linear_wgrad(*j) for j in jobs]
-    lib = H.lib()
-    arr = (H.WgradJob * len(jobs))()
-    keep = []
-    for i, (dy2, x2, w, b, gw, gb) in enumerate(jobs):
-        M, N = dy2.shape
-        K = x2.shape[1]
-        nz = lib.mmvae_linear_bwd_weight_splits(M, N, K)
-        ws = GradReducer.alloc(lib.mmvae_linear_bwd_weight_ws_floats(M, N, K), dy2.device) if nz > 1 else None
-        db = gb if b is not None else None
-        j = arr[i]
-        j.dy, j.x, j.dw, j.db, j.ws = H.ptr(dy2), H.ptr(x2), H.ptr(gw), H.ptr(db), H.ptr(ws)
-        j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, H.ACT_NONE, H.ACC_DEFER
-        keep.append((ws, nz, gw, db, N, K))
-    _call("mmvae_linear_bwd_weight_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
-    for ws, nz, gw, db, N, K in keep:
-        if nz > 1:
-            GradReducer.add(ws.data_ptr(), gw, nz, N * K, N * K)
-            if db is not None:
-                GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
-    return [(None, None)] * len(jobs)
-
-
 # Round 4: ONE launch per fused text layer for all of its weight gradients on a kernel built for tall-skinny reductions
 # (csrc/twgrad.hip: every operand row fetched once, 64 x 64 output units in registers, row slices over waves).
-TXT_WGRAD = os.environ.get("MMVAE_TXT_WGRAD", "1") != "0"
+TXT_WGRAD = True      # (module switch for the tests: False = one launch per weight gradient)
 
 
 def _txt_wgrad(jobs):
-    """the weight half of every Linear behind a fused text layer: jobs (dy2, x2, w, b, gw, gb) as _linear_wgrad_many"""
+    """the weight half of every Linear behind a fused text layer: jobs = [(dy2, x2, w, b, gw, gb)] as _linear_wgrad takes them
+    (round 2's mmvae_linear_bwd_weight_batch -- the same jobs on the split-K GEMM body in one grid -- stays in the C ABI
+    with its unit test, but nothing on the path calls it any more)"""
     lib = H.lib()
     ok = TXT_WGRAD and 1 <= len(jobs) <= H.TXT_WGRAD_MAX and all(
         b is not None and _defer(gw, gb) and dy2.is_contiguous() and x2.is_contiguous() and
         lib.mmvae_txt_wgrad_supported(dy2.shape[0], dy2.shape[1], x2.shape[1]) for (dy2, x2, _, b, gw, gb) in jobs)
-    if not ok:
-        return _linear_wgrad_many(jobs)
+    if not ok:       # shapes the kernel does not take, or gradients handed back to autograd: one launch per job
+        return [_linear_wgrad(*j) for j in jobs]
     arr = (H.TxtWgradJob * len(jobs))()
     segs = []
     for i, (dy2, x2, w, b, gw, gb) in enumerate(jobs):

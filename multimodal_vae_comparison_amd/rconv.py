@@ -325,22 +325,15 @@ class BottleneckStack(Function):
                 t = torch.empty_like(p)
                 grads[p] = (t, 0)
                 ret[p] = t
-        # Weight gradients ride in the launch of the data gradient that shares their inputs (default).  MMVAE_RC_WGRAD=side:
-        # queued and sent in batches of up to 8 jobs per launch on a side stream beside the chain of data gradients --
-        # measured SLOWER (4.55 against 4.2 ms/step at batch 24: the bulk workgroups take the CU slots the chain's short
-        # latency-bound kernels need; giving the chain's stream a higher priority made the graph 3x slower).
-        inline = os.environ.get("MMVAE_RC_WGRAD", "inline") != "side"
-        side = None
-        if not inline and ops.StreamPlan.enabled and ops.GradReducer.enabled:
-            side = ops.StreamPlan.get("rc_wgrad", dev)
-        cur = torch.cuda.current_stream(dev)
+        # Weight gradients ride in the launch of the data gradient that shares their inputs.  (Round 3 also had them queued
+        # and sent in batches of up to 8 jobs per launch on a side stream beside the chain of data gradients: measured SLOWER,
+        # 4.55 against 4.2 ms/step at batch 24 -- the bulk workgroups take the CU slots the chain's short latency-bound kernels
+        # need; giving the chain's stream a higher priority made the graph 3x slower.  Removed in round 4.)
         pending, held = [], []
         nb = H.RC_MAX_JOBS
 
         def take_wgrads():
-            """inline mode: the queued weight-gradient jobs join the next data-gradient launch"""
-            if not inline:
-                return []
+            """the queued weight-gradient jobs join the next data-gradient launch"""
             out = pending[:]
             del pending[:]
             return out
@@ -349,12 +342,7 @@ class BottleneckStack(Function):
             while len(pending) >= nb or (force and pending):
                 batch = pending[:nb]
                 del pending[:nb]
-                if side is None:
-                    launch(*batch)
-                else:
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):
-                        launch(*batch)
+                launch(*batch)
 
         ready = False          # the statistics of this block's bn3 (/ projection bn) already came out of the next block
         for bi in range(len(blocks) - 1, -1, -1):
@@ -428,14 +416,6 @@ class BottleneckStack(Function):
             flush_wgrads()
             ready = True
         flush_wgrads(force=True)
-        if side is not None and ret:
-            cur.wait_stream(side)       # gradients handed back to autograd are read as soon as this function returns
-        elif side is not None:
-            # the side stream's kernels read the saved activations and the gradients of this pass: hold them, and have the
-            # end-of-backward fold join the stream (GradReducer.flush)
-            ops.GradReducer.note_stream(dev, side)
-            ops.GradReducer.keep(dev, *held, *[t for sv in saved for t in sv[:5]])
-            ops.GradReducer.ensure_flush(dev)
         ctx.saved = None
         return (G if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None) + \
             tuple(ret.get(p) for p in ctx.params)

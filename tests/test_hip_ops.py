@@ -873,7 +873,7 @@ def test_txt_layer_fused_matches_op_by_op(ops, hip_lib, family, dec, L, N, d, tr
 
 
 # ---------------------------------------------------------------------------------------------
-# ResNet-50 tower: global average pooling (csrc/resnet.hip)
+# ResNet-50 tower: global average pooling (csrc/rconv.hip)
 # ---------------------------------------------------------------------------------------------
 def _nhwc(t):        # (B,C,H,W) -> (B*H*W, C)
     B, C, Hh, W = t.shape
