@@ -255,6 +255,7 @@ class POE(TorchMMVAE):
         # utils.subsample_input_modalities (utils.py:86-112) iterates a Python set => its order within one subset
         # size depends on PYTHONHASHSEED; the default here is itertools order, `subset_order` pins another one.
         self.subset_order = None
+        self.batch_dropout_towers = True      # decoders with dropout: all subset passes in one call (objective docstring)
 
     @property
     def pz_params(self):
@@ -267,43 +268,97 @@ class POE(TorchMMVAE):
         return [c for n in range(1, len(names) + 1) for c in combinations(names, n)]
 
     def objective(self, mods):
-        """mmvae_models.py:159-187: sum over input subsets of -(sum_b sum_m lpx - beta sum_b KL(joint || prior))"""
+        """mmvae_models.py:159-187: sum over input subsets of -(sum_b sum_m lpx - beta sum_b KL(joint || prior)).
+
+        The reference runs the whole model once per subset (2^M - 1 passes: every encoder 2^(M-1) times on the SAME
+        input, every decoder 2^M - 1 times).  Round 4: a tower without dropout (the CNN image towers; any tower in eval
+        mode) takes all of its passes in ONE call -- the encoder's output is simply shared by the subsets it belongs to,
+        the decoder decodes the (n_subsets * B) latent samples as one batch and the row-sum kernels pair output row r with
+        target row r % B.  Same sums, same noise draws in the same order.  Decoders WITH dropout do the same
+        (`batch_dropout_towers`: their masks are then drawn once for all passes); encoders with dropout keep one call per
+        subset -- the text encoder's positional encoding is indexed by the BATCH position (nn_modules.py:430-438), which a
+        repeated batch would change.  BASELINE configs[0]: 181 -> 96 C-ABI calls per step."""
         self._begin_step()
         names = list(self.vaes.keys())
         M = len(names)
         theta = self._pz_params[1]
-        rows, W_loss, W_kld = [], [], []
-        rec_log = [None] * M
         subsets = self._subsets()
+        NS = len(subsets)
         dev = next(v["data"] for v in mods.values() if v["data"] is not None).device
         streams = self._tower_streams(dev)
-        for s_idx, S in enumerate(subsets):
-            self._fork(streams, dev)
-            packed = []
-            for n, st in zip(names, streams):
-                if n in S:
-                    with torch.cuda.stream(st):
-                        packed.append(packed_head(*self.vaes[n].enc(mods[n])))
-            self._join(streams, dev)
-            B, D = packed[0].shape[0], self.n_latents
-            eps = [self._draw(B, D, packed[0].device)]
-            E = len(packed)
-            _, kl, z = ops.poe_reparam_kl(theta, packed, eps, True, 1 << E, theta.grad)
-            self._fork(streams, dev)
-            for i, (n, st) in enumerate(zip(names, streams)):
-                vae = self.vaes[n]
-                with torch.cuda.stream(st):
-                    out, _ = vae.dec({"latents": z[0].unsqueeze(0), "masks": mods[n]["masks"] if n in S else None})
-                    r = recon_rowsum(vae.ltype, out, mods[n])
-                rows.append(r)
-                W_loss.append(float(vae.llik_scaling))
+
+        def one_call(part):      # every pass of this tower gives the same function of its input
+            return getattr(part, "drop_state", None) is None or not part.training
+
+        # ---- encoders: packed[s][n] for n in subset s ----
+        packed = [dict() for _ in subsets]
+        self._fork(streams, dev)
+        for n, st in zip(names, streams):
+            member = [s for s, S in enumerate(subsets) if n in S]
+            with torch.cuda.stream(st):
+                enc = self.vaes[n].enc
+                if one_call(enc):
+                    p = packed_head(*enc(mods[n]))
+                    for s in member:
+                        packed[s][n] = p
+                else:
+                    for s in member:
+                        packed[s][n] = packed_head(*enc(mods[n]))
+        self._join(streams, dev)
+        # ---- fusion per subset (one noise draw each, in subset order) ----
+        zs, kls = [], []
+        D = self.n_latents
+        for s, S in enumerate(subsets):
+            ps = [packed[s][n] for n in names if n in S]
+            B = ps[0].shape[0]
+            eps = [self._draw(B, D, ps[0].device)]
+            E = len(ps)
+            _, kl, z = ops.poe_reparam_kl(theta, ps, eps, True, 1 << E, theta.grad)
+            zs.append(z[0])
+            kls.append(kl[E])
+        # ---- decoders: rec[s][i] (B,) row sums ----
+        rec = [[None] * M for _ in subsets]
+        self._fork(streams, dev)
+        for i, (n, st) in enumerate(zip(names, streams)):
+            vae = self.vaes[n]
+            with torch.cuda.stream(st):
+                # One call for all passes of a decoder that run under the SAME mask: the B-row latent samples of those
+                # subsets are one batch (row k * B + b).  Subsets that contain the modality decode under its mask, the
+                # others under `masks=None` (the decoder's full-length all-ones mask, another sequence length for the text
+                # tower): two groups.  optimal_sigma fits ONE sigma per call, so its passes cannot share one.  A decoder
+                # WITH dropout then draws its masks once per group instead of per pass (independent masks either way;
+                # the extracted-mask parity test splits them by pass).
+                mk = mods[n]["masks"]
+                share = vae.ltype != "optimal_sigma" and (one_call(vae.dec) or self.batch_dropout_towers)
+                groups = [[s_ for s_, S in enumerate(subsets) if n not in S], [s_ for s_, S in enumerate(subsets) if n in S]]
+                if mk is None:
+                    groups = [list(range(NS))]
+                groups = sorted([g for g in groups if g], key=lambda g: g[0])          # call order = first member's order
+                for g in groups:
+                    gm = mk if (mk is not None and n in subsets[g[0]]) else None
+                    if share and len(g) > 1:
+                        z_all = torch.cat([zs[s_] for s_ in g], 0)
+                        out, _ = vae.dec({"latents": z_all.unsqueeze(0), "masks": None if gm is None else gm.repeat(len(g), 1)})
+                        r = recon_rowsum(vae.ltype, out, mods[n])                # target row = output row % B
+                        for k, s_ in enumerate(g):
+                            rec[s_][i] = r[k * B:(k + 1) * B]
+                    else:
+                        for s_ in g:
+                            out, _ = vae.dec({"latents": zs[s_].unsqueeze(0), "masks": gm})
+                            rec[s_][i] = recon_rowsum(vae.ltype, out, mods[n])
+        self._join(streams, dev)
+        rows, W_loss, W_kld = [], [], []
+        rec_log = [None] * M
+        for s in range(NS):
+            for i, n in enumerate(names):
+                rows.append(rec[s][i])
+                W_loss.append(float(self.vaes[n].llik_scaling))
                 W_kld.append(0.0)
-                if i == s_idx:
-                    rec_log[i] = r
-            self._join(streams, dev)
-            rows.append(kl[E])
+                if i == s:
+                    rec_log[i] = rec[s][i]
+            rows.append(kls[s])
             W_loss.append(float(self.obj_fn.beta))
-            W_kld.append(1.0 / len(subsets))
+            W_kld.append(1.0 / NS)
         out = ops.lincomb_rows(rows, [W_loss, W_kld])
         ind = [r.sum() for r in rec_log]
         return {"loss": out[0], "reconstruction_loss": ind, "kld": out[1]}
