@@ -17,19 +17,19 @@
 // ------------------------------------------------------------------------------------------------
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <typename G, typename W>
+template <typename G, typename W, bool SPEC = false>
 __global__ __launch_bounds__(256) void conv2d_bwd_fused_kernel(ConvScatterArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
   MMVAE_TRACE_STAMP(10 + G::LGH);
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
-  if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<W, SPEC>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
   else   // (the data-gradient tiles XCD-contiguous, see xcd_contiguous: needs the body's first workgroup on XCD 0)
     conv_scatter_body<G>(ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w), smem);
 }
-template <typename G, typename W>
+template <typename G, typename W, bool SPEC = false>
 __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
   MMVAE_TRACE_STAMP(14 - G::LGH);
   __shared__ __attribute__((aligned(16))) float smem[cmax(G::SMEM, W::SMEM)];
-  if ((int)blockIdx.x < n_w) conv_wgrad_body<W>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
+  if ((int)blockIdx.x < n_w) conv_wgrad_body<W, SPEC>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, smem);
   else
     conv_gather_body<G, G::RWONLY>(ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w),
                                    smem);
@@ -90,7 +90,10 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
       if (wgrad_qc8(nsplit, n_macro)) {
         using W = WgradGeom<32, G::LGH, 8>;
         const int n_w = nsplit * W::NCH;
-        hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+        if (wgrad_spec(n_macro, nsplit))
+          hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W, true>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+        else
+          hipLaunchKernelGGL((conv2d_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
       } else {
         using W = WgradGeom<32, G::LGH>;
         const int n_w = nsplit * W::NCH;
@@ -132,11 +135,17 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
       if (G::CIN == 32 && wgrad_qc8(nsplit, n_macro)) {
         using W = WgradGeom<G::CIN, G::LGH - 1, G::CIN == 32 ? 8 : WGRAD_QC_DEFAULT(G::CIN)>;
         const int n_w = nsplit * W::NCH;
-        hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+        if (wgrad_spec(n_macro, nsplit))
+          hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W, true>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+        else
+          hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
       } else {
         using W = WgradGeom<G::CIN, G::LGH - 1>;
         const int n_w = nsplit * W::NCH;
-        hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+        if (wgrad_spec(n_macro, nsplit))
+          hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W, true>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+        else
+          hipLaunchKernelGGL((convT_bwd_fused_kernel<G, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
       }
       launched = true;
     }
