@@ -354,17 +354,21 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   const int n0 = k.bx * 64, m0 = k.by * RC_BM;
   RcWave wv;
   wv.init(tid);
-  RcStg<true> sa, sb;
-  sa.init(tid);
-  sb.init(tid);
-  // geometry of this thread's 8 rows: pix = row of (b, oh S - P, ow S - P) (may lie outside), hw = (oh S - P, ow S - P)
+  // Round 4: both operands of a forward stage are k-contiguous (x rows along Cin, channels-last weight rows along Cin), so
+  // a thread stages FOUR consecutive k of TWO rows with one 16-byte load each (it was one float of eight rows: 16 dword
+  // loads with their 64-bit address arithmetic per stage, and the per-tap geometry of eight rows -- VALU work that ADDS to
+  // the fp32 MFMA time on a SIMD).  LDS image unchanged ([k][row], pitch 65): the four k go to four rows of it, the 32
+  // lanes of a store hit banks (4 k4 + row) mod 32, all distinct.
+  static_assert(RC_BK == 32, "float4 staging: 8 k-quads x 32 rows per pass");
+  constexpr int NR = 2;                               // rows per thread: r0 and r0 + 32
+  const int k4 = (tid & 7) * 4, r0 = tid >> 3;
   const bool ident = a.T == 1 && a.g.S == 1;
-  int pix[RC_NS], hw[RC_NS], src[RC_NS], wrow[RC_NS];
-  float ra[RC_NS], rb[RC_NS];
+  int pix[NR], hw[NR], src[NR], wrow[NR];
+  float4 ra[NR], rb[NR];
 #pragma unroll
-  for (int i = 0; i < RC_NS; ++i) {
-    const int r = m0 + sa.row(i);
-    wrow[i] = (n0 + sb.row(i)) * a.T;
+  for (int i = 0; i < NR; ++i) {
+    const int r = m0 + r0 + 32 * i;
+    wrow[i] = (n0 + r0 + 32 * i) * a.T;
     if (ident) {
       pix[i] = r < a.M ? r : -1;
       hw[i] = 0;
@@ -376,7 +380,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       hw[i] = r < a.M ? ((h0 + 0x4000) << 16 | (w0 + 0x4000)) : -1;
     }
   }
-  float pm = 0.f, ps = 1.f, pb = 0.f;
+  float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned oka = 0;
   // this workgroup's share of the T * Cin / 32 stages (blockIdx.z of nz)
   const int spc = a.Cin / RC_BK, nstage_all = a.T * spc, sper = (nstage_all + a.nz - 1) / a.nz;
@@ -387,7 +391,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     if (newtap) {
       const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
 #pragma unroll
-      for (int i = 0; i < RC_NS; ++i) {
+      for (int i = 0; i < NR; ++i) {
         if (ident) {
           src[i] = pix[i];
         } else {
@@ -398,31 +402,42 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       }
       newtap = false;
     }
-    const int c = lc0 + sa.kl;
-    if (a.pre == RC_PRE_BN_RELU) { pm = a.xmean[c]; ps = a.xsc[c]; pb = a.xbeta[c]; }
+    const int c = lc0 + k4;
+    if (a.pre == RC_PRE_BN_RELU) {
+      pm = *reinterpret_cast<const float4*>(a.xmean + c);
+      ps = *reinterpret_cast<const float4*>(a.xsc + c);
+      pb = *reinterpret_cast<const float4*>(a.xbeta + c);
+    }
     oka = 0;
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const bool ok = src[i] >= 0;
       oka |= (ok ? 1u : 0u) << i;
-      ra[i] = a.x[ok ? (size_t)src[i] * a.Cin + c : 0];
+      ra[i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)src[i] * a.Cin + c : 0));
     }
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) rb[i] = a.w[(size_t)(wrow[i] + ltap) * a.Cin + lc0 + sb.kl];
+    for (int i = 0; i < NR; ++i) rb[i] = *reinterpret_cast<const float4*>(a.w + (size_t)(wrow[i] + ltap) * a.Cin + c);
     lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
   auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
-    float va[RC_NS];
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
-      float v = ra[i];
-      if (a.pre == RC_PRE_BN_RELU) v = fmaxf(rc_bn(v, pm, ps, pb), 0.f);
-      else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
-      va[i] = (oka >> i & 1u) ? v : 0.f;
+    for (int i = 0; i < NR; ++i) {
+      float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      const float m4[4] = {pm.x, pm.y, pm.z, pm.w}, s4[4] = {ps.x, ps.y, ps.z, ps.w}, b4[4] = {pb.x, pb.y, pb.z, pb.w};
+      const bool ok = oka >> i & 1u;
+      float* da = As_ + k4 * RC_AP + r0 + 32 * i;
+      float* db = Bs_ + k4 * RC_AP + r0 + 32 * i;
+      const float w4[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = v[q];
+        if (a.pre == RC_PRE_BN_RELU) t = fmaxf(rc_bn(t, m4[q], s4[q], b4[q]), 0.f);
+        else if (a.pre == RC_PRE_RELU) t = fmaxf(t, 0.f);
+        da[q * RC_AP] = ok ? t : 0.f;
+        db[q * RC_AP] = w4[q];
+      }
     }
-    sa.store(As_, va);
-    sb.store(Bs_, rb);
   };
   f32x16 acc;
 #pragma unroll
@@ -566,18 +581,20 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   RC_STAMP(k, 0);
   RcWave wv;
   wv.init(tid);
-  RcStg<true> sa;
-  RcStg<false> sb;
-  sa.init(tid);
-  sb.init(tid);
-  // this thread's 8 input pixels: bh = (b, ih + P, iw + P) packed; the output pixel that reads pixel (ih, iw) through
+  // float4 staging as in rc_fwd_body: A = (G, Y) rows, four consecutive Cout channels of two pixels per thread; B = the
+  // weights' [k][n] view (n = Cin contiguous), four consecutive n of two k per thread
+  static_assert(RC_BK == 32, "float4 staging: 8 k-quads x 32 rows per pass");
+  constexpr int NR = 2;
+  const int k4 = (tid & 7) * 4, r0 = tid >> 3;            // A: k quad, row (and row + 32)
+  const int nb4 = (tid & 15) * 4, kb = tid >> 4;          // B: n quad, k (and k + 16)
+  // this thread's 2 input pixels: bh = (b, ih + P, iw + P) packed; the output pixel that reads pixel (ih, iw) through
   // tap (kh, kw) is ((ih + P - kh) / S, (iw + P - kw) / S) when both divide and lie inside
   const bool ident = a.T == 1 && a.g.S == 1;
-  int pb_[RC_NS], hw[RC_NS], src[RC_NS];
-  float rg_[RC_NS], ry[RC_NS], rb[RC_NS];
+  int pb_[NR], hw[NR], src[NR];
+  float4 rg_[NR], ry[NR], rb[NR];
 #pragma unroll
-  for (int i = 0; i < RC_NS; ++i) {
-    const int rr = m0 + sa.row(i);
+  for (int i = 0; i < NR; ++i) {
+    const int rr = m0 + r0 + 32 * i;
     const int r = cls ? rmap[min(rr, rows_c - 1)] : rr;
     if (ident) {
       pb_[i] = r < a.Min ? r : -1;
@@ -589,7 +606,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       hw[i] = rr < rows_c ? ((ih + a.g.P) << 16 | (iw + a.g.P)) : -1;
     }
   }
-  float pp = 1.f, pq = 0.f, pr = 0.f;
+  float4 pp = make_float4(1.f, 1.f, 1.f, 1.f), pq = make_float4(0.f, 0.f, 0.f, 0.f), pr = pq;
   unsigned oka = 0;
   int wtap = 0;           // the filter tap (kh KW + kw) of the stage being loaded
   const int spc = a.Cout / RC_BK, nstage_all = ntap * spc, sper = (nstage_all + a.nz - 1) / a.nz;
@@ -602,7 +619,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       const int kh = cls ? kh0 + 2 * ta : ta, kw = cls ? kw0 + 2 * tb : tb;
       wtap = kh * a.g.KW + kw;
 #pragma unroll
-      for (int i = 0; i < RC_NS; ++i) {
+      for (int i = 0; i < NR; ++i) {
         if (ident) {
           src[i] = pb_[i];
         } else {
@@ -624,31 +641,42 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       }
       newtap = false;
     }
-    const int kc = lk0 + sa.kl;
-    if (a.pqr) { pp = a.pqr[kc]; pq = a.pqr[a.Cout + kc]; pr = a.pqr[2 * a.Cout + kc]; }
+    const int kc = lk0 + k4;
+    if (a.pqr) {
+      pp = *reinterpret_cast<const float4*>(a.pqr + kc);
+      pq = *reinterpret_cast<const float4*>(a.pqr + a.Cout + kc);
+      pr = *reinterpret_cast<const float4*>(a.pqr + 2 * a.Cout + kc);
+    }
     oka = 0;
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const bool ok = src[i] >= 0;
       oka |= (ok ? 1u : 0u) << i;
       const size_t o = ok ? (size_t)src[i] * a.Cout + kc : 0;
-      rg_[i] = a.G[o];
-      ry[i] = a.pqr ? a.Y[o] : 0.f;
+      rg_[i] = *reinterpret_cast<const float4*>(a.G + o);
+      ry[i] = a.pqr ? *reinterpret_cast<const float4*>(a.Y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) rb[i] = a.w[((size_t)(lk0 + sb.kk(i)) * a.T + wtap) * a.Cin + n0 + sb.rl];
+    for (int i = 0; i < NR; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(a.w + ((size_t)(lk0 + kb + 16 * i) * a.T + wtap) * a.Cin + n0 + nb4);
     lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
   auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
-    float va[RC_NS];
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
-      const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
-      va[i] = (oka >> i & 1u) ? v : 0.f;
+    for (int i = 0; i < NR; ++i) {
+      const float g4[4] = {rg_[i].x, rg_[i].y, rg_[i].z, rg_[i].w}, y4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+      const float p4[4] = {pp.x, pp.y, pp.z, pp.w}, q4[4] = {pq.x, pq.y, pq.z, pq.w}, r4[4] = {pr.x, pr.y, pr.z, pr.w};
+      const bool ok = oka >> i & 1u;
+      float* da = As_ + k4 * RC_AP + r0 + 32 * i;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = a.pqr ? fmaf(g4[q], p4[q], fmaf(y4[q], q4[q], r4[q])) : g4[q];
+        da[q * RC_AP] = ok ? v : 0.f;
+      }
+      float* db = Bs_ + (kb + 16 * i) * RC_AP + nb4;
+      db[0] = rb[i].x; db[1] = rb[i].y; db[2] = rb[i].z; db[3] = rb[i].w;
     }
-    sa.store(As_, va);
-    sb.store(Bs_, rb);
   };
   f32x16 acc;
 #pragma unroll
@@ -850,21 +878,31 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   const int kbeg = zi * a.kper, kend = min(a.M, kbeg + a.kper);
   RcWave wv;
   wv.init(tid);
-  RcStg<false> sa, sb;
-  sa.init(tid);
-  sb.init(tid);
-  float rg_[RC_NS], ry[RC_NS], rb[RC_NS];
-  int sr[RC_NS];              // source rows of the stage being loaded next (one stage ahead of the data)
+  // float4 staging (as rc_fwd_body): both operands are row-contiguous here -- G / Y along Cout, x along Cin -- so a thread
+  // stages four consecutive columns of two reduction rows (pixels kb and kb + 16 of the stage) per operand
+  static_assert(RC_BK == 32, "float4 staging: 16 column quads x 16 rows per pass");
+  constexpr int NR = 2;
+  const int q4 = (tid & 15) * 4, kb = tid >> 4;
+  float4 rg_[NR], ry[NR], rb[NR];
+  int sr[NR];                 // source rows of the stage being loaded next (one stage ahead of the data)
   unsigned oka = 0, okb = 0;
-  const int n = n0 + sa.rl, c = c0 + sb.rl;
-  float pp = 1.f, pq = 0.f, pr = 0.f, pm = 0.f, ps = 1.f, pb = 0.f;
-  if (a.pqr) { pp = a.pqr[n]; pq = a.pqr[a.Cout + n]; pr = a.pqr[2 * a.Cout + n]; }
-  if (a.pre == RC_PRE_BN_RELU) { pm = a.xmean[c]; ps = a.xsc[c]; pb = a.xbeta[c]; }
+  const int n = n0 + q4, c = c0 + q4;
+  float4 pp = make_float4(1.f, 1.f, 1.f, 1.f), pq = make_float4(0.f, 0.f, 0.f, 0.f), pr = pq, pm = pq, ps = pp, pb = pq;
+  if (a.pqr) {
+    pp = *reinterpret_cast<const float4*>(a.pqr + n);
+    pq = *reinterpret_cast<const float4*>(a.pqr + a.Cout + n);
+    pr = *reinterpret_cast<const float4*>(a.pqr + 2 * a.Cout + n);
+  }
+  if (a.pre == RC_PRE_BN_RELU) {
+    pm = *reinterpret_cast<const float4*>(a.xmean + c);
+    ps = *reinterpret_cast<const float4*>(a.xsc + c);
+    pb = *reinterpret_cast<const float4*>(a.xbeta + c);
+  }
   const int* tb = a.tbl ? a.tbl + (size_t)tap * a.M : nullptr;
   auto rows = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
-      const int m = k0 + sb.kk(i);
+    for (int i = 0; i < NR; ++i) {
+      const int m = k0 + kb + 16 * i;
       sr[i] = m < kend ? (tb ? tb[m] : m) : -1;
     }
   };
@@ -872,38 +910,42 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
     oka = 0;
     okb = 0;
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
-      const int m = k0 + sa.kk(i);
+    for (int i = 0; i < NR; ++i) {
+      const int m = k0 + kb + 16 * i;
       const bool ok = m < kend;
       oka |= (ok ? 1u : 0u) << i;
       const size_t o = ok ? (size_t)m * a.Cout + n : 0;
-      rg_[i] = a.G[o];
-      ry[i] = a.pqr ? a.Y[o] : 0.f;
+      rg_[i] = *reinterpret_cast<const float4*>(a.G + o);
+      ry[i] = a.pqr ? *reinterpret_cast<const float4*>(a.Y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const bool ok = sr[i] >= 0;
       okb |= (ok ? 1u : 0u) << i;
-      rb[i] = a.x[ok ? (size_t)sr[i] * a.Cin + c : 0];
+      rb[i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)sr[i] * a.Cin + c : 0));
     }
     if (k0 + RC_BK < kend) rows(k0 + RC_BK);      // the table entries of the stage after: not a dependent round trip then
   };
   auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
-    float va[RC_NS], vb[RC_NS];
+    const float p4[4] = {pp.x, pp.y, pp.z, pp.w}, qq4[4] = {pq.x, pq.y, pq.z, pq.w}, r4[4] = {pr.x, pr.y, pr.z, pr.w};
+    const float m4[4] = {pm.x, pm.y, pm.z, pm.w}, s4[4] = {ps.x, ps.y, ps.z, ps.w}, b4[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
-      const float v = a.pqr ? fmaf(rg_[i], pp, fmaf(ry[i], pq, pr)) : rg_[i];
-      va[i] = (oka >> i & 1u) ? v : 0.f;
-    }
+    for (int i = 0; i < NR; ++i) {
+      const float g4[4] = {rg_[i].x, rg_[i].y, rg_[i].z, rg_[i].w}, y4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+      const float x4[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+      const bool oa = oka >> i & 1u, ob = okb >> i & 1u;
+      float* da = As_ + (kb + 16 * i) * RC_AP + q4;
+      float* db = Bs_ + (kb + 16 * i) * RC_AP + q4;
 #pragma unroll
-    for (int i = 0; i < RC_NS; ++i) {
-      float v = rb[i];
-      if (a.pre == RC_PRE_BN_RELU) v = fmaxf(rc_bn(v, pm, ps, pb), 0.f);
-      else if (a.pre == RC_PRE_RELU) v = fmaxf(v, 0.f);
-      vb[i] = (okb >> i & 1u) ? v : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const float v = a.pqr ? fmaf(g4[q], p4[q], fmaf(y4[q], qq4[q], r4[q])) : g4[q];
+        da[q] = oa ? v : 0.f;
+        float t = x4[q];
+        if (a.pre == RC_PRE_BN_RELU) t = fmaxf(rc_bn(t, m4[q], s4[q], b4[q]), 0.f);
+        else if (a.pre == RC_PRE_RELU) t = fmaxf(t, 0.f);
+        db[q] = ob ? t : 0.f;
+      }
     }
-    sa.store(As_, va);
-    sb.store(Bs_, vb);
   };
   f32x16 acc;
 #pragma unroll
