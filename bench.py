@@ -442,6 +442,14 @@ def main():
                                           "one all-reduce of the flat gradient buffer per step after the graph, then the "
                                           "fused Adam launch"),
                                  "bytes": int(tr.flat.grad.numel() * 4)}
+            stager = getattr(tr, "_stager", None)
+            if in_graph and stager is not None:
+                res["collective"]["what"] = (f"{stager.n_collectives} bucketed all-reduces of the flat gradient buffer per step, "
+                                             "sent while the ResNet tower's backward pass is still running "
+                                             "(parallel.StagedGradReducer, >= 25 MB buckets), captured into the step's "
+                                             "hipGraph with the Adam launch")
+            res["collective_bytes"] = res["collective"]["bytes"]
+            res["n_collectives"] = stager.n_collectives if (in_graph and stager is not None) else 1
             res["replicas_in_sync"] = in_sync
             res["config"]["collective"] = res["collective"]["what"]
     if world == 1 and rank == 0:

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .. import flat as flatmod
 from .. import hipops as H
-from .. import parallel
+from .. import parallel, rconv
 from . import mmvae_models  # noqa: F401
 from .mmvae_base import TorchMMVAE
 from .vae import VAE
@@ -258,7 +258,14 @@ class MultimodalVAE(nn.Module):
                         ops.GradReducer.side_tail = ops.GradReducer.pre_join = ring.pull_next
                     # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
                     ops.GradReducer.defer_next = self._adam_in_graph and self.optimizer.supports_fold
-                    res = self._fwd_bwd(batch)
+                    stager = self._stager if with_collective else None
+                    if stager is not None:
+                        stager.begin()
+                        rconv.BLOCK_DONE_HOOK = lambda blk: stager.mark_final(self._stager_index[id(blk.mod)])
+                    try:
+                        res = self._fwd_bwd(batch)
+                    finally:
+                        rconv.BLOCK_DONE_HOOK = None
                     ops.GradReducer.defer_next = False
                     ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
                     if self._input_ring is not None:
@@ -268,11 +275,25 @@ class MultimodalVAE(nn.Module):
                         self.optimizer.step()
                         ops.Marks.mark("adam done")
                     self._finish_step()
-                    if with_collective:
+                    if with_collective and stager is not None:
+                        # the ResNet tower's buckets went out while its backward pass ran (rconv.BLOCK_DONE_HOOK); the
+                        # rest of the flat buffer now, then the optimiser step on the joined stream
+                        stager.finish()
+                        self.optimizer.step()
+                    elif with_collective:
                         parallel.reduce_gradients_and_step(self.flat.grad, self.optimizer, self.dp_world, None,
                                                            self.dp_force_collective)
                 self.abi_calls_in_graph = ops.CALLS[0] - calls0      # C-ABI calls of one captured step (~ graph kernel nodes)
                 return res
+            # the 102 MB model (encoder: CNN): bucketed all-reduce beside the ResNet tower's backward pass instead of one
+            # collective behind it (parallel.StagedGradReducer; only when the collective is part of the captured step)
+            self._stager = None
+            if self._collective_in_graph and os.environ.get("MMVAE_DP_STAGED", "1") == "1":
+                ranges, mods = parallel.resnet_block_ranges(self.model, self.flat)
+                if ranges:
+                    self._stager = parallel.StagedGradReducer(self.flat.grad, ranges, self.dp_world,
+                                                              force=self.dp_force_collective)
+                    self._stager_index = {id(m): i for i, m in enumerate(mods)}
             if self._collective_in_graph:
                 # EVERY rank reaches the verdict all-reduce (a rank whose capture raised used to skip it and
                 # leave the others hanging in it), and a failed capture leaves no hook set on GradReducer

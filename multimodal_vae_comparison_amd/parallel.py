@@ -85,3 +85,97 @@ def reduce_gradients_and_step(flat_grad, optimizer, world_size, group=None, forc
     assert abs(optimizer.grad_scale - scale) < 1e-12, \
         f"optimizer.grad_scale {optimizer.grad_scale} != 1/world_size {scale}: call parallel.setup_replica() first"
     optimizer.step()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the 102 MB model.  `encoder: CNN` (ResNet-50, 25.6 M parameters: what every shipped CdSprites+ / CUB / VILANRO
+# config selects) would put ONE 102 MB all-reduce behind a ~4 ms backward pass: 2 (N-1)/N x 102 MB over 153 GB/s xGMI
+# links is ~1.2 ms at 8 GPUs, none of it hidden.  The tower's backward walks its 16 bottlenecks from layer4 down, and
+# layer4 alone is 15 M of the parameters: its gradients are final after 3 of the 16 blocks.
+# ---------------------------------------------------------------------------------------------------------------------
+class StagedGradReducer:
+    """All-reduce of the flat gradient buffer in BUCKETS that go out while the backward pass is still running.
+
+    `order`: [(start, end)] element ranges of the flat buffer in the order they become final during the backward pass
+    (the ResNet bottlenecks, last block first -- flat.py lays parameters out in module order, so these ranges grow
+    downwards contiguously).  `mark_final(i)` is called by the backward pass (rconv.BLOCK_DONE_HOOK) when range i can no
+    longer change; whenever >= `bucket_bytes` of final, not yet reduced gradient have accumulated one all-reduce of that
+    contiguous range is issued on the communication stream (RCCL: behind an event of the compute stream, so it runs beside
+    the rest of the backward pass -- in a captured step the collective nodes sit on a side branch of the graph; gloo: at
+    once).  `finish()` reduces what is left -- the ranges outside `order` included: the other towers, folded partials --
+    and joins the streams; the optimiser step follows.  The sum of slices is the slice of the sum: the result is
+    bit-identical to ONE all-reduce of the whole buffer for any bucket size (tests/test_parallel_gloo.py)."""
+
+    def __init__(self, flat_grad, order, world_size, bucket_bytes=25 << 20, group=None, force=False):
+        self.g, self.order, self.world, self.group = flat_grad, [(int(a), int(b)) for a, b in order], int(world_size), group
+        self.bucket = int(bucket_bytes) // 4
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        for (a0, b0), (a1, b1) in zip(self.order, self.order[1:]):
+            assert b1 == a0 or b1 <= a0, "ranges must be listed from the back of the buffer to the front, without overlap"
+        self.comm = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        self.n_collectives = 0
+        self.begin()
+
+    def begin(self):
+        """start of a backward pass"""
+        self._final = 0                 # ranges order[:_final] are final
+        self._sent_lo = None            # [sent_lo, sent_hi): already reduced
+        self._sent_hi = None
+        self.n_collectives = 0
+
+    def _all_reduce(self, lo, hi):
+        if hi <= lo:
+            return
+        self.n_collectives += 1
+        if not self.active:
+            return
+        view = self.g[lo:hi]
+        if self.comm is None:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        self.comm.wait_stream(torch.cuda.current_stream(self.g.device))      # everything that wrote the range is queued
+        with torch.cuda.stream(self.comm):
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+
+    def mark_final(self, i):
+        """range i (and every range before it in `order`) is final"""
+        self._final = max(self._final, i + 1)
+        hi = self.order[0][1] if self._sent_lo is None else self._sent_lo
+        lo = self.order[self._final - 1][0]
+        if hi - lo >= self.bucket:
+            self._all_reduce(lo, hi)
+            if self._sent_hi is None:
+                self._sent_hi = hi
+            self._sent_lo = lo
+
+    def finish(self):
+        """end of the backward pass (after the fold of the deferred partials): everything not reduced yet, then join"""
+        n = self.g.numel()
+        if self._sent_lo is None:
+            self._all_reduce(0, n)
+        else:
+            self._all_reduce(0, self._sent_lo)
+            self._all_reduce(self._sent_hi, n)
+        if self.comm is not None and self.active:
+            torch.cuda.current_stream(self.g.device).wait_stream(self.comm)
+        return 1.0 / self.world
+
+
+def resnet_block_ranges(model, flat):
+    """[(start, end)] of the flat buffer per ResNet bottleneck, LAST block first (the order their gradients become
+    final), + the modules in that order; ([], []) for a model without a ResNet tower.  flat.py keeps the tower's
+    convolution weights (25.5 of its 25.56 M parameters) in module order in one region and the BatchNorm vectors in
+    another: a block's range is the span of its convolution weights, the 53 K BatchNorm parameters go out with the rest of
+    the buffer at the end of the backward pass."""
+    from .models.resnet import Bottleneck
+    blocks = [m for m in model.modules() if isinstance(m, Bottleneck)]
+    base = flat.grad.data_ptr()
+    out = []
+    for b in blocks:
+        ps = [p for p in b.parameters() if p.dim() == 4]
+        lo = min((p.grad.data_ptr() - base) // 4 for p in ps)
+        hi = max((p.grad.data_ptr() - base) // 4 + p.numel() for p in ps)
+        out.append((lo, hi))
+    if any(a1 < b0 for (a0, b0), (a1, b1) in zip(out, out[1:])):      # not laid out in module order: one collective
+        return [], []
+    return out[::-1], blocks[::-1]

@@ -65,6 +65,9 @@ def channels_last_ptr(w):
     return H.ptr(w)
 
 
+BLOCK_DONE_HOOK = None      # callable(rconv.Block): every gradient of that bottleneck has been launched (backward pass)
+
+
 class Unit:
     """one convolution + the BatchNorm behind it: parameters and the per-step vectors the kernels hand to each other"""
 
@@ -415,7 +418,13 @@ class BottleneckStack(Function):
                 launch(j, *take_wgrads())
             flush_wgrads()
             ready = True
+            # block bi + 1 is final now: its last queued weight gradient went out with this block's first launch
+            # (data parallel: parallel.StagedGradReducer sends finished buckets while the rest of the tower runs)
+            if BLOCK_DONE_HOOK is not None and bi + 1 < len(blocks):
+                BLOCK_DONE_HOOK(blocks[bi + 1])
         flush_wgrads(force=True)
+        if BLOCK_DONE_HOOK is not None and blocks:
+            BLOCK_DONE_HOOK(blocks[0])
         ctx.saved = None
         return (G if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None) + \
             tuple(ret.get(p) for p in ctx.params)

@@ -168,3 +168,53 @@ def test_flat_params_layout_is_aligned_and_grouped():
     for p in holder.ps:
         assert p.data_ptr() >= flat.data.data_ptr() and p.grad.data_ptr() >= flat.grad.data_ptr()
         assert (p.data_ptr() - flat.data.data_ptr()) == (p.grad.data_ptr() - flat.grad.data_ptr())
+
+
+def _staged_worker(rank, world, port, q):
+    """parallel.StagedGradReducer on two gloo ranks: buckets that go out as ranges become final == ONE all-reduce"""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from multimodal_vae_comparison_amd import parallel
+    parallel.init_from_env("gloo")
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        n = 50_000
+        grad = torch.randn(n, generator=g)
+        ref = grad.clone()
+        dist.all_reduce(ref)
+        # 7 "blocks" at the back of the buffer, last block first; [0, 9000) and [46000, n) belong to other towers
+        cuts = [9000, 12000, 20000, 21000, 30000, 38000, 41000, 46000]
+        order = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 2, -1, -1)]
+        res = {}
+        for bucket_bytes in (4, 4 * 9000, 4 * 20000, 1 << 30):
+            buf = grad.clone()
+            sr = parallel.StagedGradReducer(buf, order, world, bucket_bytes=bucket_bytes)
+            for i in range(len(order)):
+                sr.mark_final(i)
+            scale = sr.finish()
+            assert scale == 1.0 / world
+            res[bucket_bytes] = (torch.equal(buf, ref), sr.n_collectives)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_reducer_is_one_all_reduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 17
+    ps = [ctx.Process(target=_staged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        for bucket, (same, ncoll) in res.items():
+            assert same, (rank, bucket)
+        assert res[4][1] == 7 + 2 and res[1 << 30][1] == 1, res      # one bucket per block + the two outer ranges | one
+        assert 1 < res[4 * 20000][1] < res[4][1]
