@@ -828,6 +828,7 @@ static inline bool txt_layer_visit(int D, int FF, int NH, int dec, F&& f) {
   if (D == 32 && !dec) { f(Geom<32, 128, 2, false>{}); return true; }
   if (D == 54 && dec) { f(Geom<54, 128, 2, true>{}); return true; }
   if (D == 16 && dec) { f(Geom<16, 128, 2, true>{}); return true; }     // BASELINE configs[0]: latent_dim 16
+  if (D == 24 && dec) { f(Geom<24, 128, 2, true>{}); return true; }     // the shipped config_cdspritesplus.yml: n_latents 24
   return false;
 }
 

@@ -1347,6 +1347,7 @@ static inline bool txt_wave_visit(int D, int FF, int NH, int dec, F&& f) {
   if (D == 32 && !dec) { f(tv::Geom<32, 128, 2, false>{}); return true; }
   if (D == 54 && dec) { f(tv::Geom<54, 128, 2, true>{}); return true; }
   if (D == 16 && dec) { f(tv::Geom<16, 128, 2, true>{}); return true; }
+  if (D == 24 && dec) { f(tv::Geom<24, 128, 2, true>{}); return true; }     // the shipped config_cdspritesplus.yml: n_latents 24
   return false;
 }
 

@@ -426,6 +426,8 @@ class MOE(TorchMMVAE):
     def pz_params(self):
         return self._pz_params[0], F.softmax(self._pz_params[1], dim=1) * self._pz_params[1].size(-1)
 
+    batch_passes = True      # elbo: a decoder's own + cross pass in one call (objective)
+
     def _draw_k(self, m, K, B, D, dev):
         """(K,B,D) standard variates of q_m's family: one recorded draw (`eps_override`) or the device generator"""
         if self.eps_override is not None:
@@ -440,7 +442,22 @@ class MOE(TorchMMVAE):
         names = list(self.vaes.keys())
         M = len(names)
         dev = next(v["data"] for v in data.values() if v["data"] is not None).device
-        packed = [packed_head(*self.vaes[n].enc(data[n])) for n in names]
+        # Round 4: the towers on two streams (encoders side by side, decoders + their loss terms side by side; autograd
+        # replays every node on its forward stream), and each decoder's own + cross pass as ONE call over 2 B latent
+        # samples (rows [0, B) decode z_r, rows [B, 2B) z_o; the row-sum kernels pair output row k with target row k % B).
+        # Same sums; a decoder with dropout draws its masks once for both passes (independent masks either way: the
+        # extracted-mask parity test splits them by pass).  optimal_sigma fits ONE sigma per call: its passes stay apart.
+        # The shipped config_cdspritesplus.yml step is a chain of ~260 launches, ~115 of them the text decoder's two
+        # op-by-op passes: 4.00 -> 3.4 ms/step.
+        streams = self._tower_streams(dev)
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        real = [cur if st is None else st for st in streams]
+        self._fork(streams, dev)
+        packed = [None] * M
+        for i, (n, st) in enumerate(zip(names, streams)):
+            with torch.cuda.stream(st):
+                packed[i] = packed_head(*self.vaes[n].enc(data[n]))
+        self._join(streams, dev)
         B, D = packed[0].shape[0], self.n_latents
         zs, kls = [], []
         for i in range(M):
@@ -452,22 +469,38 @@ class MOE(TorchMMVAE):
                 _, kl, z = ops.poe_reparam_kl(self._theta0, [packed[i]], [eps], 2, 0b10)
                 kls.append(kl[1])
             zs.append(z[0])
-        rows, W = [], []
-        for r, n in enumerate(names):
+        for t in packed + zs:         # read by both towers' decoder sides
+            for st in real:
+                _uses(t, st)
+        rows, W = [None] * (2 * M), []
+        self._fork(streams, dev)
+        for r, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
-            own, _ = vae.dec({"latents": zs[r].unsqueeze(0), "masks": data[n]["masks"]})
             o = [s for s in range(M) if s != r][-1]
-            cross, _ = vae.dec({"latents": zs[o].unsqueeze(0), "masks": data[n]["masks"]})
-            ratio = ops.laplace_logratio if self._laplace[r] else ops.normal_logratio
-            lw = ratio(packed[r], packed[o].detach(), zs[o].detach())
-            # own: dist.Normal(*px_z) (:101-103); cross: vae.px_z = the config's `prior` family (:115)
-            rows += [recon_rowsum(vae.ltype, own, data[n]),
-                     ops.expmul(lw, recon_rowsum(vae.ltype, cross, data[n], laplace=self._laplace[r]))]
+            with torch.cuda.stream(st):
+                mk = data[n]["masks"]
+                if vae.ltype != "optimal_sigma" and self.batch_passes:
+                    z2 = torch.cat([zs[r], zs[o]], 0)
+                    out, _ = vae.dec({"latents": z2.unsqueeze(0), "masks": None if mk is None else mk.repeat(2, 1)})
+                    # own: dist.Normal(*px_z) (:101-103); cross (rows B..2B): vae.px_z = the config's `prior` family (:115)
+                    rs = recon_rowsum(vae.ltype, out, data[n], laplace=(0b10, B) if self._laplace[r] else False)
+                    own_r, cross_r = rs.view(2, B).unbind(0)      # (backward: one stack instead of two zero-fill + copy pairs)
+                else:
+                    own, _ = vae.dec({"latents": zs[r].unsqueeze(0), "masks": mk})
+                    cross, _ = vae.dec({"latents": zs[o].unsqueeze(0), "masks": mk})
+                    own_r = recon_rowsum(vae.ltype, own, data[n])
+                    cross_r = recon_rowsum(vae.ltype, cross, data[n], laplace=self._laplace[r])
+                ratio = ops.laplace_logratio if self._laplace[r] else ops.normal_logratio
+                lw = ratio(packed[r], packed[o].detach(), zs[o].detach())
+                rows[2 * r], rows[2 * r + 1] = own_r, ops.expmul(lw, cross_r)
+            for t in (rows[2 * r], rows[2 * r + 1]):
+                _uses(t, cur)
             W += [float(vae.llik_scaling)] * 2
+        self._join(streams, dev)
         kld = torch.stack(kls)                                              # (M, B), also the logged "kld"
         loss = ops.moe_elbo(rows, W, kld, self.obj_fn.beta, M)
         with torch.no_grad():                                               # logged only: lpx rows, reference sign
-            lpx = [-w * r for w, r in zip(W, rows)]
+            lpx = list(torch._foreach_mul([r.detach() for r in rows], [-w for w in W]))      # (one launch)
         return {"loss": loss, "reconstruction_loss": lpx, "kld": kld}
 
     def _objective_dreg(self, data):

@@ -821,7 +821,8 @@ def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
                                              (True, 32, 128, 32, False), (True, 32, 16, 32, True), (True, 9, 7, 32, True),
                                              (False, 6, 5, 32, True), (True, 6, 5, 54, True),
                                              (False, 32, 128, 54, "mean"), (False, 7, 6, 54, "mean"),
-                                             (True, 8, 32, 16, True), (True, 5, 3, 16, False)])
+                                             (True, 8, 32, 16, True), (True, 5, 3, 16, False),
+                                             (True, 32, 24, 24, True), (True, 7, 5, 24, False)])
 @pytest.mark.parametrize("family", ["wave", "wave_fwd", "workgroup"])
 def test_txt_layer_fused_matches_op_by_op(ops, hip_lib, family, dec, L, N, d, train):
     """csrc/txtlayer.hip / csrc/txtwave.hip (one launch per layer and direction; family: wave-per-sequence kernels in
