@@ -330,9 +330,17 @@ def _relu(x, site):
     if RELU_MASKS is None:
         return torch.relu(x)
     calls = RELU_MASKS.setdefault("_calls", {})
-    k = calls.get(site, 0)
-    calls[site] = k + 1
-    return x * RELU_MASKS[site][k].reshape(x.shape).to(x.dtype)
+    # a recorded mask may cover n passes of this site at once (the implementation under test decodes a tower's n passes
+    # as one batch, rows pass-major: row k * B + b): it then serves the next n calls, pass k first
+    pending = RELU_MASKS.setdefault("_pending", {}).setdefault(site, [])
+    if not pending:
+        k = calls.get(site, 0)
+        calls[site] = k + 1
+        m = RELU_MASKS[site][k]
+        n = m.numel() // x.numel()
+        assert n >= 1 and n * x.numel() == m.numel(), (site, tuple(m.shape), tuple(x.shape))
+        pending.extend(m.reshape(n, -1).unbind(0))
+    return x * pending.pop(0).reshape(x.shape).to(x.dtype)
 
 
 def dec_cnn(p, pre, z, data_dim=(64, 64, 3)):
