@@ -153,12 +153,24 @@ class TorchMMVAE(nn.Module):
             out.append(s)
         return out
 
-    @staticmethod
-    def _fork(streams, device):
+    def _fork(self, streams, device, batch=None):
+        """the side streams wait for what is queued on the current one.  `batch`: the step's input dict -- a tower on a
+        side stream reads its modality's data / masks (encoder input, loss target) from tensors that were allocated on
+        the caller's stream: they are registered with the side stream, or the caching allocator hands their memory out
+        again as soon as the caller drops the batch -- while the side stream's last kernels (the text encoder's embedding
+        backward) have yet to read it.  (Found in round 4: `objective(to_device(batch))` with a temporary dict, two
+        streams, a step following smaller ones in the same process: wrong embedding gradient.)"""
         cur = torch.cuda.current_stream(device)
         for s in streams:
             if s is not None:
                 s.wait_stream(cur)
+        if batch is not None:      # (every side stream: MoPoE's decoders rotate streams after the fusion)
+            side = [s for s in streams if s is not None]
+            for entry in batch.values():
+                for t in entry.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        for s in side:
+                            t.record_stream(s)
 
     @staticmethod
     def _join(streams, device):

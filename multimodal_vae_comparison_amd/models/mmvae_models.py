@@ -83,7 +83,7 @@ class MoPOE(TorchMMVAE):
         streams = self._tower_streams(dev, main_tower)
         cur = torch.cuda.current_stream(dev)
         real = [cur if st is None else st for st in streams]
-        self._fork(streams, dev)
+        self._fork(streams, dev, mods)
         B, D = next(v["data"] for v in mods.values() if v["data"] is not None).shape[0], self.n_latents
         W = self._elbo_weights(B)
         # the M rsamples (:363-369): drawn by the fusion kernel itself unless the noise is replayed (`eps_override`)
@@ -292,7 +292,7 @@ class POE(TorchMMVAE):
 
         # ---- encoders: packed[s][n] for n in subset s ----
         packed = [dict() for _ in subsets]
-        self._fork(streams, dev)
+        self._fork(streams, dev, mods)
         for n, st in zip(names, streams):
             member = [s for s, S in enumerate(subsets) if n in S]
             with torch.cuda.stream(st):
@@ -318,7 +318,7 @@ class POE(TorchMMVAE):
             kls.append(kl[E])
         # ---- decoders: rec[s][i] (B,) row sums ----
         rec = [[None] * M for _ in subsets]
-        self._fork(streams, dev)
+        self._fork(streams, dev, mods)
         for i, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
             with torch.cuda.stream(st):
@@ -452,7 +452,7 @@ class MOE(TorchMMVAE):
         streams = self._tower_streams(dev)
         cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         real = [cur if st is None else st for st in streams]
-        self._fork(streams, dev)
+        self._fork(streams, dev, data)
         packed = [None] * M
         for i, (n, st) in enumerate(zip(names, streams)):
             with torch.cuda.stream(st):
@@ -473,7 +473,7 @@ class MOE(TorchMMVAE):
             for st in real:
                 _uses(t, st)
         rows, W = [None] * (2 * M), []
-        self._fork(streams, dev)
+        self._fork(streams, dev, data)
         for r, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
             o = [s for s in range(M) if s != r][-1]
@@ -513,7 +513,15 @@ class MOE(TorchMMVAE):
         names = list(self.vaes.keys())
         M, K, D = len(names), int(self.K), self.n_latents
         dev = next(v["data"] for v in data.values() if v["data"] is not None).device
-        packed = [packed_head(*self.vaes[n].enc(data[n])) for n in names]
+        streams = self._tower_streams(dev)
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        real = [cur if st is None else st for st in streams]
+        self._fork(streams, dev, data)
+        packed = [None] * M
+        for i, (n, st) in enumerate(zip(names, streams)):
+            with torch.cuda.stream(st):
+                packed[i] = packed_head(*self.vaes[n].enc(data[n]))
+        self._join(streams, dev)
         B = packed[0].shape[0]
         eps = [self._draw_k(m, K, B, D, dev) for m in range(M)]
         theta = self._pz_params[1]
@@ -522,20 +530,27 @@ class MOE(TorchMMVAE):
         lat, z = ops.moe_ksample(theta, packed, eps, self._laplace, theta.grad,
                                  beta=float(self.obj_fn.beta) if iwae else 1.0)          # z: (M,K,B,D)
         KB = K * B
-        rows, lam = [], []
-        for r, n in enumerate(names):
+        rows, lam = [None] * (2 * M), []
+        for st in real:
+            _uses(z, st)
+        self._fork(streams, dev, data)
+        for r, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
             if not iwae and (vae.ltype != "lprob" or data[n]["masks"] is not None):
                 raise NotImplementedError("moe dreg: recon_loss lprob on unmasked modalities (the MNIST / SVHN towers) "
                                           "is what keeps the K axis in the reference")
             self.obj_fn.set_ltype(vae.ltype)
             o = 1 - r
-            out, _ = vae.dec({"latents": z.view(M * K, B, D), "masks": data[n]["masks"]})     # (M*K, B, ...) / (M*K*B, ...)
-            # own block r: dist.Normal (:101-103); cross block o: vae.px_z = the config's `prior` family (:115)
-            lap_mask = (1 << o) if self._laplace[r] else 0
-            rs = recon_rowsum(vae.ltype, out, data[n], laplace=(lap_mask, KB))          # (M*K*B,)
-            rows += [rs[r * KB:(r + 1) * KB], rs[o * KB:(o + 1) * KB]]
+            with torch.cuda.stream(st):
+                out, _ = vae.dec({"latents": z.view(M * K, B, D), "masks": data[n]["masks"]})     # (M*K, B, ...) / (M*K*B, ...)
+                # own block r: dist.Normal (:101-103); cross block o: vae.px_z = the config's `prior` family (:115)
+                lap_mask = (1 << o) if self._laplace[r] else 0
+                rs = recon_rowsum(vae.ltype, out, data[n], laplace=(lap_mask, KB))          # (M*K*B,)
+                blocks = rs.view(M, KB).unbind(0)
+                rows[2 * r], rows[2 * r + 1] = blocks[r], blocks[o]
+            _uses(rs, cur)
             lam.append(float(vae.llik_scaling))
+        self._join(streams, dev)
         return self.obj_fn.calculate_loss({"lat": lat, "rows": rows, "lam": lam})
 
     def modality_mixing(self, mods):
@@ -608,7 +623,7 @@ class DMVAE(TorchMMVAE):
         streams = self._tower_streams(dev)
         cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         real = [cur if st is None else st for st in streams]
-        self._fork(streams, dev)
+        self._fork(streams, dev, mods)
         packed = [None] * M
         for i, (n, st) in enumerate(zip(names, streams)):
             with torch.cuda.stream(st):
@@ -641,7 +656,7 @@ class DMVAE(TorchMMVAE):
             for st in real:
                 _uses(t, st)
         per = [None] * M
-        self._fork(streams, dev)
+        self._fork(streams, dev, mods)
         for i, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
             with torch.cuda.stream(st):

@@ -98,6 +98,16 @@ class GradReducer:
             ar = torch.empty(max(n, 16 << 20), dtype=torch.float32, device=device)   # 64 MB chunks
             cls._arena[key] = ar
             st["off"] = 0
+            # The caching allocator may hand out memory that kernels already QUEUED on the allocating stream still use
+            # (freed on the host, ordered on that stream only) -- but the arena is written from every stream of the step:
+            # the other streams wait for what the allocating stream has queued so far.  (Found as a wrong embedding
+            # gradient when a large two-stream step followed small ones in one process; only on this first-use / spill
+            # path -- the next step starts with an arena allocated at the end-of-backward join.)
+            if device.type == "cuda" and StreamPlan.enabled:
+                cur = torch.cuda.current_stream(device)
+                for other in set(StreamPlan.pair.get(key, ())) | set(st["used"]):
+                    if other != cur:
+                        other.wait_stream(cur)
         out = ar[st["off"]:st["off"] + n]
         st["off"] += n
         return out

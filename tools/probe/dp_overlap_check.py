@@ -31,3 +31,5 @@ for ov in ("0", "1"):
 d = (res["0"][1] - res["1"][1]).abs().max().item()
 print("max |param diff| after 20 steps:", d, " max |param|:", res["0"][1].abs().max().item())
 print("loss diff:", max(abs(a - b) for a, b in zip(res["0"][0], res["1"][0])))
+if d != 0.0:
+    sys.exit(1)
