@@ -7,6 +7,7 @@
 #include "conv_common.hpp"
 
 #include "conv_gather.inc"
+#include "conv_gather_b16.inc"
 #include "conv_scatter.inc"
 #include "conv_wgrad.inc"
 
