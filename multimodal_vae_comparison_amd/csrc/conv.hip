@@ -36,6 +36,18 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
                                    smem);
 }
 
+// the same launch with the data gradient on the split-bf16 gather body (conv_gather_b16.inc; input activation NONE)
+template <typename GB, typename W, bool SPEC = false>
+__global__ __launch_bounds__(256) void convT_bwd_fused_b16_kernel(ConvGatherArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  MMVAE_TRACE_STAMP(14 - GB::LGH);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(GB::SMEM_TOTAL, 4 * W::SMEM)];
+  if ((int)blockIdx.x < n_w)
+    conv_wgrad_body<W, SPEC>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, reinterpret_cast<float*>(smem));
+  else
+    conv_gather_b16p_body<GB, MMVAE_ACT_NONE>(
+        ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w), 0, smem);
+}
+
 // 32-channel weight gradients: 8-channel chunks (4 x splits workgroups) when 16-channel chunks would leave the chip
 // half empty.
 // (Round 2, in the step: with at most 8 macro tiles per split -- batch <= 128 on the 32-wide maps -- the 16-channel
@@ -117,7 +129,13 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   const int ep = dact_ep(x_act);
   const bool fused = Cin == 32 && (Cout == 32 || Cout == 3) && Hin >= 4 && Hin <= 32 && !(Hin & (Hin - 1)) &&
-                     !(Cout == 3 && Hin != 32) && !(Cout == 32 && Hin > 16);
+                     !(Cout == 3 && Hin != 32) && !(Cout == 32 && Hin > 16)
+#ifdef MMVAE_B16_UNFUSE
+                     // large grids are throughput-bound, the fusion buys nothing there: two launches, so that the data
+                     // gradient runs on the split-bf16 gather kernel (conv_gather_b16.inc)
+                     && !(Cout == 32 && Hin == 16 && (long)B * Hin * Hin / 32 >= MMVAE_B16_UNFUSE)
+#endif
+      ;
   if (!fused) {
     int rc = conv_wgrad_dispatch(x, dy, dw, db, ws, B, Cin, Cout, Hin, x_act, MMVAE_ACT_NONE, db ? 2 : 0, accumulate, st);
     if (rc) return rc;
@@ -129,6 +147,32 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
   ConvWgradArgs aw{x, dy, ws, B, x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro, 32, (long)32 * Cout * 16 + 32};
   bool launched = false;
+#ifndef MMVAE_B16_OFF
+  // the 32-channel layers whose data gradient the split-bf16 gather body serves (as conv_gather_b16_launch)
+  auto b16 = [&](auto gb) {
+    using GB = decltype(gb);
+    const int n_d = (int)((long)B * GB::HOUT / GB::NR);
+    auto go = [&](auto wg) {
+      using W = decltype(wg);
+      const int n_w = nsplit * W::NCH;
+      if (wgrad_spec(n_macro, nsplit))
+        hipLaunchKernelGGL((convT_bwd_fused_b16_kernel<GB, W, true>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      else
+        hipLaunchKernelGGL((convT_bwd_fused_b16_kernel<GB, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+    };
+    if (wgrad_qc8(nsplit, n_macro)) go(WgradGeom<32, GB::LGH - 1, 8>{});
+    else go(WgradGeom<32, GB::LGH - 1>{});
+    launched = true;
+  };
+  if (Cout == 32 && Hin == 16 && tiles >= 512) b16(GatherB16Geom<32, 5, 4, 4>{});
+  else if (Cout == 32 && Hin == 8 && tiles >= 1024) b16(GatherB16Geom<32, 4, 2, 4>{});
+  else if (Cout == 32 && Hin == 8 && tiles >= 256) b16(GatherB16Geom<32, 4, 1, 8>{});
+  if (launched) {
+    int rc0 = mmvae_launch_status();
+    if (rc0) return rc0;
+    return conv_bwd_reduce(ws, dw, db, B, Cout, Hin, Cout, accumulate, stream);
+  }
+#endif
   gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles, 2 * Hin), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH >= 3 && (G::CIN == 32 || G::LGH == 6)) {

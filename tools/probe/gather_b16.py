@@ -50,7 +50,7 @@ if __name__ == "__main__":
           err = float((y.double() - ref).abs().max() / ref.abs().max()) if ref is not None else float("nan")
           t = timed(call)
           out[name] = y
-          print(f"B={B:5d} {name:13s} rc={rc} max rel err vs fp64 {err:.2e}   {t:7.1f} us   {2 * B * 256 * 32 * 512 / t / 1e6:6.1f} TFLOP/s")
+          print(f"B={B:5d} {name:14s} rc={rc} max rel err vs fp64 {err:.2e}   {t:7.1f} us   {2 * B * 256 * 32 * 512 / t / 1e6:6.1f} TFLOP/s")
       print("      b16 vs f32 max abs diff", float((out["b16p tm4 cc4"] - out["f32 plan5"]).abs().max()))
 
   print("conv3 shape (32 ch, 16 x 16 -> 8 x 8)")
@@ -67,4 +67,4 @@ if __name__ == "__main__":
         rc = call()
         torch.cuda.synchronize()
         err = float((y.double() - ref).abs().max() / ref.abs().max())
-        print(f"B={B:5d} {name:13s} rc={rc} max rel err vs fp64 {err:.2e}   {timed(call):7.1f} us")
+        print(f"B={B:5d} {name:14s} rc={rc} max rel err vs fp64 {err:.2e}   {timed(call):7.1f} us")
