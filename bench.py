@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 at 32 cycles: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
 METRIC = {"cfg2": "training samples/sec, MoPoE CdSprites+ L2 (fwd+bwd+Adam)"}
 
 
@@ -216,9 +217,11 @@ def _kernel_flops(name, B, T=32):
         fwd = T * D * 3 * D + 2 * T * T * D + T * D * D + 2 * T * D * FF + (T * D * D + D * D if dec else 0)   # MAC / sequence
         bwd = fwd + 2 * T * T * D                             # data-gradient chain + the recomputed scores
         return 2.0 * B * (bwd if "bwd" in name else fwd)
-    if "conv2d_bwd_fused_kernel<ScatterGeom<4," in name or "convT_bwd_fused_kernel<GatherGeom<32, 5," in name:
+    if ("conv2d_bwd_fused_kernel<ScatterGeom<4," in name or "convT_bwd_fused_kernel<GatherGeom<32, 5," in name or
+            "convT_bwd_fused_b16_kernel<GatherB16Geom<32, 5," in name):
         return 2 * conv2
-    if "conv_gather_kernel<GatherGeom<32, 5," in name or "conv_scatter_kernel<ScatterGeom<4," in name:
+    if ("conv_gather_kernel<GatherGeom<32, 5," in name or "conv_scatter_kernel<ScatterGeom<4," in name or
+            "conv_gather_b16p_kernel<GatherB16Geom<32, 5," in name):
         return conv2
     if "txt_wgrad_kernel" in name:                            # both layers' launches averaged: (enc + dec) / 2
         M = T * B
@@ -328,8 +331,14 @@ def dominant_kernel_roofline(meta, device):
         b = torch.zeros(32, device=device)
         us = _event_time_us(lambda: ops.conv2d_k4s2(x, w, b, H.ACT_SILU))
         flops = 2.0 * B * 16 * 16 * 32 * 512
-        kernel = "conv_gather_kernel<32,*> (conv2 fwd shape)"
-        traffic, src = _pmc_traffic("conv_gather_kernel<GatherGeom<32, 5")
+        # (round 4: this shape runs on the split-bf16 gather kernel from 512 pixel tiles -- batch 64 -- on; fp32 in,
+        # fp32 accumulate, fp32 out, six v_mfma_f32_32x32x16_bf16 per 16-deep step: csrc/conv_gather_b16.inc)
+        b16 = B * 8 >= 512
+        kernel = ("conv_gather_b16p_kernel<GatherB16Geom<32,5,4,4>> (conv2 fwd shape; split-bf16 MFMAs)" if b16
+                  else "conv_gather_kernel<32,*> (conv2 fwd shape)")
+        traffic, src = _pmc_traffic("conv_gather_b16p_kernel<GatherB16Geom<32, 5" if b16 else "conv_gather_kernel<GatherGeom<32, 5")
+        if traffic is None:
+            traffic, src = _pmc_traffic("conv_gather_kernel<GatherGeom<32, 5")
         if B != 128:
             traffic = None
     ach = flops / (us * 1e-6) / 1e12
@@ -338,6 +347,13 @@ def dominant_kernel_roofline(meta, device):
            "traffic": traffic, "traffic_unit": "bytes/launch",
            "traffic_source": (f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
                               f"16-B/lane correction); algorithmic 21.0e6 at B=128") if src else None}
+    if "split-bf16" in kernel:
+        # `peak` stays the fp32 MFMA peak (the arithmetic the path promises and the reference's matrix rate on this part);
+        # the instructions the kernel actually issues have their own ceiling: dense bf16 peak / 6 MFMAs per fp32 product
+        out["peak_as_issued"] = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
+        out["frac_as_issued"] = round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
+        out["note"] = ("fp32 operands as three exact bf16 terms, six bf16 MFMAs per product, fp32 accumulate: error vs fp64 "
+                       "3e-7 of the tensor maximum, as the fp32-MFMA kernel (tools/probe/gather_b16.py)")
     if meta["mixing"] == "mopoe" and len(meta["mods"]) == 2 and meta["mods"][1]["enc"] == "TxtTransformer":    # cfg2
         out["dominant_by_time"] = _dominant_by_time(B)
     return out
