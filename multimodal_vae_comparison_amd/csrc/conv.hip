@@ -160,10 +160,18 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
       else
         hipLaunchKernelGGL((convT_bwd_fused_b16_kernel<GB, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
     };
-    if (wgrad_qc8(nsplit, n_macro)) go(WgradGeom<32, GB::LGH - 1, 8>{});
-    else go(WgradGeom<32, GB::LGH - 1>{});
+    if constexpr (GB::CIN == 32) {
+      if (wgrad_qc8(nsplit, n_macro)) go(WgradGeom<32, GB::LGH - 1, 8>{});
+      else go(WgradGeom<32, GB::LGH - 1>{});
+    } else {
+      go(WgradGeom<GB::CIN, GB::LGH - 1>{});
+    }
     launched = true;
   };
+#ifndef MMVAE_B16_NO3
+  if (Cout == 3 && Hin == 32 && tiles >= 1024) b16(GatherB16Geom<3, 6, 4, 3>{});
+  else
+#endif
   if (Cout == 32 && Hin == 16 && tiles >= 512) b16(GatherB16Geom<32, 5, 4, 4>{});
   else if (Cout == 32 && Hin == 8 && tiles >= 1024) b16(GatherB16Geom<32, 4, 2, 4>{});
   else if (Cout == 32 && Hin == 8 && tiles >= 256) b16(GatherB16Geom<32, 4, 1, 8>{});

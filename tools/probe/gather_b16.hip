@@ -2,9 +2,9 @@
 #include "../../multimodal_vae_comparison_amd/csrc/conv_gather.inc"
 #include "../../multimodal_vae_comparison_amd/csrc/conv_gather_b16.inc"
 
-template <int LGH, int TM, int CC>
+template <int LGH, int TM, int CC, int CIN = 32>
 static int launch(const ConvGatherArgs& a, int Cout, hipStream_t st) {
-  using G = GatherB16Geom<32, LGH, TM, CC>;
+  using G = GatherB16Geom<CIN, LGH, TM, CC>;
   hipLaunchKernelGGL((conv_gather_b16p_kernel<G, MMVAE_ACT_RELU>), dim3(a.B * G::HOUT / G::NR, Cout / 32), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -12,7 +12,9 @@ static int launch(const ConvGatherArgs& a, int Cout, hipStream_t st) {
 extern "C" int probe_conv_b16(const float* x, const float* w, const float* bias, const float* aux, float* y, int B,
                               int Cin, int Cout, int Hin, int in_act, int ep, int geom, hipStream_t st) {
   ConvGatherArgs a{x, w, bias, aux, y, B, in_act, ep, Cout};
-  if (Cin != 32 || Cout % 32 || in_act != MMVAE_ACT_RELU) return 1;
+  if (Cout % 32 || in_act != MMVAE_ACT_RELU) return 1;
+  if (Cin == 3 && Hin == 64) return launch<6, 4, 3, 3>(a, Cout, st);
+  if (Cin != 32) return 1;
   if (Hin == 32) {
     if (geom == 12) return launch<5, 2, 8>(a, Cout, st);
     if (geom == 14) return launch<5, 4, 8>(a, Cout, st);

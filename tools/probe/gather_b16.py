@@ -68,3 +68,18 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         err = float((y.double() - ref).abs().max() / ref.abs().max())
         print(f"B={B:5d} {name:14s} rc={rc} max rel err vs fp64 {err:.2e}   {timed(call):7.1f} us")
+
+  print("conv1 shape (3 ch, 64 x 64 -> 32 x 32)")
+  for B in (128, 1000):
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 3, 64, 64, generator=g).cuda()
+    w = (torch.randn(32, 3, 4, 4, generator=g) * 0.1).cuda()
+    b = torch.randn(32, generator=g).cuda()
+    ref = F.conv2d(torch.relu(x.double()), w.double(), b.double(), stride=2, padding=1)
+    for name, fn, arg in (("f32", L.probe_conv_f32, 0), ("b16p tm4 cc3", L.probe_conv_b16, 0)):
+        y = torch.full((B, 32, 32, 32), float("nan"), device="cuda")
+        call = lambda: fn(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), B, 3, 32, 64, 2, 0, arg, torch.cuda.current_stream().cuda_stream)
+        rc = call()
+        torch.cuda.synchronize()
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        print(f"B={B:5d} {name:13s} rc={rc} max rel err vs fp64 {err:.2e}   {timed(call):7.1f} us")
