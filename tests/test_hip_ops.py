@@ -37,7 +37,9 @@ def ops(hip_lib):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,Cin,Hin,act", [(3, 3, 64, 0), (5, 32, 32, 1), (6, 32, 16, 1), (5, 32, 8, 1), (128, 32, 8, 2),
-                                           (2, 32, 32, 0), (130, 32, 16, 1), (64, 3, 64, 0)])
+                                           (2, 32, 32, 0), (130, 32, 16, 1), (64, 3, 64, 0),
+                                           # shapes served by the split-bf16 kernels (conv_gather_b16.inc): every geometry
+                                           (70, 32, 32, 2), (70, 32, 32, 1), (520, 32, 16, 2), (33, 3, 64, 0)])
 def test_conv2d_fwd_bwd(ops, B, Cin, Hin, act):
     g = torch.Generator().manual_seed(B * 1000 + Hin)
     x = torch.randn(B, Cin, Hin, Hin, generator=g)
@@ -63,7 +65,10 @@ def test_conv2d_fwd_bwd(ops, B, Cin, Hin, act):
 
 
 @pytest.mark.parametrize("B,Cout,Hin,act,ep", [(3, 32, 4, 2, 0), (5, 32, 8, 2, 0), (6, 32, 16, 2, 0), (128, 32, 4, 0, 0),
-                                               (4, 3, 32, 2, 6), (130, 32, 8, 2, 0), (33, 3, 32, 2, 6), (7, 3, 16, 0, 0)])
+                                               (4, 3, 32, 2, 6), (130, 32, 8, 2, 0), (33, 3, 32, 2, 6), (7, 3, 16, 0, 0),
+                                               # split-bf16: the fused backward's data-gradient body on every geometry,
+                                               # the 32 -> 3 forward (conv_scatter3_b16.inc)
+                                               (70, 32, 16, 2, 0), (520, 32, 8, 2, 0), (70, 3, 32, 2, 6), (66, 3, 32, 0, 0)])
 def test_convT2d_fwd_bwd(ops, B, Cout, Hin, act, ep):
     g = torch.Generator().manual_seed(B * 1000 + Hin + Cout)
     x = torch.randn(B, 32, Hin, Hin, generator=g)
