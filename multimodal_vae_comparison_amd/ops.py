@@ -666,13 +666,23 @@ def convT2d(x, w, b, stride=2, pad=1, in_act=H.ACT_NONE, out_ep=H.EP_NONE, gw=No
     return y
 
 
+_conv_layouts = {}
+
+
 def _conv_segments(ws, dw, db, B, c_small, c_large, h_small, n_bias):
-    rows, rowlen, bias_col = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _call("mmvae_conv_wgrad_layout", B, c_small, c_large, h_small, ctypes.byref(rows), ctypes.byref(rowlen),
-          ctypes.byref(bias_col))
-    GradReducer.add(ws.data_ptr(), dw, rows.value, dw.numel(), rowlen.value)
+    # (the layout of the partial rows is a pure function of the shape: a host-side query, asked once per shape -- it used
+    # to be repeated on every backward pass and was counted among the step's C-ABI calls, 8 of cfg2's 54)
+    key = (B, c_small, c_large, h_small)
+    lay = _conv_layouts.get(key)
+    if lay is None:
+        rows, rowlen, bias_col = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        H.check(H.lib().mmvae_conv_wgrad_layout(B, c_small, c_large, h_small, ctypes.byref(rows), ctypes.byref(rowlen),
+                                                ctypes.byref(bias_col)), "mmvae_conv_wgrad_layout")
+        lay = _conv_layouts[key] = (rows.value, rowlen.value, bias_col.value)
+    rows, rowlen, bias_col = lay
+    GradReducer.add(ws.data_ptr(), dw, rows, dw.numel(), rowlen)
     if db is not None:
-        GradReducer.add(ws.data_ptr() + 4 * bias_col.value, db, rows.value, n_bias, rowlen.value)
+        GradReducer.add(ws.data_ptr() + 4 * bias_col, db, rows, n_bias, rowlen)
 
 
 def conv2d_k4s2(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None):
