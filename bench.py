@@ -445,7 +445,12 @@ def main():
                           "abi_calls_per_step": getattr(tr, "abi_calls_in_graph", None),
                           "step_mflop_per_sample": round(flops / 1e6, 1),
                           "step_flops_fraction_of_f32_mfma_peak": round(
-                              sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
+                              sps / world * flops / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                          # dtype f32 = the arithmetic contract of every kernel: fp32 operands, fp32 accumulation, the
+                          # reference's results to 1e-4.  The gather-form convolutions meet it with split-bf16 MFMAs
+                          "arithmetic": "fp32 operands / accumulate / results everywhere; the gather-form convolutions "
+                                        "form each fp32 product from six bf16 MFMAs on three exact bf16 terms per operand "
+                                        "(error vs fp64 as the fp32-MFMA kernels, DESIGN 5d)"},
                "final_loss": round(loss, 3)}
         if world > 1 or path_world > 1:
             # top level, so that the driver's scaling record can read them: which collective path the step took and
