@@ -9,6 +9,7 @@
 #include "conv_gather.inc"
 #include "conv_gather_b16.inc"
 #include "conv_scatter.inc"
+#include "conv_scatter_b16.inc"
 #include "conv_wgrad.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -34,6 +35,18 @@ __global__ __launch_bounds__(256) void convT_bwd_fused_kernel(ConvGatherArgs ad,
   else
     conv_gather_body<G, G::RWONLY>(ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w),
                                    smem);
+}
+
+// Conv2d backward with the data gradient on the split-bf16 scatter body (conv_scatter_b16.inc; input activation NONE)
+template <typename GS, typename W, bool SPEC = false>
+__global__ __launch_bounds__(256) void conv2d_bwd_fused_b16_kernel(ConvScatterArgs ad, ConvWgradArgs aw, int n_w, int w_gx) {
+  MMVAE_TRACE_STAMP(10 + GS::LGH);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(GS::SMEM_TOTAL, 4 * W::SMEM)];
+  if ((int)blockIdx.x < n_w)
+    conv_wgrad_body<W, SPEC>(aw, blockIdx.x % w_gx, blockIdx.x / w_gx, w_gx, reinterpret_cast<float*>(smem));
+  else
+    conv_scatter_b16_body<GS, MMVAE_ACT_NONE>(
+        ad, (n_w & 7) ? (int)blockIdx.x - n_w : xcd_contiguous(blockIdx.x - n_w, gridDim.x - n_w), 0, smem);
 }
 
 // the same launch with the data gradient on the split-bf16 gather body (conv_gather_b16.inc; input activation NONE)
@@ -96,6 +109,28 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
   // one instantiation per layer shape: the scatter plan is a function of the map size at a given batch, but both
   // template arguments must be compile-time, so the (few) combinations are enumerated by the two visitors
   bool launched = false;
+#ifndef MMVAE_B16_OFF
+#ifndef MMVAE_B16_SCATTER_FUSED_MIN
+#define MMVAE_B16_SCATTER_FUSED_MIN 2048      // (at batch 128 the fused launch is faster on the fp32 body: 0.391 vs 0.400 ms/step; from batch 256 on 80 KB per workgroup pays)
+#endif
+  if (Hout == 16 && tiles >= MMVAE_B16_SCATTER_FUSED_MIN) {       // the layer whose data gradient the split-bf16 scatter body serves
+    using GS = ScatterB16Geom<4>;
+    const int n_d = (int)((long)B * GS::HIN / GS::NR);
+    auto go = [&](auto wg) {
+      using W = decltype(wg);
+      const int n_w = nsplit * W::NCH;
+      if (wgrad_spec(n_macro, nsplit))
+        hipLaunchKernelGGL((conv2d_bwd_fused_b16_kernel<GS, W, true>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+      else
+        hipLaunchKernelGGL((conv2d_bwd_fused_b16_kernel<GS, W>), dim3(n_w + n_d), dim3(256), 0, st, ad, aw, n_w, nsplit);
+    };
+    if (wgrad_qc8(nsplit, n_macro)) go(WgradGeom<32, 4, 8>{});
+    else go(WgradGeom<32, 4>{});
+    int rc0 = mmvae_launch_status();
+    if (rc0) return rc0;
+    return conv_bwd_reduce(ws, dw, db, B, Cin, Hout, 32, accumulate, stream);
+  }
+#endif
   scatter_visit(Hout, scatter_plan(tiles, 32, Hout), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH <= 4) {
