@@ -114,8 +114,8 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
 #define MMVAE_B16_SCATTER_FUSED_MIN 2048      // (at batch 128 the fused launch is faster on the fp32 body: 0.391 vs 0.400 ms/step; from batch 256 on 80 KB per workgroup pays)
 #endif
   if (Hout == 16 && tiles >= MMVAE_B16_SCATTER_FUSED_MIN) {       // the layer whose data gradient the split-bf16 scatter body serves
-    using GS = ScatterB16Geom<4>;
-    const int n_d = (int)((long)B * GS::HIN / GS::NR);
+    using GS = ScatterB16Geom<32, 4>;
+    const int n_d = (int)(((long)B * GS::HIN + GS::NR - 1) / GS::NR);
     auto go = [&](auto wg) {
       using W = decltype(wg);
       const int n_w = nsplit * W::NCH;

@@ -367,7 +367,10 @@ def test_seeded_losses_write_their_own_backward(ops, B, Fd):
     (False, 3, 32, 64, 32, 2, 1, 0, 0), (False, 6, 64, 32, 16, 2, 1, 2, 0), (False, 40, 64, 128, 4, 2, 0, 2, 0),
     (True, 260, 64, 64, 4, 2, 1, 2, 0), (True, 65, 64, 32, 8, 2, 1, 2, 0), (True, 900, 64, 32, 8, 2, 1, 2, 0),
     (True, 5, 32, 64, 8, 2, 1, 0, 0), (True, 3, 64, 32, 16, 2, 1, 1, 0), (True, 33, 128, 64, 1, 1, 0, 2, 0),
-    (True, 1100, 128, 64, 1, 1, 0, 2, 0)])
+    (True, 1100, 128, 64, 1, 1, 0, 2, 0),
+    # split-bf16 scatter body on the 8 x 8 grid (conv_scatter_b16.inc): 64 reduced channels, odd image counts (the last
+    # workgroup holds one image), two output-channel groups, a SiLU' epilogue on the data gradient
+    (False, 515, 32, 64, 16, 2, 1, 1, 0), (True, 513, 64, 64, 8, 2, 1, 2, 0)])
 def test_conv_generic(ops, transposed, B, Cin, Cout, Hin, S, P, act, ep):
     """ops.conv2d / ops.convT2d (generic kernels, or the MFMA kernels when the shape is theirs) vs torch fp64: the
     SVHN tower layers (channels 64 / 128, k4 s2 p0, k4 s1 p0) and the plain-sigmoid epilogue"""

@@ -10,9 +10,11 @@ extern "C" int probe_scatter(const float* x, const float* w, const float* bias, 
   const unsigned ngrp = Cout / 32;
   const long tiles = ((long)B * Hin * Hin + 31) / 32 * ngrp;
   if (b16) {
-    if (Hin != 16 || in_act != MMVAE_ACT_RELU) return 1;
-    using G = ScatterB16Geom<4>;
-    hipLaunchKernelGGL((conv_scatter_b16_kernel<G, MMVAE_ACT_RELU>), dim3((unsigned)((long)B * G::HIN / G::NR), ngrp), dim3(256), 0, st, a);
+    bool ok = false;
+    if (Hin == 16 && Cred == 32) ok = conv_scatter_b16_launch_geom<ScatterB16Geom<32, 4>>(a, ngrp, st);
+    else if (Hin == 8 && Cred == 32) ok = conv_scatter_b16_launch_geom<ScatterB16Geom<32, 3>>(a, ngrp, st);
+    else if (Hin == 8 && Cred == 64) ok = conv_scatter_b16_launch_geom<ScatterB16Geom<64, 3>>(a, ngrp, st);
+    if (!ok) return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
   }
   const int plan = scatter_plan(tiles, Cred, Hin);
