@@ -218,10 +218,12 @@ def _kernel_flops(name, B, T=32):
         bwd = fwd + 2 * T * T * D                             # data-gradient chain + the recomputed scores
         return 2.0 * B * (bwd if "bwd" in name else fwd)
     if ("conv2d_bwd_fused_kernel<ScatterGeom<4," in name or "convT_bwd_fused_kernel<GatherGeom<32, 5," in name or
-            "convT_bwd_fused_b16_kernel<GatherB16Geom<32, 5," in name):
+            "convT_bwd_fused_b16_kernel<GatherB16Geom<32, 5," in name or
+            "conv2d_bwd_fused_b16_kernel<ScatterB16Geom<32, 4>" in name):
         return 2 * conv2
     if ("conv_gather_kernel<GatherGeom<32, 5," in name or "conv_scatter_kernel<ScatterGeom<4," in name or
-            "conv_gather_b16p_kernel<GatherB16Geom<32, 5," in name):
+            "conv_gather_b16p_kernel<GatherB16Geom<32, 5," in name or
+            "conv_scatter_b16_kernel<ScatterB16Geom<32, 4>" in name):
         return conv2
     if "txt_wgrad_kernel" in name:                            # both layers' launches averaged: (enc + dec) / 2
         M = T * B
@@ -230,7 +232,7 @@ def _kernel_flops(name, B, T=32):
         return (enc + dec) / 2
     if "rgemm_kernel<16, false, false>" in name:              # (round 3: a text layer's (T*B, 162) x (T*B, 54) weight gradient)
         return 2.0 * T * B * 162 * 54
-    if "rgemm_grouped_kernel<64, 16, true>" in name:          # Linear(512, 512) backward: dX + dW
+    if "rgemm_grouped_kernel<64, 16, " in name:               # Linear(512, 512) backward: dX + dW
         return 2 * 2.0 * B * 512 * 512
     if "rgemm16_kernel<64, true, true>" in name:
         return 2.0 * B * 512 * 512
@@ -312,7 +314,9 @@ def dominant_kernel_roofline(meta, device):
         b = torch.zeros(32, device=device)
         us = _event_time_us(lambda: ops.convT2d(x, w, b, 2, 1, H.ACT_RELU))
         flops = 2.0 * N * 64 * 64 * 32 * 16
-        kernel = f"conv_scatter_kernel<ScatterGeom<3,*,*,64>> (Dec_SVHN conv3 fwd, N={N})"
+        # (round 4: from 1024 position tiles -- N = 512 -- on this shape runs on the split-bf16 scatter body, conv_scatter_b16.inc)
+        kernel = (f"conv_scatter_b16_kernel<ScatterB16Geom<64,3>> (Dec_SVHN conv3 fwd, N={N}; split-bf16 MFMAs)" if N * 2 >= 1024
+                  else f"conv_scatter_kernel<ScatterGeom<3,*,*,64>> (Dec_SVHN conv3 fwd, N={N})")
         traffic, src = None, None
     elif meta.get("K", 1) > 1:
         # K-sample MoE on the CdSprites+ towers: both decoders decode M*K*B latent samples, the image decoder's
@@ -323,7 +327,8 @@ def dominant_kernel_roofline(meta, device):
         b = torch.zeros(32, device=device)
         us = _event_time_us(lambda: ops.convT2d_k4s2(x, w, b, H.ACT_RELU, 0), reps=20)
         flops = 2.0 * N * 16 * 16 * 32 * 512
-        kernel = f"conv_scatter_kernel<ScatterGeom<4,*,*,32>> (Dec_CNN convT2 fwd, N={N})"
+        kernel = (f"conv_scatter_b16_kernel<ScatterB16Geom<32,4>> (Dec_CNN convT2 fwd, N={N}; split-bf16 MFMAs)" if N * 8 >= 512
+                  else f"conv_scatter_kernel<ScatterGeom<4,*,*,32>> (Dec_CNN convT2 fwd, N={N})")
         traffic, src = None, None
     else:
         x = torch.randn(B, 32, 32, 32, device=device)
@@ -353,7 +358,7 @@ def dominant_kernel_roofline(meta, device):
         out["peak_as_issued"] = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
         out["frac_as_issued"] = round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
         out["note"] = ("fp32 operands as three exact bf16 terms, six bf16 MFMAs per product, fp32 accumulate: error vs fp64 "
-                       "3e-7 of the tensor maximum, as the fp32-MFMA kernel (tools/probe/gather_b16.py)")
+                       "3e-7 of the tensor maximum, as the fp32-MFMA kernel (tools/probe/gather_b16.py, scatter_b16.py)")
     if meta["mixing"] == "mopoe" and len(meta["mods"]) == 2 and meta["mods"][1]["enc"] == "TxtTransformer":    # cfg2
         out["dominant_by_time"] = _dominant_by_time(B)
     return out
