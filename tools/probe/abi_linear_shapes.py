@@ -1,5 +1,11 @@
+"""The Linear / weight-gradient C-ABI calls of one captured cfg2 step with their integer arguments (M, N, K, ...):
+
+    python tools/probe/abi_linear_shapes.py 1000
+"""
+import os
 import sys
-sys.path.insert(0, "/root/repo")
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from multimodal_vae_comparison_amd import ops
 from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
