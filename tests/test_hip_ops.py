@@ -39,7 +39,10 @@ def ops(hip_lib):
 @pytest.mark.parametrize("B,Cin,Hin,act", [(3, 3, 64, 0), (5, 32, 32, 1), (6, 32, 16, 1), (5, 32, 8, 1), (128, 32, 8, 2),
                                            (2, 32, 32, 0), (130, 32, 16, 1), (64, 3, 64, 0),
                                            # shapes served by the split-bf16 kernels (conv_gather_b16.inc): every geometry
-                                           (70, 32, 32, 2), (70, 32, 32, 1), (520, 32, 16, 2), (33, 3, 64, 0)])
+                                           (70, 32, 32, 2), (70, 32, 32, 1), (520, 32, 16, 2), (33, 3, 64, 0),
+                                           # 2080 position tiles: the fused backward with the split-bf16 SCATTER body as its
+                                           # data-gradient half (conv2d_bwd_fused_b16_kernel, from 2048 tiles on)
+                                           (260, 32, 32, 1)])
 def test_conv2d_fwd_bwd(ops, B, Cin, Hin, act):
     g = torch.Generator().manual_seed(B * 1000 + Hin)
     x = torch.randn(B, Cin, Hin, Hin, generator=g)
