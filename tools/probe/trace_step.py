@@ -47,7 +47,7 @@ torch.cuda.synchronize()
 print(f"step: {e0.elapsed_time(e1) * 10:.1f} us")
 v = table.cpu().tolist()
 last = max(v)
-ev = sorted((v[i], n) for i, n in NAMES.items() if v[i] and last - v[i] < 200000)   # stamps of the last replay only
+ev = sorted((v[i], n) for i, n in NAMES.items() if v[i] and last - v[i] < (200000 if B <= 256 else 2000000))   # stamps of the last replay only
 t0 = ev[0][0]
 for t, n in ev:
     print(f"{(t - t0) / 100.0:8.2f} us  {n}")
