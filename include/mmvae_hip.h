@@ -147,6 +147,12 @@ int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const float* w, float
                           int B, int Cin, int Cout, int Hout, int x_act, int accumulate, mmvae_stream_t stream);
 int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
                            int B, int Cin, int Cout, int Hin, int x_act, int accumulate, mmvae_stream_t stream);
+/* The 32-channel layers on 16x16 / 32x32 maps and the 3-channel image layers run on one of two GEMM cores from a
+ * tile-count threshold on: "split-bf16" (every fp32 operand split EXACTLY into three bf16 terms, six bf16 MFMAs per
+ * product, fp32 accumulate; dropped terms <= 3 * 2^-24 |a b|, i.e. fp32-equivalent: tests/test_hip_ops.py holds it to
+ * 2e-6 of the tensor maximum against fp64) or fp32 MFMA.  split_bf16 = 1 (default) / 0 selects, < 0 keeps; returns the
+ * previous setting.  Non-finite inputs: see DESIGN.md "split-bf16 and non-finite values". */
+int mmvae_conv_plan(int split_bf16);
 
 /* ------------------------------------------------------------------------------------------------
  * Small dense layers: torch.nn.Linear and the projections inside nn.MultiheadAttention /

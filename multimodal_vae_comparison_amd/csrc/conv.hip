@@ -109,11 +109,8 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
   // one instantiation per layer shape: the scatter plan is a function of the map size at a given batch, but both
   // template arguments must be compile-time, so the (few) combinations are enumerated by the two visitors
   bool launched = false;
-#ifndef MMVAE_B16_OFF
-#ifndef MMVAE_B16_SCATTER_FUSED_MIN
-#define MMVAE_B16_SCATTER_FUSED_MIN 2048      // (at batch 128 the fused launch is faster on the fp32 body: 0.391 vs 0.400 ms/step; from batch 256 on 80 KB per workgroup pays)
-#endif
-  if (Hout == 16 && tiles >= MMVAE_B16_SCATTER_FUSED_MIN) {       // the layer whose data gradient the split-bf16 scatter body serves
+  // (at batch 128 the fused launch is faster on the fp32 body: 0.391 vs 0.400 ms/step; from batch 256 on 80 KB per workgroup pays)
+  if (conv_split_bf16_enabled() && Hout == 16 && tiles >= 2048) {       // the layer whose data gradient the split-bf16 scatter body serves
     using GS = ScatterB16Geom<32, 4>;
     const int n_d = (int)(((long)B * GS::HIN + GS::NR - 1) / GS::NR);
     auto go = [&](auto wg) {
@@ -130,7 +127,6 @@ extern "C" int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const floa
     if (rc0) return rc0;
     return conv_bwd_reduce(ws, dw, db, B, Cin, Hout, 32, accumulate, stream);
   }
-#endif
   scatter_visit(Hout, scatter_plan(tiles, 32, Hout), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH <= 4) {
@@ -164,13 +160,7 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   const int ep = dact_ep(x_act);
   const bool fused = Cin == 32 && (Cout == 32 || Cout == 3) && Hin >= 4 && Hin <= 32 && !(Hin & (Hin - 1)) &&
-                     !(Cout == 3 && Hin != 32) && !(Cout == 32 && Hin > 16)
-#ifdef MMVAE_B16_UNFUSE
-                     // large grids are throughput-bound, the fusion buys nothing there: two launches, so that the data
-                     // gradient runs on the split-bf16 gather kernel (conv_gather_b16.inc)
-                     && !(Cout == 32 && Hin == 16 && (long)B * Hin * Hin / 32 >= MMVAE_B16_UNFUSE)
-#endif
-      ;
+                     !(Cout == 3 && Hin != 32) && !(Cout == 32 && Hin > 16);
   if (!fused) {
     int rc = conv_wgrad_dispatch(x, dy, dw, db, ws, B, Cin, Cout, Hin, x_act, MMVAE_ACT_NONE, db ? 2 : 0, accumulate, st);
     if (rc) return rc;
@@ -182,7 +172,6 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
   const int n_macro = wgrad_n_macro(B, Hin), nsplit = wgrad_splits(n_macro, Cout);
   ConvWgradArgs aw{x, dy, ws, B, x_act, MMVAE_ACT_NONE, db ? 2 : 0, n_macro, 32, (long)32 * Cout * 16 + 32};
   bool launched = false;
-#ifndef MMVAE_B16_OFF
   // the 32-channel layers whose data gradient the split-bf16 gather body serves (as conv_gather_b16_launch)
   auto b16 = [&](auto gb) {
     using GB = decltype(gb);
@@ -203,11 +192,10 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
     }
     launched = true;
   };
-#ifndef MMVAE_B16_NO3
-  if (Cout == 3 && Hin == 32 && tiles >= 1024) b16(GatherB16Geom<3, 6, 4, 3>{});
-  else
-#endif
-  if (Cout == 32 && Hin == 16 && tiles >= 512) b16(GatherB16Geom<32, 5, 4, 4>{});
+  const bool sb = conv_split_bf16_enabled();
+  if (!sb) {}
+  else if (Cout == 3 && Hin == 32 && tiles >= 1024) b16(GatherB16Geom<3, 6, 4, 3>{});
+  else if (Cout == 32 && Hin == 16 && tiles >= 512) b16(GatherB16Geom<32, 5, 4, 4>{});
   else if (Cout == 32 && Hin == 8 && tiles >= 1024) b16(GatherB16Geom<32, 4, 2, 4>{});
   else if (Cout == 32 && Hin == 8 && tiles >= 256) b16(GatherB16Geom<32, 4, 1, 8>{});
   if (launched) {
@@ -215,7 +203,6 @@ extern "C" int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const flo
     if (rc0) return rc0;
     return conv_bwd_reduce(ws, dw, db, B, Cout, Hin, Cout, accumulate, stream);
   }
-#endif
   gather_visit(Cout, 2 * Hin, gather_plan(Cout, tiles, 2 * Hin), [&](auto g) {
     using G = decltype(g);
     if constexpr (G::LGH >= 3 && (G::CIN == 32 || G::LGH == 6)) {
@@ -295,3 +282,10 @@ extern "C" int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall
 }
 
 MMVAE_TRACE_SETTER(conv)
+
+// split_bf16: 1 / 0 sets the GEMM core of the layers both cores cover (conv_common.hpp), < 0 keeps it; returns the old value
+extern "C" int mmvae_conv_plan(int split_bf16) {
+  const int old = g_conv_split_bf16;
+  if (split_bf16 >= 0) g_conv_split_bf16 = split_bf16 ? 1 : 0;
+  return old;
+}

@@ -5,6 +5,12 @@
 #define CONV_CO 32   // MFMA N tile = all 32 output channels of the towers
 #define CONV_CC 8    // input channels staged per LDS chunk (K = 128 per chunk)
 
+// Which GEMM core serves the layers both cores cover: the split-bf16 bodies (conv_*_b16.inc; default) or the fp32-MFMA
+// bodies everywhere (mmvae_conv_plan(0): the tests compare the two on the same inputs in one process).  A runtime switch
+// of the dispatchers; there are no compile-time variants of the product kernels.
+inline int g_conv_split_bf16 = 1;
+static inline bool conv_split_bf16_enabled() { return g_conv_split_bf16 != 0; }
+
 __host__ __device__ __forceinline__ int ilog2i(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -59,9 +65,5 @@ __host__ __device__ __forceinline__ bool conv_ep_supported(int ep) {
 // tiles share two of their ten staged input rows (and the four tiles of an image all of them, one row apart): the remap
 // gives every XCD a CONTIGUOUS eighth of the tiles, so a halo row is an L2 hit instead of a second HBM fetch.
 __device__ __forceinline__ int xcd_contiguous(unsigned p, unsigned n) {
-#ifdef MMVAE_NO_XCD_REMAP
-  return (int)p;
-#else
   return (n & 7u) ? (int)p : (int)((p & 7u) * (n >> 3) + (p >> 3));
-#endif
 }

@@ -985,10 +985,8 @@ extern "C" int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int 
 // Falls back to two launches when either problem wants a different tiling.
 // rows up to which the grouped backward runs on the register-operand bodies (round 4: 256 -> 1024; same box, ms/step of
 // the cfg2 step at batch 512 / 1000: 0.996 -> 0.958, 1.660 -> 1.635; 2048 and 4096 measured level on the K-sample workloads)
-#ifndef MMVAE_RGEMM_BWD_MAX_M
-#define MMVAE_RGEMM_BWD_MAX_M 1024
-#endif
-static inline bool linear_bwd_rgemm(int M, int N) { return rgemm_enabled() && M <= MMVAE_RGEMM_BWD_MAX_M && (N & 3) == 0 && N >= 4; }
+constexpr int RGEMM_BWD_MAX_M = 1024;
+static inline bool linear_bwd_rgemm(int M, int N) { return rgemm_enabled() && M <= RGEMM_BWD_MAX_M && (N & 3) == 0 && N >= 4; }
 extern "C" size_t mmvae_linear_bwd_ws_floats(int M, int N, int K) {
   return linear_bwd_rgemm(M, N) ? 0 : mmvae_linear_bwd_weight_ws_floats(M, N, K);
 }

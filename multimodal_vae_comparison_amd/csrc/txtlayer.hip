@@ -851,7 +851,7 @@ static inline void txt_plan_init() {
   g_txt_plan[0] = m & 1;
   const int never = 1 << 30;
   g_txt_plan[1] = !(m & 2) ? never : getenv("MMVAE_TXT_WAVE_BWD_MIN_N") ? atoi(getenv("MMVAE_TXT_WAVE_BWD_MIN_N")) : 384;
-  g_txt_plan[2] = g_txt_plan[1];
+  g_txt_plan[2] = !(m & 2) ? never : getenv("MMVAE_TXT_WAVE_BWD_MIN_N_DEC") ? atoi(getenv("MMVAE_TXT_WAVE_BWD_MIN_N_DEC")) : g_txt_plan[1];
 }
 extern "C" int mmvae_txt_layer_plan(int fwd_wave, int bwd_min_n, int bwd_min_n_dec) {
   txt_plan_init();

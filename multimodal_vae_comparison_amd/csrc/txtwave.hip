@@ -86,16 +86,8 @@ struct Ctx {
 };
 __device__ const uint32_t tv_zero[64] = {0};          // zeros: weight rows of padding lanes, generator words of a disabled dropout site
 
-#ifndef TV_VARIANT
-#define TV_VARIANT 0      // probe builds: 1 = no MFMA, 2 = no stores of the saved tensors, 4 = no dropout hash / GELU
-#endif
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-#if TV_VARIANT & 1
-  c[0] += a * b;
-  return c;
-#else
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -117,9 +109,6 @@ __device__ __forceinline__ void gelu_parts(float x, float& tail, float& e) {
   tail = 0.5f * (poly * t) * e;
 }
 __device__ __forceinline__ float gelu(float x) {
-#if TV_VARIANT & 4
-  return x * 0.5f;
-#endif
   float tail, e;
   gelu_parts(x, tail, e);
   return x * (x >= 0.f ? 1.0f - tail : tail);
@@ -151,10 +140,6 @@ __device__ __forceinline__ float drop1_nb(const DropKey& k, const uint32_t idx) 
 }
 // multipliers of 4 consecutive elements idx0 .. idx0 + 3
 __device__ __forceinline__ void drop4_even(const DropKey& k, const uint32_t idx0, float (&m)[4]) {   // idx0 even
-#if TV_VARIANT & 4
-  m[0] = m[1] = m[2] = m[3] = k.inv_keep;
-  return;
-#endif
   const uint32_t h0 = drop_pair_hash(k, idx0 >> 1), h1 = drop_pair_hash(k, (idx0 >> 1) + 1);
   m[0] = nb_lo(k, h0);
   m[1] = nb_hi(k, h0);
@@ -240,9 +225,6 @@ __device__ __forceinline__ float half_max(float v) {
 // therefore store too, into a per-lane trash slot: the layer is ONE straight-line region.
 template <int NVALID>
 __device__ __forceinline__ void tl_store(float* __restrict__ p, const f32x16& v, const bool tok_ok, const Ctx& c) {
-#if TV_VARIANT & 2
-  if (p) return;
-#endif
   float* const tr = c.trash;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -1332,10 +1314,14 @@ extern "C" int mmvae_txt_wave_stamps(long long* out) {
 
 // masked stores land here (device memory nobody reads; one 16-byte slot per lane, shared by all waves)
 __device__ float tv_trash_buf[64 * 4];
+// (a __device__ symbol has one address PER DEVICE: cached by device ordinal, never across devices -- ADVICE r4)
 static float* tv_trash_ptr() {
-  static float* p = nullptr;
-  if (!p && hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(tv_trash_buf)) != hipSuccess) p = nullptr;
-  return p;
+  static float* p[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!p[dev] && hipGetSymbolAddress(reinterpret_cast<void**>(&p[dev]), HIP_SYMBOL(tv_trash_buf)) != hipSuccess)
+    p[dev] = nullptr;
+  return p[dev];
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -342,14 +342,19 @@ class MultimodalVAE(nn.Module):
         state += tuple(b for b in self.model.buffers() if b.is_cuda)
         keep = [t.clone() for t in state]
         bad, why = 0.0, None
-        if capture_error is not None:       # this rank has no graph to replay: it only votes
-            bad, why = 1.0, capture_error
-        else:
-            try:
-                self._graph.replay()
-                torch.cuda.synchronize()
-            except RuntimeError as e:
-                bad, why = 1.0, f"replay of the graph with the captured all-reduce failed ({e})"
+        # Vote BEFORE anyone replays: a rank whose capture raised has no graph, and a replay on the other
+        # ranks would put gradient-bucket all-reduces on the communicator against this rank's one-element verdict
+        # reduce (mismatched collectives: a hang or garbage).  So the capture outcome is reduced with MAX first; only
+        # when every rank captured does any rank replay.
+        failed = torch.tensor([0.0 if capture_error is None else 1.0], device=self.flat.data.device)
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if float(failed.item()) != 0.0:
+            return capture_error or "another rank could not capture the all-reduce"
+        try:
+            self._graph.replay()
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            bad, why = 1.0, f"replay of the graph with the captured all-reduce failed ({e})"
         cs = self.flat.data.double().sum().reshape(1)
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -638,6 +643,7 @@ class InputPipe:
         self._mods = (H.InputMod * len(mods))(*mods)
         self._sig = _packed_signature(packed)   # every later batch must have exactly this layout
         self._checked = {}
+        self._checked_max = 16                  # ring sizes in use are 2-4; a dropped entry is simply re-validated
         self._keep = trainer._static_batch      # the raw pointers above point into these tensors
         h = ctypes.c_void_p()
         rc = H.lib().mmvae_input_pipe_create(ctypes.byref(h), self.staging.data_ptr(), self.bytes)
@@ -656,6 +662,8 @@ class InputPipe:
                 raise ValueError("InputPipe: this packed batch has another layout (offsets / shapes / dtypes) than the "
                                  "one the pipe was created for")
             self._checked[ptr] = buf
+            while len(self._checked) > self._checked_max:      # a fresh pinned batch per step must not pin host memory
+                self._checked.pop(next(iter(self._checked)))   # without bound: oldest validated buffer out
         return ptr
 
     def prefetch(self, packed):

@@ -166,7 +166,13 @@ def resnet_block_ranges(model, flat):
     final), + the modules in that order; ([], []) for a model without a ResNet tower.  flat.py keeps the tower's
     convolution weights (25.5 of its 25.56 M parameters) in module order in one region and the BatchNorm vectors in
     another: a block's range is the span of its convolution weights, the 53 K BatchNorm parameters go out with the rest of
-    the buffer at the end of the backward pass."""
+    the buffer at the end of the backward pass.
+
+    `StagedGradReducer.mark_final(i)` reduces the whole span from range i up to what was already sent, so that span must
+    hold nothing but finished blocks: the ranges are only returned when they tile ONE contiguous region --
+    consecutive blocks touch up to the 16-byte group alignment -- which also rules out a model with two ResNet towers
+    (the second tower's stem and the first tower's head layers would sit in the gap, their kernels possibly not even
+    launched when the hook fires).  Anything else gets ([], []): one collective behind the backward pass."""
     from .models.resnet import Bottleneck
     blocks = [m for m in model.modules() if isinstance(m, Bottleneck)]
     base = flat.grad.data_ptr()
@@ -176,6 +182,11 @@ def resnet_block_ranges(model, flat):
         lo = min((p.grad.data_ptr() - base) // 4 for p in ps)
         hi = max((p.grad.data_ptr() - base) // 4 + p.numel() for p in ps)
         out.append((lo, hi))
-    if any(a1 < b0 for (a0, b0), (a1, b1) in zip(out, out[1:])):      # not laid out in module order: one collective
-        return [], []
-    return out[::-1], blocks[::-1]
+    return (out[::-1], blocks[::-1]) if ranges_tile_one_region(out) else ([], [])
+
+
+def ranges_tile_one_region(ranges, align=4):
+    """ascending [(lo, hi)] that touch each other up to `align` elements of padding (flat.py aligns groups to 16 bytes)"""
+    if not ranges:
+        return False
+    return all(b0 <= a1 < b0 + align for (a0, b0), (a1, b1) in zip(ranges, ranges[1:]))

@@ -72,3 +72,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(hipops, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no fallback"):
         hipops.lib()
+
+
+def test_live_knob_list_matches_the_sources():
+    """tools/live_knobs.sh (the A/B scripts refuse knobs outside it) == the MMVAE_* variables the sources really read"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    pkg = os.path.join(root, "multimodal_vae_comparison_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".inc", ".hpp")):
+                continue
+            src = open(os.path.join(dirpath, f), errors="replace").read()
+            read |= set(re.findall(r'getenv\("(MMVAE_[A-Z0-9_]+)"\)', src))
+            read |= set(re.findall(r'environ(?:\.get\(|\[)"(MMVAE_[A-Z0-9_]+)"', src))
+    read |= set(re.findall(r'environ(?:\.get\(|\[)"(MMVAE_[A-Z0-9_]+)"', open(os.path.join(root, "bench.py")).read()))
+    listed = re.search(r'LIVE_KNOBS="([^"]*)"', open(os.path.join(root, "tools", "live_knobs.sh")).read()).group(1).split()
+    assert set(listed) == read, (sorted(set(listed) - read), sorted(read - set(listed)))

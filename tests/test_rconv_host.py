@@ -98,3 +98,29 @@ def test_resnet50_weights_file_is_loaded(tmp_path, monkeypatch):
     monkeypatch.setenv("MMVAE_RESNET50_WEIGHTS", str(bad))
     with pytest.raises(RuntimeError):
         resnet.maybe_load_pretrained(resnet.ResNet50())
+
+
+def test_staged_ranges_only_for_one_contiguous_tower():
+    """parallel.resnet_block_ranges: block ranges are handed to the staged reducer only when they tile ONE
+    contiguous region of the flat buffer; two towers (a gap holding the other tower's layers) get one collective."""
+    import torch.nn as nn
+    from multimodal_vae_comparison_amd import parallel
+    assert parallel.ranges_tile_one_region([(0, 10), (10, 20), (22, 30)])
+    assert not parallel.ranges_tile_one_region([(0, 10), (14, 20)])          # a gap wider than the group alignment
+    assert not parallel.ranges_tile_one_region([(10, 20), (0, 10)])          # not in module order
+    assert not parallel.ranges_tile_one_region([])
+    torch.manual_seed(0)
+    one = nn.Sequential(Bottleneck(64, 16, 1, True), Bottleneck(64, 16, 1, False))
+    flat = FlatParams(one)
+    ranges, mods = parallel.resnet_block_ranges(one, flat)
+    assert len(ranges) == 2 and mods[0] is one[1] and ranges[0][0] >= ranges[1][1]     # last block first
+
+    class Two(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Sequential(Bottleneck(64, 16, 1, True), Bottleneck(64, 16, 1, False))
+            self.mid = nn.Linear(40, 40)          # another tower's head / stem in between
+            self.b = nn.Sequential(Bottleneck(64, 16, 1, True), Bottleneck(64, 16, 1, False))
+    two = Two()
+    flat2 = FlatParams(two)
+    assert parallel.resnet_block_ranges(two, flat2) == ([], [])

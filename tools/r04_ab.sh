@@ -2,6 +2,8 @@
 # same-box A/B of one env knob on the cfg2 step: tools/r04_ab.sh KNOB a b [batch ...]; interleaved pairs, 3 rounds
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 knob=$1; a=$2; b=$3; shift 3
+. tools/live_knobs.sh
+require_live_knob "$knob"
 batches=${@:-128}
 for bs in $batches; do
   for round in 1 2 3; do

@@ -1,6 +1,8 @@
 #!/bin/bash
 # bench.py under every combination of the given env knobs: tools/sweep_env.sh "A=0,1" "B=x,y" ...
 combos=("")
+. "$(dirname "$0")/live_knobs.sh"
+for spec in "$@"; do require_live_knob "${spec%%=*}"; done
 for spec in "$@"; do
   name=${spec%%=*}; vals=${spec#*=}
   next=()
