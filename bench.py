@@ -396,8 +396,36 @@ def _build(name, batch, dev, rank, world, path_world, input_ring=None):
     return tr, desc, meta
 
 
+def _self_launch(a):
+    """`python bench.py --gpus N` as a BARE command (no torchrun around it, WORLD_SIZE unset): start the N ranks ourselves,
+    exactly as the driver would -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>` -- as a CHILD process, launched before this process has made any GPU
+    call (never a re-exec: a process that has initialised the GPU must not be replaced), relay rank 0's one JSON line and
+    the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    for l in r.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(r.returncode if r.returncode or lines else 1)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(a)
     from multimodal_vae_comparison_amd import parallel
     from multimodal_vae_comparison_amd.synthetic import step_flops_per_sample, workload
     # torchrun: the process group comes up before anything touches the GPU
@@ -467,7 +495,10 @@ def main():
                                           "at capture)" if in_graph else
                                           "one all-reduce of the flat gradient buffer per step after the graph, then the "
                                           "fused Adam launch"),
-                                 "bytes": int(tr.flat.grad.numel() * 4)}
+                                 "bytes": int(tr.flat.grad.numel() * 4),
+                                 # ranks of the communicator the all-reduce runs on, as the process group reports it
+                                 "nranks": (torch.distributed.get_world_size() if torch.distributed.is_initialized()
+                                            else 1)}
             stager = getattr(tr, "_stager", None)
             if in_graph and stager is not None:
                 res["collective"]["what"] = (f"{stager.n_collectives} bucketed all-reduces of the flat gradient buffer per step, "

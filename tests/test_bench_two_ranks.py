@@ -57,3 +57,21 @@ def test_bench_rccl_collective_paths_single_rank(hip_lib, in_graph):
     assert res["collective"]["path"] == ("in graph" if in_graph == "1" else "after graph")
     assert res["collective"]["backend"] == "nccl"
     assert res["final_loss"] == res["final_loss"] and res["final_loss"] > 0
+
+
+def test_bench_bare_command_starts_its_own_ranks(hip_lib):
+    """`python bench.py --gpus 2 ...` with NO torchrun around it: bench.py starts the ranks itself as a
+    child `torch.distributed.run` before touching the GPU and relays rank 0's line"""
+    env = {k: None for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e = {k: v for k, v in os.environ.items() if k not in env}
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-3000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["replicas_in_sync"] is True
+    assert res["collective"]["nranks"] == 2 and res["n_collectives"] == 1
+    assert res["collective"]["path"] in ("in graph", "after graph")
