@@ -222,34 +222,6 @@ int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const floa
 size_t mmvae_linear_bwd_ws_floats(int M, int N, int K);
 
 /* ------------------------------------------------------------------------------------------------
- * A chain of batch-row linear layers in ONE launch (round 5; csrc/chain.hip): the image towers' MLPs
- *   Enc_CNN2: lin1 -> [mu | logvar] heads        models/encoders.py:194,218-223,43-54
- *   Dec_CNN : lin1 -> lin2 -> lin3               models/decoders.py:58-60,86-88
- * and the data gradients of the same chains.  Stage s reads the output of stage s-1 (stage 0 reads x, leading dim ldx):
- *   transposed == 0:  y = act_in(in) W^T + bias            W (n_out, n_in)   [F.linear]
- *   transposed != 0:  y = ep( in W , aux )                 W (n_in, n_out)   [dx = (dy W) * act'(saved pre-activation aux)]
- * ep: MMVAE_EP_NONE | MMVAE_EP_MUL_RELU_MASK | MMVAE_EP_MUL_SILU_GRAD with aux (M, n_out).  Every y (M, n_out) is written
- * (the forward pre-activations / the backward's per-layer gradients: the weight gradients are ordinary
- * mmvae_linear_bwd_weight* calls on them).  Persistent column-sliced workgroups with per-row-block hand-over inside the
- * launch; M <= 256 rows, widths multiples of 4 up to 512, 16-byte aligned pointers.
- * sync: mmvae_linear_chain_sync_words() unsigned words, zeroed ONCE by the caller and then owned by this call site (the
- * kernel leaves them zeroed); two launches that may overlap need two blocks.  Word 65 is a sticky timeout flag.
- * ---------------------------------------------------------------------------------------------- */
-#define MMVAE_CHAIN_MAX_STAGES 4
-typedef struct {
-  const float* w;
-  const float* bias; /* forward stages: (n_out) or NULL */
-  const float* aux;  /* backward stages with a MUL_* epilogue: (M, n_out) */
-  float* y;
-  int n_out, n_in, in_act, ep, transposed;
-} mmvae_chain_stage_t;
-int mmvae_linear_chain(const float* x, long ldx, const mmvae_chain_stage_t* stages, int n_stages, int M, unsigned* sync,
-                       mmvae_stream_t stream);
-/* widths: n_stages + 1 values (input width, then every stage's n_out) */
-int mmvae_linear_chain_supported(int M, const int* widths, int n_stages);
-size_t mmvae_linear_chain_sync_words(void);
-
-/* ------------------------------------------------------------------------------------------------
  * Encoder heads: VaeComponent.process_output, models/encoders.py:49-54
  *   h (B, 2D) = [mu | pre-softmax]  ->  lv = softmax(h[:, D:], -1) + 1e-6, written in place.
  * bwd: dh[:, D:] = softmax backward of dlv (in place on dh, which holds [dmu | dlv]).

@@ -96,14 +96,6 @@ class RcJob(ctypes.Structure):       # mmvae_rc_job_t
     _fields_ = [("kind", c_i), ("f", RcFwd), ("d", RcDgrad), ("w", RcWgrad)]
 
 
-CHAIN_MAX_STAGES = 4
-
-
-class ChainStage(ctypes.Structure):  # mmvae_chain_stage_t
-    _fields_ = [("w", c_p), ("bias", c_p), ("aux", c_p), ("y", c_p), ("n_out", c_i), ("n_in", c_i), ("in_act", c_i),
-                ("ep", c_i), ("transposed", c_i)]
-
-
 c_dp = ctypes.POINTER(Dropout)
 DROPOUT_SLOTS = 16
 
@@ -134,9 +126,6 @@ SIGNATURES = {
     "mmvae_linear_bwd_weight_batch": (c_i, [c_p, c_i, c_p]),
     "mmvae_txt_layer_plan": (c_i, [c_i] * 3),
     "mmvae_conv_plan": (c_i, [c_i]),
-    "mmvae_linear_chain": (c_i, [c_p, c_l, ctypes.POINTER(ChainStage), c_i, c_i, c_p, c_p]),
-    "mmvae_linear_chain_supported": (c_i, [c_i, ctypes.POINTER(c_i), c_i]),
-    "mmvae_linear_chain_sync_words": (c_sz, []),
     "mmvae_txt_wgrad": (c_i, [c_p, c_i, c_p]),
     "mmvae_txt_wgrad_splits": (c_i, [c_i] * 3),
     "mmvae_txt_wgrad_ws_floats": (c_sz, [c_i] * 3),

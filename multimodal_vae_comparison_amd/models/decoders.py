@@ -60,11 +60,7 @@ class Dec_CNN(VaeDecoder):
         if z.dim() == 2:
             z = z.unsqueeze(0)
         K, bs = z.shape[0], z.shape[1]
-        # lin1 -> lin2 -> lin3 as ONE launch (ops.linear_chain: <= 256 rows; else one launch per layer)
-        u = ops.linear_chain(z.reshape(K * bs, -1),
-                             [(l.weight, l.bias, l.in_act, l.weight.grad, l.bias.grad)
-                              for l in (self.lin1.module, self.lin2.module, self.lin3.module)], id(self),
-                             taps=(self.lin1, self.lin2, self.lin3))
+        u = self.lin3(self.lin2(self.lin1(z.reshape(K * bs, -1))))
         u = u.view(bs * K, *self.reshape)
         # (K*B,3,64,64) clamped sigmoid.  `raw` holds the same values, but its gradient is the LOGITS' gradient; `d` goes
         # through SigmoidClampOut.  A bce loss takes the fused closed-form path via `out._bce_src` (objectives.py).

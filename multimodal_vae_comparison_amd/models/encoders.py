@@ -134,15 +134,7 @@ class Enc_CNN2(VaeEncoder):
             x = x["data"]
         bs = x.size(0)
         u = self.conv4(self.conv3(self.conv2(self.conv1(x.float()))))
-        uf = u.view(bs, -1)
-        packed = self.packed_heads() if (self.enc_mu_logvar and uf.requires_grad) else None
-        if packed is not None:      # lin1 -> [mu | logvar] heads as ONE launch (ops.linear_chain: <= 256 rows)
-            l1 = self.lin1
-            h = ops.linear_chain(uf, [(l1.weight, l1.bias, l1.in_act, l1.weight.grad, l1.bias.grad),
-                                      (packed[0], packed[1], H.ACT_NONE, packed[2], packed[3])], id(self),
-                                 taps=(l1, None))
-            return self.finish_heads(h)
-        o5 = self.lin1(uf)
+        o5 = self.lin1(u.view(bs, -1))
         return self.process_output(o5)
 
 

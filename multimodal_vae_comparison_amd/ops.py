@@ -770,170 +770,6 @@ def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None, out_ep=H.EP_NONE):
     return Linear.apply(x, w, b, in_act, gw, gb, out_ep)
 
 
-# ---- a chain of batch-row linears in ONE launch (csrc/chain.hip) ---------------------------------------------------------
-LINEAR_CHAIN = True        # module switch (tests run both forms): False = one launch per layer, as before round 5
-CHAIN_TAP = None           # tests: callable(module, pre-activation) for every layer of a chain that names its module
-_CHAIN_SYNC = {}           # device -> (zeroed int32 pool, {(site, stream): slot}, words per block)
-
-
-def _chain_sync(dev, site):
-    """the hand-over counter block of one call site on the current stream (mmvae_linear_chain leaves it zeroed).  The pool
-    is allocated by the first call -- a warm-up pass --, so a site first seen during graph capture costs no allocation"""
-    pool = _CHAIN_SYNC.get(dev.index)
-    if pool is None:
-        words = int(H.lib().mmvae_linear_chain_sync_words())
-        pool = _CHAIN_SYNC[dev.index] = (torch.zeros(128 * words, dtype=torch.int32, device=dev), {}, words)
-    buf, slots, words = pool
-    slot = slots.setdefault((site, H.stream()), len(slots))
-    if slot >= 128:
-        return None
-    return buf.data_ptr() + 4 * words * slot
-
-
-def chain_timeouts(dev):
-    """number of counter blocks whose sticky timeout word is set (a hand-over inside a chain launch gave up: tests)"""
-    pool = _CHAIN_SYNC.get(dev.index)
-    if pool is None:
-        return 0
-    buf, _, words = pool
-    return int((buf.view(-1, words)[:, 65] != 0).sum())
-
-
-def _linear_wgrad_batch(jobs):
-    """[(dy2, x2, w, b, gw, gb, x_act)] -> the weight halves of several Linear.backward in one launch
-    (mmvae_linear_bwd_weight_batch: every job keeps the tiling / partial layout of mmvae_linear_bwd_weight); returns
-    [(ret_w, ret_b)] as _linear_wgrad would"""
-    lib = H.lib()
-    if len(jobs) < 2 or len(jobs) > H.WGRAD_BATCH_MAX:
-        return [_linear_wgrad(*j) for j in jobs]
-    arr = (H.WgradJob * len(jobs))()
-    out, segs, keep = [], [], []
-    for i, (dy2, x2, w, b, gw, gb, x_act) in enumerate(jobs):
-        M, N = dy2.shape
-        K = x2.shape[1]
-        dw, acc_w, ret_w = _new_like_param(w, gw)
-        db, ret_b = None, None
-        if b is not None:
-            if gb is not None:
-                db = gb
-            else:
-                db = ret_b = torch.empty(N, device=dy2.device)
-        nws = lib.mmvae_linear_bwd_weight_ws_floats(M, N, K)
-        nz = lib.mmvae_linear_bwd_weight_splits(M, N, K)
-        defer = _defer(gw, gb if b is not None else gw)
-        if defer:
-            ws = GradReducer.alloc(nws, dy2.device) if nz > 1 else None
-            acc = H.ACC_DEFER
-        else:
-            ws, acc = H.workspace(nws, dy2.device) if i == 0 else torch.empty(max(nws, 1), device=dy2.device), acc_w
-        j = arr[i]
-        j.dy, j.x, j.dw, j.db, j.ws = H.ptr(dy2), H.ptr(x2), H.ptr(dw), H.ptr(db), H.ptr(ws)
-        j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, x_act, acc
-        keep.append((dw, db, ws))
-        if defer and nz > 1:
-            segs.append((ws, nz, dw, db, N, K))
-        out.append((ret_w, ret_b))
-    _call("mmvae_linear_bwd_weight_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
-    for ws, nz, dw, db, N, K in segs:
-        GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
-        if db is not None:
-            GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
-    return out
-
-
-class LinearChain(Function):
-    """y = L_n(... L_1(x)), L_i(v) = act_i(v) W_i^T + b_i: the image towers' MLPs (Enc_CNN2.lin1 -> heads,
-    models/encoders.py:194,218-223; Dec_CNN.lin1 -> lin2 -> lin3, models/decoders.py:58-60,86-88) as ONE launch forward,
-    ONE launch for the whole chain's data gradients and one for its weight gradients."""
-
-    @staticmethod
-    def forward(ctx, x, acts, site, taps, *tensors):
-        """tensors: (w_i, b_i, gw_i, gb_i) per layer"""
-        n = len(acts)
-        ws, bs = [tensors[4 * i] for i in range(n)], [tensors[4 * i + 1] for i in range(n)]
-        K0 = x.shape[-1]
-        x2 = H.f32c(x).reshape(-1, K0)
-        M = x2.shape[0]
-        dev = x2.device
-        ys = [torch.empty(M, w.shape[0], device=dev, dtype=torch.float32) for w in ws]
-        st = (H.ChainStage * n)()
-        for i in range(n):
-            s = st[i]
-            s.w, s.bias, s.aux, s.y = H.ptr(ws[i]), H.ptr(bs[i]), None, H.ptr(ys[i])
-            s.n_out, s.n_in, s.in_act, s.ep, s.transposed = ws[i].shape[0], ws[i].shape[1], acts[i], H.EP_NONE, 0
-        _call("mmvae_linear_chain", H.ptr(x2), K0, st, n, M, _chain_sync(dev, (site, 0)), H.stream())
-        if CHAIN_TAP is not None and taps is not None:
-            for m, y in zip(taps, ys):
-                if m is not None:
-                    CHAIN_TAP(m, y)
-        ctx.save_for_backward(x2, *ws, *ys[:-1])
-        ctx.cfg = (acts, site, [(tensors[4 * i + 2], tensors[4 * i + 3], bs[i] is not None) for i in range(n)], x.shape)
-        return ys[-1].view(*x.shape[:-1], ws[-1].shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        acts, site, grads, xshape = ctx.cfg
-        n = len(acts)
-        saved = ctx.saved_tensors
-        x2, ws, ins = saved[0], saved[1:1 + n], [saved[0]] + list(saved[1 + n:])      # ins[i]: input of layer i
-        M = x2.shape[0]
-        dev = x2.device
-        g = H.f32c(dy).reshape(M, -1)
-        if g.data_ptr() % 16:
-            g = g.clone()
-        need_dx = ctx.needs_input_grad[0]
-        first = 0 if need_dx else 1
-        gs = [None] * n            # gs[i]: gradient of layer i's output
-        gs[n - 1] = g
-        dx = None
-        if n - first > 0:
-            st = (H.ChainStage * (n - first))()
-            for k, i in enumerate(range(n - 1, first - 1, -1)):       # layer i: gradient of its input
-                out = torch.empty(M, ws[i].shape[1], device=dev, dtype=torch.float32)
-                if i > 0:
-                    gs[i - 1] = out
-                else:
-                    dx = out
-                s = st[k]
-                ep = _DACT[acts[i]]
-                s.w, s.bias, s.aux, s.y = H.ptr(ws[i]), None, (H.ptr(ins[i]) if ep else None), H.ptr(out)
-                s.n_out, s.n_in, s.in_act, s.ep, s.transposed = ws[i].shape[1], ws[i].shape[0], H.ACT_NONE, ep, 1
-            _call("mmvae_linear_chain", H.ptr(g), g.shape[1], st, n - first, M, _chain_sync(dev, (site, 1)), H.stream())
-        jobs = []
-        for i in range(n):
-            gw, gb, has_b = grads[i]
-            jobs.append((gs[i], ins[i], ws[i], (ws[i] if has_b else None), gw, gb, acts[i]))
-        rets = _linear_wgrad_batch(jobs)
-        flat = []
-        for (ret_w, ret_b) in rets:
-            flat += [ret_w, ret_b, None, None]
-        return (dx.view(xshape) if dx is not None else None, None, None, None, *flat)
-
-
-def linear_chain_supported(M, widths):
-    if not LINEAR_CHAIN:
-        return False
-    arr = (ctypes.c_int * len(widths))(*widths)
-    return bool(H.lib().mmvae_linear_chain_supported(M, arr, len(widths) - 1))
-
-
-def linear_chain(x, layers, site, taps=None):
-    """layers: [(w, b, in_act, gw, gb)]; -> the last layer's output.  taps: the module behind each layer (or None), for CHAIN_TAP.  One launch when the shapes allow (<= 256 rows, widths
-    multiples of 4 up to 512), else one ops.linear per layer."""
-    K0 = x.shape[-1]
-    M = x.numel() // K0
-    widths = [K0] + [w.shape[0] for (w, _, _, _, _) in layers]
-    if (x.is_cuda and len(layers) <= H.CHAIN_MAX_STAGES and all(b is not None for (_, b, _, _, _) in layers)
-            and linear_chain_supported(M, widths)):
-        flat = []
-        for (w, b, _, gw, gb) in layers:
-            flat += [w, b, gw, gb]
-        return LinearChain.apply(x, tuple(a for (_, _, a, _, _) in layers), site, taps, *flat)
-    for (w, b, act, gw, gb) in layers:
-        x = linear(x, w, b, act, gw, gb)
-    return x
-
-
 class SigmoidOut(Function):
     """Identity on the forward values of a layer whose kernel already applied sigmoid(.) in its epilogue (and whose
     backward takes the LOGITS' gradient); in backward it turns the gradient of that output into the gradient of the

@@ -221,91 +221,6 @@ def test_linear_fwd_bwd(ops, M, K, N, act):
     check(xg.grad, xr.grad, 5e-5, "dx")
 
 
-# ---------------------------------------------------------------------------------------------
-# a chain of linears in one launch (csrc/chain.hip): persistent workgroups, per-row-block hand-over inside the launch
-CHAIN_CASES = [(128, [32, 512, 512, 512], [0, 2, 2]),      # Dec_CNN lin1 -> lin2 -> lin3 at the headline batch
-               (128, [512, 512, 64], [1, 0]),              # Enc_CNN2 lin1 -> [mu | logvar] heads
-               (7, [8, 512, 512, 512], [0, 2, 2]), (200, [512, 512, 84], [1, 0]), (256, [24, 512, 512, 512], [0, 2, 2]),
-               (33, [16, 512, 512, 512], [0, 2, 2]), (96, [512, 512, 32], [1, 0]), (1, [4, 40, 512], [0, 1]),
-               (130, [36, 100, 260, 12], [2, 1, 2]), (128, [64, 512, 512, 512, 128], [0, 2, 1, 2])]
-
-
-def _chain_problem(M, widths, acts, seed=0):
-    g = torch.Generator().manual_seed(M * 7 + sum(widths) + seed)
-    x = torch.randn(M, widths[0], generator=g)
-    layers = [(torch.randn(widths[i + 1], widths[i], generator=g) / math.sqrt(widths[i]),
-               torch.randn(widths[i + 1], generator=g) * 0.1) for i in range(len(acts))]
-    dy = torch.randn(M, widths[-1], generator=g)
-    return x, layers, dy
-
-
-def _chain_run(ops, x, layers, acts, dy, fused):
-    old = ops.LINEAR_CHAIN
-    ops.LINEAR_CHAIN = fused
-    try:
-        xg = x.to(DEV).requires_grad_(True)
-        ps = [(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in layers]
-        y = ops.linear_chain(xg, [(w, b, a, None, None) for (w, b), a in zip(ps, acts)], ("test", len(acts)))
-        y.backward(dy.to(DEV))
-        torch.cuda.synchronize()
-    finally:
-        ops.LINEAR_CHAIN = old
-    return [y.detach(), xg.grad] + [t.grad for p in ps for t in p]
-
-
-@pytest.mark.parametrize("M,widths,acts", CHAIN_CASES)
-def test_linear_chain_matches_float64_and_the_separate_launches(ops, M, widths, acts):
-    x, layers, dy = _chain_problem(M, widths, acts)
-    xr = x.double().requires_grad_(True)
-    pr = [(w.double().requires_grad_(True), b.double().requires_grad_(True)) for w, b in layers]
-    h = xr
-    for (w, b), a in zip(pr, acts):
-        h = F.linear(_act(h, a), w, b)
-    h.backward(dy.double())
-    ref = [h.detach(), xr.grad] + [t.grad for p in pr for t in p]
-    assert ops.linear_chain_supported(M, widths)
-    got = _chain_run(ops, x, layers, acts, dy, True)
-    sep = _chain_run(ops, x, layers, acts, dy, False)
-    names = ["y", "dx"] + [f"{k}{i}" for i in range(len(acts)) for k in ("dw", "db")]
-    for n, a, b, r in zip(names, got, sep, ref):
-        check(a, r, 2e-5 if n == "y" else 5e-5, f"chain {n} vs fp64")
-        check(a, b, 2e-5, f"chain {n} vs one launch per layer")
-    assert ops.chain_timeouts(torch.device(DEV, torch.cuda.current_device())) == 0
-
-
-def test_linear_chain_hand_over_under_uneven_load(ops):
-    """The hand-over inside the launch (sc1 stores -> drained -> row-block counter -> sc1 loads) under what hides a broken one
-    on an idle chip: a stream of back-to-back launches with fresh inputs (consumer L1 warm with the previous launch's rows
-    at the same addresses), a bandwidth-heavy kernel running beside them on another stream, every word of every output
-    compared with the one-launch-per-layer result; and the counter block must come back zeroed."""
-    M, widths, acts = 128, [32, 512, 512, 512], [0, 2, 2]
-    dev = torch.device(DEV, torch.cuda.current_device())
-    _, layers, _ = _chain_problem(M, widths, acts)
-    ps = [(w.to(DEV), b.to(DEV)) for w, b in layers]
-    lay = [(w, b, a, None, None) for (w, b), a in zip(ps, acts)]
-    g = torch.Generator().manual_seed(5)
-    xs = [torch.randn(M, widths[0], generator=g).to(DEV) for _ in range(40)]
-    old = ops.LINEAR_CHAIN
-    ops.LINEAR_CHAIN = False
-    want = [ops.linear_chain(x, lay, "uneven") for x in xs]
-    ops.LINEAR_CHAIN = old
-    big = torch.randn(64 << 20, device=DEV)
-    side = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    with torch.no_grad():
-        for rep in range(5):
-            with torch.cuda.stream(side):
-                for _ in range(6):
-                    big.mul_(1.0001)
-            got = [ops.linear_chain(x, lay, "uneven") for x in xs]
-            torch.cuda.synchronize()
-            for i, (a, b) in enumerate(zip(got, want)):
-                assert torch.equal(a, b) or rel_err(a, b) < 1e-6, (rep, i, rel_err(a, b))
-    assert ops.chain_timeouts(dev) == 0
-    buf, _, words = ops._CHAIN_SYNC[dev.index]
-    assert int(buf.abs().sum()) == 0, "the hand-over counters must be left zeroed"
-
-
 @pytest.mark.parametrize("M,K,N,act", [(1, 4, 1, 0), (17, 20, 33, 1), (128, 1024, 64, 0), (256, 36, 512, 2), (130, 516, 100, 1),
                                        (64, 54, 54, 0), (3, 1028, 5, 0), (200, 8, 8, 3), (16, 512, 2048, 1)])
 def test_linear_small_batch_paths(ops, M, K, N, act):
