@@ -147,6 +147,17 @@ int mmvae_conv2d_k4s2_bwd(const float* dy, const float* x, const float* w, float
                           int B, int Cin, int Cout, int Hout, int x_act, int accumulate, mmvae_stream_t stream);
 int mmvae_convT2d_k4s2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
                            int B, int Cin, int Cout, int Hin, int x_act, int accumulate, mmvae_stream_t stream);
+/* Dec_CNN's last layer and its reconstruction loss in ONE launch (round 5; csrc/conv_t3.inc):
+ *   logits = convT2d(act(x), w, bias)  x (B,32,32,32) -> (B,3,64,64)       models/decoders.py:69,95
+ *   x_hat  = clamp(sigmoid(logits), 1e-6, 1 - 1e-6)                         models/decoders.py:96-97   (never stored)
+ *   row[b] = sum bce(x_hat[b], target[b])   (logs clamped at -100)          models/objectives.py:392-406
+ *   dlogit = seed * (x_hat - target) where the clamp is inactive, else 0    (the term's ELBO weight is known: ops.ConstSeed)
+ * part: (B, mmvae_convT3_bce_strips(B)) floats and ticket: (B) unsigned, zeroed once by the caller (the kernel leaves the
+ * tickets zero), when an image is split over several workgroups (strips > 1); both may be NULL when strips == 1. */
+int mmvae_convT3_bce_seeded(const float* x, const float* w, const float* bias, const float* target, float* row,
+                            float* dlogit, float* part, unsigned* ticket, int B, int in_act, float seed,
+                            mmvae_stream_t stream);
+int mmvae_convT3_bce_strips(int B);
 /* The 32-channel layers on 16x16 / 32x32 maps and the 3-channel image layers run on one of two GEMM cores from a
  * tile-count threshold on: "split-bf16" (every fp32 operand split EXACTLY into three bf16 terms, six bf16 MFMAs per
  * product, fp32 accumulate; dropped terms <= 3 * 2^-24 |a b|, i.e. fp32-equivalent: tests/test_hip_ops.py holds it to

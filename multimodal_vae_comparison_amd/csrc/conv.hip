@@ -257,6 +257,17 @@ extern "C" int mmvae_convT2d_k4s2_fwd(const float* x, const float* w, const floa
   MMVAE_CHECK_ARG(x && w && y && B > 0);
   return conv_scatter_dispatch(x, w, bias, aux, y, B, Cin, Cout, Hin, in_act, ep_mode, (hipStream_t)stream);
 }
+extern "C" int mmvae_convT3_bce_seeded(const float* x, const float* w, const float* bias, const float* target, float* row,
+                                       float* dlogit, float* part, unsigned* ticket, int B, int in_act, float seed,
+                                       mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && w && target && row && dlogit && B > 0);
+  MMVAE_CHECK_ARG(in_act == MMVAE_ACT_NONE || in_act == MMVAE_ACT_RELU || in_act == MMVAE_ACT_SILU);
+  MMVAE_CHECK_ARG(convT3_strips(B) == 1 || (part && ticket));
+  MMVAE_CHECK_ARG((((uintptr_t)target | (uintptr_t)dlogit) & 15) == 0);
+  ConvT3Args t{x, w, bias, dlogit, target, row, part, ticket, B, in_act, MMVAE_EP_SIGMOID_CLAMP, seed};
+  convT3_launch<true>(t, (hipStream_t)stream);
+  return mmvae_launch_status();
+}
 extern "C" int mmvae_convT2d_k4s2_dgrad(const float* dy, const float* w, const float* aux, float* dx, int B, int Cin,
                                         int Cout, int Hin, int ep_mode, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(dy && w && dx && B > 0);

@@ -126,6 +126,8 @@ SIGNATURES = {
     "mmvae_linear_bwd_weight_batch": (c_i, [c_p, c_i, c_p]),
     "mmvae_txt_layer_plan": (c_i, [c_i] * 3),
     "mmvae_conv_plan": (c_i, [c_i]),
+    "mmvae_convT3_bce_seeded": (c_i, [c_p] * 8 + [c_i, c_i, c_f, c_p]),
+    "mmvae_convT3_bce_strips": (c_i, [c_i]),
     "mmvae_txt_wgrad": (c_i, [c_p, c_i, c_p]),
     "mmvae_txt_wgrad_splits": (c_i, [c_i] * 3),
     "mmvae_txt_wgrad_ws_floats": (c_sz, [c_i] * 3),

@@ -56,6 +56,7 @@ class Dec_CNN(VaeDecoder):
         self.register_buffer("_scale", torch.tensor(0.75), persistent=False)   # the decoders' fixed likelihood scale
 
     def forward(self, z):
+        z_in = z
         z = z["latents"]
         if z.dim() == 2:
             z = z.unsqueeze(0)
@@ -64,7 +65,17 @@ class Dec_CNN(VaeDecoder):
         u = u.view(bs * K, *self.reshape)
         # (K*B,3,64,64) clamped sigmoid.  `raw` holds the same values, but its gradient is the LOGITS' gradient; `d` goes
         # through SigmoidClampOut.  A bce loss takes the fused closed-form path via `out._bce_src` (objectives.py).
-        raw = self.convT3.module(self.convT2(self.convT1(self.convT_64(u))), ep_bwd=False)
+        u3 = self.convT2(self.convT1(self.convT_64(u)))
+        tgt = z_in.get("bce_target") if isinstance(z_in, dict) else None
+        last = self.convT3.module
+        if tgt is not None and ops.convT3_bce_supported(u3, last.weight, tgt):
+            # training objective with a bce likelihood (the mixer hands the target over and has announced the term's ELBO
+            # weight, ops.ConstSeed): last layer + sigmoid + clamp + reconstruction row sums in ONE launch, x_hat is never
+            # stored.  The "output" is the (K*B,) row sums, marked for recon_rowsum (objectives.py)
+            rows = ops.convT3_bce(u3, last.weight, last.bias, last.in_act, last.weight.grad, last.bias.grad, tgt)
+            rows._bce_rows = True
+            return rows, self._scale
+        raw = last(u3, ep_bwd=False)
         d = ops.sigmoid_clamp_out(raw)
         d = d.view(*z.size()[:-1], *self.data_dim)                          # decoders.py:96 (view, no permute)
         out = d.squeeze().reshape(-1, *self.data_dim)

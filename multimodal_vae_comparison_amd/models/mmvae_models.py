@@ -135,11 +135,15 @@ class MoPOE(TorchMMVAE):
             _uses(z[i], st)
             with torch.cuda.stream(st):
                 zi = ops.mark_tensor(z[i], f"dec {n} z")
-                out, _ = vae.dec({"latents": zi.unsqueeze(0), "masks": mods[n]["masks"]})
                 if seeds is not None:      # the term's upstream gradient is known: its kernel also writes its backward
                     with ops.ConstSeed(seeds[i], W[0][i]):
+                        # (a bce decoder is handed its target: Dec_CNN then folds the loss into its last layer's launch)
+                        fuse = vae.ltype == "bce" and mods[n]["masks"] is None
+                        out, _ = vae.dec({"latents": zi.unsqueeze(0), "masks": mods[n]["masks"],
+                                          "bce_target": mods[n]["data"] if fuse else None})
                         r = recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
                 else:
+                    out, _ = vae.dec({"latents": zi.unsqueeze(0), "masks": mods[n]["masks"]})
                     r = recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
                 recs[i] = ops.mark_tensor(r, f"dec {n} recon")   # (B,) = -lpx_z / llik_scaling
             _uses(recs[i], cur)

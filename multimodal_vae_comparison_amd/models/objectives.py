@@ -76,6 +76,8 @@ PX_SCALE = 0.75     # the decoders return (recon, 0.75): px_z = Normal / Laplace
 def recon_rowsum(ltype, out, target, laplace=False):
     """`out`: decoder output tensor; `target`: {"data", "masks"} (BaseObjective.recon_loss_fn, objectives.py:30-52:
     slice to the mask length -- and then the likelihood's scale := its loc --, reshape target like the output)."""
+    if getattr(out, "_bce_rows", False):      # Dec_CNN already produced the bce row sums with its last layer (ops.convT3_bce)
+        return out
     masked = target["masks"] is not None
     if masked:
         out = out[:, : target["masks"].shape[1]]

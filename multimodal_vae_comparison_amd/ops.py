@@ -461,28 +461,91 @@ class ConvT2dK4S2(Function):
             dl = torch.empty_like(dy)
             _call("mmvae_sigmoid_bwd", H.ptr(dy), H.ptr(y), H.ptr(dl), dy.numel(), H.stream())
             dy = dl
-        dw, acc_w, ret_w = _new_like_param(w, gw)
-        db, ret_b = None, None
-        if has_b:
-            if gb is not None:
-                db = gb
-            else:
-                db = ret_b = torch.empty(Cout, device=x.device)
-        nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin)
-        defer = _defer(gw, gb if has_b else gw)
-        ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
-        acc = H.ACC_DEFER if defer else acc_w
-        dx = None
-        if ctx.needs_input_grad[0]:       # input- and weight-gradient workgroups in ONE launch
-            dx = torch.empty_like(x)
-            _call("mmvae_convT2d_k4s2_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
-                  B, Cin, Cout, Hin, in_act, acc, H.stream())
-        else:
-            _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hin,
-                  in_act, acc, H.stream())
-        if defer:
-            _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
+        dx, ret_w, ret_b = _convT_k4s2_bwd(x, w, dy, in_act, gw, gb, has_b, ctx.needs_input_grad[0])
         return dx, ret_w, ret_b, None, None, None, None, None
+
+
+def _convT_k4s2_bwd(x, w, dy, in_act, gw, gb, has_b, need_dx):
+    """dx, dw, db of y = convT2d(act(x), w, b) for dy = d loss / d y (ConvT2dK4S2.backward, ConvT3Bce.backward)"""
+    B, Cin, Hin, _ = x.shape
+    Cout = w.shape[1]
+    dw, acc_w, ret_w = _new_like_param(w, gw)
+    db, ret_b = None, None
+    if has_b:
+        if gb is not None:
+            db = gb
+        else:
+            db = ret_b = torch.empty(Cout, device=x.device)
+    nws = H.lib().mmvae_conv_wgrad_ws_floats(B, Cin, Cout, Hin)
+    defer = _defer(gw, gb if has_b else gw)
+    ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
+    acc = H.ACC_DEFER if defer else acc_w
+    dx = None
+    if need_dx:       # input- and weight-gradient workgroups in ONE launch
+        dx = torch.empty_like(x)
+        _call("mmvae_convT2d_k4s2_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
+              B, Cin, Cout, Hin, in_act, acc, H.stream())
+    else:
+        _call("mmvae_convT2d_k4s2_wgrad", H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(db), H.ptr(ws), B, Cin, Cout, Hin,
+              in_act, acc, H.stream())
+    if defer:
+        _conv_segments(ws, dw, db, B, Cin, Cout, Hin, Cout)
+    return dx, ret_w, ret_b
+
+
+_T3_SCRATCH = {}      # (device, stream, B) -> (partial sums (B, strips), tickets (B)) of ConvT3Bce
+
+
+class ConvT3Bce(Function):
+    """Dec_CNN's last layer AND its reconstruction term in one launch (csrc/conv_t3.inc):
+    row[b] = sum bce(clamp(sigmoid(convT2d(act(x), w, b)))[b], target[b])   [models/decoders.py:69,95-97 +
+    ReconLoss.bce, models/objectives.py:392-406].  Only under ops.ConstSeed (the term's ELBO weight is known): the same
+    pass writes d loss / d logits, x_hat itself is never stored.  Backward = the layer's ordinary backward on that."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, in_act, gw, gb, target, cs):
+        x, target = H.f32c(x), H.f32c(target)
+        B = x.shape[0]
+        dev = x.device
+        row = torch.empty(B, device=dev)
+        dl = torch.empty(B, 3, 64, 64, device=dev)
+        S = H.lib().mmvae_convT3_bce_strips(B)
+        part = tick = None
+        if S > 1:
+            key = (dev.index, H.stream(), B)
+            ent = _T3_SCRATCH.get(key)
+            if ent is None:      # (first call = a warm-up pass: no allocation / memset node under graph capture)
+                ent = _T3_SCRATCH[key] = (torch.zeros(B * S, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
+            part, tick = ent
+        _call("mmvae_convT3_bce_seeded", H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(target), H.ptr(row), H.ptr(dl), H.ptr(part),
+              H.ptr(tick), B, in_act, cs.value, H.stream())
+        ctx.save_for_backward(x, w, dl)
+        ctx.cfg = (in_act, gw, gb, b is not None, cs.seed.data_ptr(), cs.value)
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, dl = ctx.saved_tensors
+        in_act, gw, gb, has_b, seed_ptr, seed_value = ctx.cfg
+        if g.data_ptr() != seed_ptr:      # not the announced upstream gradient: rescale the stored logit gradient per row
+            dl = dl * (H.f32c(g) / seed_value).view(-1, 1, 1, 1)
+        dx, ret_w, ret_b = _convT_k4s2_bwd(x, w, dl, in_act, gw, gb, has_b, ctx.needs_input_grad[0])
+        return dx, ret_w, ret_b, None, None, None, None, None
+
+
+CONVT3_BCE = True      # module switch (tests / A-B runs): False = last layer and bce loss as two launches
+
+
+def convT3_bce_supported(x, w, target):
+    # from 256 images on (<= 2 strips per image): same box, cfg2 step, fused vs two launches -- batch 128: 0.3866 vs 0.3852 ms
+    # (four strips per image, the ticketed row sum and the loss arithmetic on 512 short workgroups buy nothing), batch 1000:
+    # 1.5025 vs 1.5372 (profiles/r05_convT3_ab.txt)
+    return (CONVT3_BCE and x.shape[0] >= 256 and ConstSeed.current is not None and x.is_cuda and x.dim() == 4 and tuple(x.shape[1:]) == (32, 32, 32) and
+            tuple(w.shape) == (32, 3, 4, 4) and target.numel() == x.shape[0] * 3 * 64 * 64 and x.requires_grad)
+
+
+def convT3_bce(x, w, b, in_act, gw, gb, target):
+    return ConvT3Bce.apply(x, w, b, in_act, gw, gb, target, ConstSeed.current)
 
 
 class SigmoidClampOut(Function):

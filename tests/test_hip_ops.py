@@ -92,6 +92,39 @@ def test_convT2d_fwd_bwd(ops, B, Cout, Hin, act, ep):
     check(xg.grad, xr.grad, 5e-5, "dx")
 
 
+@pytest.mark.parametrize("B,act", [(4, 2), (33, 2), (128, 2), (300, 2), (520, 2), (5, 0), (6, 1)])
+def test_convT3_bce_fused_matches_float64(ops, B, act):
+    """Dec_CNN's last layer + clamp(sigmoid) + bce row sums + d loss / d logits in ONE launch (csrc/conv_t3.inc): rows, and
+    the layer's dx / dw / db through the stored logit gradient, against float64 torch -- every strip plan (4 / 2 strips per
+    image with the ticketed row sum, whole images), announced seed and another upstream gradient."""
+    g = torch.Generator().manual_seed(B + 17)
+    x = torch.randn(B, 32, 32, 32, generator=g)
+    w = torch.randn(32, 3, 4, 4, generator=g) * (1.0 / math.sqrt(32 * 4))
+    b = torch.randn(3, generator=g) * 0.1
+    tgt = torch.rand(B, 3, 64, 64, generator=g)
+    tgt[:, :, :8] = (tgt[:, :, :8] > 0.5).float()          # exact 0 / 1 targets too (images are mostly saturated)
+    x[0, :, 3, 5] *= 40.0                                  # logits far out: the clamp is active there
+    seed = 0.37
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    xh = torch.sigmoid(F.conv_transpose2d(_act(xr, act), wr, br, stride=2, padding=1)).clamp(1e-6, 1 - 1e-6)
+    rows_r = F.binary_cross_entropy(xh, tgt.double(), reduction="none").sum((1, 2, 3))
+    for other in (False, True):
+        up = torch.full((B,), seed) if not other else torch.linspace(0.1, 1.0, B)
+        for t in (xr, wr, br):
+            t.grad = None
+        rows_r.backward(up.double(), retain_graph=True)
+        xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        seed_t = torch.full((B,), seed, device=DEV)
+        with ops.ConstSeed(seed_t, seed):
+            assert ops.convT3_bce_supported(xg, wg, tgt.to(DEV)) == (B >= 256)      # (the dispatch rule; the op takes any batch)
+            rows = ops.convT3_bce(xg, wg, bg, act, None, None, tgt.to(DEV))
+        rows.backward(seed_t if not other else up.to(DEV))
+        check(rows, rows_r, 1e-5, "bce rows")
+        check(xg.grad, xr.grad, 5e-5, "dx")
+        check(wg.grad, wr.grad, 5e-5, "dw")
+        check(bg.grad, br.grad, 5e-5, "db")
+
+
 # ---------------------------------------------------------------------------------------------
 # split-bf16 == fp32 (VERDICT r4 "What's weak" #2): every shape the split-bf16 bodies serve, held to the accuracy that only a
 # THREE-term split reaches -- 2e-6 of the tensor maximum against fp64 (measured 2-6e-7; a two-term split sits at ~1e-5) -- and
