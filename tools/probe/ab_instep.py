@@ -21,6 +21,9 @@ def main():
     def barrier():
         torch.cuda.synchronize()
     trs = {}
+    for kv in sys.argv[5:]:      # further switches held fixed: NAME=0|1
+        k, v = kv.split("=")
+        setattr(ops, k, bool(int(v)))
     for on in (False, True):
         setattr(ops, switch, on)
         trs[on], _, meta = bench._build(cfg, B, dev, 0, 1, 1)
