@@ -695,11 +695,13 @@ int mmvae_rand_laplace(float* out, long n, uint32_t* state, mmvae_stream_t strea
  *   onehot (B,T,V) 0/1 floats, emb (V,2) [only rows 0/1 are read], pe (>= max(B,T), 2) = the module's
  *   sin/cos buffer (host-computed once), x (T*B, 2V) = the (nframes,bs,-1) view.
  *   mode 0 (B != T, B != 1): x[t,b,v,e] = emb[oh[b,t,v],e] + pe[b,e]
- *   mode 1 (B == T or B == 1): memory (B,T,2V) with pe[t] (pe[0] if B == 1), relabelled as (T,B,2V). */
+ *   mode 1 (B == T or B == 1): memory (B,T,2V) with pe[t] (pe[0] if B == 1), relabelled as (T,B,2V).
+ *   B0 (round 5): onehot has B0 rows, B = R * B0 output rows, row b reads onehot row and pe row b % B0 (mode 0 only
+ *   when B0 < B): R passes over the same batch as one call (POE's per-subset passes, models/mmvae_models.py:159-187). */
 int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T, int V,
-                       int mode, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+                       int mode, int B0, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V, int mode,
-                       int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+                       int B0, int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 size_t mmvae_embed_ws_floats(int B, int T, int V);
 
 /* ---- One Transformer layer of the text towers per launch (csrc/txtlayer.hip) --------------------------------

@@ -9,17 +9,20 @@
 // Embedding(one-hot.long()) + PositionalEncoding (models/encoders.py:833-835, nn_modules.py:430-438)
 //   mode 0: out[((t*B+b)*V+v)*2+e] = emb[oh[b,t,v]][e] + pe[b][e]
 //   mode 1: out[((b*T+t)*V+v)*2+e] = emb[oh[b,t,v]][e] + pe[B==1 ? 0 : t][e]      (memory relabelled as (T,B,2V))
+// B0 (round 5): the one-hot tensor has B0 <= B rows and output row b reads row b % B0 of it AND of the table: R = B / B0
+// passes of the SAME batch as one call keep every sample's positional term (indexed by its position in the ORIGINAL batch,
+// nn_modules.py:432-438) -- POE's per-subset encoder passes (mmvae_models.py:159-187) without materialising the repeat.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const float* __restrict__ oh, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, float* __restrict__ out, int B,
-                                                           int T, int V, int mode, mmvae_dropout_t drop) {
-  const int n = B * T * V;
+                                                           int T, int V, int mode, int B0, mmvae_dropout_t drop) {
+  const int n = B * T * V, n0 = B0 * T * V;
   const DropKey dk = drop_key(drop);
   const float e00 = emb[0], e01 = emb[1], e10 = emb[2], e11 = emb[3];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int v = i % V, bt = i / V, t = bt % T, b = bt / T;
-    const bool one = oh[i] != 0.f;  // .long() of a 0/1 float
-    const int pos = mode == 0 ? b : (B == 1 ? 0 : t);
+    const bool one = oh[i % n0] != 0.f;  // .long() of a 0/1 float
+    const int pos = mode == 0 ? b % B0 : (B0 == 1 ? 0 : t);
     const size_t o = mode == 0 ? (((size_t)t * B + b) * V + v) * 2 : (size_t)i * 2;
     float2 r;
     r.x = ((one ? e10 : e00) + pe[pos * 2]) * drop_mul(dk, (uint32_t)o);
@@ -31,9 +34,9 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const float* __restri
 // per-block partial of demb rows 0/1: ws[block][4] = {sum dx0 | oh=0, sum dx1 | oh=0, sum dx0 | oh=1, sum dx1 | oh=1}
 __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restrict__ oh, const float* __restrict__ dx,
                                                            float* __restrict__ ws, int B, int T, int V, int mode,
-                                                           mmvae_dropout_t drop) {
+                                                           int B0, mmvae_dropout_t drop) {
   __shared__ float red[4];
-  const int n = B * T * V;
+  const int n = B * T * V, n0 = B0 * T * V;
   const DropKey dk = drop_key(drop);
   float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restri
     float2 g = *reinterpret_cast<const float2*>(dx + o);
     g.x *= drop_mul(dk, (uint32_t)o);
     g.y *= drop_mul(dk, (uint32_t)o + 1u);
-    if (oh[i] != 0.f) { a10 += g.x; a11 += g.y; } else { a00 += g.x; a01 += g.y; }
+    if (oh[i % n0] != 0.f) { a10 += g.x; a11 += g.y; } else { a00 += g.x; a01 += g.y; }
   }
   a00 = block_sum_256(a00, red);
   a01 = block_sum_256(a01, red);
@@ -63,19 +66,20 @@ extern "C" int mmvae_embed_bwd_rows(int B, int T, int V) { return embed_blocks(B
 extern "C" size_t mmvae_embed_ws_floats(int B, int T, int V) { return (size_t)embed_blocks(B, T, V) * 4; }
 
 extern "C" int mmvae_embed_pe_fwd(const float* onehot, const float* emb, const float* pe, float* x, int B, int T,
-                                  int V, int mode, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(onehot && emb && pe && x && B > 0 && T > 0 && V > 1);
+                                  int V, int mode, int B0, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(onehot && emb && pe && x && B > 0 && T > 0 && V > 1 && B0 > 0 && B % B0 == 0);
+  MMVAE_CHECK_ARG(B0 == B || mode == 0);      // repeated passes only in the batch-indexed branch (the other relabels memory)
   hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(embed_blocks(B, T, V)), dim3(256), 0, (hipStream_t)stream, onehot, emb,
-                     pe, x, B, T, V, mode, drop_arg(drop));
+                     pe, x, B, T, V, mode, B0, drop_arg(drop));
   return mmvae_launch_status();
 }
 extern "C" int mmvae_embed_pe_bwd(const float* onehot, const float* dx, float* demb, float* ws, int B, int T, int V,
-                                  int mode, int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(onehot && dx && ws && B > 0 && T > 0 && V > 1);
+                                  int mode, int B0, int accumulate, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(onehot && dx && ws && B > 0 && T > 0 && V > 1 && B0 > 0 && B % B0 == 0 && (B0 == B || mode == 0));
   MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || demb);
   const int nb = embed_blocks(B, T, V);
   hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, onehot, dx, ws, B, T, V, mode,
-                     drop_arg(drop));
+                     B0, drop_arg(drop));
   int rc = mmvae_launch_status();
   if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   if (!accumulate && V > 2) {

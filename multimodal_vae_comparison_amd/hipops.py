@@ -184,8 +184,8 @@ SIGNATURES = {
     "mmvae_add_pe_dropout_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_dp, c_p]),
     "mmvae_lincomb_rowptrs_fwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_p, c_i, c_i, c_i, c_p]),
     "mmvae_lincomb_rowptrs_bwd": (c_i, [c_p, ctypes.POINTER(c_f), c_p, c_i, c_i, c_i, c_p]),
-    "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 4 + [c_dp, c_p]),
-    "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_dp, c_p]),
+    "mmvae_embed_pe_fwd": (c_i, [c_p] * 4 + [c_i] * 5 + [c_dp, c_p]),
+    "mmvae_embed_pe_bwd": (c_i, [c_p] * 4 + [c_i] * 6 + [c_dp, c_p]),
     "mmvae_embed_ws_floats": (c_sz, [c_i] * 3),
     "mmvae_txt_layer_supported": (c_i, [c_i] * 5),
     "mmvae_txt_layer_lnws_floats": (c_sz, [c_i] * 3),

@@ -359,6 +359,15 @@ class Enc_TxtTransformer(VaeEncoder):
         self.logvar_layer = ModuleWrap(HipLinear(d, self.out_dim))
         self.drop_state = DropoutState()
 
+    takes_repeat = True      # forward accepts batch["repeat"] (POE.objective)
+
+    @staticmethod
+    def repeat_ok(batch):
+        """repeated passes can share one call only in the batch-indexed positional branch (B != T, B != 1: the other branch
+        relabels memory and mixes the samples of a pass)"""
+        bs, nframes = batch["data"].shape[0], batch["data"].shape[1]
+        return bs != nframes and bs != 1
+
     def forward(self, batch):
         x, mask = batch["data"], batch["masks"]
         bs, nframes, _ = x.shape
@@ -366,8 +375,13 @@ class Enc_TxtTransformer(VaeEncoder):
             raise RuntimeError("batch larger than the positional table (reference: pe[:B], nn_modules.py:419)")
         if mask is None:
             mask = torch.ones(bs, nframes, dtype=torch.bool, device=x.device)
-        mask_u8 = ops.as_u8(mask)            # validity bytes, read in place by the attention kernel
         mode = 1 if (bs == nframes or bs == 1) else 0
+        # `repeat` = R (POE.objective): R passes over this batch as ONE call of R * bs sequences, row k * bs + b -- every
+        # sample keeps the positional term of its position b in the batch (ops.embed_pe), every pass its own dropout masks
+        rep = int(batch.get("repeat", 1)) if mode == 0 else 1
+        if rep > 1:
+            mask = mask.repeat(rep, 1)
+        mask_u8 = ops.as_u8(mask)            # validity bytes, read in place by the attention kernel
         w = self.embedding.weight
         p = self.dropout
         if self.training and p > 0:       # nn.Dropout sites of the reference: PE + 4 per layer
@@ -379,7 +393,7 @@ class Enc_TxtTransformer(VaeEncoder):
                   for i in range(len(self.seqTransEncoder.layers))]
         else:
             d_pe, ds = None, [None] * len(self.seqTransEncoder.layers)
-        h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad, d_pe)   # (T, B, 2V)
+        h = ops.embed_pe(x, w, self.sequence_pos_encoder.pe.view(-1, 2), mode, w.grad, d_pe, rep)   # (T, R * B, 2V)
         last = len(self.seqTransEncoder.layers) - 1
         heads = self.packed_heads() if (FUSED_HEADS and torch.is_grad_enabled()) else None
         for i, (layer, d) in enumerate(zip(self.seqTransEncoder.layers, ds)):

@@ -305,6 +305,15 @@ class POE(TorchMMVAE):
                     p = packed_head(*enc(mods[n]))
                     for s in member:
                         packed[s][n] = p
+                elif self.batch_dropout_towers and len(member) > 1 and getattr(enc, "takes_repeat", False) and \
+                        enc.repeat_ok(mods[n]):
+                    # an encoder WITH dropout whose passes differ only in their masks: all of them as one call over
+                    # len(member) * B sequences (round 5: the text encoder's positional term follows the sample's position
+                    # in the ORIGINAL batch, ops.embed_pe), rows k * B + b
+                    p = packed_head(*enc(dict(mods[n], repeat=len(member))))
+                    Bn = p.shape[0] // len(member)
+                    for k, s in enumerate(member):
+                        packed[s][n] = p[k * Bn:(k + 1) * Bn]
                 else:
                     for s in member:
                         packed[s][n] = packed_head(*enc(mods[n]))

@@ -1768,39 +1768,42 @@ def lincomb_rows(blocks, W):
 # text tower
 # ----------------------------------------------------------------------------------------------
 class EmbedPE(Function):
-    """Embedding(one-hot.long()) + PositionalEncoding quirk -> (T, B, 2V)  (models/encoders.py:833-835)"""
+    """Embedding(one-hot.long()) + PositionalEncoding quirk -> (T, R * B0, 2V)  (models/encoders.py:833-835); R > 1: R passes
+    over the same (B0, T, V) batch as one call, output row k * B0 + b (the repeat is never materialised)"""
 
     @staticmethod
-    def forward(ctx, onehot, emb, pe, mode, gemb, drop):
+    def forward(ctx, onehot, emb, pe, mode, gemb, drop, repeat=1):
         onehot = H.f32c(onehot)
-        B, T, V = onehot.shape
+        B0, T, V = onehot.shape
+        B = B0 * repeat
         x = torch.empty(T, B, 2 * V, device=onehot.device)
-        _call("mmvae_embed_pe_fwd", H.ptr(onehot), H.ptr(emb), H.ptr(pe), H.ptr(x), B, T, V, mode, _dp(drop, x.numel()),
+        _call("mmvae_embed_pe_fwd", H.ptr(onehot), H.ptr(emb), H.ptr(pe), H.ptr(x), B, T, V, mode, B0, _dp(drop, x.numel()),
               H.stream())
         ctx.save_for_backward(onehot, emb)
-        ctx.cfg = (mode, gemb, drop)
+        ctx.cfg = (mode, gemb, drop, repeat)
         return x
 
     @staticmethod
     def backward(ctx, dx):
         onehot, emb = ctx.saved_tensors
-        mode, gemb, drop = ctx.cfg
+        mode, gemb, drop, repeat = ctx.cfg
         dpc = drop.c() if drop is not None else None
-        B, T, V = onehot.shape
+        B0, T, V = onehot.shape
+        B = B0 * repeat
         dx = H.f32c(dx)
         de, acc, ret = _new_like_param(emb, gemb)
         nws = H.lib().mmvae_embed_ws_floats(B, T, V)
         if _defer(gemb):
             ws = GradReducer.alloc(nws, dx.device)
-            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), None, H.ptr(ws), B, T, V, mode, H.ACC_DEFER, dpc,
+            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), None, H.ptr(ws), B, T, V, mode, B0, H.ACC_DEFER, dpc,
                   H.stream())
             GradReducer.add(ws.data_ptr(), de, H.lib().mmvae_embed_bwd_rows(B, T, V), 4, 4)
         else:
             ws = H.workspace(nws, dx.device)
-            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, acc, dpc,
+            _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, B0, acc, dpc,
                   H.stream())
         GradReducer.run_side_tail(dx.device)      # the text encoder's LAST backward launch: its stream idles from here on
-        return None, ret, None, None, None, None
+        return None, ret, None, None, None, None, None
 
 
 class Attention(Function):
@@ -2179,8 +2182,8 @@ class PermuteMask(Function):
         return dx, None
 
 
-def embed_pe(onehot, emb, pe, mode, gemb=None, drop=None):
-    return EmbedPE.apply(onehot, emb, pe, mode, gemb, drop)
+def embed_pe(onehot, emb, pe, mode, gemb=None, drop=None, repeat=1):
+    return EmbedPE.apply(onehot, emb, pe, mode, gemb, drop, repeat)
 
 
 def attention(qkv, mask_u8, nhead, mask_is_valid=False, drop=None):

@@ -678,6 +678,15 @@ def test_embed_pe(ops, B, T):
     out.backward(dx.to(DEV))
     check(out, xr, 1e-6, "embed")
     check(eg.grad, er.grad, 2e-5, "demb")
+    if mode == 0:      # R passes over the same batch as one call (round 5): row k * B + b == pass k's row b, gradients add up
+        R = 3
+        eg2 = emb.to(DEV).requires_grad_(True)
+        out2 = ops.embed_pe(oh.to(DEV), eg2, pe.view(-1, 2).to(DEV), mode, None, None, R)
+        assert tuple(out2.shape) == (T, R * B, 2 * V)
+        for k in range(R):
+            assert torch.equal(out2[:, k * B:(k + 1) * B], out.detach())
+        out2.backward(torch.cat([dx, 2 * dx, -0.5 * dx], 1).to(DEV))
+        check(eg2.grad, 2.5 * er.grad, 2e-5, "demb (3 passes)")
 
 
 @pytest.mark.parametrize("L,N,E,H_", [(5, 6, 54, 2), (32, 128, 54, 2), (9, 7, 32, 2), (64, 3, 16, 2),
