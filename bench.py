@@ -510,6 +510,11 @@ def main():
             res["replicas_in_sync"] = in_sync
             res["config"]["collective"] = res["collective"]["what"]
     if world == 1 and rank == 0:
+        # the timed region above is short (K x ~0.4 ms); three more timed repeats of the same K steps say how much one
+        # reading moves on THIS box (box-to-box spread is larger: profiles/ keeps the builder boxes' lines)
+        reps = [round(1e3 * _timed(tr, a.steps, 0, path_world, barrier)[0] / a.steps, 4) for _ in range(3)]
+        res["spread"] = {"ms_per_step_repeats": reps, "steps": a.steps,
+                         "what": "three further timed repeats of the same K steps on this box (not the headline value)"}
         res["roofline"] = dominant_kernel_roofline(meta, dev)
         # context for the dominant-kernel figure: the WHOLE step's algorithmic FLOPs over its wall time, same peak
         res["roofline"]["step_frac"] = res["config"]["step_flops_fraction_of_f32_mfma_peak"]

@@ -558,8 +558,18 @@ class MOE(TorchMMVAE):
                 out, _ = vae.dec({"latents": z.view(M * K, B, D), "masks": data[n]["masks"]})     # (M*K, B, ...) / (M*K*B, ...)
                 # own block r: dist.Normal (:101-103); cross block o: vae.px_z = the config's `prior` family (:115)
                 lap_mask = (1 << o) if self._laplace[r] else 0
-                rs = recon_rowsum(vae.ltype, out, data[n], laplace=(lap_mask, KB))          # (M*K*B,)
-                blocks = rs.view(M, KB).unbind(0)
+                if vae.ltype == "optimal_sigma":
+                    # optimal_sigma fits ONE sigma per reference call, and the reference evaluates the own and the cross
+                    # reconstruction in separate calls (mmvae_models.py:63-78): row sums per source posterior (found by
+                    # the K-sample test on the action towers, round 5: one sigma over all M K B rows was 9e-4 off)
+                    flat = out.reshape(M, KB, *out.shape[-3:]) if out.dim() >= 4 else out.reshape(M, KB, -1)
+                    blocks = [recon_rowsum(vae.ltype, flat[m], data[n]) for m in range(M)]
+                    rs = blocks[0]
+                    for blk in blocks:
+                        _uses(blk, cur)
+                else:
+                    rs = recon_rowsum(vae.ltype, out, data[n], laplace=(lap_mask, KB))          # (M*K*B,)
+                    blocks = rs.view(M, KB).unbind(0)
                 rows[2 * r], rows[2 * r + 1] = blocks[r], blocks[o]
             _uses(rs, cur)
             lam.append(float(vae.llik_scaling))

@@ -92,7 +92,10 @@ def recon_rowsum(ltype, out, target, laplace=False):
                                     logit_grad=True)
         return ops.lprob_rowsum(out, tgt, None if masked else PX_SCALE, laplace)
     if ltype == "optimal_sigma":
-        return ops.optimal_sigma_rowsum(out, data.float().reshape(out.shape))
+        tgt = data.float()
+        if out.numel() != tgt.numel():      # K-sample output (K*B rows): the target repeated K times, as reshape_for_loss
+            tgt = tgt.reshape(data.shape[0], -1).repeat(out.numel() // tgt.numel(), 1)      # does (objectives.py:118-120)
+        return ops.optimal_sigma_rowsum(out, tgt.reshape(out.shape))
     if ltype == "bce":
         raw = getattr(out, "_bce_src", None)       # Dec_CNN: the producing layer's raw output (gradient = d logits)
         if raw is not None and raw.numel() == out.numel():

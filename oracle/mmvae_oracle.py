@@ -612,6 +612,8 @@ def dec_transformer(p, pre, z, mask, data_dim, train=False):
     B = z.shape[1]
     if mask is None:
         mask = torch.ones(B, data_dim[0], dtype=torch.bool)
+    elif B > mask.shape[0]:      # K samples per posterior: the mask is repeated K times (decoders.py:603-604)
+        mask = mask.repeat(B // mask.shape[0], 1)
     T = mask.shape[1]
     joints = data_dim[1]
     feats = data_dim[2] if len(data_dim) > 2 else 1
