@@ -311,15 +311,14 @@ class POE(TorchMMVAE):
                     # len(member) * B sequences (round 5: the text encoder's positional term follows the sample's position
                     # in the ORIGINAL batch, ops.embed_pe), rows k * B + b
                     p = packed_head(*enc(dict(mods[n], repeat=len(member))))
-                    Bn = p.shape[0] // len(member)
-                    for k, s in enumerate(member):
-                        packed[s][n] = p[k * Bn:(k + 1) * Bn]
+                    for s, part in zip(member, ops.split_rows(p, len(member))):      # (row blocks; ONE cat in backward)
+                        packed[s][n] = part
                 else:
                     for s in member:
                         packed[s][n] = packed_head(*enc(mods[n]))
         self._join(streams, dev)
         # ---- fusion per subset (one noise draw each, in subset order) ----
-        zs, kls = [], []
+        zs, kl_blocks = [], []
         D = self.n_latents
         for s, S in enumerate(subsets):
             ps = [packed[s][n] for n in names if n in S]
@@ -328,9 +327,9 @@ class POE(TorchMMVAE):
             E = len(ps)
             _, kl, z = ops.poe_reparam_kl(theta, ps, eps, True, 1 << E, theta.grad)
             zs.append(z[0])
-            kls.append(kl[E])
-        # ---- decoders: rec[s][i] (B,) row sums ----
-        rec = [[None] * M for _ in subsets]
+            kl_blocks.append(kl)             # (E + 1, B): the joint's KL is the last row
+        # ---- decoders: one (passes, B) block of row sums per call ----
+        rec_blocks = []
         self._fork(streams, dev, mods)
         for i, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
@@ -353,27 +352,51 @@ class POE(TorchMMVAE):
                         z_all = torch.cat([zs[s_] for s_ in g], 0)
                         out, _ = vae.dec({"latents": z_all.unsqueeze(0), "masks": None if gm is None else gm.repeat(len(g), 1)})
                         r = recon_rowsum(vae.ltype, out, mods[n])                # target row = output row % B
-                        for k, s_ in enumerate(g):
-                            rec[s_][i] = r[k * B:(k + 1) * B]
+                        rec_blocks.append((r.view(len(g), B), i, list(g)))       # the call's rows as ONE (passes, B) block
                     else:
                         for s_ in g:
                             out, _ = vae.dec({"latents": zs[s_].unsqueeze(0), "masks": gm})
-                            rec[s_][i] = recon_rowsum(vae.ltype, out, mods[n])
+                            rec_blocks.append((recon_rowsum(vae.ltype, out, mods[n]).view(1, B), i, [s_]))
         self._join(streams, dev)
-        rows, W_loss, W_kld = [], [], []
-        rec_log = [None] * M
-        for s in range(NS):
-            for i, n in enumerate(names):
-                rows.append(rec[s][i])
-                W_loss.append(float(self.vaes[n].llik_scaling))
+        # ELBO assembly straight on the calls' row BLOCKS (round 5: slicing the batched row sums and selecting the joint KL
+        # row cost ~40 ATen fill / copy / add launches per step in forward + autograd): every block is addressed in place,
+        # a row that does not enter an output has weight 0.  Outputs: loss, kld and -- while they fit (<= 4 outputs) -- the
+        # logged per-modality reconstruction sums of each modality's own singleton subset (mmvae_models.py:181-182).
+        blocks, W_loss, W_kld = [], [], []
+        W_ind = [[] for _ in range(M)]
+        n_rows = sum(b.shape[0] for b, _, _ in rec_blocks) + sum(k.shape[0] for k in kl_blocks)
+        whole_kl = n_rows <= 32
+        for blk, i, subs in rec_blocks:
+            blocks.append(blk)
+            for s_ in subs:
+                W_loss.append(float(self.vaes[names[i]].llik_scaling))
                 W_kld.append(0.0)
-                if i == s:
-                    rec_log[i] = rec[s][i]
-            rows.append(kls[s])
-            W_loss.append(float(self.obj_fn.beta))
-            W_kld.append(1.0 / NS)
-        out = ops.lincomb_rows(rows, [W_loss, W_kld])
-        ind = [r.sum() for r in rec_log]
+                for j in range(M):
+                    W_ind[j].append(1.0 if (j == i and s_ == i) else 0.0)
+        for s_, kl in enumerate(kl_blocks):
+            E1 = kl.shape[0]
+            if whole_kl:
+                blocks.append(kl)
+                W_loss += [0.0] * (E1 - 1) + [float(self.obj_fn.beta)]
+                W_kld += [0.0] * (E1 - 1) + [1.0 / NS]
+                for j in range(M):
+                    W_ind[j] += [0.0] * E1
+            else:
+                blocks.append(kl[E1 - 1])
+                W_loss.append(float(self.obj_fn.beta))
+                W_kld.append(1.0 / NS)
+                for j in range(M):
+                    W_ind[j].append(0.0)
+        if M <= 2 and len(W_loss) <= 32:
+            out = ops.lincomb_rows(blocks, [W_loss, W_kld] + W_ind)
+            ind = [o.detach() for o in out[2:]]
+        else:
+            out = ops.lincomb_rows(blocks, [W_loss, W_kld])
+            ind = [None] * M
+            for blk, i, subs in rec_blocks:
+                for k, s_ in enumerate(subs):
+                    if s_ == i:
+                        ind[i] = blk[k].detach().sum()
         return {"loss": out[0], "reconstruction_loss": ind, "kld": out[1]}
 
     def modality_mixing(self, x):

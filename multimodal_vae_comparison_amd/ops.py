@@ -1466,6 +1466,26 @@ def lincomb_rows_args(blocks, W):
     return {"args": (rp, flat, out, n, B, k), "keep": blocks, "done": False}
 
 
+class SplitRows(Function):
+    """(R * B, F) -> R row blocks (B, F) as views; backward is ONE concatenation of the blocks' gradients (autograd's own
+    slice backward costs a zero-fill and a copy per block plus the additions)."""
+
+    @staticmethod
+    def forward(ctx, x, R):
+        B = x.shape[0] // R
+        ctx.R = R
+        return tuple(x[k * B:(k + 1) * B] for k in range(R))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        return torch.cat([g if g is not None else torch.zeros_like(ref) for g in gs], 0), None
+
+
+def split_rows(x, R):
+    return SplitRows.apply(x, R)
+
+
 class NormalLogRatio(Function):
     """lw[b] = sum_d [log N(z; mu_r, s_r) - log N(z; mu_o, s_o)]; gradient only into packed_r (MoE, :56-62)"""
 
