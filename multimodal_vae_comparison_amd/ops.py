@@ -502,8 +502,11 @@ class ConvT3Bce(Function):
     ReconLoss.bce, models/objectives.py:392-406].  Only under ops.ConstSeed (the term's ELBO weight is known): the same
     pass writes d loss / d logits, x_hat itself is never stored.  Backward = the layer's ordinary backward on that."""
 
+    calls = 0      # (tests: how often the fused form ran)
+
     @staticmethod
     def forward(ctx, x, w, b, in_act, gw, gb, target, cs):
+        ConvT3Bce.calls += 1
         x, target = H.f32c(x), H.f32c(target)
         B = x.shape[0]
         dev = x.device
