@@ -97,6 +97,18 @@ int mmvae_ffn32_fwd(const float* x, const float* w1, const float* b1, const floa
                     int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, float* dx,
                     float* ws, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+/* The same three launches on split-bf16 MFMA (every fp32 operand = the exact sum of three bf16 terms, six bf16 MFMAs per
+ * product, fp32 accumulation: the contract of the fp32 kernels above to ~3e-7 of the tensor maximum).  The weights are
+ * split ONCE per step into wsplit (mmvae_ffn32_wsplit_bytes(FF) bytes, 16-byte aligned; mmvae_ffn32_prep_weights) and
+ * that image replaces w1 / w2 in the calls; the weight-gradient launch also needs rsplit (mmvae_ffn32_rsplit_bytes(M)
+ * bytes of scratch, written and read by that call in stream order).  Same partial-row layout in ws, same dropout mask. */
+size_t mmvae_ffn32_wsplit_bytes(int FF);
+size_t mmvae_ffn32_rsplit_bytes(int M);
+int mmvae_ffn32_prep_weights(const float* w1, const float* w2, void* wsplit, int FF, mmvae_stream_t stream);
+int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const float* b1, const float* b2, float* y, int M, int FF,
+                        const mmvae_dropout_t* drop, mmvae_stream_t stream);
+int mmvae_ffn32_bwd_b16(const float* x, const float* dy, const void* wsplit, const float* b1, float* dx, float* ws,
+                        void* rsplit, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 
 int mmvae_version(void);
 const char* mmvae_arch(void); /* "gfx950" */

@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256) void ffn32_bwd_weight_kernel(FfnArgs a) {
   }
 }
 
+#include "ffn_b16.inc"
+
 static inline bool ffn_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int ffn_slices(int M, int FF) {
   // row slices of the weight-gradient launch: ~2048 waves in flight, 8 to 13 row blocks per wave
@@ -278,5 +280,46 @@ extern "C" int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1,
   FfnArgs a{x, dy, w1, b1, w2, nullptr, nullptr, dx, ws, M, FF, rps, (int)mmvae_ffn32_bwd_rowlen(FF), drop_arg(drop)};
   if (dx) hipLaunchKernelGGL(ffn32_bwd_data_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
   if (ws) hipLaunchKernelGGL(ffn32_bwd_weight_kernel, dim3((FF / 32 + 3) / 4, S), dim3(256), 0, (hipStream_t)stream, a);
+  return mmvae_launch_status();
+}
+
+// ---- the same three launches on split-bf16 MFMA (ffn_b16.inc) ---------------------------------------------------------
+extern "C" size_t mmvae_ffn32_wsplit_bytes(int FF) { return (size_t)4 * 3 * FFN_D * 2 * (size_t)FF; }
+extern "C" size_t mmvae_ffn32_rsplit_bytes(int M) { return (size_t)4 * 3 * FFN_D * 2 * (size_t)((M + 31) / 32 * 32); }
+extern "C" int mmvae_ffn32_prep_weights(const float* w1, const float* w2, void* wsplit, int FF, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(w1 && w2 && wsplit);
+  if (!mmvae_ffn32_supported(FFN_D, FF)) return MMVAE_ERR_UNSUPPORTED;
+  if (!ffn_al16(wsplit)) return MMVAE_ERR_ARG;
+  hipLaunchKernelGGL(ffn32_prep_weights_kernel, dim3((16 * FF + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2,
+                     (unsigned short*)wsplit, FF);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const float* b1, const float* b2, float* y, int M,
+                                   int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && wsplit && b1 && b2 && y && M > 0);
+  if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
+  if (!ffn_al16(x) || !ffn_al16(wsplit) || !ffn_al16(b1)) return MMVAE_ERR_ARG;
+  FfnB16Args a{x, nullptr, b1, b2, (const unsigned short*)wsplit, nullptr, y, nullptr, nullptr, M, 0, FF, 0, 0, drop_arg(drop)};
+  hipLaunchKernelGGL(ffn32_fwd_b16_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  return mmvae_launch_status();
+}
+// as mmvae_ffn32_bwd; rsplit (mmvae_ffn32_rsplit_bytes(M) bytes, needed with ws) receives the split images of x and dy
+// that the weight-gradient launch reads -- scratch of THIS call, in stream order
+extern "C" int mmvae_ffn32_bwd_b16(const float* x, const float* dy, const void* wsplit, const float* b1, float* dx, float* ws,
+                                   void* rsplit, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && dy && wsplit && b1 && (ws || dx) && (!ws || rsplit) && M > 0);
+  if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
+  if (!ffn_al16(x) || !ffn_al16(dy) || !ffn_al16(wsplit) || !ffn_al16(b1) || !ffn_al16(rsplit)) return MMVAE_ERR_ARG;
+  const int S = ffn_slices(M, FF), Mpad = (M + 31) / 32 * 32;
+  int rps = ((M + S - 1) / S + 31) / 32 * 32;
+  FfnB16Args a{x, dy, b1, nullptr, (const unsigned short*)wsplit, (const unsigned short*)rsplit, nullptr, dx, ws, M, Mpad, FF,
+               rps, (int)mmvae_ffn32_bwd_rowlen(FF), drop_arg(drop)};
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) hipLaunchKernelGGL(ffn32_bwd_data_b16_kernel, dim3((M + 31) / 32), dim3(256), 0, st, a);
+  if (ws) {
+    hipLaunchKernelGGL(ffn32_prep_rows_kernel, dim3((16 * Mpad + 255) / 256), dim3(256), 0, st, x, dy, (unsigned short*)rsplit, M,
+                       Mpad);
+    hipLaunchKernelGGL(ffn32_bwd_weight_b16_kernel, dim3((FF / 32 + 3) / 4, S), dim3(256), 0, st, a);
+  }
   return mmvae_launch_status();
 }

@@ -2282,9 +2282,18 @@ class Ffn32(Function):
         x = H.f32c(x)
         M, FF = x.numel() // 32, w1.shape[0]
         y = torch.empty_like(x)
-        _call("mmvae_ffn32_fwd", H.ptr(x), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(b2), H.ptr(y), M, FF,
-              _dp(drop, M * FF), H.stream())
+        wsplit = None
+        if FFN32_SPLIT_BF16:
+            # the weights' three-term bf16 image, made once per call and shared by the three launches (csrc/ffn_b16.inc)
+            wsplit = torch.empty(H.lib().mmvae_ffn32_wsplit_bytes(FF), dtype=torch.uint8, device=x.device)
+            _call("mmvae_ffn32_prep_weights", H.ptr(w1), H.ptr(w2), H.ptr(wsplit), FF, H.stream())
+            _call("mmvae_ffn32_fwd_b16", H.ptr(x), H.ptr(wsplit), H.ptr(b1), H.ptr(b2), H.ptr(y), M, FF,
+                  _dp(drop, M * FF), H.stream())
+        else:
+            _call("mmvae_ffn32_fwd", H.ptr(x), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(b2), H.ptr(y), M, FF,
+                  _dp(drop, M * FF), H.stream())
         ctx.save_for_backward(x, w1, b1, w2)
+        ctx.wsplit = wsplit
         ctx.cfg = (drop, gw1, gb1, gw2, gb2)
         return y
 
@@ -2301,25 +2310,36 @@ class Ffn32(Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dc = drop.c() if drop else None
         other = StreamPlan.other_stream(x.device) if (dx is not None and defer and M * FF >= (1 << 20)) else None
+        wsplit = ctx.wsplit
+        if wsplit is not None:
+            rsplit = torch.empty(lib.mmvae_ffn32_rsplit_bytes(M), dtype=torch.uint8, device=x.device)
+
+            def bwd(dx_, ws_):
+                _call("mmvae_ffn32_bwd_b16", H.ptr(x), H.ptr(dy), H.ptr(wsplit), H.ptr(b1), H.ptr(dx_) if dx_ is not None else None,
+                      H.ptr(ws_) if ws_ is not None else None, H.ptr(rsplit), M, FF, dc, H.stream())
+        else:
+            rsplit = None
+
+            def bwd(dx_, ws_):
+                _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2),
+                      H.ptr(dx_) if dx_ is not None else None, H.ptr(ws_) if ws_ is not None else None, M, FF, dc, H.stream())
         if other is not None:
             # the weight-gradient launch (nothing but the end-of-backward fold reads it) goes to the step's OTHER stream,
             # which idles while a long tower's chain runs on this one; only dy and x have to exist, not the data gradient
             cur = torch.cuda.current_stream(x.device)
             ev = torch.cuda.Event()
             ev.record(cur)
-            _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(dx), None, M, FF, dc,
-                  H.stream())
+            bwd(dx, None)
             other.wait_event(ev)
             with torch.cuda.stream(other):
-                _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), None, H.ptr(ws), M, FF, dc,
-                      H.stream())
-            for t in (x, dy):
+                bwd(None, ws)
+            held = (x, dy) if wsplit is None else (x, dy, wsplit, rsplit)
+            for t in held:
                 t.record_stream(other)
-            GradReducer.keep(x.device, x, dy)
+            GradReducer.keep(x.device, *held)
             GradReducer.note_stream(x.device, other)
         else:
-            _call("mmvae_ffn32_bwd", H.ptr(x), H.ptr(dy), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(dx), H.ptr(ws), M, FF, dc,
-                  H.stream())
+            bwd(dx, ws)
         offs = (0, 32 * FF, 32 * FF + FF, 64 * FF + FF)
         lens = (32 * FF, FF, 32 * FF, 32)
         rets = [None, None, None, None]
@@ -2332,6 +2352,10 @@ class Ffn32(Function):
                 _call("mmvae_reduce_rows", H.ptr(ws) + 4 * o, H.ptr(dst), parts, ln, rowlen, acc, H.stream())
                 rets[i] = ret
         return (dx, *rets, None, None, None, None, None)
+
+
+# the fused feed-forward launches on split-bf16 MFMA (csrc/ffn_b16.inc) instead of fp32 MFMA (csrc/ffn.hip); both are tested
+FFN32_SPLIT_BF16 = True
 
 
 def ffn32_supported(d, ff):

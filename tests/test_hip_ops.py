@@ -905,13 +905,16 @@ def test_adam_fold_flat_is_fold_then_adam(ops, hip_lib, rider):
     assert rc == 1      # MMVAE_ERR_ARG
 
 
+@pytest.mark.parametrize("core", ["split_bf16", "fp32"])
 @pytest.mark.parametrize("M,FF,p", [(600, 1024, 0.1), (70, 128, 0.0), (12800, 1024, 0.1), (33, 96, 0.3), (1, 32, 0.5)])
-def test_ffn32_fused_matches_torch_and_op_by_op(ops, M, FF, p):
-    """csrc/ffn.hip: linear2(dropout(gelu(linear1(x)))) with d_model 32 in three fused launches (forward, data
-    gradient, weight gradients) against torch in fp64 with the very dropout mask the kernel used (extracted with
-    mmvae_dropout_mask: same element index row * FF + col as the op-by-op activation-dropout pass), ragged row counts
-    (partial row blocks, partial row slices), FF not a multiple of the 4-wave stride"""
+def test_ffn32_fused_matches_torch_and_op_by_op(ops, monkeypatch, M, FF, p, core):
+    """csrc/ffn.hip / ffn_b16.inc: linear2(dropout(gelu(linear1(x)))) with d_model 32 in three fused launches (forward,
+    data gradient, weight gradients; on split-bf16 MFMA -- what ships -- and on fp32 MFMA) against torch in fp64 with the
+    very dropout mask the kernel used (extracted with mmvae_dropout_mask: same element index row * FF + col as the
+    op-by-op activation-dropout pass), ragged row counts (partial row blocks, partial row slices), FF not a multiple of the
+    4-wave stride.  Same bars for both cores: 2e-6 / 5e-6 of the tensor maximum (a two-term split would sit at ~1e-5)."""
     from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    monkeypatch.setattr(ops, "FFN32_SPLIT_BF16", core == "split_bf16")
     g = torch.Generator().manual_seed(M + FF)
     x = torch.randn(M, 32, generator=g).to(DEV).requires_grad_(True)
     w1 = (torch.randn(FF, 32, generator=g) * 0.3).to(DEV).requires_grad_(True)
