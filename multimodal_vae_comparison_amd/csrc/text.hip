@@ -1008,23 +1008,45 @@ extern "C" int mmvae_dropout_act_bwd(const float* dy, const float* x, float* dx,
   return mmvae_launch_status();
 }
 // out[l,n,c] = v[n,c] * mask[(n*H + c/hd)*L + l]   (attention-weight dropout over a length-1 memory)
-__global__ __launch_bounds__(256) void head_bcast_dropout_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                                 int L, int N, int H, int hd, int bwd,
-                                                                 mmvae_dropout_t drop) {
+// forward: one thread per OUTPUT element (round 5: it was one thread per (n, c) walking the L steps -- 16 workgroups at the
+// action decoder's 128 x 32 x 100, 20 us per call); backward: one workgroup per n, its 256 threads = (l mod 8, c), summed
+// over the 8 time groups through LDS in a fixed order.
+__global__ __launch_bounds__(256) void head_bcast_dropout_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                     int L, int N, int H, int hd, mmvae_dropout_t drop) {
   const DropKey dk = drop_key(drop);
   const int E = H * hd;
-  const long ne = (long)N * E;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ne; i += (long)gridDim.x * 256) {
+  const long ne = (long)N * E, tot = ne * L;
+  for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < tot; j += (long)gridDim.x * 256) {
+    const int l = (int)(j / ne);
+    const long i = j - (long)l * ne;
     const int n = (int)(i / E), c = (int)(i - (long)n * E), h = c / hd;
-    const uint32_t base = (uint32_t)(((size_t)n * H + h) * L);
-    if (!bwd) {
-      const float v = src[i];
-      for (int l = 0; l < L; ++l) dst[(size_t)l * ne + i] = v * drop_mul(dk, base + l);
-    } else {
-      float a = 0.f;
-      for (int l = 0; l < L; ++l) a += src[(size_t)l * ne + i] * drop_mul(dk, base + l);
-      dst[i] = a;
+    dst[j] = src[i] * drop_mul(dk, (uint32_t)(((size_t)n * H + h) * L) + (uint32_t)l);
+  }
+}
+#define HB_TG 8
+__global__ __launch_bounds__(256) void head_bcast_dropout_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                     int L, int N, int H, int hd, mmvae_dropout_t drop) {
+  __shared__ float red[256];
+  const DropKey dk = drop_key(drop);
+  const int E = H * hd, n = blockIdx.x;
+  const long ne = (long)N * E;
+  // E <= 32: thread = (time group tid / 32, channel tid % 32); wider rows: channel loop
+  for (int c0 = 0; c0 < E; c0 += 32) {
+    const int c = c0 + (threadIdx.x & 31), tg = threadIdx.x >> 5;
+    float a = 0.f;
+    if (c < E) {
+      const uint32_t base = (uint32_t)(((size_t)n * H + c / hd) * L);
+      for (int l = tg; l < L; l += HB_TG) a += src[(size_t)l * ne + (size_t)n * E + c] * drop_mul(dk, base + l);
     }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < E) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int g = 0; g < HB_TG; ++g) s_ += red[g * 32 + threadIdx.x];
+      dst[(size_t)n * E + c] = s_;
+    }
+    __syncthreads();
   }
 }
 // y[t,b,:] = dropout(x[t,b,:] + pe[t,:]): the time positional encoding of the action Transformer towers
@@ -1054,19 +1076,17 @@ extern "C" int mmvae_add_pe_dropout_fwd(const float* x, const float* pe, float* 
 extern "C" int mmvae_head_bcast_dropout_fwd(const float* v, float* out, int L, int N, int H, int hd,
                                             const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(v && out && L > 0 && N > 0 && H > 0 && hd > 0);
-  long blocks = ((long)N * H * hd + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(head_bcast_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, v, out, L,
-                     N, H, hd, 0, drop_arg(drop));
+  long blocks = ((long)L * N * H * hd + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(head_bcast_dropout_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, v, out, L, N,
+                     H, hd, drop_arg(drop));
   return mmvae_launch_status();
 }
 extern "C" int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L, int N, int H, int hd,
                                             const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(dout && dv && L > 0 && N > 0 && H > 0 && hd > 0);
-  long blocks = ((long)N * H * hd + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(head_bcast_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, dv, L,
-                     N, H, hd, 1, drop_arg(drop));
+  hipLaunchKernelGGL(head_bcast_dropout_bwd_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, dout, dv, L, N, H,
+                     hd, drop_arg(drop));
   return mmvae_launch_status();
 }
 

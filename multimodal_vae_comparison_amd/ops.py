@@ -2309,7 +2309,8 @@ class Ffn32(Function):
         ws = GradReducer.alloc(parts * rowlen, x.device) if defer else torch.empty(parts * rowlen, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dc = drop.c() if drop else None
-        other = StreamPlan.other_stream(x.device) if (dx is not None and defer and M * FF >= (1 << 20)) else None
+        other = StreamPlan.other_stream(x.device) if (dx is not None and defer and M * FF >= (1 << 20)
+                                                      and FFN32_WGRAD_OTHER_STREAM) else None
         wsplit = ctx.wsplit
         if wsplit is not None:
             rsplit = torch.empty(lib.mmvae_ffn32_rsplit_bytes(M), dtype=torch.uint8, device=x.device)
@@ -2356,6 +2357,8 @@ class Ffn32(Function):
 
 # the fused feed-forward launches on split-bf16 MFMA (csrc/ffn_b16.inc) instead of fp32 MFMA (csrc/ffn.hip); both are tested
 FFN32_SPLIT_BF16 = True
+# large feed-forward weight-gradient launches go to the step's other stream (nothing but the end-of-backward fold reads them)
+FFN32_WGRAD_OTHER_STREAM = True
 
 
 def ffn32_supported(d, ff):

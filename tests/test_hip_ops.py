@@ -949,6 +949,30 @@ def test_ffn32_fused_matches_torch_and_op_by_op(ops, monkeypatch, M, FF, p, core
     check(w1.grad, w12.grad, 5e-6, "dW1 vs op-by-op")
 
 
+@pytest.mark.parametrize("L,N,H,hd,p", [(100, 128, 2, 16, 0.1), (7, 5, 2, 16, 0.3), (33, 3, 4, 12, 0.0)])
+def test_head_bcast_dropout_matches_torch(ops, L, N, H, hd, p):
+    """cross-attention over a length-1 memory (models/decoders.py: the action decoder's layers): out[l, n, c] = v[n, c] *
+    mask[(n H + c / hd) L + l], backward the masked sum over time; mask extracted from the kernels' own generator"""
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    g = torch.Generator().manual_seed(L + N)
+    v = torch.randn(N, H * hd, generator=g).to(DEV).requires_grad_(True)
+    dout = torch.randn(L, N, H * hd, generator=g).to(DEV)
+    drop, mask = None, torch.ones(N, H, L, dtype=torch.float64, device=DEV)
+    if p > 0:
+        st = DropoutState().to(DEV)
+        slot, call = st.begin()
+        drop = st.spec(slot, call, 5, p, "attn")
+        mask = ops.dropout_mask(drop, N * H * L).double().view(N, H, L)
+    out = ops.head_bcast_dropout(v, L, H, drop)
+    out.backward(dout)
+    m = mask.permute(2, 0, 1).unsqueeze(-1).expand(L, N, H, hd).reshape(L, N, H * hd)
+    vr = v.detach().double().requires_grad_(True)
+    ref = vr.unsqueeze(0) * m
+    ref.backward(dout.double())
+    check(out, ref, 1e-6, "out")
+    check(v.grad, vr.grad, 2e-6, "dv")
+
+
 @pytest.mark.parametrize("self_counting", [False, True])
 def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
     """self_counting: step = -1, the kernel bumps the device step counter itself (what FlatAdam uses)"""
