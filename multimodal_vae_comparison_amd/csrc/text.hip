@@ -799,7 +799,97 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-static inline int ln_blocks(int rows, int* rpb) {
+// ---- d == 32 (the action towers' d_model; round 5): a row is EIGHT threads with one float4 each, 32 rows per workgroup
+// and pass -- coalesced 16-byte accesses and every lane busy, where the generic kernels give a 32-float row a whole wave
+// (half its lanes idle, one dependent load round per row).  Same arithmetic, same dropout mask (element row * 32 + c; one
+// hash per even-aligned pair), same partial-row layout of the parameter gradients.
+__device__ __forceinline__ float ln32_sum8(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ float4 ln32_mask4(const DropKey& dk, uint32_t idx) {      // idx % 4 == 0
+  const uint32_t h0 = drop_pair_hash(dk, idx >> 1), h1 = drop_pair_hash(dk, (idx >> 1) + 1);
+  return make_float4(drop_pair_lo(dk, h0), drop_pair_hi(dk, h0), drop_pair_lo(dk, h1), drop_pair_hi(dk, h1));
+}
+__global__ __launch_bounds__(256) void ln32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, float* __restrict__ xhat,
+                                                       float* __restrict__ rstd, int rows, int r_rows, mmvae_dropout_t drop) {
+  const int q = threadIdx.x & 7, row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (row >= rows) return;
+  const DropKey dkey = drop_key(drop);
+  const size_t o = (size_t)row * 32 + 4 * q;
+  float4 v = *reinterpret_cast<const float4*>(x + o);
+  if (dkey.on) {
+    const float4 m = ln32_mask4(dkey, (uint32_t)o);
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+  }
+  if (r) {
+    const float4 rv = *reinterpret_cast<const float4*>(r + (size_t)(r_rows > 0 ? row % r_rows : row) * 32 + 4 * q);
+    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+  }
+  const float mean = ln32_sum8((v.x + v.y) + (v.z + v.w)) * (1.0f / 32.0f);
+  const float4 dv = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+  const float rs = rsqrtf(ln32_sum8((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w)) * (1.0f / 32.0f) + 1e-5f);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * q), b = *reinterpret_cast<const float4*>(beta + 4 * q);
+  const float4 xh = make_float4(dv.x * rs, dv.y * rs, dv.z * rs, dv.w * rs);
+  *reinterpret_cast<float4*>(xhat + o) = xh;
+  *reinterpret_cast<float4*>(y + o) = make_float4(xh.x * g.x + b.x, xh.y * g.y + b.y, xh.z * g.z + b.z, xh.w * g.w + b.w);
+  if (q == 0) rstd[row] = rs;
+}
+__global__ __launch_bounds__(256) void ln32_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       float* __restrict__ dsum, float* __restrict__ dxd,
+                                                       float* __restrict__ ws, int rows, int rows_per_block,
+                                                       mmvae_dropout_t drop) {
+  __shared__ float sg[32][65];
+  const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const DropKey dkey = drop_key(drop);
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+  const int row_beg = blockIdx.x * rows_per_block, row_end = min(rows, row_beg + rows_per_block);
+  for (int row = row_beg + rl; row < row_end; row += 32) {
+    const size_t o = (size_t)row * 32 + 4 * q;
+    const float4 d4 = *reinterpret_cast<const float4*>(dy + o), xh = *reinterpret_cast<const float4*>(xhat + o);
+    const float rs = rstd[row];
+    const float4 g = make_float4(d4.x * gm.x, d4.y * gm.y, d4.z * gm.z, d4.w * gm.w);
+    dg.x += d4.x * xh.x; dg.y += d4.y * xh.y; dg.z += d4.z * xh.z; dg.w += d4.w * xh.w;
+    db.x += d4.x; db.y += d4.y; db.z += d4.z; db.w += d4.w;
+    const float s1 = ln32_sum8((g.x + g.y) + (g.z + g.w)) * (1.0f / 32.0f);
+    const float s2 = ln32_sum8((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w)) * (1.0f / 32.0f);
+    const float4 ds = make_float4(rs * (g.x - s1 - xh.x * s2), rs * (g.y - s1 - xh.y * s2), rs * (g.z - s1 - xh.z * s2),
+                                  rs * (g.w - s1 - xh.w * s2));
+    *reinterpret_cast<float4*>(dsum + o) = ds;
+    if (dxd) {
+      float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (dkey.on) m = ln32_mask4(dkey, (uint32_t)o);
+      *reinterpret_cast<float4*>(dxd + o) = make_float4(ds.x * m.x, ds.y * m.y, ds.z * m.z, ds.w * m.w);
+    }
+  }
+  float* srow = sg[rl];
+  srow[4 * q] = dg.x; srow[4 * q + 1] = dg.y; srow[4 * q + 2] = dg.z; srow[4 * q + 3] = dg.w;
+  srow[32 + 4 * q] = db.x; srow[32 + 4 * q + 1] = db.y; srow[32 + 4 * q + 2] = db.z; srow[32 + 4 * q + 3] = db.w;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) a += sg[i][threadIdx.x];
+    ws[(size_t)blockIdx.x * 64 + threadIdx.x] = a;          // [dgamma (32) | dbeta (32)]
+  }
+}
+
+static inline bool ln32_ok(const void* a, const void* b, const void* c, const void* d_) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d_)) & 15) == 0;
+}
+static inline int ln_blocks(int rows, int d, int* rpb) {
+  if (d == 32) {      // ln32_bwd_kernel: 32 rows per pass, whole passes per workgroup
+    int nb = (rows + 31) / 32;
+    if (nb > 1024) nb = 1024;
+    *rpb = ((rows + nb - 1) / nb + 31) / 32 * 32;
+    return (rows + *rpb - 1) / *rpb;
+  }
   // a wave walks its rows one after the other (one dependent load round per row): at most ~4 rows per wave, i.e. 16 per
   // workgroup, up to 1024 workgroups (the action towers' 12 800-row LayerNorms: 26.5 -> 6 us; 128 workgroups of 100 rows
   // before).  The per-workgroup [dgamma | dbeta] partials grow with it: 1024 x 2d floats, folded with the others.
@@ -809,19 +899,23 @@ static inline int ln_blocks(int rows, int* rpb) {
   return (rows + *rpb - 1) / *rpb;
 }
 extern "C" int mmvae_layernorm_bwd_rows(int rows, int d) {
-  (void)d;
   int rpb;
-  return ln_blocks(rows, &rpb);
+  return ln_blocks(rows, d, &rpb);
 }
 extern "C" size_t mmvae_layernorm_ws_floats(int rows, int d) {
   int rpb;
-  return (size_t)ln_blocks(rows, &rpb) * 2 * d;
+  return (size_t)ln_blocks(rows, d, &rpb) * 2 * d;
 }
 extern "C" int mmvae_layernorm_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta,
                                             float* y, float* xhat, float* rstd, int rows, int d, int r_rows,
                                             const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && gamma && beta && y && xhat && rstd && rows > 0 && d > 0);
   if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
+  if (d == 32 && ln32_ok(x, y, xhat, r) && ln32_ok(gamma, beta, nullptr, nullptr)) {
+    hipLaunchKernelGGL(ln32_fwd_kernel, dim3((rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y, xhat,
+                       rstd, rows, r_rows, drop_arg(drop));
+    return mmvae_launch_status();
+  }
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, y,
                      xhat, rstd, rows, d, r_rows, drop_arg(drop));
   return mmvae_launch_status();
@@ -835,9 +929,15 @@ extern "C" int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, 
   MMVAE_CHECK_ARG(accumulate == MMVAE_ACC_DEFER || (dgamma && dbeta));
   if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   int rpb;
-  const int nb = ln_blocks(rows, &rpb);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, dx_drop,
-                     ws, rows, d, rpb, drop_arg(drop));
+  const int nb = ln_blocks(rows, d, &rpb);
+  if (d == 32) {
+    if (!ln32_ok(dy, xhat, dsum, dx_drop) || !ln32_ok(gamma, nullptr, nullptr, nullptr)) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(ln32_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, dx_drop, ws,
+                       rows, rpb, drop_arg(drop));
+  } else {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, dx_drop,
+                       ws, rows, d, rpb, drop_arg(drop));
+  }
   int rc = mmvae_launch_status();
   if (rc || accumulate == MMVAE_ACC_DEFER) return rc;
   if (dbeta == dgamma + d) return mmvae_reduce_rows(ws, dgamma, nb, 2L * d, 2L * d, accumulate, stream);

@@ -750,19 +750,30 @@ def test_attention_weight_dropout(ops, L, N, E, H_, p):
     check(qg.grad, qr.grad, 5e-5, "attn dqkv")
 
 
-@pytest.mark.parametrize("L,N,d,bcast", [(5, 6, 54, False), (32, 128, 32, True), (1, 300, 8, False), (9, 7, 70, True)])
-def test_layernorm_residual(ops, L, N, d, bcast):
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("L,N,d,bcast", [(5, 6, 54, False), (32, 128, 32, True), (1, 300, 8, False), (9, 7, 70, True),
+                                         (7, 5, 32, False), (100, 128, 32, False), (33, 1100, 32, True)])
+def test_layernorm_residual(ops, L, N, d, bcast, p):
+    """LayerNorm(dropout(x) + r) forward / backward (generic kernels and the d = 32 ones: eight threads per row; partial
+    row blocks, more rows than one pass of 1024 workgroups), dropout mask extracted from the kernels' generator"""
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
     g = torch.Generator().manual_seed(L + N + d)
     x = torch.randn(L, N, d, generator=g)
     r = torch.randn(N, d, generator=g) if bcast else torch.randn(L, N, d, generator=g)
     ga = 1 + 0.1 * torch.randn(d, generator=g)
     be = 0.1 * torch.randn(d, generator=g)
     dy = torch.randn(L, N, d, generator=g)
+    drop, mask = None, 1.0
+    if p > 0:
+        st = DropoutState().to(DEV)
+        slot, call = st.begin()
+        drop = st.spec(slot, call, 2, p, "drop1")
+        mask = ops.dropout_mask(drop, L * N * d).double().view(L, N, d).cpu()
     xr, rr, gr, br = (t.double().requires_grad_(True) for t in (x, r, ga, be))
-    ref = F.layer_norm(xr + rr, (d,), gr, br, 1e-5)
+    ref = F.layer_norm(xr * mask + rr, (d,), gr, br, 1e-5)
     ref.backward(dy.double())
     xg, rg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, r, ga, be))
-    out = ops.layernorm_residual(xg, rg, gg, bg)
+    out = ops.layernorm_residual(xg, rg, gg, bg, drop=drop)
     out.backward(dy.to(DEV))
     check(out, ref, 1e-5, "ln out")
     check(xg.grad, xr.grad, 2e-5, "ln dx")
