@@ -650,6 +650,150 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
     }
   }
 }
+// ---- forward, transposed form (round 5): one WAVE per (sample, head, 32 query rows), scores as S^T = K Q^T --------------
+// The tile's register r of lane (li, lh) is then score(key 32 kb + at_i(r, lh), query l0 + li): a query's whole row of
+// keys lives in ONE lane pair, so the softmax is in-lane arithmetic plus one exchange with the other half (the kernel above
+// reduces 16 rows over 32 lanes each: 160 shuffles), consecutive registers are consecutive keys (one mask hash per pair,
+// 16-byte stores of the probabilities), and the normalised, dropped tile IS the A operand of P V (the accumulator-as-
+// operand layout of ffn.hip: reduction index = key at_i(r, lh), so V is read in that order) -- no L x S tile in LDS at all.
+// 16 KB of LDS per wave instead of 92 KB per workgroup: the 4 x N x H waves of a launch are all resident at once.
+__global__ __launch_bounds__(64) void attn_t_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const uint8_t* __restrict__ kpm,
+                                                        float* __restrict__ out, float* __restrict__ probs, int L, int S,
+                                                        int N, int H, long ldq, long ldk, long ldv, int mask_is_valid,
+                                                        mmvae_dropout_t drop) {
+  __shared__ __attribute__((aligned(16))) float sk[128 * AT_HP + 16], sv[128 * AT_HP + 16], sq[32 * AT_HP];
+  __shared__ float smask[128];
+  constexpr int hd = AT_HD;
+  const int n = blockIdx.x, h = blockIdx.y, l0 = blockIdx.z * 32, lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const float scale = 1.0f / sqrtf((float)hd);
+  {   // K, V: 128 rows x 4 quads each (rows >= S: zeros), Q: this wave's 32 rows; all loads in flight before the LDS writes
+    float4 kq[8], vq[8], qq[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = lane + 64 * u, r = e >> 2, c = e & 3;
+      kq[u] = r < S ? *reinterpret_cast<const float4*>(k + ((size_t)r * N + n) * ldk + h * hd + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vq[u] = r < S ? *reinterpret_cast<const float4*>(v + ((size_t)r * N + n) * ldv + h * hd + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u, r = e >> 2, c = e & 3;
+      qq[u] = l0 + r < L ? *reinterpret_cast<const float4*>(q + ((size_t)(l0 + r) * N + n) * ldq + h * hd + 4 * c)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = lane + 64 * u, r = e >> 2, c = e & 3;
+      float* dk_ = sk + r * AT_HP + 4 * c;
+      dk_[0] = kq[u].x; dk_[1] = kq[u].y; dk_[2] = kq[u].z; dk_[3] = kq[u].w;
+      float* dv_ = sv + r * AT_HP + 4 * c;
+      dv_[0] = vq[u].x; dv_[1] = vq[u].y; dv_[2] = vq[u].z; dv_[3] = vq[u].w;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u, r = e >> 2, c = e & 3;
+      float* dq_ = sq + r * AT_HP + 4 * c;
+      dq_[0] = qq[u].x * scale; dq_[1] = qq[u].y * scale; dq_[2] = qq[u].z * scale; dq_[3] = qq[u].w * scale;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s_ = lane + 64 * u;
+      smask[s_] = (s_ >= S || (kpm && ((kpm[(size_t)n * S + s_] != 0) != (mask_is_valid != 0)))) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
+  float qb[AT_HD / 2];
+#pragma unroll
+  for (int kk = 0; kk < AT_HD / 2; ++kk) qb[kk] = sq[li * AT_HP + 2 * kk + lh];
+  f32x16 acc[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+    if (kb * 32 < S) {
+#pragma unroll
+      for (int kk = 0; kk < AT_HD / 2; ++kk)
+        acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[(kb * 32 + li) * AT_HP + 2 * kk + lh], qb[kk], acc[kb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[kb][r] = smask[kb * 32 + at_i(r, lh)] != 0.f ? -INFINITY : acc[kb][r];
+      mx = fmaxf(mx, acc[kb][r]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[kb][r] = __expf(acc[kb][r] - mx);          // exp(-inf - mx) = 0 for masked keys; NaN for a fully masked row
+      sum += acc[kb][r];
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const DropKey dkey = drop_key(drop);
+  const int l = l0 + li;
+  const uint32_t dbase = (uint32_t)(((size_t)n * H + h) * L * S) + (uint32_t)(l * S);
+  float* P = probs + ((size_t)n * H + h) * L * S + (size_t)l * S;
+  const bool vec = (S & 3) == 0 && (((uintptr_t)probs) & 15) == 0;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    if (kb * 32 < S) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key0 = kb * 32 + 8 * g + 4 * lh;              // registers 4 g .. 4 g + 3: keys key0 .. key0 + 3
+        float p4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p4[j] = acc[kb][4 * g + j] * inv;
+        if (l < L) {
+          if (vec && key0 + 3 < S) {
+            *reinterpret_cast<float4*>(P + key0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (key0 + j < S) P[key0 + j] = p4[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const uint32_t i0 = dbase + (uint32_t)(key0 + j);
+          float m0, m1;
+          if ((i0 & 1u) == 0u) {
+            const uint32_t hh = drop_pair_hash(dkey, i0 >> 1);
+            m0 = drop_pair_lo(dkey, hh);
+            m1 = drop_pair_hi(dkey, hh);
+          } else {
+            m0 = drop_mul(dkey, i0);
+            m1 = drop_mul(dkey, i0 + 1);
+          }
+          p4[j] *= m0;
+          p4[j + 1] *= m1;
+        }
+        // O += (P . mask) V over these four keys: the tile's registers are the A operand, reduction index = key
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = li < AT_HD ? sv[(key0 + j) * AT_HP + li] : 0.f;
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4[j], b, o, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (li < hd) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lo = l0 + at_i(r, lh);
+      if (lo < L) out[((size_t)lo * N + n) * ((size_t)H * hd) + h * hd + li] = o[r];
+    }
+  }
+}
+static inline bool attn_t_ok(const float* q, const float* k, const float* v, int hd, long ldq, long ldk, long ldv) {
+  return hd == AT_HD && ((ldq | ldk | ldv) & 3) == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0;
+}
 static inline bool attn_use_mfma(int L, int S, int hd) {
   return hd <= AT_HD && (L > 64 || S > 64) && L <= 128 && S <= 128;
 }
@@ -659,6 +803,11 @@ extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, co
                               int mask_is_valid, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(q && k && v && out && probs && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
+  if (attn_use_mfma(L, S, hd) && attn_t_ok(q, k, v, hd, ldq, ldk, ldv)) {
+    hipLaunchKernelGGL(attn_t_fwd_kernel, dim3(N, H, (L + 31) / 32), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs,
+                       L, S, N, H, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
+    return mmvae_launch_status();
+  }
   if (attn_use_mfma(L, S, hd)) {
     hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, q, k, v, kpm, out, probs, L, S,
                        N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));

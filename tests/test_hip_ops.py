@@ -716,7 +716,7 @@ def test_attention(ops, L, N, E, H_):
     check(qg.grad, qr.grad, 5e-5, "attn dqkv")
 
 
-@pytest.mark.parametrize("L,N,E,H_,p", [(100, 9, 32, 2, 0.1), (128, 3, 32, 2, 0.3), (65, 4, 24, 2, 0.1), (70, 2, 16, 4, 0.2),
+@pytest.mark.parametrize("L,N,E,H_,p", [(100, 9, 32, 2, 0.1), (128, 3, 32, 2, 0.3), (65, 4, 24, 2, 0.1), (70, 2, 16, 4, 0.2), (99, 3, 32, 2, 0.2), (67, 130, 32, 2, 0.1),
                                         (40, 5, 32, 2, 0.1), (100, 3, 64, 2, 0.1)])
 def test_attention_weight_dropout(ops, L, N, E, H_, p):
     """attention with dropout on the softmax weights (nn.MultiheadAttention(dropout=p), the action towers' train mode)
