@@ -105,6 +105,9 @@ int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1, const floa
 size_t mmvae_ffn32_wsplit_bytes(int FF);
 size_t mmvae_ffn32_rsplit_bytes(int M);
 int mmvae_ffn32_prep_weights(const float* w1, const float* w2, void* wsplit, int FF, mmvae_stream_t stream);
+/* ... of up to 16 layers (host arrays of n device pointers each) in ONE launch */
+int mmvae_ffn32_prep_weights_many(const float* const* w1, const float* const* w2, void* const* wsplit, int n, int FF,
+                                  mmvae_stream_t stream);
 int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const float* b1, const float* b2, float* y, int M, int FF,
                         const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_ffn32_bwd_b16(const float* x, const float* dy, const void* wsplit, const float* b1, float* dx, float* ws,

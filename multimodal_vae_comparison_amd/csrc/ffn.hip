@@ -286,13 +286,23 @@ extern "C" int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1,
 // ---- the same three launches on split-bf16 MFMA (ffn_b16.inc) ---------------------------------------------------------
 extern "C" size_t mmvae_ffn32_wsplit_bytes(int FF) { return (size_t)4 * 3 * FFN_D * 2 * (size_t)FF; }
 extern "C" size_t mmvae_ffn32_rsplit_bytes(int M) { return (size_t)4 * 3 * FFN_D * 2 * (size_t)((M + 31) / 32 * 32); }
-extern "C" int mmvae_ffn32_prep_weights(const float* w1, const float* w2, void* wsplit, int FF, mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(w1 && w2 && wsplit);
+extern "C" int mmvae_ffn32_prep_weights_many(const float* const* w1, const float* const* w2, void* const* wsplit, int n,
+                                             int FF, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(w1 && w2 && wsplit && n > 0 && n <= FFN_PREP_MAX);
   if (!mmvae_ffn32_supported(FFN_D, FF)) return MMVAE_ERR_UNSUPPORTED;
-  if (!ffn_al16(wsplit)) return MMVAE_ERR_ARG;
-  hipLaunchKernelGGL(ffn32_prep_weights_kernel, dim3((16 * FF + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2,
-                     (unsigned short*)wsplit, FF);
+  FfnPrepJobs jobs;
+  for (int i = 0; i < FFN_PREP_MAX; ++i) {
+    const int j = i < n ? i : 0;
+    MMVAE_CHECK_ARG(w1[j] && w2[j] && wsplit[j] && ffn_al16(wsplit[j]));
+    jobs.w1[i] = w1[j];
+    jobs.w2[i] = w2[j];
+    jobs.out[i] = (unsigned short*)wsplit[j];
+  }
+  hipLaunchKernelGGL(ffn32_prep_weights_kernel, dim3((16 * FF + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, jobs, FF);
   return mmvae_launch_status();
+}
+extern "C" int mmvae_ffn32_prep_weights(const float* w1, const float* w2, void* wsplit, int FF, mmvae_stream_t stream) {
+  return mmvae_ffn32_prep_weights_many(&w1, &w2, &wsplit, 1, FF, stream);
 }
 extern "C" int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const float* b1, const float* b2, float* y, int M,
                                    int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream) {

@@ -216,6 +216,7 @@ SIGNATURES = {
     "mmvae_ffn32_wsplit_bytes": (c_sz, [c_i]),
     "mmvae_ffn32_rsplit_bytes": (c_sz, [c_i]),
     "mmvae_ffn32_prep_weights": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "mmvae_ffn32_prep_weights_many": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "mmvae_ffn32_fwd_b16": (c_i, [c_p] * 5 + [c_i, c_i, c_p, c_p]),
     "mmvae_ffn32_bwd_b16": (c_i, [c_p] * 7 + [c_i, c_i, c_p, c_p]),
     "mmvae_adam_fold_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_p, c_f, c_i] + [c_p] * 4 + [c_i, c_i, c_i, c_p]),

@@ -115,7 +115,7 @@ class HipTransformerDecoderLayer(nn.Module):
                                  {k: v.grad for k, v in p.items()})
         fused_ffn = encoders.FUSED_FFN and x.is_cuda and ops.ffn32_supported(d, ff)
         ffn = lambda t, drop: ops.ffn32(t, self.linear1.weight, self.linear1.bias, self.linear2.weight,
-                                        self.linear2.bias, drop)
+                                        self.linear2.bias, drop, encoders.stack_ffn_image(self))
         if ds is None:
             x = self.norm1(self.self_attn(x, mask_u8), x)
             x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
@@ -134,6 +134,7 @@ class HipTransformerDecoderStack(nn.Module):
     def __init__(self, layers):
         super().__init__()
         self.layers = nn.ModuleList(layers)
+        encoders.link_ffn_stack(self.layers)
 
 
 class Dec_TxtTransformer(VaeDecoder):

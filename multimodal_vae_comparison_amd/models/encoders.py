@@ -328,13 +328,38 @@ class HipTransformerEncoderLayer(nn.Module):
         return self.norm2(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop2"])
 
     def _ffn(self, x, drop):
-        return ops.ffn32(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop)
+        return ops.ffn32(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop,
+                         stack_ffn_image(self))
+
+
+def stack_ffn_image(layer):
+    """The split-bf16 weight image of this layer's feed-forward block (ops.ffn32's `wsplit`): the FIRST layer of a stack
+    prepares the images of all its layers in one launch (ops.ffn32_prep_many), the others pick theirs up -- every layer
+    splitting its own weights is one 5 us launch per layer on the tower's chain.  None: ops.Ffn32 makes its own."""
+    stack, idx = getattr(layer, "_ffn_stack", (None, 0))
+    if stack is None or not ops.FFN32_SPLIT_BF16 or len(stack) > 16:
+        return None
+    if idx == 0:
+        stack[0]._ffn_images = ops.ffn32_prep_many([(l.linear1.weight, l.linear2.weight) for l in stack])
+    imgs = getattr(stack[0], "_ffn_images", None)
+    if imgs is None:
+        return None
+    img = imgs[idx]
+    if idx == len(stack) - 1:
+        stack[0]._ffn_images = None        # (a forward that stops early keeps the list until the next first layer's call)
+    return img
+
+
+def link_ffn_stack(layers):
+    for i, l in enumerate(layers):
+        object.__setattr__(l, "_ffn_stack", (list(layers), i))      # (not a submodule registration)
 
 
 class HipTransformerStack(nn.Module):
     def __init__(self, layers):
         super().__init__()
         self.layers = nn.ModuleList(layers)
+        link_ffn_stack(self.layers)
 
 
 class Enc_TxtTransformer(VaeEncoder):

@@ -2278,15 +2278,18 @@ class Ffn32(Function):
     w2 (32,FF), b2 (32); drop: DropSpec of the hidden dropout or None; g*: the parameters' flat gradient views."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2):
+    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2, wsplit=None):
         x = H.f32c(x)
         M, FF = x.numel() // 32, w1.shape[0]
         y = torch.empty_like(x)
-        wsplit = None
+        if not FFN32_SPLIT_BF16:
+            wsplit = None
         if FFN32_SPLIT_BF16:
-            # the weights' three-term bf16 image, made once per call and shared by the three launches (csrc/ffn_b16.inc)
-            wsplit = torch.empty(H.lib().mmvae_ffn32_wsplit_bytes(FF), dtype=torch.uint8, device=x.device)
-            _call("mmvae_ffn32_prep_weights", H.ptr(w1), H.ptr(w2), H.ptr(wsplit), FF, H.stream())
+            # the weights' three-term bf16 image, shared by the three launches (csrc/ffn_b16.inc): the caller's (one launch
+            # for all layers of a tower: ffn32_prep_many), else made here
+            if wsplit is None:
+                wsplit = torch.empty(H.lib().mmvae_ffn32_wsplit_bytes(FF), dtype=torch.uint8, device=x.device)
+                _call("mmvae_ffn32_prep_weights", H.ptr(w1), H.ptr(w2), H.ptr(wsplit), FF, H.stream())
             _call("mmvae_ffn32_fwd_b16", H.ptr(x), H.ptr(wsplit), H.ptr(b1), H.ptr(b2), H.ptr(y), M, FF,
                   _dp(drop, M * FF), H.stream())
         else:
@@ -2352,7 +2355,7 @@ class Ffn32(Function):
                 dst, acc, ret = _new_like_param(like, g)
                 _call("mmvae_reduce_rows", H.ptr(ws) + 4 * o, H.ptr(dst), parts, ln, rowlen, acc, H.stream())
                 rets[i] = ret
-        return (dx, *rets, None, None, None, None, None)
+        return (dx, *rets, None, None, None, None, None, None)
 
 
 # the fused feed-forward launches on split-bf16 MFMA (csrc/ffn_b16.inc) instead of fp32 MFMA (csrc/ffn.hip); both are tested
@@ -2365,8 +2368,22 @@ def ffn32_supported(d, ff):
     return bool(H.lib().mmvae_ffn32_supported(int(d), int(ff)))
 
 
-def ffn32(x, w1, b1, w2, b2, drop=None):
-    return Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad)
+def ffn32(x, w1, b1, w2, b2, drop=None, wsplit=None):
+    return Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad, wsplit)
+
+
+def ffn32_prep_many(pairs):
+    """split-bf16 weight images of several feed-forward blocks [(w1, w2), ...] (same FF, <= 16) in ONE launch; returns one
+    uint8 tensor per block for `ffn32(..., wsplit=)`.  None when the fp32 core is selected."""
+    if not FFN32_SPLIT_BF16 or not pairs:
+        return None
+    FF, n, dev = pairs[0][0].shape[0], len(pairs), pairs[0][0].device
+    nb = H.lib().mmvae_ffn32_wsplit_bytes(FF)
+    buf = torch.empty(n, nb, dtype=torch.uint8, device=dev)
+    arr = ctypes.c_void_p * n
+    _call("mmvae_ffn32_prep_weights_many", arr(*[w1.data_ptr() for w1, _ in pairs]), arr(*[w2.data_ptr() for _, w2 in pairs]),
+          arr(*[buf[i].data_ptr() for i in range(n)]), n, FF, H.stream())
+    return [buf[i] for i in range(n)]
 
 
 def dropout_act(x, act, drop):
