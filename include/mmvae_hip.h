@@ -46,7 +46,8 @@ enum {
   MMVAE_EP_GELU = 4,          /* y = gelu(acc + bias); aux (if non-null) RECEIVES acc + bias        */
   MMVAE_EP_MUL_GELU_GRAD = 5, /* y = acc * gelu'(aux)                                              */
   MMVAE_EP_SIGMOID_CLAMP = 6, /* y = clamp(sigmoid(acc + bias), 1e-6, 1 - 1e-6)  (Dec_CNN, decoders.py:96-97) */
-  MMVAE_EP_SIGMOID = 7        /* y = sigmoid(acc + bias)                          (Dec_SVHN, decoders.py:144) */
+  MMVAE_EP_SIGMOID = 7,       /* y = sigmoid(acc + bias)                          (Dec_SVHN, decoders.py:144) */
+  MMVAE_EP_ADD_AUX = 8        /* y = acc + bias + aux   (dgrad of a sub-layer's first op + the residual branch's gradient) */
 };
 
 /* Inverted dropout (train mode of the text towers: nn.Dropout(0.1) in PositionalEncoding and in every
@@ -101,7 +102,8 @@ int mmvae_ffn32_bwd(const float* x, const float* dy, const float* w1, const floa
  * product, fp32 accumulation: the contract of the fp32 kernels above to ~3e-7 of the tensor maximum).  The weights are
  * split ONCE per step into wsplit (mmvae_ffn32_wsplit_bytes(FF) bytes, 16-byte aligned; mmvae_ffn32_prep_weights) and
  * that image replaces w1 / w2 in the calls; the weight-gradient launch also needs rsplit (mmvae_ffn32_rsplit_bytes(M)
- * bytes of scratch, written and read by that call in stream order).  Same partial-row layout in ws, same dropout mask. */
+ * bytes of scratch, written and read by that call in stream order).  Same partial-row layout in ws, same dropout mask.
+ * dx_add (M,32) or NULL is added to dx (the gradient of the residual connection around the block). */
 size_t mmvae_ffn32_wsplit_bytes(int FF);
 size_t mmvae_ffn32_rsplit_bytes(int M);
 int mmvae_ffn32_prep_weights(const float* w1, const float* w2, void* wsplit, int FF, mmvae_stream_t stream);
@@ -111,7 +113,8 @@ int mmvae_ffn32_prep_weights_many(const float* const* w1, const float* const* w2
 int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const float* b1, const float* b2, float* y, int M, int FF,
                         const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_ffn32_bwd_b16(const float* x, const float* dy, const void* wsplit, const float* b1, float* dx, float* ws,
-                        void* rsplit, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+                        void* rsplit, const float* dx_add, int M, int FF, const mmvae_dropout_t* drop,
+                        mmvae_stream_t stream);
 
 int mmvae_version(void);
 const char* mmvae_arch(void); /* "gfx950" */

@@ -51,11 +51,12 @@ __device__ __forceinline__ float apply_epilogue(float v, float aux_v, int ep) {
     case MMVAE_EP_MUL_GELU_GRAD: return v * dev_gelu_grad(aux_v);
     case MMVAE_EP_SIGMOID_CLAMP: return fminf(fmaxf(dev_sigmoid(v), 1e-6f), 1.0f - 1e-6f);
     case MMVAE_EP_SIGMOID: return dev_sigmoid(v);
+    case MMVAE_EP_ADD_AUX: return v + aux_v;
     default: return v;
   }
 }
 __host__ __device__ __forceinline__ bool ep_reads_aux(int ep) {
-  return ep == MMVAE_EP_MUL_RELU_MASK || ep == MMVAE_EP_MUL_SILU_GRAD || ep == MMVAE_EP_MUL_GELU_GRAD;
+  return ep == MMVAE_EP_MUL_RELU_MASK || ep == MMVAE_EP_MUL_SILU_GRAD || ep == MMVAE_EP_MUL_GELU_GRAD || ep == MMVAE_EP_ADD_AUX;
 }
 
 // ---- counter-based dropout -----------------------------------------------------------------------------

@@ -81,7 +81,8 @@ __device__ __forceinline__ int ffn_i(int r, int lh) { return 8 * (r >> 2) + 4 * 
 
 // sum of the 4 waves' 32 x 32 accumulators (register r <-> row ffn_i(r), lane li <-> column), + bias, -> out rows
 __device__ __forceinline__ void ffn_reduce_store(const f32x16& acc, float* __restrict__ red, int wave, int lane,
-                                                 float* __restrict__ out, int R0, int M, const float* __restrict__ bias) {
+                                                 float* __restrict__ out, int R0, int M, const float* __restrict__ bias,
+                                                 const float* __restrict__ add = nullptr) {
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
@@ -92,7 +93,7 @@ __device__ __forceinline__ void ffn_reduce_store(const f32x16& acc, float* __res
     const int r = 4 * wave + i;
     const float s = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
     const int row = R0 + ffn_i(r, lh);
-    if (row < M) out[(size_t)row * FFN_D + li] = s + b;
+    if (row < M) out[(size_t)row * FFN_D + li] = s + b + (add ? add[(size_t)row * FFN_D + li] : 0.f);
   }
 }
 
@@ -316,13 +317,14 @@ extern "C" int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const flo
 // as mmvae_ffn32_bwd; rsplit (mmvae_ffn32_rsplit_bytes(M) bytes, needed with ws) receives the split images of x and dy
 // that the weight-gradient launch reads -- scratch of THIS call, in stream order
 extern "C" int mmvae_ffn32_bwd_b16(const float* x, const float* dy, const void* wsplit, const float* b1, float* dx, float* ws,
-                                   void* rsplit, int M, int FF, const mmvae_dropout_t* drop, mmvae_stream_t stream) {
+                                   void* rsplit, const float* dx_add, int M, int FF, const mmvae_dropout_t* drop,
+                                   mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && dy && wsplit && b1 && (ws || dx) && (!ws || rsplit) && M > 0);
   if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
   if (!ffn_al16(x) || !ffn_al16(dy) || !ffn_al16(wsplit) || !ffn_al16(b1) || !ffn_al16(rsplit)) return MMVAE_ERR_ARG;
   const int S = ffn_slices(M, FF), Mpad = (M + 31) / 32 * 32;
   int rps = ((M + S - 1) / S + 31) / 32 * 32;
-  FfnB16Args a{x, dy, b1, nullptr, (const unsigned short*)wsplit, (const unsigned short*)rsplit, nullptr, dx, ws, M, Mpad, FF,
+  FfnB16Args a{x, dy, b1, dx_add, (const unsigned short*)wsplit, (const unsigned short*)rsplit, nullptr, dx, ws, M, Mpad, FF,
                rps, (int)mmvae_ffn32_bwd_rowlen(FF), drop_arg(drop)};
   hipStream_t st = (hipStream_t)stream;
   if (dx) hipLaunchKernelGGL(ffn32_bwd_data_b16_kernel, dim3((M + 31) / 32), dim3(256), 0, st, a);

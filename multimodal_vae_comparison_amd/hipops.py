@@ -23,7 +23,7 @@ c_sz = ctypes.c_size_t
 MAX_EXPERTS = 8
 
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
-EP_NONE, EP_RELU, EP_MUL_RELU_MASK, EP_MUL_SILU_GRAD, EP_GELU, EP_MUL_GELU_GRAD, EP_SIGMOID_CLAMP, EP_SIGMOID = range(8)
+EP_NONE, EP_RELU, EP_MUL_RELU_MASK, EP_MUL_SILU_GRAD, EP_GELU, EP_MUL_GELU_GRAD, EP_SIGMOID_CLAMP, EP_SIGMOID, EP_ADD_AUX = range(9)
 
 _ERR = {1: "invalid argument", 2: "unsupported shape", 3: "kernel launch failed"}
 
@@ -218,7 +218,7 @@ SIGNATURES = {
     "mmvae_ffn32_prep_weights": (c_i, [c_p, c_p, c_p, c_i, c_p]),
     "mmvae_ffn32_prep_weights_many": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "mmvae_ffn32_fwd_b16": (c_i, [c_p] * 5 + [c_i, c_i, c_p, c_p]),
-    "mmvae_ffn32_bwd_b16": (c_i, [c_p] * 7 + [c_i, c_i, c_p, c_p]),
+    "mmvae_ffn32_bwd_b16": (c_i, [c_p] * 8 + [c_i, c_i, c_p, c_p]),
     "mmvae_adam_fold_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_p, c_f, c_i] + [c_p] * 4 + [c_i, c_i, c_i, c_p]),
     "mmvae_normal_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_normal_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),

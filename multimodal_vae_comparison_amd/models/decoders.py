@@ -114,18 +114,24 @@ class HipTransformerDecoderLayer(nn.Module):
             return ops.txt_layer(x, mem, mask_u8, ops.TxtLayerMeta(d, ff, nh, True, ds), p,
                                  {k: v.grad for k, v in p.items()})
         fused_ffn = encoders.FUSED_FFN and x.is_cuda and ops.ffn32_supported(d, ff)
-        ffn = lambda t, drop: ops.ffn32(t, self.linear1.weight, self.linear1.bias, self.linear2.weight,
-                                        self.linear2.bias, drop, encoders.stack_ffn_image(self))
+        ffn = lambda t, drop, sink: ops.ffn32(t, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                              self.linear2.bias, drop, encoders.stack_ffn_image(self), sink)
+        # residual gradients of the self-attention and feed-forward blocks join those blocks' first backward kernels
+        s1 = ops.residual_sink(x)
         if ds is None:
-            x = self.norm1(self.self_attn(x, mask_u8), x)
+            x = self.norm1(self.self_attn(x, mask_u8, res_sink=s1), x, res_sink=s1)
             x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
-            return self.norm3(ffn(x, None) if fused_ffn else self.linear2(self.linear1(x)), x)
+            if fused_ffn:
+                s3 = ops.residual_sink(x)
+                return self.norm3(ffn(x, None, s3), x, res_sink=s3)
+            return self.norm3(self.linear2(self.linear1(x)), x)
         L = x.shape[0]
-        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"]), x, ds["drop1"])
+        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1), x, ds["drop1"], res_sink=s1)
         ca = self.multihead_attn.value_path(mem, L, ds["xattn"])          # (L,N,d): weight dropout varies with l
         x = self.norm2(ca, x, ds["drop2"])
         if fused_ffn:
-            return self.norm3(ffn(x, ds["ffn"]), x, ds["drop3"])
+            s3 = ops.residual_sink(x)
+            return self.norm3(ffn(x, ds["ffn"], s3), x, ds["drop3"], res_sink=s3)
         h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])
         return self.norm3(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop3"])
 

@@ -316,20 +316,24 @@ class HipTransformerEncoderLayer(nn.Module):
         if time_mean:
             return ops.mean_over_time(self.forward(x, mask_u8, ds))
         fused_ffn = FUSED_FFN and x.is_cuda and ops.ffn32_supported(d, ff)
+        # the gradients of the two residual connections join their sub-layers' first backward kernels (ops.ResidualGrad)
+        s1 = ops.residual_sink(x)
         if ds is None:
-            x = self.norm1(self.self_attn(x, mask_u8), x)
+            x = self.norm1(self.self_attn(x, mask_u8, res_sink=s1), x, res_sink=s1)
             if fused_ffn:
-                return self.norm2(self._ffn(x, None), x)
+                s2 = ops.residual_sink(x)
+                return self.norm2(self._ffn(x, None, s2), x, res_sink=s2)
             return self.norm2(self.linear2(self.linear1(x)), x)
-        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"]), x, ds["drop1"])
+        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1), x, ds["drop1"], res_sink=s1)
         if fused_ffn:      # the (L*N, ff) hidden activation never leaves the registers (csrc/ffn.hip)
-            return self.norm2(self._ffn(x, ds["ffn"]), x, ds["drop2"])
+            s2 = ops.residual_sink(x)
+            return self.norm2(self._ffn(x, ds["ffn"], s2), x, ds["drop2"], res_sink=s2)
         h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])           # dropout(gelu(.)) materialised
         return self.norm2(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop2"])
 
-    def _ffn(self, x, drop):
+    def _ffn(self, x, drop, res_sink=None):
         return ops.ffn32(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop,
-                         stack_ffn_image(self))
+                         stack_ffn_image(self), res_sink)
 
 
 def stack_ffn_image(layer):

@@ -124,12 +124,12 @@ class HipLayerNorm(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x, residual=None, drop=None):
-        """LayerNorm(dropout(x) + residual)"""
+    def forward(self, x, residual=None, drop=None, res_sink=None):
+        """LayerNorm(dropout(x) + residual); res_sink: ops.ResidualGrad shared with the op that made x from `residual`"""
         gg, gb = self.weight.grad, self.bias.grad
         if gg is not None and gb is not None and gb.data_ptr() != gg.data_ptr() + 4 * gg.numel():
             gg = gb = None      # not laid out adjacently: let autograd accumulate
-        return ops.layernorm_residual(x, residual, self.weight, self.bias, gg, gb, drop)
+        return ops.layernorm_residual(x, residual, self.weight, self.bias, gg, gb, drop, res_sink)
 
 
 class HipSelfAttention(nn.Module):
@@ -149,10 +149,11 @@ class HipSelfAttention(nn.Module):
     def flat_groups(self):
         return [[self.in_proj_weight, self.in_proj_bias]]
 
-    def forward(self, x, mask_u8, drop=None):
-        """mask_u8: (N, L) validity bytes (1 = real token); padded keys are ignored; `drop`: attention-weight dropout"""
+    def forward(self, x, mask_u8, drop=None, res_sink=None):
+        """mask_u8: (N, L) validity bytes (1 = real token); padded keys are ignored; `drop`: attention-weight dropout;
+        res_sink: ops.ResidualGrad of the residual connection around this block (its gradient joins the in-projection's)"""
         qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, H.ACT_NONE, self.in_proj_weight.grad,
-                         self.in_proj_bias.grad)
+                         self.in_proj_bias.grad, res_sink=res_sink)
         a = ops.attention(qkv, mask_u8, self.nhead, mask_is_valid=True, drop=drop)
         return self.out_proj(a)
 

@@ -770,13 +770,40 @@ def bce_sigmoid_rowsum(y_raw, target):
 # ----------------------------------------------------------------------------------------------
 # dense
 # ----------------------------------------------------------------------------------------------
+# y = norm(sub(x) + x): hand the residual branch's gradient to the sub-layer's first backward kernel (below)
+RESIDUAL_HANDOFF = True
+
+
+class ResidualGrad:
+    """Side channel for the gradient of a residual connection y = LayerNorm(sub(x) + x).  Autograd would return the
+    LayerNorm's residual gradient and the sub-layer's input gradient separately and add them in an elementwise launch of
+    its own (24 per step of the trimodal workload).  Instead the LayerNorm's backward -- which runs first: the sub-layer
+    feeds it -- leaves its residual gradient HERE and returns nothing for that input, and the backward of the sub-layer's
+    FIRST op on x (ops.Linear: the attention in-projection; ops.Ffn32) adds it in its kernel's epilogue and returns the
+    sum: the same gradient for x.  One object per residual connection, passed to both ops."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+def residual_sink(x):
+    """a ResidualGrad for a residual connection around x, or None when nothing is differentiated / the switch is off"""
+    return ResidualGrad() if (RESIDUAL_HANDOFF and torch.is_grad_enabled() and x.requires_grad and x.is_cuda) else None
+
+
 class Linear(Function):
     """y = act(x) W^T + b over the last dim   [nn.Linear / MHA projections / FFN]"""
 
     @staticmethod
-    def forward(ctx, x, w, b, in_act, gw, gb, out_ep=H.EP_NONE):
+    def forward(ctx, x, w, b, in_act, gw, gb, out_ep=H.EP_NONE, res_sink=None):
         """out_ep: EP_NONE, or EP_SIGMOID -- y = sigmoid(.) in the GEMM's epilogue; the incoming gradient is then
-        taken as the gradient of the LOGITS (wrap the output in ops.sigmoid_out, see SigmoidOut)"""
+        taken as the gradient of the LOGITS (wrap the output in ops.sigmoid_out, see SigmoidOut).  res_sink: ResidualGrad"""
+        ctx.res_sink = res_sink
         x = H.f32c(x)
         K = x.shape[-1]
         M = x.numel() // K
@@ -810,6 +837,9 @@ class Linear(Function):
         dx = torch.empty_like(x) if need_dx else None
         ep = _DACT[in_act]
         aux = H.ptr(x) if ep else None
+        radd = ctx.res_sink.take() if ctx.res_sink is not None else None      # the residual branch's gradient of x
+        if radd is not None and need_dx and not ep and radd.is_contiguous() and radd.numel() == x.numel():
+            ep, aux, radd = H.EP_ADD_AUX, H.ptr(radd), None                    # ... added in the data gradient's epilogue
         defer = _defer(gw, gb if has_b else gw)
         nz = lib.mmvae_linear_bwd_splits(M, N, K) if need_dx else lib.mmvae_linear_bwd_weight_splits(M, N, K)
         if defer:
@@ -829,11 +859,13 @@ class Linear(Function):
             GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
             if db is not None:
                 GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
-        return dx, ret_w, ret_b, None, None, None, None
+        if radd is not None and dx is not None:
+            dx = dx + radd.view_as(dx)
+        return dx, ret_w, ret_b, None, None, None, None, None
 
 
-def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None, out_ep=H.EP_NONE):
-    return Linear.apply(x, w, b, in_act, gw, gb, out_ep)
+def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None, out_ep=H.EP_NONE, res_sink=None):
+    return Linear.apply(x, w, b, in_act, gw, gb, out_ep, res_sink)
 
 
 class SigmoidOut(Function):
@@ -2106,7 +2138,7 @@ class LayerNormResidual(Function):
     """y = LayerNorm(x + r); r None, same shape, or (N,d) broadcast over the leading (time) axis"""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, gg, gb, drop):
+    def forward(ctx, x, r, gamma, beta, gg, gb, drop, res_sink=None):
         x = H.f32c(x)
         d = x.shape[-1]
         rows = x.numel() // d
@@ -2122,6 +2154,7 @@ class LayerNormResidual(Function):
               H.ptr(rstd), rows, d, r_rows, _dp(drop, x.numel()), H.stream())
         ctx.save_for_backward(xhat, rstd, gamma)
         ctx.cfg = (gg, gb, r is not None, r_rows, tuple(x.shape), tuple(r.shape) if r is not None else None, drop)
+        ctx.res_sink = res_sink if (r is not None and r_rows == 0) else None
         return y
 
     @staticmethod
@@ -2157,10 +2190,12 @@ class LayerNormResidual(Function):
             if r_rows:
                 dr = torch.empty(rshape, device=dy.device)
                 _call("mmvae_sum_over_time", H.ptr(dsum), H.ptr(dr), rows // r_rows, r_rows, d, H.stream())
+            elif ctx.res_sink is not None:
+                ctx.res_sink.grad = dsum          # picked up by the sub-layer's first backward (ResidualGrad)
             else:
                 dr = dsum
         dx = dxd if drop is not None else dsum
-        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None, None
 
 
 class MeanOverTime(Function):
@@ -2221,9 +2256,9 @@ def as_u8(mask):
     return mask.to(torch.uint8).contiguous()
 
 
-def layernorm_residual(x, r, gamma, beta, gg=None, gb=None, drop=None):
-    """LayerNorm(dropout(x) + r)"""
-    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop)
+def layernorm_residual(x, r, gamma, beta, gg=None, gb=None, drop=None, res_sink=None):
+    """LayerNorm(dropout(x) + r); res_sink: the ResidualGrad that the op producing x from r also holds"""
+    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop, res_sink)
 
 
 class DropoutAct(Function):
@@ -2278,7 +2313,8 @@ class Ffn32(Function):
     w2 (32,FF), b2 (32); drop: DropSpec of the hidden dropout or None; g*: the parameters' flat gradient views."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2, wsplit=None):
+    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2, wsplit=None, res_sink=None):
+        ctx.res_sink = res_sink
         x = H.f32c(x)
         M, FF = x.numel() // 32, w1.shape[0]
         y = torch.empty_like(x)
@@ -2315,12 +2351,18 @@ class Ffn32(Function):
         other = StreamPlan.other_stream(x.device) if (dx is not None and defer and M * FF >= (1 << 20)
                                                       and FFN32_WGRAD_OTHER_STREAM) else None
         wsplit = ctx.wsplit
+        radd = ctx.res_sink.take() if ctx.res_sink is not None else None      # the residual branch's gradient of x
+        if dx is None:
+            radd = None
+        kadd = None                                                            # ... added by the data-gradient kernel
         if wsplit is not None:
             rsplit = torch.empty(lib.mmvae_ffn32_rsplit_bytes(M), dtype=torch.uint8, device=x.device)
+            if radd is not None and radd.is_contiguous() and radd.numel() == x.numel():
+                kadd, radd = radd, None
 
             def bwd(dx_, ws_):
-                _call("mmvae_ffn32_bwd_b16", H.ptr(x), H.ptr(dy), H.ptr(wsplit), H.ptr(b1), H.ptr(dx_) if dx_ is not None else None,
-                      H.ptr(ws_) if ws_ is not None else None, H.ptr(rsplit), M, FF, dc, H.stream())
+                _call("mmvae_ffn32_bwd_b16", H.ptr(x), H.ptr(dy), H.ptr(wsplit), H.ptr(b1), H.ptr(dx_), H.ptr(ws_), H.ptr(rsplit),
+                      H.ptr(kadd) if dx_ is not None else None, M, FF, dc, H.stream())
         else:
             rsplit = None
 
@@ -2355,7 +2397,9 @@ class Ffn32(Function):
                 dst, acc, ret = _new_like_param(like, g)
                 _call("mmvae_reduce_rows", H.ptr(ws) + 4 * o, H.ptr(dst), parts, ln, rowlen, acc, H.stream())
                 rets[i] = ret
-        return (dx, *rets, None, None, None, None, None, None)
+        if radd is not None and dx is not None:
+            dx = dx + radd.view_as(dx)
+        return (dx, *rets, None, None, None, None, None, None, None)
 
 
 # the fused feed-forward launches on split-bf16 MFMA (csrc/ffn_b16.inc) instead of fp32 MFMA (csrc/ffn.hip); both are tested
@@ -2368,8 +2412,8 @@ def ffn32_supported(d, ff):
     return bool(H.lib().mmvae_ffn32_supported(int(d), int(ff)))
 
 
-def ffn32(x, w1, b1, w2, b2, drop=None, wsplit=None):
-    return Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad, wsplit)
+def ffn32(x, w1, b1, w2, b2, drop=None, wsplit=None, res_sink=None):
+    return Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad, wsplit, res_sink)
 
 
 def ffn32_prep_many(pairs):

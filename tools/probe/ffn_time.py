@@ -26,8 +26,8 @@ for name, d in (("dropout 0.1", spec.c()), ("no dropout", None)):
     bw = lambda: L.mmvae_ffn32_bwd(P(x), P(dy), P(w1), P(b1), P(w2), None, P(ws), M, FF, d, s())
     pw = lambda: L.mmvae_ffn32_prep_weights(P(w1), P(w2), P(wsplit), FF, s())
     f16 = lambda: L.mmvae_ffn32_fwd_b16(P(x), P(wsplit), P(b1), P(b2), P(y), M, FF, d, s())
-    bd16 = lambda: L.mmvae_ffn32_bwd_b16(P(x), P(dy), P(wsplit), P(b1), P(dx), None, P(rsplit), M, FF, d, s())
-    bw16 = lambda: L.mmvae_ffn32_bwd_b16(P(x), P(dy), P(wsplit), P(b1), None, P(ws), P(rsplit), M, FF, d, s())
+    bd16 = lambda: L.mmvae_ffn32_bwd_b16(P(x), P(dy), P(wsplit), P(b1), P(dx), None, P(rsplit), None, M, FF, d, s())
+    bw16 = lambda: L.mmvae_ffn32_bwd_b16(P(x), P(dy), P(wsplit), P(b1), None, P(ws), P(rsplit), None, M, FF, d, s())
     pw()
     t = [timeit(k) for k in (f, bd, bw, pw, f16, bd16, bw16)]
     fl = 2.0 * M * 32 * FF * 2
