@@ -348,8 +348,6 @@ __device__ __forceinline__ void rc_fwd_tail(const f32x16& acc, float* __restrict
 
 __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, float* __restrict__ smem, float* __restrict__ cs,
                                             int* __restrict__ lastp) {
-  float* As = smem;
-  float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
   const int n0 = k.bx * 64, m0 = k.by * RC_BM;
   RcWave wv;
@@ -364,7 +362,10 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   const int k4 = (tid & 7) * 4, r0 = tid >> 3;
   const bool ident = a.T == 1 && a.g.S == 1;
   int pix[NR], hw[NR], src[NR], wrow[NR];
-  float4 ra[NR], rb[NR];
+  // Round 5: TWO register sets -- the loads of stage s + 2 are issued while stage s is multiplied and stage s + 1 waits in
+  // the other set (stamps at batch 24: 1.35 us per 32-deep stage against 0.43 us of MFMA with one stage in flight; a
+  // launch there is 6-9 stages per workgroup).  The loop is unrolled by two so that the set of every access is static.
+  float4 ra[2][NR], rb[2][NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int r = m0 + r0 + 32 * i;
@@ -380,14 +381,16 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       hw[i] = r < a.M ? ((h0 + 0x4000) << 16 | (w0 + 0x4000)) : -1;
     }
   }
-  float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned oka = 0;
+  float4 pm[2], ps[2], pb[2];
+  pm[0] = pm[1] = pb[0] = pb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  ps[0] = ps[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+  unsigned oka[2] = {0u, 0u};
   // this workgroup's share of the T * Cin / 32 stages (blockIdx.z of nz)
   const int spc = a.Cin / RC_BK, nstage_all = a.T * spc, sper = (nstage_all + a.nz - 1) / a.nz;
   const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
   int ltap = s_beg / spc, lc0 = (s_beg - ltap * spc) * RC_BK;
   bool newtap = true;
-  auto load = [&]() {
+  auto load = [&](const int st) {
     if (newtap) {
       const int kh = ltap / a.g.KW, kw = ltap - kh * a.g.KW;
 #pragma unroll
@@ -404,31 +407,32 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     }
     const int c = lc0 + k4;
     if (a.pre == RC_PRE_BN_RELU) {
-      pm = *reinterpret_cast<const float4*>(a.xmean + c);
-      ps = *reinterpret_cast<const float4*>(a.xsc + c);
-      pb = *reinterpret_cast<const float4*>(a.xbeta + c);
+      pm[st] = *reinterpret_cast<const float4*>(a.xmean + c);
+      ps[st] = *reinterpret_cast<const float4*>(a.xsc + c);
+      pb[st] = *reinterpret_cast<const float4*>(a.xbeta + c);
     }
-    oka = 0;
+    oka[st] = 0;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const bool ok = src[i] >= 0;
-      oka |= (ok ? 1u : 0u) << i;
-      ra[i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)src[i] * a.Cin + c : 0));
+      oka[st] |= (ok ? 1u : 0u) << i;
+      ra[st][i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)src[i] * a.Cin + c : 0));
     }
 #pragma unroll
-    for (int i = 0; i < NR; ++i) rb[i] = *reinterpret_cast<const float4*>(a.w + (size_t)(wrow[i] + ltap) * a.Cin + c);
+    for (int i = 0; i < NR; ++i) rb[st][i] = *reinterpret_cast<const float4*>(a.w + (size_t)(wrow[i] + ltap) * a.Cin + c);
     lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
-  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
+  auto store = [&](const int st, float* __restrict__ As_, float* __restrict__ Bs_) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-      const float m4[4] = {pm.x, pm.y, pm.z, pm.w}, s4[4] = {ps.x, ps.y, ps.z, ps.w}, b4[4] = {pb.x, pb.y, pb.z, pb.w};
-      const bool ok = oka >> i & 1u;
+      float v[4] = {ra[st][i].x, ra[st][i].y, ra[st][i].z, ra[st][i].w};
+      const float m4[4] = {pm[st].x, pm[st].y, pm[st].z, pm[st].w}, s4[4] = {ps[st].x, ps[st].y, ps[st].z, ps[st].w};
+      const float b4[4] = {pb[st].x, pb[st].y, pb[st].z, pb[st].w};
+      const bool ok = oka[st] >> i & 1u;
       float* da = As_ + k4 * RC_AP + r0 + 32 * i;
       float* db = Bs_ + k4 * RC_AP + r0 + 32 * i;
-      const float w4[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+      const float w4[4] = {rb[st][i].x, rb[st][i].y, rb[st][i].z, rb[st][i].w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float t = v[q];
@@ -442,22 +446,25 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // two LDS stage buffers: the next stage is stored while the other waves still read the current one -- one barrier
-  // per stage, and a wave's staging arithmetic and LDS writes run under its own issued MFMAs
-  if (s_beg < s_end) {
-    load();
-    store(As, Bs);
-  }
+  // two LDS stage buffers (the next stage is stored while the other waves still read the current one: one barrier per
+  // stage) fed from the two register sets
+  float* const b0 = smem;
+  float* const b1 = smem + 2 * RC_BK * RC_AP;
+  if (s_beg < s_end) load(0);
+  if (s_beg + 1 < s_end) load(1);
+  if (s_beg < s_end) store(0, b0, b0 + RC_BK * RC_AP);
   __syncthreads();
-  int cur = 0;
 #pragma unroll 1
-  for (int s = s_beg; s < s_end; ++s) {
-    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
-    if (s + 1 < s_end) load();
-    wv.mma(As + o, Bs + o, acc);
-    if (s + 1 < s_end) store(As + on, Bs + on);
+  for (int s = s_beg; s < s_end; s += 2) {
+    if (s + 2 < s_end) load(0);
+    wv.mma(b0, b0 + RC_BK * RC_AP, acc);
+    if (s + 1 < s_end) store(1, b1, b1 + RC_BK * RC_AP);
     __syncthreads();
-    cur ^= 1;
+    if (s + 1 >= s_end) break;
+    if (s + 3 < s_end) load(1);
+    wv.mma(b1, b1 + RC_BK * RC_AP, acc);
+    if (s + 2 < s_end) store(0, b0, b0 + RC_BK * RC_AP);
+    __syncthreads();
   }
   const int cnt = min(RC_BM, a.M - m0);
   if (!rc_acc_reduce(acc, a.ws, a.tile_ticket + k.by * k.gx + k.bx, a.nz, k.bz, (size_t)a.M * a.Cout,
@@ -466,7 +473,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
   rc_fwd_tail(acc, a.y, a.M, a.Cout, a.bn, k, m0, n0, cnt, wv, smem, cs, lastp);
 }
 
-__global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a, int gx, int gy, int gz, int xcd) {
+__global__ __launch_bounds__(256, 3) void rc_fwd_kernel(RcFwdArgs a, int gx, int gy, int gz, int xcd) {
   __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
@@ -564,8 +571,6 @@ struct RcDgradArgs {
 
 __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk k, float* __restrict__ smem,
                                               float* __restrict__ cs, int* __restrict__ lastp) {
-  float* As = smem;
-  float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
   // Stride 2 (row_map): an input pixel (ih, iw) is read through tap (kh, kw) only when ih + P - kh and iw + P - kw are
   // even, i.e. through 1, 2, 2 or 4 of a 3 x 3 filter's taps depending on the parities of (ih, iw).  Walking the pixels in
@@ -591,7 +596,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   // tap (kh, kw) is ((ih + P - kh) / S, (iw + P - kw) / S) when both divide and lie inside
   const bool ident = a.T == 1 && a.g.S == 1;
   int pb_[NR], hw[NR], src[NR];
-  float4 rg_[NR], ry[NR], rb[NR];
+  float4 rg_[2][NR], ry[2][NR], rb[2][NR];        // two register sets: loads run two stages ahead (see rc_fwd_body)
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int rr = m0 + r0 + 32 * i;
@@ -606,14 +611,16 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       hw[i] = rr < rows_c ? ((ih + a.g.P) << 16 | (iw + a.g.P)) : -1;
     }
   }
-  float4 pp = make_float4(1.f, 1.f, 1.f, 1.f), pq = make_float4(0.f, 0.f, 0.f, 0.f), pr = pq;
-  unsigned oka = 0;
+  float4 pp[2], pq[2], pr[2];
+  pp[0] = pp[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+  pq[0] = pq[1] = pr[0] = pr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned oka[2] = {0u, 0u};
   int wtap = 0;           // the filter tap (kh KW + kw) of the stage being loaded
   const int spc = a.Cout / RC_BK, nstage_all = ntap * spc, sper = (nstage_all + a.nz - 1) / a.nz;
   const int s_beg = k.bz * sper, s_end = min(nstage_all, s_beg + sper);
   int ltap = s_beg / spc, lk0 = (s_beg - ltap * spc) * RC_BK;
   bool newtap = true;
-  auto load = [&]() {
+  auto load = [&](const int st) {
     if (newtap) {
       const int ta = ltap / nkw, tb = ltap - ta * nkw;
       const int kh = cls ? kh0 + 2 * ta : ta, kw = cls ? kw0 + 2 * tb : tb;
@@ -643,31 +650,33 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
     }
     const int kc = lk0 + k4;
     if (a.pqr) {
-      pp = *reinterpret_cast<const float4*>(a.pqr + kc);
-      pq = *reinterpret_cast<const float4*>(a.pqr + a.Cout + kc);
-      pr = *reinterpret_cast<const float4*>(a.pqr + 2 * a.Cout + kc);
+      pp[st] = *reinterpret_cast<const float4*>(a.pqr + kc);
+      pq[st] = *reinterpret_cast<const float4*>(a.pqr + a.Cout + kc);
+      pr[st] = *reinterpret_cast<const float4*>(a.pqr + 2 * a.Cout + kc);
     }
-    oka = 0;
+    oka[st] = 0;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const bool ok = src[i] >= 0;
-      oka |= (ok ? 1u : 0u) << i;
+      oka[st] |= (ok ? 1u : 0u) << i;
       const size_t o = ok ? (size_t)src[i] * a.Cout + kc : 0;
-      rg_[i] = *reinterpret_cast<const float4*>(a.G + o);
-      ry[i] = a.pqr ? *reinterpret_cast<const float4*>(a.Y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rg_[st][i] = *reinterpret_cast<const float4*>(a.G + o);
+      ry[st][i] = a.pqr ? *reinterpret_cast<const float4*>(a.Y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i)
-      rb[i] = *reinterpret_cast<const float4*>(a.w + ((size_t)(lk0 + kb + 16 * i) * a.T + wtap) * a.Cin + n0 + nb4);
+      rb[st][i] = *reinterpret_cast<const float4*>(a.w + ((size_t)(lk0 + kb + 16 * i) * a.T + wtap) * a.Cin + n0 + nb4);
     lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
-  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
+  auto store = [&](const int st, float* __restrict__ As_, float* __restrict__ Bs_) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const float g4[4] = {rg_[i].x, rg_[i].y, rg_[i].z, rg_[i].w}, y4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-      const float p4[4] = {pp.x, pp.y, pp.z, pp.w}, q4[4] = {pq.x, pq.y, pq.z, pq.w}, r4[4] = {pr.x, pr.y, pr.z, pr.w};
-      const bool ok = oka >> i & 1u;
+      const float g4[4] = {rg_[st][i].x, rg_[st][i].y, rg_[st][i].z, rg_[st][i].w};
+      const float y4[4] = {ry[st][i].x, ry[st][i].y, ry[st][i].z, ry[st][i].w};
+      const float p4[4] = {pp[st].x, pp[st].y, pp[st].z, pp[st].w}, q4[4] = {pq[st].x, pq[st].y, pq[st].z, pq[st].w};
+      const float r4[4] = {pr[st].x, pr[st].y, pr[st].z, pr[st].w};
+      const bool ok = oka[st] >> i & 1u;
       float* da = As_ + k4 * RC_AP + r0 + 32 * i;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -675,27 +684,32 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
         da[q * RC_AP] = ok ? v : 0.f;
       }
       float* db = Bs_ + (kb + 16 * i) * RC_AP + nb4;
-      db[0] = rb[i].x; db[1] = rb[i].y; db[2] = rb[i].z; db[3] = rb[i].w;
+      db[0] = rb[st][i].x; db[1] = rb[st][i].y; db[2] = rb[st][i].z; db[3] = rb[st][i].w;
     }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float* const b0 = smem;
+  float* const b1 = smem + 2 * RC_BK * RC_AP;
+  if (s_beg < s_end) load(0);
+  if (s_beg + 1 < s_end) load(1);
   if (s_beg < s_end) {
-    load();
     RC_STAMP_WAIT(k, 1);
-    store(As, Bs);
+    store(0, b0, b0 + RC_BK * RC_AP);
   }
   __syncthreads();
-  int cur = 0;
 #pragma unroll 1
-  for (int s = s_beg; s < s_end; ++s) {
-    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
-    if (s + 1 < s_end) load();
-    wv.mma(As + o, Bs + o, acc);
-    if (s + 1 < s_end) store(As + on, Bs + on);
+  for (int s = s_beg; s < s_end; s += 2) {
+    if (s + 2 < s_end) load(0);
+    wv.mma(b0, b0 + RC_BK * RC_AP, acc);
+    if (s + 1 < s_end) store(1, b1, b1 + RC_BK * RC_AP);
     __syncthreads();
-    cur ^= 1;
+    if (s + 1 >= s_end) break;
+    if (s + 3 < s_end) load(1);
+    wv.mma(b1, b1 + RC_BK * RC_AP, acc);
+    if (s + 2 < s_end) store(0, b0, b0 + RC_BK * RC_AP);
+    __syncthreads();
   }
   RC_STAMP(k, 2);
   const int cnt = min(RC_BM, rows_c - m0);
@@ -781,7 +795,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   RC_STAMP_WAIT(k, 6);
 }
 
-__global__ __launch_bounds__(256) void rc_dgrad_kernel(RcDgradArgs a, int gx, int gy, int gz, int xcd) {
+__global__ __launch_bounds__(256, 3) void rc_dgrad_kernel(RcDgradArgs a, int gx, int gy, int gz, int xcd) {
   __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
@@ -870,8 +884,6 @@ struct RcWgradArgs {
 
 __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk k, float* __restrict__ smem,
                                               float* __restrict__ cs, int* __restrict__ lastp) {
-  float* As = smem;
-  float* Bs = smem + RC_BK * RC_AP;
   const int tid = threadIdx.x;
   const int c0 = k.bx * 64, n0 = k.by * 64;
   const int tap = k.bz / a.nz, zi = k.bz - tap * a.nz;
@@ -883,9 +895,9 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   static_assert(RC_BK == 32, "float4 staging: 16 column quads x 16 rows per pass");
   constexpr int NR = 2;
   const int q4 = (tid & 15) * 4, kb = tid >> 4;
-  float4 rg_[NR], ry[NR], rb[NR];
+  float4 rg_[2][NR], ry[2][NR], rb[2][NR];    // two register sets: loads run two stages ahead (see rc_fwd_body)
   int sr[NR];                 // source rows of the stage being loaded next (one stage ahead of the data)
-  unsigned oka = 0, okb = 0;
+  unsigned oka[2] = {0u, 0u}, okb[2] = {0u, 0u};
   const int n = n0 + q4, c = c0 + q4;
   float4 pp = make_float4(1.f, 1.f, 1.f, 1.f), pq = make_float4(0.f, 0.f, 0.f, 0.f), pr = pq, pm = pq, ps = pp, pb = pq;
   if (a.pqr) {
@@ -906,34 +918,35 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
       sr[i] = m < kend ? (tb ? tb[m] : m) : -1;
     }
   };
-  auto load = [&](int k0) {
-    oka = 0;
-    okb = 0;
+  auto load = [&](const int st, int k0) {
+    oka[st] = 0;
+    okb[st] = 0;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int m = k0 + kb + 16 * i;
       const bool ok = m < kend;
-      oka |= (ok ? 1u : 0u) << i;
+      oka[st] |= (ok ? 1u : 0u) << i;
       const size_t o = ok ? (size_t)m * a.Cout + n : 0;
-      rg_[i] = *reinterpret_cast<const float4*>(a.G + o);
-      ry[i] = a.pqr ? *reinterpret_cast<const float4*>(a.Y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rg_[st][i] = *reinterpret_cast<const float4*>(a.G + o);
+      ry[st][i] = a.pqr ? *reinterpret_cast<const float4*>(a.Y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const bool ok = sr[i] >= 0;
-      okb |= (ok ? 1u : 0u) << i;
-      rb[i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)sr[i] * a.Cin + c : 0));
+      okb[st] |= (ok ? 1u : 0u) << i;
+      rb[st][i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)sr[i] * a.Cin + c : 0));
     }
     if (k0 + RC_BK < kend) rows(k0 + RC_BK);      // the table entries of the stage after: not a dependent round trip then
   };
-  auto store = [&](float* __restrict__ As_, float* __restrict__ Bs_) {
+  auto store = [&](const int st, float* __restrict__ As_, float* __restrict__ Bs_) {
     const float p4[4] = {pp.x, pp.y, pp.z, pp.w}, qq4[4] = {pq.x, pq.y, pq.z, pq.w}, r4[4] = {pr.x, pr.y, pr.z, pr.w};
     const float m4[4] = {pm.x, pm.y, pm.z, pm.w}, s4[4] = {ps.x, ps.y, ps.z, ps.w}, b4[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const float g4[4] = {rg_[i].x, rg_[i].y, rg_[i].z, rg_[i].w}, y4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-      const float x4[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
-      const bool oa = oka >> i & 1u, ob = okb >> i & 1u;
+      const float g4[4] = {rg_[st][i].x, rg_[st][i].y, rg_[st][i].z, rg_[st][i].w};
+      const float y4[4] = {ry[st][i].x, ry[st][i].y, ry[st][i].z, ry[st][i].w};
+      const float x4[4] = {rb[st][i].x, rb[st][i].y, rb[st][i].z, rb[st][i].w};
+      const bool oa = oka[st] >> i & 1u, ob = okb[st] >> i & 1u;
       float* da = As_ + (kb + 16 * i) * RC_AP + q4;
       float* db = Bs_ + (kb + 16 * i) * RC_AP + q4;
 #pragma unroll
@@ -950,21 +963,26 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float* const b0 = smem;
+  float* const b1 = smem + 2 * RC_BK * RC_AP;
   if (kbeg < kend) {
     rows(kbeg);
-    load(kbeg);
+    load(0, kbeg);
   }
-  if (kbeg < kend) store(As, Bs);
+  if (kbeg + RC_BK < kend) load(1, kbeg + RC_BK);
+  if (kbeg < kend) store(0, b0, b0 + RC_BK * RC_AP);
   __syncthreads();
-  int cur = 0;
 #pragma unroll 1
-  for (int k0 = kbeg; k0 < kend; k0 += RC_BK) {
-    const int o = cur * 2 * RC_BK * RC_AP, on = (cur ^ 1) * 2 * RC_BK * RC_AP;
-    if (k0 + RC_BK < kend) load(k0 + RC_BK);
-    wv.mma(As + o, Bs + o, acc);
-    if (k0 + RC_BK < kend) store(As + on, Bs + on);
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * RC_BK) {
+    if (k0 + 2 * RC_BK < kend) load(0, k0 + 2 * RC_BK);
+    wv.mma(b0, b0 + RC_BK * RC_AP, acc);
+    if (k0 + RC_BK < kend) store(1, b1, b1 + RC_BK * RC_AP);
     __syncthreads();
-    cur ^= 1;
+    if (k0 + RC_BK >= kend) break;
+    if (k0 + 3 * RC_BK < kend) load(1, k0 + 3 * RC_BK);
+    wv.mma(b1, b1 + RC_BK * RC_AP, acc);
+    if (k0 + 2 * RC_BK < kend) store(0, b0, b0 + RC_BK * RC_AP);
+    __syncthreads();
   }
   const size_t numel = (size_t)a.Cout * a.T * a.Cin, rstride = (size_t)a.T * a.Cin;
   const size_t base = ((size_t)n0 * a.T + tap) * a.Cin + c0;
@@ -978,7 +996,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
   }
 }
 
-__global__ __launch_bounds__(256) void rc_wgrad_kernel(RcWgradArgs a, int gx, int gy, int gz, int xcd) {
+__global__ __launch_bounds__(256, 3) void rc_wgrad_kernel(RcWgradArgs a, int gx, int gy, int gz, int xcd) {
   __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
@@ -1303,7 +1321,7 @@ static_assert(sizeof(RcGroup) <= 4000, "rc_group_kernel's arguments must fit the
 
 // (the job table is read through the kernel-argument segment pointer: indexing the by-value parameter with the
 // workgroup's job number makes the compiler copy all of it into scratch -- 2.5 KB per lane, 10 x the run time)
-__global__ __launch_bounds__(256) void rc_group_kernel(RcGroup g_) {
+__global__ __launch_bounds__(256, 3) void rc_group_kernel(RcGroup g_) {
   __shared__ __attribute__((aligned(16))) float smem[4 * RC_BK * RC_AP];
   __shared__ float cs[128];
   __shared__ int last;
