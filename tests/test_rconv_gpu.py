@@ -40,7 +40,9 @@ def _unit(Cin, Cout, k, s, seed):
 
 
 SHAPES = [(3, 5, 64, 128, 3, 1), (2, 8, 128, 64, 3, 2), (5, 4, 256, 64, 1, 1), (2, 6, 64, 64, 1, 2), (6, 2, 512, 512, 3, 1),
-          (24, 8, 128, 128, 3, 1), (3, 16, 128, 128, 3, 2), (5, 6, 64, 64, 3, 2), (2, 7, 64, 64, 3, 2)]
+          (24, 8, 128, 128, 3, 1), (3, 16, 128, 128, 3, 2), (5, 6, 64, 64, 3, 2), (2, 7, 64, 64, 3, 2),
+          # 3 x 3 / 1 / 1 on 16-, 8- and 4-wide maps (ResNet-50's conv2 shapes; partial last tile at 3 x 4 x 4 pixels)
+          (3, 16, 64, 64, 3, 1), (2, 16, 64, 128, 3, 1), (24, 4, 256, 256, 3, 1), (3, 4, 256, 64, 3, 1), (5, 8, 128, 64, 3, 1)]
 
 
 @pytest.mark.parametrize("B,Hh,Cin,Cout,k,s", SHAPES)

@@ -47,6 +47,8 @@ SHAPES = [("l1.c1a", 16, 64, 64, 1, 1), ("l1.c1", 16, 256, 64, 1, 1), ("l1.c2", 
           ("l4.c1a", 4, 1024, 512, 1, 1), ("l4.c2s", 4, 512, 512, 3, 2), ("l4.ds", 4, 1024, 2048, 1, 2),
           ("l4.c1", 2, 2048, 512, 1, 1), ("l4.c2", 2, 512, 512, 3, 1), ("l4.c3", 2, 512, 2048, 1, 1)]
 
+if os.environ.get("ONLY"):
+    SHAPES = [sh for sh in SHAPES if sh[0] in os.environ["ONLY"].split(",")]
 tot = [0.0, 0.0, 0.0]
 print(f"B = {B}\n{'layer':8s} {'rows':>6s} {'Cin':>5s} {'Cout':>5s} k s | {'fwd us':>8s} {'TF/s':>6s} {'no-stat':>7s} | {'dgrad us':>8s} {'TF/s':>6s} | "
       f"{'wgrad us':>8s} {'TF/s':>6s} | {'d+w us':>7s} nz")
