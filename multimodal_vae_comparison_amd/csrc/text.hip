@@ -660,26 +660,28 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(64) void attn_t_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const uint8_t* __restrict__ kpm,
                                                         float* __restrict__ out, float* __restrict__ probs, int L, int S,
-                                                        int N, int H, long ldq, long ldk, long ldv, int mask_is_valid,
-                                                        mmvae_dropout_t drop) {
+                                                        int N, int H, int hd, long ldq, long ldk, long ldv,
+                                                        int mask_is_valid, mmvae_dropout_t drop) {
   __shared__ __attribute__((aligned(16))) float sk[128 * AT_HP + 16], sv[128 * AT_HP + 16], sq[32 * AT_HP];
   __shared__ float smask[128];
-  constexpr int hd = AT_HD;
   const int n = blockIdx.x, h = blockIdx.y, l0 = blockIdx.z * 32, lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
   const float scale = 1.0f / sqrtf((float)hd);
-  {   // K, V: 128 rows x 4 quads each (rows >= S: zeros), Q: this wave's 32 rows; all loads in flight before the LDS writes
+  {   // K, V: 128 rows x 4 quads each (rows >= S and columns >= hd: zeros; hd a multiple of 4), Q: this wave's 32 rows;
+      // all loads in flight before the LDS writes
     float4 kq[8], vq[8], qq[2];
+    const int nq = hd >> 2;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = lane + 64 * u, r = e >> 2, c = e & 3;
-      kq[u] = r < S ? *reinterpret_cast<const float4*>(k + ((size_t)r * N + n) * ldk + h * hd + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      vq[u] = r < S ? *reinterpret_cast<const float4*>(v + ((size_t)r * N + n) * ldv + h * hd + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = r < S && c < nq;
+      kq[u] = ok ? *reinterpret_cast<const float4*>(k + ((size_t)r * N + n) * ldk + h * hd + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vq[u] = ok ? *reinterpret_cast<const float4*>(v + ((size_t)r * N + n) * ldv + h * hd + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = lane + 64 * u, r = e >> 2, c = e & 3;
-      qq[u] = l0 + r < L ? *reinterpret_cast<const float4*>(q + ((size_t)(l0 + r) * N + n) * ldq + h * hd + 4 * c)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      qq[u] = (l0 + r < L && c < nq) ? *reinterpret_cast<const float4*>(q + ((size_t)(l0 + r) * N + n) * ldq + h * hd + 4 * c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -792,10 +794,13 @@ __global__ __launch_bounds__(64) void attn_t_fwd_kernel(const float* __restrict_
   }
 }
 static inline bool attn_t_ok(const float* q, const float* k, const float* v, int hd, long ldq, long ldk, long ldv) {
-  return hd == AT_HD && ((ldq | ldk | ldv) & 3) == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0;
+  return hd <= AT_HD && (hd & 3) == 0 && ((ldq | ldk | ldv) & 3) == 0 &&
+         ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0;
 }
+// the MFMA kernels take over from the thread-per-row ones past 32 rows (round 5: it was 64 -- the text decoder of a PoE
+// subset WITHOUT the text modality decodes all 45 positions of its modality: 20 / 33 us per call at 32 x 2 x 45 x 45)
 static inline bool attn_use_mfma(int L, int S, int hd) {
-  return hd <= AT_HD && (L > 64 || S > 64) && L <= 128 && S <= 128;
+  return hd <= AT_HD && (L > 32 || S > 32) && L <= 128 && S <= 128;
 }
 
 extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out,
@@ -805,7 +810,7 @@ extern "C" int mmvae_attn_fwd(const float* q, const float* k, const float* v, co
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
   if (attn_use_mfma(L, S, hd) && attn_t_ok(q, k, v, hd, ldq, ldk, ldv)) {
     hipLaunchKernelGGL(attn_t_fwd_kernel, dim3(N, H, (L + 31) / 32), dim3(64), 0, (hipStream_t)stream, q, k, v, kpm, out, probs,
-                       L, S, N, H, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
+                       L, S, N, H, hd, ldq, ldk, ldv, mask_is_valid, drop_arg(drop));
     return mmvae_launch_status();
   }
   if (attn_use_mfma(L, S, hd)) {

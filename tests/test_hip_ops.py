@@ -690,7 +690,7 @@ def test_embed_pe(ops, B, T):
 
 
 @pytest.mark.parametrize("L,N,E,H_", [(5, 6, 54, 2), (32, 128, 54, 2), (9, 7, 32, 2), (64, 3, 16, 2),
-                                      (100, 5, 32, 2), (128, 3, 64, 2), (65, 130, 32, 2)])
+                                      (100, 5, 32, 2), (128, 3, 64, 2), (65, 130, 32, 2), (45, 32, 16, 2), (33, 4, 24, 2)])
 def test_attention(ops, L, N, E, H_):
     g = torch.Generator().manual_seed(L * N)
     qkv = torch.randn(L, N, 3 * E, generator=g)
@@ -717,7 +717,7 @@ def test_attention(ops, L, N, E, H_):
 
 
 @pytest.mark.parametrize("L,N,E,H_,p", [(100, 9, 32, 2, 0.1), (128, 3, 32, 2, 0.3), (65, 4, 24, 2, 0.1), (70, 2, 16, 4, 0.2), (99, 3, 32, 2, 0.2), (67, 130, 32, 2, 0.1),
-                                        (40, 5, 32, 2, 0.1), (100, 3, 64, 2, 0.1)])
+                                        (40, 5, 32, 2, 0.1), (100, 3, 64, 2, 0.1), (45, 32, 16, 2, 0.1)])
 def test_attention_weight_dropout(ops, L, N, E, H_, p):
     """attention with dropout on the softmax weights (nn.MultiheadAttention(dropout=p), the action towers' train mode)
     against torch in fp64 using the very mask the kernel used (mmvae_dropout_mask, element ((n H + h) L + l) S + s):
