@@ -1,20 +1,38 @@
-import sys, collections, traceback
+"""Which C-ABI entry points a captured step calls, how often, and (WHERE=name) the Python stack of the first call of one of
+them: python tools/probe/abi_where.py [config] [batch]   (WHERE=mmvae_attn_fwd python ... for the stack)"""
+import collections
+import os
+import sys
+import traceback
+
 sys.path.insert(0, ".")
 import torch
 from multimodal_vae_comparison_amd import ops
 from multimodal_vae_comparison_amd.models.trainer import MultimodalVAE
 from multimodal_vae_comparison_amd.synthetic import workload
+
 dev = torch.device("cuda", 0)
-desc, cfg, dims, data, meta = workload("cfg1", None, device=dev, seed=1)
-tr = MultimodalVAE(cfg, feature_dims=dims, device=dev); tr.model.train(); tr.configure_optimizers()
+cfg_name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
+desc, cfg, dims, data, meta = workload(cfg_name, int(sys.argv[2]) if len(sys.argv) > 2 else None, device=dev, seed=1)
+tr = MultimodalVAE(cfg, feature_dims=dims, device=dev)
+tr.model.train()
+tr.configure_optimizers()
 tr.capture(data, 1)
 _c = ops._call
-seen = set()
+names, seen, where = [], set(), os.environ.get("WHERE")
+
+
 def call(name, *a):
-    if name in ("mmvae_attn_fwd",) and name not in seen:
+    names.append(name)
+    if name == where and name not in seen:
         seen.add(name)
-        print(name, [x for x in a if isinstance(x, int) and abs(x) < 10**6][:12])
+        print(name, [x for x in a if isinstance(x, int) and abs(x) < 10 ** 6][:12])
         traceback.print_stack(limit=9)
     return _c(name, *a)
+
+
 ops._call = call
 tr.capture(data, 1)
+print(len(names), "calls per step")
+for k, v in collections.Counter(names).most_common():
+    print(f"  {v:3d}  {k}")
