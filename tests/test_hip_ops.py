@@ -984,6 +984,46 @@ def test_head_bcast_dropout_matches_torch(ops, L, N, H, hd, p):
     check(v.grad, vr.grad, 2e-6, "dv")
 
 
+@pytest.mark.parametrize("dec,d,ff,L,N", [(False, 32, 256, 40, 6), (True, 32, 64, 37, 5), (False, 54, 128, 34, 4)])
+@pytest.mark.parametrize("train", [True, False])
+def test_residual_handoff_equals_autograd_add(ops, monkeypatch, dec, d, ff, L, N, train):
+    """ops.ResidualGrad: the LayerNorm's residual gradient added inside the sub-layer's first backward kernel (MMVAE_EP_ADD_AUX
+    in the in-projection's data gradient, dx_add in the fused feed-forward block) against autograd's own elementwise add, on
+    unfused post-norm layers (d = 32: fused feed-forward; d = 54: plain linears -- only the attention block hands off), in
+    train mode with identical dropout masks and in eval mode"""
+    from multimodal_vae_comparison_amd.models import decoders, encoders
+    torch.manual_seed(d + L)
+    layer = (decoders.HipTransformerDecoderLayer if dec else encoders.HipTransformerEncoderLayer)(d, 2, ff).to(DEV)
+    monkeypatch.setattr(encoders, "FUSED_TXT_LAYERS", False)
+    x0 = torch.randn(L, N, d, device=DEV)
+    mem = torch.randn(N, d, device=DEV) if dec else None
+    valid = torch.ones(N, L, dtype=torch.uint8, device=DEV)
+    valid[0, L - 3:] = 0
+    dy = torch.randn(L, N, d, device=DEV)
+    res = {}
+    st = encoders.DropoutState().to(DEV)
+    st0 = st.state.clone()
+    for on in (False, True):
+        monkeypatch.setattr(ops, "RESIDUAL_HANDOFF", on)
+        ds = None
+        if train:
+            st.state.copy_(st0)                        # the same seed and counters in both passes -> the same masks
+            st.reset_calls()
+            slot, call = st.begin()
+            names = ("attn", "drop1", "xattn", "drop2", "ffn", "drop3") if dec else ("attn", "drop1", "ffn", "drop2")
+            ds = {nm: st.spec(slot, call, 1 + i, 0.1, nm) for i, nm in enumerate(names)}
+        for p_ in layer.parameters():
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = layer(x, mem, valid, ds) if dec else layer(x, valid, ds)
+        y.backward(dy)
+        res[on] = (y.detach().clone(), x.grad.clone(), {k: p_.grad.clone() for k, p_ in layer.named_parameters()})
+    assert torch.equal(res[False][0], res[True][0])
+    check(res[True][1], res[False][1], 2e-6, "dx with the hand-off vs autograd's add")
+    for k in res[False][2]:
+        check(res[True][2][k], res[False][2][k], 2e-6, k)
+
+
 @pytest.mark.parametrize("self_counting", [False, True])
 def test_adam_amsgrad_flat_matches_torch(ops, self_counting):
     """self_counting: step = -1, the kernel bumps the device step counter itself (what FlatAdam uses)"""
