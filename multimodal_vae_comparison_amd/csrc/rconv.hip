@@ -423,6 +423,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
     lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
+  const float lo = a.pre == RC_PRE_NONE ? -INFINITY : 0.f;
   auto store = [&](const int st, float* __restrict__ As_, float* __restrict__ Bs_) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -435,9 +436,9 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       const float w4[4] = {rb[st][i].x, rb[st][i].y, rb[st][i].z, rb[st][i].w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float t = v[q];
-        if (a.pre == RC_PRE_BN_RELU) t = fmaxf(rc_bn(t, m4[q], s4[q], b4[q]), 0.f);
-        else if (a.pre == RC_PRE_RELU) t = fmaxf(t, 0.f);
+        // one branch-free form for the three prologues: (mean, sc, beta) = (0, 1, 0) outside RC_PRE_BN_RELU -- fma(t - 0, 1,
+        // 0) is t itself -- and the clamp floor -inf for RC_PRE_NONE (the per-element mode tests were 30 branches a stage)
+        const float t = fmaxf(rc_bn(v[q], m4[q], s4[q], b4[q]), lo);
         da[q * RC_AP] = ok ? t : 0.f;
         db[q * RC_AP] = w4[q];
       }
@@ -679,8 +680,8 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
       const bool ok = oka[st] >> i & 1u;
       float* da = As_ + k4 * RC_AP + r0 + 32 * i;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = a.pqr ? fmaf(g4[q], p4[q], fmaf(y4[q], q4[q], r4[q])) : g4[q];
+      for (int q = 0; q < 4; ++q) {      // (p, q, r) = (1, 0, 0) and Y = 0 without a BatchNorm behind: the same fma chain
+        const float v = fmaf(g4[q], p4[q], fmaf(y4[q], q4[q], r4[q]));
         da[q * RC_AP] = ok ? v : 0.f;
       }
       float* db = Bs_ + (kb + 16 * i) * RC_AP + nb4;
@@ -911,6 +912,7 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
     pb = *reinterpret_cast<const float4*>(a.xbeta + c);
   }
   const int* tb = a.tbl ? a.tbl + (size_t)tap * a.M : nullptr;
+  const float lo = a.pre == RC_PRE_NONE ? -INFINITY : 0.f;
   auto rows = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -950,12 +952,10 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
       float* da = As_ + (kb + 16 * i) * RC_AP + q4;
       float* db = Bs_ + (kb + 16 * i) * RC_AP + q4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = a.pqr ? fmaf(g4[q], p4[q], fmaf(y4[q], qq4[q], r4[q])) : g4[q];
+      for (int q = 0; q < 4; ++q) {      // branch-free forms of both prologues (see rc_fwd_body)
+        const float v = fmaf(g4[q], p4[q], fmaf(y4[q], qq4[q], r4[q]));
         da[q] = oa ? v : 0.f;
-        float t = x4[q];
-        if (a.pre == RC_PRE_BN_RELU) t = fmaxf(rc_bn(t, m4[q], s4[q], b4[q]), 0.f);
-        else if (a.pre == RC_PRE_RELU) t = fmaxf(t, 0.f);
+        const float t = fmaxf(rc_bn(x4[q], m4[q], s4[q], b4[q]), lo);
         db[q] = ob ? t : 0.f;
       }
     }
