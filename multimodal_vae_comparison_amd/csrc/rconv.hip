@@ -727,58 +727,63 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
   for (int t = 0; t < 2; ++t)
     if (t < a.nstat) { tm[t] = a.st[t].mean[c]; tr[t] = a.st[t].rstd[c]; }
   // the epilogue in two halves of 8 accumulator rows: the operands of a half first (all in flight), then its arithmetic.
-  // st[0].Y is the mask source itself at the BatchNorm-mask call sites (one load serves both)
+  // st[0].Y is the mask source itself at the BatchNorm-mask call sites (one load serves both).  Every mode test is hoisted
+  // out of the per-row loops (round 5: the workgroup-uniform tests inside them were ~100 branches per tile) and the
+  // arithmetic is one form for all modes: no mask = a mask source of 1, a raw mask = the BatchNorm form with (0, 1, 0).
   const bool st0_is_mask = a.nstat > 0 && a.mask != RC_MASK_NONE && a.st[0].Y == a.mY;
+  const float* const y0p = a.nstat > 0 ? a.st[0].Y : nullptr;
+  const float* const y1p = a.nstat > 1 ? a.st[1].Y : nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    int arow[8];            // the output rows of this half's accumulator registers
+    size_t off[8];          // element offsets of this half's accumulator registers in the (rows, Cin) tensors
+    int arow[8];
     float vadd[8], vmy[8], vy0[8], vy1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int r = 8 * h + q;
-      const int rr = m0 + min(wv.row_of(r), cnt - 1);
+      const int rr = m0 + min(wv.row_of(8 * h + q), cnt - 1);
       arow[q] = cls ? rmap[rr] : rr;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const size_t o = (size_t)arow[q] * a.Cin + c;
+      off[q] = (size_t)arow[q] * a.Cin + c;
       vadd[q] = 0.f;
-      if (a.add) {
-        if (a.add_tbl) {
-          const int rr = a.add_tbl[arow[q]];
-          vadd[q] = a.add[rr >= 0 ? (size_t)rr * a.Cin + c : 0];
-          if (rr < 0) vadd[q] = 0.f;
-        } else {
-          vadd[q] = a.add[o];
-        }
+      vmy[q] = 1.f;
+      vy0[q] = vy1[q] = 0.f;
+    }
+    if (a.add && a.add_tbl) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int rr = a.add_tbl[arow[q]];
+        const float t = a.add[rr >= 0 ? (size_t)rr * a.Cin + c : 0];
+        vadd[q] = rr >= 0 ? t : 0.f;
       }
-      vmy[q] = a.mask != RC_MASK_NONE ? a.mY[o] : 0.f;
-      vy0[q] = (a.nstat > 0 && !st0_is_mask) ? a.st[0].Y[o] : 0.f;
-      vy1[q] = a.nstat > 1 ? a.st[1].Y[o] : 0.f;
+    } else if (a.add) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vadd[q] = a.add[off[q]];
+    }
+    if (a.mask != RC_MASK_NONE) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vmy[q] = a.mY[off[q]];
+    }
+    if (y0p && !st0_is_mask) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vy0[q] = y0p[off[q]];
+    }
+    if (y1p) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vy1[q] = y1p[off[q]];
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = 8 * h + q;
-      if (wv.row_of(r) < cnt) {
-        const size_t o = (size_t)arow[q] * a.Cin + c;
-        float g = acc[r] + vadd[q];
-        if (a.mask != RC_MASK_NONE) {
-          const float z = a.mask == RC_MASK_BN ? rc_bn(vmy[q], mm, ms, mb) : vmy[q];
-          g = z > 0.f ? g : 0.f;
-        }
-        a.out[o] = g;
-        if (a.nstat > 0) {
-          const float y0 = st0_is_mask ? vmy[q] : vy0[q];
-          s1[0] += g;
-          s2[0] = fmaf(g, (y0 - tm[0]) * tr[0], s2[0]);
-        }
-        if (a.nstat > 1) {
-          s1[1] += g;
-          s2[1] = fmaf(g, (vy1[q] - tm[1]) * tr[1], s2[1]);
-        }
-      }
+      const bool live = wv.row_of(r) < cnt;
+      const float z = rc_bn(vmy[q], mm, ms, mb);              // raw mask / no mask: (mm, ms, mb) = (0, 1, 0)
+      const float g = (live && z > 0.f) ? acc[r] + vadd[q] : 0.f;
+      if (live) a.out[off[q]] = g;
+      const float y0 = st0_is_mask ? vmy[q] : vy0[q];
+      s1[0] += g;                                             // (unused without statistics; rows past the tile add 0)
+      s2[0] = fmaf(g, (y0 - tm[0]) * tr[0], s2[0]);
+      s2[1] = fmaf(g, (vy1[q] - tm[1]) * tr[1], s2[1]);
     }
   }
+  s1[1] = s1[0];
   RC_STAMP_WAIT(k, 4);
   if (a.nstat == 0) return;
 #pragma unroll
