@@ -122,12 +122,28 @@ struct RcWave {
   }
   __device__ __forceinline__ int row_of(int r) const { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; }
   __device__ __forceinline__ int col() const { return wn * 32 + li; }
+  // Half of a stage's fragments are read before its first MFMA, the other half under the first eight (hipcc otherwise sinks
+  // every ds_read next to its consumer: {2 ds_read2_b32, s_waitcnt lgkmcnt(0), 2 MFMAs} x 8)
   __device__ __forceinline__ void mma(const float* __restrict__ As, const float* __restrict__ Bs, f32x16& acc) const {
     const float* a = As + lh * RC_AP + wm * 32 + li;
     const float* b = Bs + lh * RC_AP + wn * 32 + li;
+    float av[2][RC_BK / 4], bv[2][RC_BK / 4];
 #pragma unroll
-    for (int kk = 0; kk < RC_BK; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * RC_AP], b[kk * RC_AP], acc, 0, 0, 0);
+    for (int i = 0; i < RC_BK / 4; ++i) {
+      av[0][i] = a[2 * i * RC_AP];
+      bv[0][i] = b[2 * i * RC_AP];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RC_BK / 4; ++i) {
+      av[1][i] = a[(RC_BK / 2 + 2 * i) * RC_AP];
+      bv[1][i] = b[(RC_BK / 2 + 2 * i) * RC_AP];
+    }
+#pragma unroll
+    for (int i = 0; i < RC_BK / 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][i], bv[0][i], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RC_BK / 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][i], bv[1][i], acc, 0, 0, 0);
   }
 };
 
