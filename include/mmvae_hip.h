@@ -831,7 +831,8 @@ int mmvae_add_pe_dropout_fwd(const float* x, const float* pe, float* y, int T, i
 /* Scaled-dot-product attention with key padding mask for L,S <= 64 (nn.MultiheadAttention core).
  *   q (L*N, ldq) rows r = l*N+n, head h at columns [h*hd,(h+1)*hd); k, v (S*N, ld) likewise.
  *   kpm (N,S) bytes, 1 = ignore key (may be NULL); with mask_is_valid != 0 the bytes are the batch's validity
- *   mask instead (1 = real token).  out (L*N, E=H*hd).  probs (N,H,L,S) saved for bwd. */
+ *   mask instead (1 = real token).  out (L*N, E=H*hd).  probs (N,H,L,S) saved for bwd: the normalised weights before
+ *   dropout, a weight that the dropout removed stored NEGATED (sign bit = the mask: mmvae_attn_bwd hashes nothing). */
 int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* kpm, float* out, float* probs,
                    int L, int S, int N, int H, int hd, long ldq, long ldk, long ldv, int mask_is_valid,
                    const mmvae_dropout_t* drop, mmvae_stream_t stream);

@@ -223,6 +223,14 @@ __device__ __forceinline__ void att_axpy(float (&acc)[HD], float p, const float*
   }
 }
 
+// Round 5: the saved probabilities carry the attention-weight dropout decision in their SIGN bit (probabilities are >= 0;
+// a dropped weight is stored negated, -0.0 included), so that no backward kernel has to regenerate the mask: the MFMA
+// backward spent ~190 mask hashes per lane on it, ~6.5 of its 28 us at the action towers' shape.
+__device__ __forceinline__ float at_signed(float p, float m) {
+  return m == 0.f ? __uint_as_float(__float_as_uint(p) | 0x80000000u) : p;
+}
+__device__ __forceinline__ float at_mask_of(float v, float inv_keep) { return (__float_as_uint(v) >> 31) ? 0.f : inv_keep; }
+
 template <int AM, int HD>
 __global__ __launch_bounds__(AM) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const uint8_t* __restrict__ kpm,
@@ -276,8 +284,11 @@ __global__ __launch_bounds__(AM) void attn_fwd_kernel(const float* __restrict__ 
   __syncthreads();
   // normalised probabilities, written row by row with lane = key index (coalesced)
   float* P = probs + ((size_t)n * H + h) * L * S;
-  if (lane < S)
-    for (int l = 0; l < L; ++l) P[(size_t)l * S + lane] = sp[l * SP + lane] * sinv[l];
+  if (lane < S) {
+    const DropKey dk = drop_key(drop);
+    for (int l = 0; l < L; ++l)
+      P[(size_t)l * S + lane] = at_signed(sp[l * SP + lane] * sinv[l], drop_mul(dk, (uint32_t)((((size_t)n * H + h) * L + l) * S + lane)));
+  }
 }
 
 // dV[s] = sum_l P[l,s] dO[l];  dP[l,s] = dO[l].V[s];  dS = P (dP - sum_s P dP);
@@ -314,8 +325,8 @@ __global__ __launch_bounds__(AM) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < HD; ++d) dvr[d] = 0.f;
     for (int l = 0; l < L; ++l) {
-      const uint32_t di = (uint32_t)((((size_t)n * H + h) * L + l) * S + s);
-      att_axpy<HD>(dvr, sp[l * SP + s] * drop_mul(dkey, di), sdo + l * (HD + 4));
+      const float pv = sp[l * SP + s];
+      att_axpy<HD>(dvr, fabsf(pv) * at_mask_of(pv, dkey.inv_keep), sdo + l * (HD + 4));
     }
     float* dvrow = dv + ((size_t)s * N + n) * ldv + h * hd;
 #pragma unroll
@@ -329,15 +340,17 @@ __global__ __launch_bounds__(AM) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < HD; ++d) dor[d] = sdo[l * (HD + 4) + d];
     float delta = 0.f;
-    const uint32_t drow = (uint32_t)((((size_t)n * H + h) * L + l) * S);
-    for (int s = 0; s < S; ++s)
-      delta += sp[l * SP + s] * att_dot<HD>(sv + s * (HD + 4), dor) * drop_mul(dkey, drow + s);   // through the weight dropout
+    for (int s = 0; s < S; ++s) {
+      const float pv = sp[l * SP + s];
+      delta += fabsf(pv) * att_dot<HD>(sv + s * (HD + 4), dor) * at_mask_of(pv, dkey.inv_keep);   // through the weight dropout
+    }
     float dqr[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) dqr[d] = 0.f;
     for (int s = 0; s < S; ++s) {
-      const float dp = att_dot<HD>(sv + s * (HD + 4), dor) * drop_mul(dkey, drow + s);
-      const float ds = sp[l * SP + s] * (dp - delta);
+      const float pv = sp[l * SP + s];
+      const float dp = att_dot<HD>(sv + s * (HD + 4), dor) * at_mask_of(pv, dkey.inv_keep);
+      const float ds = fabsf(pv) * (dp - delta);
       sp[l * SP + s] = ds;
       att_axpy<HD>(dqr, ds, sk + s * (HD + 4));
     }
@@ -474,8 +487,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) {
       const int l = l0 + at_i(r, lh);
       const float pe = acc[kb][r];
-      if (s_ < S && l < L) P[(size_t)l * S + s_] = pe * inv[r];
-      sp[l * AT_SP + s_] = s_ < S ? pe * drop_mul(dkey, dbase + (uint32_t)(l * S + s_)) : 0.f;
+      const float m = drop_mul(dkey, dbase + (uint32_t)(l * S + s_));
+      if (s_ < S && l < L) P[(size_t)l * S + s_] = at_signed(pe * inv[r], m);
+      sp[l * AT_SP + s_] = s_ < S ? pe * m : 0.f;
     }
   }
   // ---- O = (P . mask) V ----
@@ -555,7 +569,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
 #pragma unroll 4
     for (int kk = 0; kk < lsteps; ++kk) {
       const int l = 2 * kk + lh;
-      const float a = sp[l * AT_SP + b0 + li] * drop_mul(dkey, dbase + (uint32_t)(l * S + b0 + li));
+      const float pv = sp[l * AT_SP + b0 + li];
+      const float a = fabsf(pv) * at_mask_of(pv, dkey.inv_keep);
       const float b = li < AT_HD ? sdo[l * AT_HP + li] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
@@ -588,8 +603,9 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int l = b0 + at_i(r, lh), s_ = kb * 32 + li;
-          dp[kb][r] *= drop_mul(dkey, dbase + (uint32_t)(l * S + s_));
-          part[r] += sp[l * AT_SP + s_] * dp[kb][r];
+          const float pv = sp[l * AT_SP + s_];
+          dp[kb][r] *= at_mask_of(pv, dkey.inv_keep);
+          part[r] += fabsf(pv) * dp[kb][r];
         }
       }
     }
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int idx = (b0 + at_i(r, lh)) * AT_SP + kb * 32 + li;
-          sp[idx] = sp[idx] * (dp[kb][r] - part[r]);
+          sp[idx] = fabsf(sp[idx]) * (dp[kb][r] - part[r]);
         }
       }
     }
@@ -749,33 +765,33 @@ __global__ __launch_bounds__(64) void attn_t_fwd_kernel(const float* __restrict_
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int key0 = kb * 32 + 8 * g + 4 * lh;              // registers 4 g .. 4 g + 3: keys key0 .. key0 + 3
-        float p4[4];
+        float p4[4], m4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) p4[j] = acc[kb][4 * g + j] * inv;
-        if (l < L) {
-          if (vec && key0 + 3 < S) {
-            *reinterpret_cast<float4*>(P + key0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (key0 + j < S) P[key0 + j] = p4[j];
-          }
-        }
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
           const uint32_t i0 = dbase + (uint32_t)(key0 + j);
-          float m0, m1;
           if ((i0 & 1u) == 0u) {
             const uint32_t hh = drop_pair_hash(dkey, i0 >> 1);
-            m0 = drop_pair_lo(dkey, hh);
-            m1 = drop_pair_hi(dkey, hh);
+            m4[j] = drop_pair_lo(dkey, hh);
+            m4[j + 1] = drop_pair_hi(dkey, hh);
           } else {
-            m0 = drop_mul(dkey, i0);
-            m1 = drop_mul(dkey, i0 + 1);
+            m4[j] = drop_mul(dkey, i0);
+            m4[j + 1] = drop_mul(dkey, i0 + 1);
           }
-          p4[j] *= m0;
-          p4[j + 1] *= m1;
         }
+        if (l < L) {      // saved for backward with the dropout decision in the sign bit (at_signed)
+          if (vec && key0 + 3 < S) {
+            *reinterpret_cast<float4*>(P + key0) = make_float4(at_signed(p4[0], m4[0]), at_signed(p4[1], m4[1]),
+                                                                at_signed(p4[2], m4[2]), at_signed(p4[3], m4[3]));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (key0 + j < S) P[key0 + j] = at_signed(p4[j], m4[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p4[j] *= m4[j];
         // O += (P . mask) V over these four keys: the tile's registers are the A operand, reduction index = key
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
