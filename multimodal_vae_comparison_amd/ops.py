@@ -1084,7 +1084,10 @@ class PoeReparamKL(Function):
         dkl = H.f32c(dkl) if dkl is not None else torch.zeros(E + 1, B, device=dev)
         dz = [H.f32c(g) if g is not None else torch.zeros(B, D, device=dev) for g in dzs] if n_z else None
         sub = D != Dtot
-        dpacked = [(torch.zeros_like(p) if sub else torch.empty_like(p)) for p in packed]
+        if sub and all(p.shape == packed[0].shape for p in packed):
+            dpacked = list(torch.zeros(len(packed), *packed[0].shape, device=dev).unbind(0))     # ONE fill for all experts
+        else:
+            dpacked = [(torch.zeros_like(p) if sub else torch.empty_like(p)) for p in packed]
         a = H.PoeBwdArgs()
         for e, p in enumerate(packed):
             a.mu[e] = p.data_ptr() + 4 * col0
