@@ -324,9 +324,15 @@ def enc_cnn_resnet50(p, pre, x, train=False, stats=None, taps=None):
 # test saw them) every ReLU becomes `x * mask`: the same piecewise-linear branch on both sides, so every gradient can be
 # held to the plain 1e-4.  None (the default): torch.relu.
 RELU_MASKS = None
+# RELU_PRE = {} (tests): every ReLU site appends its pre-activation (detached) per call, `{site: [x of call 0, ...]}` --
+# the fp64 run of the oracle records them so that a test can BOUND where the implementation's masks may differ from
+# `pre > 0`: only at elements within rounding of the kink (tests/test_parity_e2e.py: _assert_relu_masks_near_kinks).
+RELU_PRE = None
 
 
 def _relu(x, site):
+    if RELU_PRE is not None:
+        RELU_PRE.setdefault(site, []).append(x.detach().clone())
     if RELU_MASKS is None:
         return torch.relu(x)
     calls = RELU_MASKS.setdefault("_calls", {})

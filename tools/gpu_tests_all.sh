@@ -1,5 +1,5 @@
 #!/bin/bash
-# the whole -m gpu suite as the driver runs it, plus the record of every relaxed comparison (profiles/r05_relaxed_bars.json
+# the whole -m gpu suite as the driver runs it, plus the record of every relaxed comparison (profiles/r06_relaxed_bars.json
 # is made from gpurun_out/relaxed_bars.jsonl by tools/relaxed_summary.py)
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
