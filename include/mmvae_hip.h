@@ -959,6 +959,18 @@ int mmvae_adam_fold_flat(float* p, float* g, float* m, float* v, float* vmax, lo
                          float beta2, float eps, int* step_dev, float grad_scale, int zero_grad,
                          const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows, const float* W_host,
                          float* out, int n_rows, int B, int n_out, mmvae_stream_t stream);
+/* One step's fold + update in SEVERAL launches: elements [lo, hi) of the flat buffers only (lo % 4 == 0), with those
+ * segments of `table` whose destination lies inside the range (segments outside are skipped, one that straddles lo or hi
+ * is MMVAE_ERR_ARG; table may be NULL).  Every launch of a step reads the same step number from step_dev; exactly one --
+ * the LAST in stream order -- passes advance_step = 1 and closes the step.  Per element bit-identical to
+ * mmvae_adam_fold_flat over the whole buffer.  (The captured training step updates the decoders' + prior's range beside the
+ * encoders' backward pass, so that only the encoders' parameters are left for the serial launch at the end of the step.)
+ * Same reference interface as mmvae_adam_fold_flat: torch.optim.Adam.step(), models/trainer.py:79-81. */
+int mmvae_adam_fold_range(float* p, float* g, float* m, float* v, float* vmax, long n, long lo, long hi,
+                          int advance_step, float lr, float beta1, float beta2, float eps, int* step_dev,
+                          float grad_scale, int zero_grad, const mmvae_reduce_segments_t* table,
+                          const mmvae_rowptrs_t* rows, const float* W_host, float* out, int n_rows, int B, int n_out,
+                          mmvae_stream_t stream);
 /* partial layouts: rows x rowlen floats in ws; weight part at column 0, bias part at column bias_col */
 int mmvae_conv_wgrad_layout(int B, int Csmall, int Clarge, int Hsmall, int* rows, int* rowlen, int* bias_col);
 /* linear weight gradient: `splits` partial (N*K) slabs followed by `splits` partial (N) bias rows; splits == 1

@@ -132,12 +132,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // be read back without adding graph nodes (markers change the graph's topology and with it hipGraph's scheduling) or
 // a profiler (which changes the timing).  Compiles to nothing in the product build.
 #ifdef MMVAE_TRACE
+// table[0] = event counter; event k = (id, wall clock) at table[8 + 2 k], k modulo 2048: EVERY launch of an instrumented
+// kernel leaves one, so repeated kernels (the grouped GEMMs, the two text layers) show up once per launch, in time order
 static __device__ long long* mmvae_trace_table __attribute__((unused)) = nullptr;
 #define MMVAE_TRACE_STAMP(id)                                                      \
   do {                                                                             \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
       long long* t__ = mmvae_trace_table;                                          \
-      if (t__) t__[id] = (long long)wall_clock64();                                \
+      if (t__) {                                                                   \
+        const unsigned long long k__ = atomicAdd(reinterpret_cast<unsigned long long*>(t__), 1ull) & 2047ull; \
+        t__[8 + 2 * k__] = (long long)(id);                                        \
+        t__[9 + 2 * k__] = (long long)wall_clock64();                              \
+      }                                                                            \
     }                                                                              \
   } while (0)
 #define MMVAE_TRACE_SETTER(module)                                                          \

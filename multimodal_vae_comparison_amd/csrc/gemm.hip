@@ -254,6 +254,7 @@ struct GemmGroup {
   int n;
 };
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GemmGroup grp) {
+  MMVAE_TRACE_STAMP(24);
   __shared__ float As[128 * 33];
   __shared__ float Bs[128 * 33];
   const int p = ((int)blockIdx.x >= grp.blk0[1]) ? 1 : 0;
@@ -437,12 +438,14 @@ __device__ __forceinline__ void rgemm16_body(const GemmArgs& g, const int bx, co
 
 template <int DEPTH, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(512) void rgemm16_kernel(GemmArgs g) {
+  MMVAE_TRACE_STAMP(25);
   __shared__ float red[8 * 4 * 64];
   rgemm16_body<DEPTH, A_KMAJOR, B_KMAJOR>(g, blockIdx.x, blockIdx.y, red);
 }
 
 template <int DEPTH, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(512) void rgemm_kernel(GemmArgs g) {
+  MMVAE_TRACE_STAMP(26);
   __shared__ float red[8 * 16 * 64];
   __shared__ float rsr[8 * 32];
   rgemm_body<DEPTH, A_KMAJOR, B_KMAJOR>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, red, rsr);
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(512) void rgemm_kernel(GemmArgs g) {
 // data + weight gradient of one Linear layer in one launch (see gemm_grouped_kernel), register-operand bodies
 template <int D0, int D1, bool T16>
 __global__ __launch_bounds__(512) void rgemm_grouped_kernel(GemmGroup grp) {
+  MMVAE_TRACE_STAMP(27);
   __shared__ float red[8 * 16 * 64];
   __shared__ float rsr[8 * 32];
   const int p = ((int)blockIdx.x >= grp.blk0[1]) ? 1 : 0;
@@ -1070,3 +1074,5 @@ extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w,
   }
   return rc;
 }
+
+MMVAE_TRACE_SETTER(gemm)

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void bce_rowsum_kernel(const float* __restrict
                                                          float* __restrict__ row, int F, float seed,
                                                          float* __restrict__ dl, int trows) {
   __shared__ float red[4];
+  MMVAE_TRACE_STAMP(28);
   const size_t base = (size_t)blockIdx.x * F;
   const size_t tbase = (size_t)(blockIdx.x % trows) * F;
   float acc = 0.f;
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(256) void ce_time_fwd_tile_kernel(const float* __re
   __shared__ float sl[CE_TILE], st[CE_TILE];
   __shared__ float s_mx[256], s_k[256];
   __shared__ float red[4];
+  MMVAE_TRACE_STAMP(29);
   const int b = blockIdx.x, n = T * V;
   const float* L = lg + (size_t)b * n;
   const float* Tg = tg + (size_t)(b % trows) * n;
@@ -882,3 +884,5 @@ extern "C" int mmvae_moe_elbo_bwd(const float* g, const float* out, const float*
                      dkld, n_rows, M, B, beta);
   return mmvae_launch_status();
 }
+
+MMVAE_TRACE_SETTER(loss)

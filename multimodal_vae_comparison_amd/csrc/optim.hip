@@ -469,10 +469,11 @@ struct af_table_t {
 };
 struct af_adam_t {
   float *p, *g, *m, *v, *vmax;
-  long n;
+  long lo, hi;      // this launch covers elements [lo, hi) of the flat buffers (mmvae_adam_fold_range; the whole buffer otherwise)
   int* step_dev;
   float lr, b1, b2, eps, gscale;
   int zero_grad;
+  int advance;      // 1: this launch closes step (*step_dev + 1) -- takes tickets, the last workgroup advances the counter
 };
 
 template <bool TAIL>
@@ -538,28 +539,30 @@ __global__ __launch_bounds__(256) void adam_fold_kernel(af_adam_t A, af_table_t 
       A.g[fe] = A.zero_grad ? 0.f : G;
     }
   } else {
-    __syncthreads();
-    const float lr_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
     const int pb = bid - t.fold_blocks;
     int k = 0;
     while (k < t.n_heads && pb >= t.pblk0[k + 1]) ++k;                  // uniform scan over the plain ranges
-    const long rs = k == 0 ? 0 : (long)t.seg[k - 1].dst_off + t.seg[k - 1].len;
-    const long re = k == t.n_heads ? A.n : (long)t.seg[k].dst_off;
+    const long rs = k == 0 ? A.lo : (long)t.seg[k - 1].dst_off + t.seg[k - 1].len;
+    const long re = k == t.n_heads ? A.hi : (long)t.seg[k].dst_off;
     const long cs = rs + (long)(pb - t.pblk0[k]) * AF_PLAIN;
     const long ce = cs + AF_PLAIN < re ? cs + AF_PLAIN : re;
     const long a0 = (cs + 3) & ~3L, a1 = ce & ~3L;                      // float4 body [a0, a1), dword edges
+    float4* p4 = reinterpret_cast<float4*>(A.p);
+    float4* g4 = reinterpret_cast<float4*>(A.g);
+    float4* m4 = reinterpret_cast<float4*>(A.m);
+    float4* v4 = reinterpret_cast<float4*>(A.v);
+    float4* x4 = reinterpret_cast<float4*>(A.vmax);
+    const long q0 = (a0 >> 2) + threadIdx.x, q1 = q0 + 256, qe = a1 >> 2;
+    const bool h0 = a0 < a1 && q0 < qe, h1 = a0 < a1 && q1 < qe;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 P0 = z, G0 = z, M0 = z, V0 = z, X0 = z, P1 = z, G1 = z, M1 = z, V1 = z, X1 = z;
+    // the ten state loads go out BEFORE the barrier behind which thread 0's bias corrections (a dependent global load of
+    // the step counter + double-precision divisions) become visible: round 6, the launch is the serial tail of the step
+    if (h0) { P0 = p4[q0]; G0 = g4[q0]; M0 = m4[q0]; V0 = v4[q0]; X0 = x4[q0]; }
+    if (h1) { P1 = p4[q1]; G1 = g4[q1]; M1 = m4[q1]; V1 = v4[q1]; X1 = x4[q1]; }
+    __syncthreads();
+    const float lr_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
     if (a0 < a1) {
-      float4* p4 = reinterpret_cast<float4*>(A.p);
-      float4* g4 = reinterpret_cast<float4*>(A.g);
-      float4* m4 = reinterpret_cast<float4*>(A.m);
-      float4* v4 = reinterpret_cast<float4*>(A.v);
-      float4* x4 = reinterpret_cast<float4*>(A.vmax);
-      const long q0 = (a0 >> 2) + threadIdx.x, q1 = q0 + 256, qe = a1 >> 2;
-      const bool h0 = q0 < qe, h1 = q1 < qe;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 P0 = z, G0 = z, M0 = z, V0 = z, X0 = z, P1 = z, G1 = z, M1 = z, V1 = z, X1 = z;
-      if (h0) { P0 = p4[q0]; G0 = g4[q0]; M0 = m4[q0]; V0 = v4[q0]; X0 = x4[q0]; }
-      if (h1) { P1 = p4[q1]; G1 = g4[q1]; M1 = m4[q1]; V1 = v4[q1]; X1 = x4[q1]; }
       if (h0) {
         update1(P0.x, G0.x, M0.x, V0.x, X0.x, lr_bc1, inv_sqrt_bc2);
         update1(P0.y, G0.y, M0.y, V0.y, X0.y, lr_bc1, inv_sqrt_bc2);
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256) void adam_fold_kernel(af_adam_t A, af_table_t 
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (A.advance && threadIdx.x == 0) {
     const int ticket = atomicAdd(A.step_dev + 1, 1);
     if (ticket == work_blocks - 1) {
       A.step_dev[1] = 0;
@@ -605,16 +608,62 @@ __global__ __launch_bounds__(256) void adam_fold_kernel(af_adam_t A, af_table_t 
   }
 }
 
+static int adam_fold_impl(float* p, float* g, float* m, float* v, float* vmax, long n, long lo, long hi, int advance,
+                          float lr, float beta1, float beta2, float eps, int* step_dev, float grad_scale, int zero_grad,
+                          const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows, const float* W_host, float* out,
+                          int n_rows, int B, int n_out, mmvae_stream_t stream);
+
 extern "C" int mmvae_adam_fold_flat(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float beta1,
                                     float beta2, float eps, int* step_dev, float grad_scale, int zero_grad,
                                     const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows,
                                     const float* W_host, float* out, int n_rows, int B, int n_out,
                                     mmvae_stream_t stream) {
-  MMVAE_CHECK_ARG(p && g && m && v && vmax && n > 0 && n < (1L << 31) && step_dev && table);
-  MMVAE_CHECK_ARG(table->n > 0 && table->n <= MMVAE_MAX_SEGMENTS);
+  return adam_fold_impl(p, g, m, v, vmax, n, 0, n, 1, lr, beta1, beta2, eps, step_dev, grad_scale, zero_grad, table, rows,
+                        W_host, out, n_rows, B, n_out, stream);
+}
+
+// One step's update in SEVERAL launches (round 6): elements [lo, hi) of the flat buffers only, with the segments of `table`
+// whose destination lies inside that range (the others are skipped: they belong to another launch of the same step; a
+// segment that straddles lo or hi is an error).  Every launch of a step reads the same step number; exactly ONE of them --
+// the last one in stream order -- passes advance_step = 1 and closes the step.  The captured training step runs the decoders'
+// + prior's range (the second range of the flat buffer, FlatParams.split) behind the text encoder's backward, beside the image
+// encoder's, so that only the encoders' parameters are left for the serial launch at the end of the step.  Per element the
+// same arithmetic in the same order as mmvae_adam_fold_flat over the whole buffer: bit-identical.  table may be NULL or have
+// no segment inside the range (plain Adam over [lo, hi)).
+extern "C" int mmvae_adam_fold_range(float* p, float* g, float* m, float* v, float* vmax, long n, long lo, long hi,
+                                     int advance_step, float lr, float beta1, float beta2, float eps, int* step_dev,
+                                     float grad_scale, int zero_grad, const mmvae_reduce_segments_t* table,
+                                     const mmvae_rowptrs_t* rows, const float* W_host, float* out, int n_rows, int B,
+                                     int n_out, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(lo >= 0 && lo < hi && hi <= n && (lo & 3) == 0);
+  return adam_fold_impl(p, g, m, v, vmax, n, lo, hi, advance_step ? 1 : 0, lr, beta1, beta2, eps, step_dev, grad_scale,
+                        zero_grad, table, rows, W_host, out, n_rows, B, n_out, stream);
+}
+
+static int adam_fold_impl(float* p, float* g, float* m, float* v, float* vmax, long n, long lo, long hi, int advance,
+                          float lr, float beta1, float beta2, float eps, int* step_dev, float grad_scale, int zero_grad,
+                          const mmvae_reduce_segments_t* table, const mmvae_rowptrs_t* rows, const float* W_host, float* out,
+                          int n_rows, int B, int n_out, mmvae_stream_t stream) {
+  const bool whole = lo == 0 && hi == n;
+  MMVAE_CHECK_ARG(p && g && m && v && vmax && n > 0 && n < (1L << 31) && step_dev && (table || !whole));
+  MMVAE_CHECK_ARG(!table || (table->n >= (whole ? 1 : 0) && table->n <= MMVAE_MAX_SEGMENTS));
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) != 0) return MMVAE_ERR_ARG;
   if ((((uintptr_t)step_dev) & 7) != 0) return MMVAE_ERR_ARG;
-  const mmvae_reduce_segments_t& t = *table;
+  mmvae_reduce_segments_t inside;      // the segments of this launch's range
+  inside.n = 0;
+  for (int s = 0; table && s < table->n; ++s) {
+    if (!table->dst[s] || table->len[s] <= 0) return MMVAE_ERR_ARG;
+    const float *d0 = table->dst[s], *d1 = table->dst[s] + table->len[s];
+    if (d1 <= g + lo || d0 >= g + hi) {
+      if (whole) return MMVAE_ERR_ARG;       // (outside the flat buffer)
+      continue;
+    }
+    if (d0 < g + lo || d1 > g + hi) return MMVAE_ERR_ARG;      // straddles a range boundary
+    const int k = inside.n++;
+    inside.src[k] = table->src[s]; inside.dst[k] = table->dst[s]; inside.rows[k] = table->rows[s];
+    inside.len[k] = table->len[s]; inside.stride[k] = table->stride[s];
+  }
+  const mmvae_reduce_segments_t& t = inside;
   // heads = distinct destination ranges, sorted by offset; members with the same (dst, len) chained behind their head
   int head[MMVAE_MAX_SEGMENTS], n_heads = 0;
   for (int s = 0; s < t.n; ++s) {
@@ -652,14 +701,15 @@ extern "C" int mmvae_adam_fold_flat(float* p, float* g, float* m, float* v, floa
   o.fold_blocks = blocks;
   int pblocks = 0;
   for (int k = 0; k <= n_heads; ++k) {
-    const long rs = k == 0 ? 0 : (long)o.seg[k - 1].dst_off + o.seg[k - 1].len;
-    const long re = k == n_heads ? n : (long)o.seg[k].dst_off;
+    const long rs = k == 0 ? lo : (long)o.seg[k - 1].dst_off + o.seg[k - 1].len;
+    const long re = k == n_heads ? hi : (long)o.seg[k].dst_off;
     o.pblk0[k] = pblocks;
     pblocks += (int)((re - rs + AF_PLAIN - 1) / AF_PLAIN);
   }
   o.pblk0[n_heads + 1] = pblocks;
   o.plain_blocks = pblocks;
-  af_adam_t A{p, g, m, v, vmax, n, step_dev, lr, beta1, beta2, eps, grad_scale, zero_grad};
+  af_adam_t A{p, g, m, v, vmax, lo, hi, step_dev, lr, beta1, beta2, eps, grad_scale, zero_grad, advance};
+  if (blocks + pblocks == 0) return MMVAE_ERR_ARG;
   if (rows) {
     MMVAE_CHECK_ARG(W_host && out && n_rows > 0 && B > 0 && n_out > 0);
     if (n_rows > RS_LC_ROWS || n_out > RS_LC_OUT) return MMVAE_ERR_UNSUPPORTED;

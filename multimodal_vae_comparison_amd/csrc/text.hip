@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const float* __restri
                                                            const float* __restrict__ pe, float* __restrict__ out, int B,
                                                            int T, int V, int mode, int B0, mmvae_dropout_t drop) {
   const int n = B * T * V, n0 = B0 * T * V;
+  MMVAE_TRACE_STAMP(30);
   const DropKey dk = drop_key(drop);
   const float e00 = emb[0], e01 = emb[1], e10 = emb[2], e11 = emb[3];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restri
                                                            float* __restrict__ ws, int B, int T, int V, int mode,
                                                            int B0, mmvae_dropout_t drop) {
   __shared__ float red[4];
+  MMVAE_TRACE_STAMP(31);
   const int n = B * T * V, n0 = B0 * T * V;
   const DropKey dk = drop_key(drop);
   float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
@@ -1161,6 +1163,7 @@ extern "C" int mmvae_sum_over_time(const float* x, float* y, int L, int N, int d
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void permute_mask_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
                                                            float* __restrict__ y, int T, int B, int V, int fwd) {
+  MMVAE_TRACE_STAMP(32);
   const long n = (long)T * B * V;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     // i indexes the (B,T,V) side
@@ -1213,6 +1216,7 @@ struct DropAdvanceMany {
   int n;
 };
 __global__ void dropout_advance_many_kernel(DropAdvanceMany a) {
+  MMVAE_TRACE_STAMP(33);
   const int i = threadIdx.x;
   if (i < a.n) {
     uint32_t* st = a.st[i];
@@ -1249,6 +1253,7 @@ __global__ __launch_bounds__(256) void dropout_act_kernel(const float* __restric
                                                           float* __restrict__ out, long n, int act, int bwd,
                                                           mmvae_dropout_t drop) {
   // fwd: out = act(x) * m ; bwd: out = a(=dy) * m * act'(x)
+  MMVAE_TRACE_STAMP(34);
   const DropKey dk = drop_key(drop);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float m = drop_mul(dk, (uint32_t)i);
@@ -1414,3 +1419,5 @@ extern "C" int mmvae_expand_text_tokens(const int32_t* tokens, const int32_t* le
                      onehot, mask, B, T, V);
   return mmvae_launch_status();
 }
+
+MMVAE_TRACE_SETTER(text)

@@ -196,6 +196,7 @@ __device__ __forceinline__ void unit_body(const Job& jb, const int unit, const i
 }
 
 __global__ __launch_bounds__(256, 2) void txt_wgrad_kernel(const Args args) {
+  MMVAE_TRACE_STAMP(35);
   __shared__ __attribute__((aligned(16))) float red[3 * (4 * 16 + 2) * 64];
   const int b = blockIdx.x;
   Job jb = args.job[0];
@@ -260,3 +261,5 @@ extern "C" int mmvae_txt_wgrad(const mmvae_txt_wgrad_job_t* jobs, int n_jobs, mm
   hipLaunchKernelGGL(tw::txt_wgrad_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, a);
   return mmvae_launch_status();
 }
+
+MMVAE_TRACE_SETTER(twgrad)

@@ -104,6 +104,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_dev = torch.zeros(6, dtype=torch.int32, device=flat.data.device)   # {count, ticket, b1^count, b2^count}
         self.grad_scale = grad_scale
         self._steps_since_check = 0
+        self._early = None        # (lo, hi) of a range this step's step_early() has already updated
 
     def check_grad_views(self):
         """every parameter's .grad must still be its slice of the flat gradient buffer (a zero_grad(set_to_none=True),
@@ -126,6 +127,16 @@ class FlatAdam(torch.optim.Optimizer):
         self._steps_since_check = (self._steps_since_check + 1) & 255
         g = self.param_groups[0]
         d, ops.GradReducer.deferred = ops.GradReducer.deferred, None
+        early, self._early = self._early, None
+        if early is not None:
+            # the second range [lo, n) of this step was updated behind the decoders' backward (step_early): the closing
+            # launch covers [0, lo) with the segments that are left
+            lo, hi = early
+            assert hi == self.flat.data.numel() and 0 < lo < hi
+            ops.adam_fold_range(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, 0, lo, True, float(g["lr"]),
+                                g["betas"][0], g["betas"][1], g["eps"], self.step_dev, self.grad_scale, True,
+                                d["table"] if d is not None else None, tail=d["tail"] if d is not None else None)
+            return loss
         if d is not None:
             # the backward pass left its split partials unfolded for us (GradReducer.defer_next): fold + update at once
             ops.adam_fold_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]), g["betas"][0],
@@ -135,6 +146,16 @@ class FlatAdam(torch.optim.Optimizer):
         ops.adam_amsgrad_flat(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, float(g["lr"]),
                               g["betas"][0], g["betas"][1], g["eps"], -1, self.step_dev, self.grad_scale, True)
         return loss
+
+    @torch.no_grad()
+    def step_early(self, lo, hi, table):
+        """elements [lo, hi) of this step NOW, on the current stream, without closing the step (ops.GradReducer.early_step:
+        the decoders' + prior's gradients are final when the fusion's backward has run); step() then covers the rest"""
+        assert self._early is None and self.supports_fold
+        g = self.param_groups[0]
+        ops.adam_fold_range(self.flat.data, self.flat.grad, self.m, self.v, self.vmax, lo, hi, False, float(g["lr"]),
+                            g["betas"][0], g["betas"][1], g["eps"], self.step_dev, self.grad_scale, True, table)
+        self._early = (lo, hi)
 
     def zero_grad(self, set_to_none=False):
         # step() already clears the buffer inside the Adam kernel; an explicit zero_grad() (Lightning calls it

@@ -109,6 +109,7 @@ class MoPOE(TorchMMVAE):
                     eps = self._draw_many(M, B, D, dev)
         rotate = True      # the fusion runs on the last tower's stream, the decoders rotate by one stream
         fuse = real[-1] if rotate else real[0]
+        self._fuse_stream = fuse
         for st in real:
             if st != fuse:
                 fuse.wait_stream(st)
@@ -119,6 +120,8 @@ class MoPOE(TorchMMVAE):
             _uses(t, fuse)
         with torch.cuda.stream(fuse):
             packed = [packed_head(mu, lv) for mu, lv in enc]
+            if seeds is not None and getattr(self, "early_adam", None) is not None and ops.GradReducer.defer_next:
+                packed[-1] = ops.EarlyStepPoint.apply(packed[-1])      # (its tower's stream IS the fusion's)
             if eps is None:
                 _, kl, z = ops.poe_reparam_kl(theta, packed, M, True, (1 << (M + 1)) - 1, theta.grad, raw=True,
                                               rng=self._rng_state)
@@ -190,13 +193,20 @@ class MoPOE(TorchMMVAE):
         # finished by then, and a launch of their own would sit between the fold and the optimiser (assembling them on a
         # side stream instead cost +20 us: DESIGN section 5)
         tail = ops.GradReducer.tail = ops.lincomb_rows_args(recs + [kl], W)
+        early = getattr(self, "early_adam", None)
+        if early is not None and not cut and ops.GradReducer.defer_next:
+            # (captured one-GPU step) the decoders' + prior's parameters are updated as soon as the tower that shares the
+            # fusion's stream has queued its last backward launch: ops.GradReducer.run_early_step
+            ops.GradReducer.early_step = (early[0], self._fuse_stream, early[1], early[2])
+            ops.GradReducer.dw_open = True
         if cut:
             # decoders + fusion only: the gradients of the towers' head outputs come back instead of flowing on
             self._cut = (list(self._fusion_inputs), torch.autograd.grad(recs + [kl], self._fusion_inputs, self._seeds),
                          streams, dev)
         else:
             torch.autograd.backward(recs + [kl], self._seeds)
-        ops.GradReducer.tail = None
+        ops.GradReducer.tail = ops.GradReducer.early_step = None
+        ops.GradReducer.dw_open = False
         if tail is not None and tail["done"]:
             out = tail["args"][2].unbind(0)
         if out is None:

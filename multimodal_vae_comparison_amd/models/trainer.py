@@ -258,6 +258,15 @@ class MultimodalVAE(nn.Module):
                         ops.GradReducer.side_tail = ops.GradReducer.pre_join = ring.pull_next
                     # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
                     ops.GradReducer.defer_next = self._adam_in_graph and self.optimizer.supports_fold
+                    # ... and its second range (decoders, prior) does not wait for the end of the step: MoPOE.
+                    # objective_backward runs it behind the fusion's backward (MMVAE_EARLY_ADAM=0: one launch at the end)
+                    self.model.early_adam = None
+                    if ops.GradReducer.defer_next and 0 < self.flat.split < self.flat.grad.numel() and \
+                            os.environ.get("MMVAE_EARLY_ADAM", "2") != "0":
+                        ops.GradReducer.early_at = int(os.environ.get("MMVAE_EARLY_ADAM", "2"))
+                        lo, hi, g0 = self.flat.split, self.flat.grad.numel(), self.flat.grad.data_ptr()
+                        self.model.early_adam = (lambda table, lo=lo, hi=hi: self.optimizer.step_early(lo, hi, table),
+                                                 g0 + 4 * lo, g0 + 4 * hi)
                     stager = self._stager if with_collective else None
                     if stager is not None:
                         stager.begin()
@@ -267,6 +276,7 @@ class MultimodalVAE(nn.Module):
                     finally:
                         rconv.BLOCK_DONE_HOOK = None
                     ops.GradReducer.defer_next = False
+                    self.model.early_adam = None
                     ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
                     if self._input_ring is not None:
                         self._input_ring.pull_next(self.flat.data.device, [])     # (no hook point ran: pull here)

@@ -75,13 +75,15 @@ class GradReducer:
         if device.type != "cuda":
             return
         _, st = cls._st(device)
+        cls.early_step, cls.dw_jobs, cls.dw_open = None, [], False      # (per-step state: a backward pass that raised leaves them behind)
         if cls.deferred is not None:
             cls.deferred = None
             raise RuntimeError("GradReducer: a deferred fold was never taken by an optimiser step: the split weight "
                                "gradients of the previous backward pass were lost")
         if st["armed"] or st["segs"] or st["pending"]:
             st.update(off=0, segs=[], armed=False, keep=[], used=set(), pending=[], spill=[], spilled=0)
-            cls.tail = None
+            cls.tail = cls.early_step = None
+            cls.dw_jobs = []
 
     @classmethod
     def alloc(cls, n_floats, device):
@@ -127,6 +129,68 @@ class GradReducer:
         if fn is not None:
             fn(device, [])                      # on the CURRENT stream = the side tower's
 
+    # early_step = (fn, stream, lo, hi): set by MoPOE.objective_backward for a captured one-GPU step -- when the fusion's
+    # backward has been queued on `stream` and handed its gradients over (EarlyStepPoint.backward), every gradient of the flat buffer's
+    # second range [lo, hi) (decoders, prior: FlatParams.split) is final AND stream-ordered in front of this point, so their
+    # fold + Adam update runs here, beside the encoders' backward, instead of in the serial launch at the end of the step
+    # (fn(table of the range's segments or None)).  The range's segments leave the list: nobody else folds them.
+    # (Round 6, measured: queued behind the text encoder's LAST backward launch instead, the 65 MB the update moves landed
+    # on the image encoder's first-layer weight gradient -- 14 -> 26 us -- and gave back what the shorter closing launch won.)
+    early_step = None
+
+    # dw_jobs: weight gradients of Linear layers whose backward only launched the data gradient (Linear.backward, while
+    # `early_step` is armed, on the fusion's stream): (dy, x, dw, db, M, N, K, x_act), tensors held until flush_dw queues them
+    dw_jobs = []
+    dw_open = False       # True from the arming of `early_step` until EarlyStepPoint.backward has queued the parked jobs
+    dw_later_enabled = os.environ.get("MMVAE_LINEAR_DW_LATER", "1") == "1"
+
+    @classmethod
+    def dw_later(cls, device):
+        es = cls.early_step
+        return (cls.dw_later_enabled and cls.dw_open and es is not None and torch.cuda.current_stream(device) == es[1]
+                and len(cls.dw_jobs) < H.WGRAD_BATCH_MAX)
+
+    @classmethod
+    def flush_dw(cls):
+        """the parked weight gradients in one launch on the current stream (every job direct into the flat gradient)"""
+        jobs, cls.dw_jobs = cls.dw_jobs, []
+        if not jobs:
+            return
+        arr = (H.WgradJob * len(jobs))()
+        for j, (dy, x, dw, db, M, N, K, x_act) in zip(arr, jobs):
+            j.dy, j.x, j.dw, j.db, j.ws = H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), None
+            j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, x_act, H.ACC_DEFER
+        _call("mmvae_linear_bwd_weight_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
+
+    # WHERE on the fusion's stream the update is queued (MMVAE_EARLY_ADAM): 1 = right behind the fusion's backward
+    # (EarlyStepPoint), 2 / 3 = in front of / behind the weight-gradient launch of the text encoder's layer, 4 = behind the
+    # text encoder's last backward launch (EmbedPE.backward)
+    early_at = int(os.environ.get("MMVAE_EARLY_ADAM", "2") or 0)
+
+    @classmethod
+    def run_early_step(cls, device, at=1):
+        es = cls.early_step
+        if es is None or at != cls.early_at:
+            return
+        fn, stream, lo, hi = es
+        _, st = cls._st(device)
+        if torch.cuda.current_stream(device) != stream:      # (another tower's launch of the same kind)
+            return
+        cls.early_step = None
+        if st["pending"] or st["spill"] or not cls.defer_next:
+            return
+        inside = [sg for sg in st["segs"] if lo <= sg[1] < hi]
+        if len(inside) > H.MAX_SEGMENTS or any(sg[1] + 4 * sg[3] > hi for sg in inside):
+            return
+        st["segs"] = [sg for sg in st["segs"] if not (lo <= sg[1] < hi)]
+        t = None
+        if inside:
+            t = H.ReduceSegments()
+            for j, (sp, dp, r, ln, sd) in enumerate(inside):
+                t.src[j], t.dst[j], t.rows[j], t.len[j], t.stride[j] = sp, dp, r, ln, sd
+            t.n = len(inside)
+        fn(t)
+
 
     @classmethod
     def keep(cls, device, *tensors):
@@ -167,6 +231,7 @@ class GradReducer:
 
     @classmethod
     def flush(cls, device):
+        assert not cls.dw_jobs, "parked Linear weight gradients were never launched (EarlyStepPoint.backward did not run)"
         cls.launch_pending(device)
         _, st = cls._st(device)
         cur = torch.cuda.current_stream(device)
@@ -838,10 +903,22 @@ class Linear(Function):
         ep = _DACT[in_act]
         aux = H.ptr(x) if ep else None
         radd = ctx.res_sink.take() if ctx.res_sink is not None else None      # the residual branch's gradient of x
+        kadd = None
         if radd is not None and need_dx and not ep and radd.is_contiguous() and radd.numel() == x.numel():
-            ep, aux, radd = H.EP_ADD_AUX, H.ptr(radd), None                    # ... added in the data gradient's epilogue
+            # ... added in the data gradient's epilogue; `kadd` keeps the tensor alive until the launch below is queued
+            # (dropped before the launch, its block could be handed out again by any allocation in between)
+            ep, aux, kadd, radd = H.EP_ADD_AUX, H.ptr(radd), radd, None
         defer = _defer(gw, gb if has_b else gw)
         nz = lib.mmvae_linear_bwd_splits(M, N, K) if need_dx else lib.mmvae_linear_bwd_weight_splits(M, N, K)
+        if need_dx and defer and nz == 1 and radd is None and GradReducer.dw_later(x.device) and \
+                lib.mmvae_linear_bwd_weight_splits(M, N, K) == 1:
+            # the captured one-GPU MoPoE step, a Linear of the decoder that shares the fusion's stream: only the DATA
+            # gradient sits on the critical chain decoder -> fusion -> encoders; the weight gradients of all such layers
+            # follow in ONE launch behind the fusion's backward (GradReducer.flush_dw)
+            _call("mmvae_linear_bwd_data", H.ptr(dy), H.ptr(w), aux, H.ptr(dx), M, N, K, ep, 0, H.stream())
+            GradReducer.dw_jobs.append((dy, x, dw, db, M, N, K, in_act))
+            del kadd
+            return dx, ret_w, ret_b, None, None, None, None, None
         if defer:
             ws = GradReducer.alloc(nws, x.device) if nz > 1 else None
             acc = H.ACC_DEFER
@@ -859,6 +936,7 @@ class Linear(Function):
             GradReducer.add(ws.data_ptr(), dw, nz, N * K, N * K)
             if db is not None:
                 GradReducer.add(ws.data_ptr() + 4 * nz * N * K, db, nz, N, N)
+        del kadd
         if radd is not None and dx is not None:
             dx = dx + radd.view_as(dx)
         return dx, ret_w, ret_b, None, None, None, None, None
@@ -1107,6 +1185,25 @@ class PoeReparamKL(Function):
               _poe_ticket(dev), E,
               int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, H.stream())
         return (ret, None, None, None, None, None, None, None, None, *dpacked, *([None] * ctx.n_eps_in))
+
+
+class EarlyStepPoint(Function):
+    """identity on the packed head output of the tower that shares the fusion's stream: its backward is the first node
+    that runs on that stream AFTER the fusion's backward has handed its gradients over (the engine records the events the
+    other towers' streams wait for when PoeReparamKL.backward returns -- a launch queued inside that function would sit in
+    front of them and hold the other tower's encoder backward up: measured, +9 us on both chains).  Every decoder's and the
+    prior's gradient is final and stream-ordered in front of this point: GradReducer.run_early_step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        GradReducer.dw_open = False      # (the encoders' Linear layers behind this point keep their grouped launches)
+        GradReducer.flush_dw()
+        GradReducer.run_early_step(g.device)
+        return g
 
 
 def poe_reparam_kl(theta, packed, eps, with_prior, kl_mask, gtheta=None, cols=None, raw=False, rng=None):
@@ -1861,6 +1958,7 @@ class EmbedPE(Function):
             _call("mmvae_embed_pe_bwd", H.ptr(onehot), H.ptr(dx), H.ptr(de), H.ptr(ws), B, T, V, mode, B0, acc, dpc,
                   H.stream())
         GradReducer.run_side_tail(dx.device)      # the text encoder's LAST backward launch: its stream idles from here on
+        GradReducer.run_early_step(dx.device, 4)
         return None, ret, None, None, None, None, None
 
 
@@ -1951,7 +2049,9 @@ def _txt_wgrad(jobs):
         j = arr[i]
         j.dy, j.x, j.ws, j.M, j.N, j.K = H.ptr(dy2), H.ptr(x2), H.ptr(ws), M, N, K
         segs.append((ws, nz, gw, gb, N, K))
+    GradReducer.run_early_step(jobs[0][0].device, 2)
     _call("mmvae_txt_wgrad", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
+    GradReducer.run_early_step(jobs[0][0].device, 3)
     for ws, nz, gw, gb, N, K in segs:
         GradReducer.add(ws.data_ptr(), gw, nz, N * K, N * K)
         GradReducer.add(ws.data_ptr() + 4 * nz * N * K, gb, nz, N, N)
@@ -2560,6 +2660,19 @@ def adam_fold_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step_dev, grad_scale
         extra = (None, None, None, 0, 0, 0)
     _call("mmvae_adam_fold_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), lr, beta1, beta2, eps,
           H.ptr(step_dev), grad_scale, int(zero_grad), ctypes.byref(deferred["table"]), *extra, H.stream())
+
+
+def adam_fold_range(p, g, m, v, vmax, lo, hi, advance, lr, beta1, beta2, eps, step_dev, grad_scale, zero_grad, table, tail=None):
+    """the same over elements [lo, hi) only, with the segments of `table` (H.ReduceSegments or None) that lie inside
+    (mmvae_adam_fold_range); advance: this is the launch that closes the step"""
+    if tail is not None:
+        rp, flat, out, n, B, k = tail["args"]
+        extra = (ctypes.byref(rp), flat, H.ptr(out), n, B, k)
+    else:
+        extra = (None, None, None, 0, 0, 0)
+    _call("mmvae_adam_fold_range", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), int(lo), int(hi),
+          int(advance), lr, beta1, beta2, eps, H.ptr(step_dev), grad_scale, int(zero_grad),
+          ctypes.byref(table) if table is not None else None, *extra, H.stream())
 
 
 def step_inc(step_dev):

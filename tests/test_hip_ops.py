@@ -863,7 +863,8 @@ def test_adam_fold_flat_is_fold_then_adam(ops, hip_lib, rider):
         (3100000, 0, 5, 16384, 16384), (3300000, 33000, 1, 64, 64), (3400000, n - 13, 9, 13, 16),
         (2400100, 34000, 512, 1568, 1600), (3500001, 36001, 130, 77, 79)]      # narrow-block segments (>= 128 rows)
     state = {}
-    for name in ("a", "b"):
+    split = 30000      # "c": the step in two launches (mmvae_adam_fold_range): [split, n) first, then [0, split) closes it
+    for name in ("a", "b", "c"):
         gg = torch.Generator().manual_seed(6)
         state[name] = {"p": torch.randn(n, generator=gg).to(DEV), "m": torch.zeros(n, device=DEV),
                        "v": torch.zeros(n, device=DEV), "x": torch.zeros(n, device=DEV), "g": torch.zeros(n, device=DEV),
@@ -891,20 +892,52 @@ def test_adam_fold_flat_is_fold_then_adam(ops, hip_lib, rider):
                     H.check(hip_lib.mmvae_reduce_segments(ctypes.byref(t), H.stream()), "fold")
                 ops.adam_amsgrad_flat(st["p"], st["g"], st["m"], st["v"], st["x"], 1e-3, 0.9, 0.999, 1e-8, -1, st["step"],
                                       0.5, True)
-            else:
+            elif name == "b":
                 ops.adam_fold_flat(st["p"], st["g"], st["m"], st["v"], st["x"], 1e-3, 0.9, 0.999, 1e-8, st["step"], 0.5,
                                    True, {"table": t, "tail": tail})
+            else:
+                step_before = int(st["step"][0])
+                ops.adam_fold_range(st["p"], st["g"], st["m"], st["v"], st["x"], split, n, False, 1e-3, 0.9, 0.999, 1e-8,
+                                    st["step"], 0.5, True, t)
+                torch.cuda.synchronize()
+                assert int(st["step"][0]) == step_before and float(st["g"][split:].abs().max()) == 0.0
+                # (the first range once with a table that only holds ITS segments, once with the full table)
+                if it == 1:
+                    t1 = H.ReduceSegments()
+                    keep = [sp for sp in specs if sp[1] < split]
+                    for j, (so, do, r, ln, sd) in enumerate(keep):
+                        t1.src[j], t1.dst[j] = arena.data_ptr() + 4 * so, st["g"].data_ptr() + 4 * do
+                        t1.rows[j], t1.len[j], t1.stride[j] = r, ln, sd
+                    t1.n = len(keep)
+                    t = t1
+                ops.adam_fold_range(st["p"], st["g"], st["m"], st["v"], st["x"], 0, split, True, 1e-3, 0.9, 0.999, 1e-8,
+                                    st["step"], 0.5, True, t, tail=tail)
             outs[name] = tail["args"][2].clone() if rider else None
         torch.cuda.synchronize()
-        for k in ("p", "m", "v", "x", "g", "step"):
-            da, db = state["a"][k], state["b"][k]
-            if not torch.equal(da, db):
-                bad = (da != db).nonzero().flatten()
-                raise AssertionError(f"step {it}: {k} differs at {bad.numel()} elements, first {bad[:8].tolist()}, last "
-                                     f"{bad[-4:].tolist()}, max |d| {float((da.double() - db.double()).abs().max()):.3e}")
-        if rider:
-            assert torch.equal(outs["a"], outs["b"])
+        for other in ("b", "c"):
+            for k in ("p", "m", "v", "x", "g", "step"):
+                da, db = state["a"][k], state[other][k]
+                if not torch.equal(da, db):
+                    bad = (da != db).nonzero().flatten()
+                    raise AssertionError(f"step {it} ({other}): {k} differs at {bad.numel()} elements, first {bad[:8].tolist()}, "
+                                         f"last {bad[-4:].tolist()}, max |d| {float((da.double() - db.double()).abs().max()):.3e}")
+            if rider:
+                assert torch.equal(outs["a"], outs[other])
     assert int(state["b"]["step"][0]) == 3 and float(state["b"]["g"].abs().max()) == 0.0
+    # a segment that straddles the range boundary is refused; a range without segments is plain Adam over it
+    st = state["c"]
+    tb = H.ReduceSegments()
+    tb.src[0], tb.dst[0], tb.rows[0], tb.len[0], tb.stride[0] = arena.data_ptr(), st["g"].data_ptr() + 4 * (split - 8), 2, 16, 16
+    tb.n = 1
+    with pytest.raises(RuntimeError):
+        ops.adam_fold_range(st["p"], st["g"], st["m"], st["v"], st["x"], split, n, False, 1e-3, 0.9, 0.999, 1e-8,
+                            st["step"], 0.5, True, tb)
+    p_before = st["p"].clone()
+    st["g"][split:split + 100] = 1.0
+    ops.adam_fold_range(st["p"], st["g"], st["m"], st["v"], st["x"], split, n, False, 1e-3, 0.9, 0.999, 1e-8, st["step"],
+                        0.5, True, None)
+    torch.cuda.synchronize()
+    assert torch.equal(st["p"][:split], p_before[:split]) and not torch.equal(st["p"][split:split + 100], p_before[split:split + 100])
     # destinations outside the flat buffer / overlapping ranges are refused
     t = H.ReduceSegments()
     t.src[0], t.dst[0], t.rows[0], t.len[0], t.stride[0] = arena.data_ptr(), state["b"]["g"].data_ptr() + 4 * (n - 8), 2, 16, 16

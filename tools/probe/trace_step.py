@@ -20,7 +20,10 @@ NAMES = {0: "img enc conv1", 1: "img enc conv2", 2: "img enc conv3", 3: "img enc
          8: "img dec bwd convT3", 9: "img dec bwd convT(16)", 10: "img dec bwd convT(8)", 11: "img dec bwd convT(4)",
          12: "img enc bwd conv4", 13: "img enc bwd conv3", 14: "img enc bwd conv2", 15: "img enc bwd conv1 wgrad",
          16: "txt enc layer fwd", 17: "txt dec layer fwd", 18: "txt enc layer bwd", 19: "txt dec layer bwd",
-         20: "adam", 21: "reduce_segments", 22: "poe fwd", 23: "poe bwd"}
+         20: "adam", 21: "reduce_segments", 22: "poe fwd", 23: "poe bwd",
+         24: "  gemm_grouped", 25: "  rgemm16", 26: "  rgemm", 27: "  rgemm_grouped", 28: "  bce_rowsum", 29: "  ce_time_fwd",
+         30: "  embed_pe_fwd", 31: "  embed_pe_bwd", 32: "  permute_mask", 33: "  dropout_advance", 34: "  dropout_act",
+         35: "  txt_wgrad", 36: "img dec convT3 col2im fwd"}
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("TRACE_BATCH", 128))
 torch.manual_seed(0)
@@ -28,27 +31,38 @@ tr = MultimodalVAE(cdsprites_config("mopoe", 32, batch_size=B), device=dev)
 tr.model.train()
 tr.configure_optimizers()
 batch = cdsprites_batch(B, 32, seed=1, device=dev)
-table = torch.zeros(64, dtype=torch.int64, device=dev)
+table = torch.zeros(8 + 2 * 2048, dtype=torch.int64, device=dev)
 L = ctypes.CDLL(os.environ["MMVAE_HIP_LIB"])
-for m in ("conv", "txtlayer", "txtwave", "optim", "latent"):
-    fn = getattr(L, f"mmvae_trace_set_{m}")
+for m in ("conv", "txtlayer", "txtwave", "optim", "latent", "gemm", "loss", "text", "twgrad"):
+    fn = getattr(L, f"mmvae_trace_set_{m}", None)      # (the product build has no stamps: the step time only)
+    if fn is None:
+        continue
     fn.argtypes = [ctypes.c_void_p]
     assert fn(table.data_ptr()) == 0
 tr.capture(batch, 1)
-for _ in range(30):
+for _ in range(60):
     tr.fused_step(1)
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(100):
-    tr.fused_step(1)
-e1.record()
-torch.cuda.synchronize()
-print(f"step: {e0.elapsed_time(e1) * 10:.1f} us")
+for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(300):
+        tr.fused_step(1)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"step: {e0.elapsed_time(e1) * 1000 / 300:.1f} us")
+if int(table[0]) == 0:
+    sys.exit(0)
 v = table.cpu().tolist()
-last = max(v)
-ev = sorted((v[i], n) for i, n in NAMES.items() if v[i] and last - v[i] < (200000 if B <= 256 else 2000000))   # stamps of the last replay only
-t0 = ev[0][0]
-for t, n in ev:
-    print(f"{(t - t0) / 100.0:8.2f} us  {n}")
-print(f"(adam start + ~18 us = end of step; next step's first kernel follows)")
+n_ev = v[0]
+ev = [(v[9 + 2 * (k & 2047)], v[8 + 2 * (k & 2047)]) for k in range(max(0, n_ev - 2047), n_ev)]     # (time, id), launch order
+ev.sort()
+starts = [i for i, (t, k) in enumerate(ev) if k == 0]           # conv1 opens a step
+assert len(starts) >= 3, "no complete step in the event log"
+step = ev[starts[-2]:starts[-1]]
+t0 = step[0][0]
+prev = t0
+for t, k in step:
+    print(f"{(t - t0) / 100.0:8.2f} us  (+{(t - prev) / 100.0:6.2f})  {NAMES.get(k, k)}")
+    prev = t
+print(f"{(ev[starts[-1]][0] - t0) / 100.0:8.2f} us  next step's conv1   ({len(step)} instrumented launches per step)")
