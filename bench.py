@@ -49,6 +49,10 @@ def parse():
                    help="process-group backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo moves the CUDA "
                         "buffers through the host and lets several ranks share one GPU (N > 1 readiness test on a "
                         "1-GPU box: LOCAL_RANK is taken modulo the visible device count)")
+    p.add_argument("--settle", type=int, default=SETTLE_STEPS,
+                   help="untimed set-up replays between the first window (W warm-ups + K timed steps right after the capture, "
+                        "reported as first_window_ms_per_step) and the headline region (W warm-ups + K timed steps); "
+                        "0 = the headline IS the first window")
     p.add_argument("--force-collective", action="store_true",
                    help="one GPU, but the multi-GPU step structure (graph, RCCL all-reduce over 1 rank, Adam launch)")
     return p.parse_args()
@@ -458,11 +462,23 @@ def main():
     # box run ~2 % slow (clocks, instruction / constant caches, first-touch of the arena): with the driver's `--steps 20
     # --warmup 5` the timed region would otherwise BE that transient (measured: 0.396 vs 0.388 ms on the same box, the three
     # `spread` repeats right behind it 0.388).  The W warm-up steps and the K timed steps follow unchanged.
-    settle = max(0, SETTLE_STEPS - a.warmup)
-    for _ in range(settle):
-        tr.fused_step(path_world)
-    barrier()
+    # (round 6) the caller's protocol on the fresh graph is measured FIRST and reported beside the headline
+    # (`first_window_ms_per_step`: W warm-ups, K timed steps, nothing in front), so that lines of different rounds can be
+    # compared on either footing; `untimed_steps_before_timed_region` is everything that ran before the headline's K steps.
+    settle = max(0, a.settle)
+    first_dt = None
+    if settle > 0:
+        first_dt, _ = _timed(tr, a.steps, a.warmup, path_world, barrier)
+        for _ in range(settle):
+            tr.fused_step(path_world)
+        barrier()
     dt, out = _timed(tr, a.steps, a.warmup, path_world, barrier)
+    if first_dt is None:
+        first_dt = dt
+    if world > 1:
+        t = torch.tensor([first_dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        first_dt = float(t.item())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -482,7 +498,10 @@ def main():
         sps = a.steps * B * world / dt
         res = {"metric": METRIC.get(a.config, f"training samples/sec, {a.config} (fwd+bwd+Adam)"), "value": round(sps, 1),
                "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * dt / a.steps, 4),
+               "first_window_ms_per_step": round(1e3 * first_dt / a.steps, 4),
+               "untimed_steps_before_timed_region": (a.warmup + a.steps + settle if settle > 0 else 0) + a.warmup,
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{desc}; Adam(amsgrad) lr 1e-4, beta 1, train mode (dropout on)",
                           "global_batch": B * world, "parallelism": f"dp{world}", "settle_steps": settle,

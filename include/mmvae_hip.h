@@ -199,6 +199,11 @@ int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias, const flo
 size_t mmvae_gemm_ws_floats(int M, int N, int splitk);
 /* number of partial results (rows of M*N [+ M] floats in ws) mmvae_gemm_f32 writes for a requested splitk */
 int mmvae_gemm_splits(int M, int N, int K, int splitk);
+/* Runtime switch of the LDS-tiled split-bf16 kernels that take wide layers (N, K >= 128) at 2048 .. 4096 rows over from the
+ * fp32-MFMA bodies in mmvae_gemm_f32 / mmvae_linear_fwd / _bwd_data / _bwd (csrc/gemm_b16.inc; same fp32 contract, every
+ * product from six bf16 MFMAs on three exact bf16 terms per operand).  Returns the previous setting; the environment
+ * variable MMVAE_GEMM_B16=0 starts with it off.  (nn.Linear: reference models/encoders.py:196-200, models/decoders.py:58-62.) */
+int mmvae_gemm_b16_set(int on);
 /* grouped bias of a layer whose N outputs are C channels x G positions (nn.ConvTranspose2d on a 1x1 input run as a
  * GEMM, models/decoders.py:116,129-131):  y[r, c*G + g] += bias[c];   db[c] (+)= sum_r sum_g dy[r, c*G + g] */
 int mmvae_bias_group_add(float* y, const float* bias, int rows, int C, int G, mmvae_stream_t stream);

@@ -101,6 +101,8 @@ __device__ __forceinline__ void act_inplace(float (&v)[N], int act) {
   }
 }
 
+#include "gemm_b16.inc"
+
 // Output phase shared by the staged and the register-operand bodies: (KSPLIT > 1) sum the waves' partial accumulators
 // through LDS (`red`: KSPLIT x 16 x 64 floats, `rsr`: KSPLIT x 32), then bias / epilogue / accumulate / store.
 template <int KSPLIT>
@@ -747,6 +749,32 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
   g.M = M; g.N = N; g.K = K; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.a_act = a_act; g.b_act = b_act; g.ep = ep_mode;
   g.accumulate = accumulate ? 1 : 0;   // DEFER without a split == plain accumulation
+  // wide layers at large row counts: the LDS-tiled split-bf16 kernel (gemm_b16.inc); forward and data gradient
+  if (splitk == 1 && !a_rowsum && ep_mode != MMVAE_EP_GELU && gb_act_ok(a_act) && gb_act_ok(b_act) && gb_shape_ok(M, N, K) &&
+      M <= G16_MAX_ROWS) {
+    const bool akc = sak == 1, bkc = (sbk == 1 && sbn != 1);
+    const long lda = akc ? sam : sak, ldb = bkc ? sbn : sbk;
+    const bool a_ok = (akc || sam == 1) && gb_al16(A) && (lda & 3) == 0 && (akc || (M & 3) == 0);
+    const bool b_ok = (bkc || sbn == 1) && gb_al16(Bm) && (ldb & 3) == 0;
+    if (a_ok && b_ok && (!akc || !bkc || true)) {
+      GbArgs b{A, Bm, bias, aux, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, a_act, b_act, ep_mode, g.accumulate, K};
+      const dim3 grid((N + G16_TM - 1) / G16_TM, (M + G16_TM - 1) / G16_TM, 1);
+      hipStream_t st = (hipStream_t)stream;
+      // fewer tiles than CUs: two k-groups per tile (twice the waves, half the chain)
+      const bool ks2 = (long)grid.x * grid.y < 256 && K >= 4 * G16_BK;
+#define G16_LAUNCH(AK_, BK_)                                                                                   \
+  do {                                                                                                         \
+    if (ks2) hipLaunchKernelGGL((gemm_b16_kernel<AK_, BK_, 2>), grid, dim3(512), 0, st, b);                     \
+    else hipLaunchKernelGGL((gemm_b16_kernel<AK_, BK_, 1>), grid, dim3(256), 0, st, b);                         \
+  } while (0)
+      if (akc && bkc) G16_LAUNCH(true, true);
+      else if (akc) G16_LAUNCH(true, false);
+      else if (bkc) G16_LAUNCH(false, true);
+      else G16_LAUNCH(false, false);
+#undef G16_LAUNCH
+      return mmvae_launch_status();
+    }
+  }
   const int ntn = (N + 31) / 32;
   // Tiling choice (all that matters at batch 128 is the length of the serial load -> MFMA chain per workgroup):
   //   K <= 128 and many rows : 128x32 tiles, one stage, no cross-wave reduction            (KSPLIT 1)
@@ -991,10 +1019,17 @@ extern "C" int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int 
 // the cfg2 step at batch 512 / 1000: 0.996 -> 0.958, 1.660 -> 1.635; 2048 and 4096 measured level on the K-sample workloads)
 constexpr int RGEMM_BWD_MAX_M = 1024;
 static inline bool linear_bwd_rgemm(int M, int N) { return rgemm_enabled() && M <= RGEMM_BWD_MAX_M && (N & 3) == 0 && N >= 4; }
+// the tiled split-bf16 grouped launch (gemm_b16.inc): data gradient (M x K, reduction N) + weight gradient (N x K, reduction M)
+static inline bool linear_bwd_b16(int M, int N, int K) { return gb_shape_ok(M, K, N) && M <= G16_MAX_ROWS; }
 extern "C" size_t mmvae_linear_bwd_ws_floats(int M, int N, int K) {
+  if (linear_bwd_b16(M, N, K)) {
+    const int nz = gb_wgrad_nz(M, N, K);
+    return nz > 1 ? (size_t)nz * ((size_t)N * K + N) : 0;
+  }
   return linear_bwd_rgemm(M, N) ? 0 : mmvae_linear_bwd_weight_ws_floats(M, N, K);
 }
 extern "C" int mmvae_linear_bwd_splits(int M, int N, int K) {
+  if (linear_bwd_b16(M, N, K)) return gb_wgrad_nz(M, N, K);
   return linear_bwd_rgemm(M, N) ? 1 : mmvae_linear_bwd_weight_splits(M, N, K);
 }
 extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w, const float* aux, float* dx,
@@ -1004,6 +1039,33 @@ extern "C" int mmvae_linear_bwd(const float* dy, const float* x, const float* w,
   if (ep_reads_aux(ep_mode) && !aux) return MMVAE_ERR_ARG;
   // problem 0 (data):   C[M,K] = dy[M,N] W[N,K]            reduction N
   // problem 1 (weight): C[N,K] = dy^T[N,M] act(x)[M,K]     reduction M, split over workgroups
+  if (linear_bwd_b16(M, N, K)) {
+    if (!gb_al16(dy) || !gb_al16(x) || !gb_al16(w) || (ldx & 3) != 0) return MMVAE_ERR_ARG;   // float4 staging
+    const int nz = gb_wgrad_nz(M, N, K);
+    if (nz > 1 && !ws) return MMVAE_ERR_ARG;
+    GbGroup grp;
+    grp.g[0] = GbArgs{dy, w, nullptr, aux, dx, nullptr, nullptr, M, K, N, (long)N, (long)K, (long)K, MMVAE_ACT_NONE,
+                      MMVAE_ACT_NONE, ep_mode, 0, N};
+    grp.g[1] = GbArgs{dy, x, nullptr, nullptr, dw, db, ws, N, K, M, (long)N, ldx, (long)K, MMVAE_ACT_NONE, x_act,
+                      MMVAE_EP_NONE, accumulate ? 1 : 0, gb_wgrad_kper(M, gb_wgrad_splits(M, N, K))};
+    grp.nx[0] = (K + G16_TM - 1) / G16_TM; grp.ny[0] = (M + G16_TM - 1) / G16_TM; grp.nz[0] = 1;
+    grp.nx[1] = (K + G16_TM - 1) / G16_TM; grp.ny[1] = (N + G16_TM - 1) / G16_TM; grp.nz[1] = nz;
+    grp.blk0[0] = 0;
+    grp.blk0[1] = grp.nx[0] * grp.ny[0];
+    grp.blk0[2] = grp.blk0[1] + grp.nx[1] * grp.ny[1] * nz;
+    if (grp.blk0[2] < 256 && M >= 4 * G16_BK && N >= 4 * G16_BK)
+      hipLaunchKernelGGL(gemm_b16_linear_bwd_kernel<2>, dim3(grp.blk0[2]), dim3(512), 0, (hipStream_t)stream, grp);
+    else
+      hipLaunchKernelGGL(gemm_b16_linear_bwd_kernel<1>, dim3(grp.blk0[2]), dim3(256), 0, (hipStream_t)stream, grp);
+    int rc = mmvae_launch_status();
+    if (rc) return rc;
+    if (nz > 1 && accumulate != MMVAE_ACC_DEFER) {
+      rc = mmvae_reduce_rows(ws, dw, nz, (long)N * K, (long)N * K, accumulate, stream);
+      if (rc) return rc;
+      if (db) rc = mmvae_reduce_rows(ws + (size_t)nz * N * K, db, nz, N, N, accumulate, stream);
+    }
+    return rc;
+  }
   if (linear_bwd_rgemm(M, N)) {
     if (!rgemm_aligned(dy, N, N)) return MMVAE_ERR_ARG;   // this regime needs a 16-byte aligned dy
     GemmGroup grp;

@@ -454,7 +454,9 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       for (int q = 0; q < 4; ++q) {
         // one branch-free form for the three prologues: (mean, sc, beta) = (0, 1, 0) outside RC_PRE_BN_RELU -- fma(t - 0, 1,
         // 0) is t itself -- and the clamp floor -inf for RC_PRE_NONE (the per-element mode tests were 30 branches a stage)
-        const float t = fmaxf(rc_bn(v[q], m4[q], s4[q], b4[q]), lo);
+        // (select, not v_max: a NaN input stays a NaN in every mode, as torch.relu / the plain pass-through keep it)
+        const float u = rc_bn(v[q], m4[q], s4[q], b4[q]);
+        const float t = u < lo ? lo : u;
         da[q * RC_AP] = ok ? t : 0.f;
         db[q * RC_AP] = w4[q];
       }
@@ -976,7 +978,8 @@ __device__ __forceinline__ void rc_wgrad_body(const RcWgradArgs& a, const RcBlk 
       for (int q = 0; q < 4; ++q) {      // branch-free forms of both prologues (see rc_fwd_body)
         const float v = fmaf(g4[q], p4[q], fmaf(y4[q], qq4[q], r4[q]));
         da[q] = oa ? v : 0.f;
-        const float t = fmaxf(rc_bn(x4[q], m4[q], s4[q], b4[q]), lo);
+        const float u = rc_bn(x4[q], m4[q], s4[q], b4[q]);
+        const float t = u < lo ? lo : u;      // (NaN-preserving, see the forward's prologue)
         db[q] = ob ? t : 0.f;
       }
     }

@@ -1102,8 +1102,8 @@ extern "C" int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, 
   if (d > 64 * LN_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   int rpb;
   const int nb = ln_blocks(rows, d, &rpb);
-  if (d == 32) {
-    if (!ln32_ok(dy, xhat, dsum, dx_drop) || !ln32_ok(gamma, nullptr, nullptr, nullptr)) return MMVAE_ERR_ARG;
+  // (a misaligned view falls back to the generic kernel, as the forward does: same 2 d floats per block in ws)
+  if (d == 32 && ln32_ok(dy, xhat, dsum, dx_drop) && ln32_ok(gamma, nullptr, nullptr, nullptr)) {
     hipLaunchKernelGGL(ln32_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma, dsum, dx_drop, ws,
                        rows, rpb, drop_arg(drop));
   } else {

@@ -344,13 +344,19 @@ def stack_ffn_image(layer):
     if stack is None or not ops.FFN32_SPLIT_BF16 or len(stack) > 16:
         return None
     if idx == 0:
-        stack[0]._ffn_images = ops.ffn32_prep_many([(l.linear1.weight, l.linear2.weight) for l in stack])
-    imgs = getattr(stack[0], "_ffn_images", None)
-    if imgs is None:
+        imgs = ops.ffn32_prep_many([(l.linear1.weight, l.linear2.weight) for l in stack])
+        # tagged with the weight generation (every optimiser launch of this package bumps ops.WEIGHT_GEN) and the index of
+        # the layer that may take the next image: a layer called on its own, after a forward that stopped early, or after
+        # an optimiser step gets None and splits its own weights (the list used to be trusted blindly)
+        stack[0]._ffn_images = {"imgs": imgs, "gen": ops.WEIGHT_GEN[0], "next": 0} if imgs is not None else None
+    tag = getattr(stack[0], "_ffn_images", None)
+    if tag is None or tag["gen"] != ops.WEIGHT_GEN[0] or tag["next"] != idx:
+        stack[0]._ffn_images = None
         return None
-    img = imgs[idx]
+    tag["next"] = idx + 1
+    img = tag["imgs"][idx]
     if idx == len(stack) - 1:
-        stack[0]._ffn_images = None        # (a forward that stops early keeps the list until the next first layer's call)
+        stack[0]._ffn_images = None
     return img
 
 

@@ -583,6 +583,10 @@ class ConvT3Bce(Function):
             key = (dev.index, H.stream(), B)
             ent = _T3_SCRATCH.get(key)
             if ent is None:      # (first call = a warm-up pass: no allocation / memset node under graph capture)
+                # a first call INSIDE a capture would put the buffers into the graph's private pool and the
+                # memset into the graph, while this cache hands them to eager calls as well
+                assert not torch.cuda.is_current_stream_capturing(), \
+                    "ConvT3Bce: first call at this batch size inside a graph capture (run one eager warm-up step first)"
                 ent = _T3_SCRATCH[key] = (torch.zeros(B * S, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
             part, tick = ent
         _call("mmvae_convT3_bce_seeded", H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(target), H.ptr(row), H.ptr(dl), H.ptr(part),
@@ -608,7 +612,9 @@ def convT3_bce_supported(x, w, target):
     # from 256 images on (<= 2 strips per image): same box, cfg2 step, fused vs two launches -- batch 128: 0.3866 vs 0.3852 ms
     # (four strips per image, the ticketed row sum and the loss arithmetic on 512 short workgroups buy nothing), batch 1000:
     # 1.5025 vs 1.5372 (profiles/r05_convT3_ab.txt)
-    return (CONVT3_BCE and x.shape[0] >= 256 and ConstSeed.current is not None and x.is_cuda and x.dim() == 4 and tuple(x.shape[1:]) == (32, 32, 32) and
+    # (an ELBO weight of 0 -- llik_scaling 0 -- leaves no way to rescale the stored logit gradient: two launches then)
+    return (CONVT3_BCE and x.shape[0] >= 256 and ConstSeed.current is not None and ConstSeed.current.value != 0 and
+            x.is_cuda and x.dim() == 4 and tuple(x.shape[1:]) == (32, 32, 32) and
             tuple(w.shape) == (32, 3, 4, 4) and target.numel() == x.shape[0] * 3 * 64 * 64 and x.requires_grad)
 
 
@@ -2640,18 +2646,24 @@ def gru_cell0(pt, b_ih, b_hh, ids_last, oh_last, h_fwd):
     return GruCell0.apply(pt, b_ih, b_hh, ids_last, oh_last, h_fwd, None)
 
 
+WEIGHT_GEN = [0]      # bumped by every optimiser launch: caches derived from the weights (split-bf16 images) carry it
+
+
 def adam_amsgrad_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step, step_dev=None, grad_scale=1.0, zero_grad=True):
+    WEIGHT_GEN[0] += 1
     _call("mmvae_adam_amsgrad_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(vmax), p.numel(), lr, beta1, beta2,
           eps, int(step), H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())
 
 
 def adabelief_flat(p, g, m, s, lr, beta1, beta2, eps, step, step_dev=None, grad_scale=1.0, zero_grad=True):
+    WEIGHT_GEN[0] += 1
     _call("mmvae_adabelief_flat", H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(s), p.numel(), lr, beta1, beta2, eps, int(step),
           H.ptr(step_dev), grad_scale, int(zero_grad), H.stream())
 
 
 def adam_fold_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step_dev, grad_scale, zero_grad, deferred):
     """GradReducer.deferred + Adam(amsgrad) in one launch (mmvae_adam_fold_flat)"""
+    WEIGHT_GEN[0] += 1
     tail = deferred["tail"]
     if tail is not None:
         rp, flat, out, n, B, k = tail["args"]
@@ -2665,6 +2677,7 @@ def adam_fold_flat(p, g, m, v, vmax, lr, beta1, beta2, eps, step_dev, grad_scale
 def adam_fold_range(p, g, m, v, vmax, lo, hi, advance, lr, beta1, beta2, eps, step_dev, grad_scale, zero_grad, table, tail=None):
     """the same over elements [lo, hi) only, with the segments of `table` (H.ReduceSegments or None) that lie inside
     (mmvae_adam_fold_range); advance: this is the launch that closes the step"""
+    WEIGHT_GEN[0] += 1
     if tail is not None:
         rp, flat, out, n, B, k = tail["args"]
         extra = (ctypes.byref(rp), flat, H.ptr(out), n, B, k)

@@ -278,6 +278,46 @@ def test_linear_small_batch_paths(ops, M, K, N, act):
         check(gb - 1 if preset else bg.grad, br.grad, 5e-5, "db")
 
 
+@pytest.mark.parametrize("M,K,N,act", [(2048, 512, 512, 1), (3000, 512, 512, 2), (2100, 784, 400, 0), (2052, 132, 260, 3),
+                                       (4096, 128, 128, 0), (2049, 516, 1028, 2)])
+def test_linear_tiled_split_bf16_is_fp32_equivalent(ops, hip_lib, M, K, N, act):
+    """csrc/gemm_b16.inc: the LDS-tiled split-bf16 kernels that take wide Linear layers (N, K >= 128) at 2048 .. 4096 rows
+    -- forward, data gradient, and the grouped data + weight gradient launch with its row-split partials -- against fp64 at
+    3e-6 of each tensor's maximum (a two-term split would sit at ~1e-5), against the fp32-MFMA bodies on the same inputs,
+    ragged edges in every dimension, gradients returned to autograd and accumulated into preset views"""
+    g = torch.Generator().manual_seed(M + 3 * K + 7 * N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(_act(xr, act), wr, br)
+    yr.backward(dy.double())
+    outs = {}
+    was = hip_lib.mmvae_gemm_b16_set(1)
+    try:
+        for core in (1, 0):
+            hip_lib.mmvae_gemm_b16_set(core)
+            assert hip_lib.mmvae_linear_bwd_splits(M, N, K) >= 1
+            for preset in (False, True):
+                xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+                gw = torch.ones(N, K, device=DEV) if preset else None
+                gb = torch.ones(N, device=DEV) if preset else None
+                y = ops.linear(xg, wg, bg, act, gw, gb)
+                y.backward(dy.to(DEV))
+                torch.cuda.synchronize()
+                outs[(core, preset)] = (y.detach(), xg.grad, gw - 1 if preset else wg.grad, gb - 1 if preset else bg.grad)
+    finally:
+        hip_lib.mmvae_gemm_b16_set(was)
+    refs = (yr.detach(), xr.grad, wr.grad, br.grad)
+    for (core, preset), got in outs.items():
+        tol = 3e-6 if core else 5e-5
+        for name, a_, r_ in zip(("y", "dx", "dw", "db"), got, refs):
+            check(a_, r_, tol if name != "db" else 5e-6 if core else 5e-5, f"{name} (b16={core}, preset={preset})")
+    for name, a_, b_ in zip(("y", "dx", "dw", "db"), outs[(1, True)], outs[(0, True)]):
+        check(a_, b_.double(), 2e-5, f"{name}: split-bf16 vs fp32-MFMA")
+
+
 def test_input_expansion_bit_exact(ops):
     """uint8 pixels / 255 and token ids -> one-hot + mask on the device, bit-identical to the
     reference's host preprocessing (torch.tensor(uint8) / 255; one_hot_encode + lengths_to_mask)"""
