@@ -248,7 +248,7 @@ def _kernel_flops(name, B, T=32):
 
 def _dominant_by_time(B):
     """the kernel with the largest share of GPU time in the newest committed rocprofv3 kernel-stats file of this workload
-    (profiles/r*_cfg2_b<B>_kernel_stats.csv, made by tools/gpu_evidence_r04.sh from `rocprofv3 --kernel-trace --stats --
+    (profiles/r*_cfg2_b<B>_kernel_stats.csv, made by tools/gpu_evidence_r06.sh from `rocprofv3 --kernel-trace --stats --
     python3 bench.py ...`), and its fraction of the fp32 MFMA peak from the FLOP model above -- the conv2-forward entry of
     `roofline` is the best-tuned kernel, not the one the step spends most of its time in"""
     import csv

@@ -946,6 +946,7 @@ struct GemmBatch {
 // beside the conv kernels of the other stream instead of waiting for a whole free CU
 template <bool ANY_DEEP>
 __global__ __launch_bounds__(512) void rgemm_batch_kernel(GemmBatch bt) {
+  MMVAE_TRACE_STAMP(39);
   __shared__ float red[8 * 16 * 64];
   __shared__ float rsr[8 * 32];
   int p = 0;

@@ -56,6 +56,14 @@ extern "C" int mmvae_rc_probe(long long* buf) {
 #define RC_MASK_NONE 0
 #define RC_MASK_RAW 1
 #define RC_MASK_BN 2
+// -DRC_HALF_B (make probe_rc_halfb; tools/probe/rc_time.py): an UPPER BOUND for what 128-row tiles could buy -- two row
+// tiles sharing one staged weight tile stage the B operand half as often -- measured without building them: the odd stages
+// neither load nor store their B tile (results are wrong, the instruction stream is the shared-B kernel's per row tile)
+#ifdef RC_HALF_B
+#define RC_B_STAGE(st) ((st) == 0)
+#else
+#define RC_B_STAGE(st) true
+#endif
 #define RC_BM 64
 #ifndef RC_BK
 #define RC_BK 32
@@ -435,7 +443,8 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
       ra[st][i] = *reinterpret_cast<const float4*>(a.x + (ok ? (size_t)src[i] * a.Cin + c : 0));
     }
 #pragma unroll
-    for (int i = 0; i < NR; ++i) rb[st][i] = *reinterpret_cast<const float4*>(a.w + (size_t)(wrow[i] + ltap) * a.Cin + c);
+    for (int i = 0; i < NR; ++i)
+      if (RC_B_STAGE(st)) rb[st][i] = *reinterpret_cast<const float4*>(a.w + (size_t)(wrow[i] + ltap) * a.Cin + c);
     lc0 += RC_BK;
     if (lc0 >= a.Cin) { lc0 = 0; ++ltap; newtap = true; }
   };
@@ -458,7 +467,7 @@ __device__ __forceinline__ void rc_fwd_body(const RcFwdArgs& a, const RcBlk k, f
         const float u = rc_bn(v[q], m4[q], s4[q], b4[q]);
         const float t = u < lo ? lo : u;
         da[q * RC_AP] = ok ? t : 0.f;
-        db[q * RC_AP] = w4[q];
+        if (RC_B_STAGE(st)) db[q * RC_AP] = w4[q];
       }
     }
   };
@@ -684,7 +693,8 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i)
-      rb[st][i] = *reinterpret_cast<const float4*>(a.w + ((size_t)(lk0 + kb + 16 * i) * a.T + wtap) * a.Cin + n0 + nb4);
+      if (RC_B_STAGE(st))
+        rb[st][i] = *reinterpret_cast<const float4*>(a.w + ((size_t)(lk0 + kb + 16 * i) * a.T + wtap) * a.Cin + n0 + nb4);
     lk0 += RC_BK;
     if (lk0 >= a.Cout) { lk0 = 0; ++ltap; newtap = true; }
   };
@@ -703,7 +713,7 @@ __device__ __forceinline__ void rc_dgrad_body(const RcDgradArgs& a, const RcBlk 
         da[q * RC_AP] = ok ? v : 0.f;
       }
       float* db = Bs_ + (kb + 16 * i) * RC_AP + nb4;
-      db[0] = rb[st][i].x; db[1] = rb[st][i].y; db[2] = rb[st][i].z; db[3] = rb[st][i].w;
+      if (RC_B_STAGE(st)) { db[0] = rb[st][i].x; db[1] = rb[st][i].y; db[2] = rb[st][i].z; db[3] = rb[st][i].w; }
     }
   };
   f32x16 acc;

@@ -143,6 +143,11 @@ class GradReducer:
     dw_jobs = []
     dw_open = False       # True from the arming of `early_step` until EarlyStepPoint.backward has queued the parked jobs
     dw_later_enabled = os.environ.get("MMVAE_LINEAR_DW_LATER", "1") == "1"
+    # where the parked launch goes: right behind the fusion's backward (default) or in front of the early optimiser launch
+    # (MMVAE_LINEAR_DW_LATER_AT=adam).  Behind the fusion its 528 workgroups reach the CUs before the image encoder's first
+    # backward kernels, which sit behind a cross-stream wait, and hold that chain up by 8 us; in front of the optimiser
+    # launch it lands, with that launch, on the image encoder's conv2 backward: 383.2 vs 389.4 us (same box, 3 pairs)
+    dw_at_fusion = os.environ.get("MMVAE_LINEAR_DW_LATER_AT", "fusion") == "fusion"
 
     @classmethod
     def dw_later(cls, device):
@@ -183,6 +188,7 @@ class GradReducer:
         if len(inside) > H.MAX_SEGMENTS or any(sg[1] + 4 * sg[3] > hi for sg in inside):
             return
         st["segs"] = [sg for sg in st["segs"] if not (lo <= sg[1] < hi)]
+        cls.flush_dw()      # (their results belong to the range this launch folds and updates)
         t = None
         if inside:
             t = H.ReduceSegments()
@@ -231,7 +237,7 @@ class GradReducer:
 
     @classmethod
     def flush(cls, device):
-        assert not cls.dw_jobs, "parked Linear weight gradients were never launched (EarlyStepPoint.backward did not run)"
+        cls.flush_dw()      # (no early optimiser launch took them with it: here, behind the whole backward pass)
         cls.launch_pending(device)
         _, st = cls._st(device)
         cur = torch.cuda.current_stream(device)
@@ -1207,7 +1213,8 @@ class EarlyStepPoint(Function):
     @staticmethod
     def backward(ctx, g):
         GradReducer.dw_open = False      # (the encoders' Linear layers behind this point keep their grouped launches)
-        GradReducer.flush_dw()
+        if GradReducer.dw_at_fusion:
+            GradReducer.flush_dw()
         GradReducer.run_early_step(g.device)
         return g
 

@@ -23,7 +23,8 @@ NAMES = {0: "img enc conv1", 1: "img enc conv2", 2: "img enc conv3", 3: "img enc
          20: "adam", 21: "reduce_segments", 22: "poe fwd", 23: "poe bwd",
          24: "  gemm_grouped", 25: "  rgemm16", 26: "  rgemm", 27: "  rgemm_grouped", 28: "  bce_rowsum", 29: "  ce_time_fwd",
          30: "  embed_pe_fwd", 31: "  embed_pe_bwd", 32: "  permute_mask", 33: "  dropout_advance", 34: "  dropout_act",
-         35: "  txt_wgrad", 36: "img dec convT3 col2im fwd"}
+         35: "  txt_wgrad", 36: "img dec convT3 col2im fwd", 37: "  gemm_b16", 38: "  gemm_b16 linear bwd",
+         39: "  rgemm_batch (parked dW)"}
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("TRACE_BATCH", 128))
 torch.manual_seed(0)
