@@ -112,7 +112,7 @@ class MoPOE(TorchMMVAE):
         # on the image chain in either direction -- replays at 0.490 ms against 0.388: hipGraph serialises that layout.)
         rotate = True
         fuse = real[-1] if rotate else real[0]
-        self._fuse_stream = fuse
+        self._fuse_stream = fuse0 = fuse
         for st in real:
             if st != fuse:
                 fuse.wait_stream(st)
@@ -141,6 +141,8 @@ class MoPOE(TorchMMVAE):
             _uses(z[i], st)
             with torch.cuda.stream(st):
                 zi = ops.mark_tensor(z[i], f"dec {n} z")
+                if seeds is not None and st != fuse0 and ops.GradReducer.side_head is not None:
+                    zi = ops.StreamIdlePoint.apply(zi)      # (this decoder's stream idles behind its backward pass)
                 if seeds is not None:      # the term's upstream gradient is known: its kernel also writes its backward
                     with ops.ConstSeed(seeds[i], W[0][i]):
                         # (a bce decoder is handed its target: Dec_CNN then folds the loss into its last layer's launch)

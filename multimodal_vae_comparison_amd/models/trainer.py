@@ -256,6 +256,9 @@ class MultimodalVAE(nn.Module):
                         ring.expand()
                         ring.done = False
                         ops.GradReducer.side_tail = ops.GradReducer.pre_join = ring.pull_next
+                        ring.split_pct = int(os.environ.get("MMVAE_RING_SPLIT", "50"))
+                        ring.split = ring.split_pct > 0 and hasattr(self.model, "objective_backward")
+                        ops.GradReducer.side_head = ring.pull_first_half if ring.split else None
                     # one GPU: the optimiser follows the backward at once, so the end-of-backward fold is left to it
                     ops.GradReducer.defer_next = self._adam_in_graph and self.optimizer.supports_fold
                     # ... and its second range (decoders, prior) does not wait for the end of the step: MoPOE.
@@ -277,7 +280,7 @@ class MultimodalVAE(nn.Module):
                         rconv.BLOCK_DONE_HOOK = None
                     ops.GradReducer.defer_next = False
                     self.model.early_adam = None
-                    ops.GradReducer.pre_join = ops.GradReducer.side_tail = None
+                    ops.GradReducer.pre_join = ops.GradReducer.side_tail = ops.GradReducer.side_head = None
                     if self._input_ring is not None:
                         self._input_ring.pull_next(self.flat.data.device, [])     # (no hook point ran: pull here)
                     ops.Marks.mark("backward done")
@@ -541,7 +544,12 @@ class GraphInputRing:
     measured and dropped (tools/probe/ring_time.py): the expansion launches beside the optimiser on the side stream (two
     more cross-stream edges: 0.470), the pull in two halves at the text stream's two idle windows (no gain), and pull +
     expansion as ONE node writing the other of two input-buffer sets with the step captured twice, ping / pong (0.473:
-    alternating two graph executables costs 20 us per step by itself)."""
+    alternating two graph executables costs 20 us per step by itself).
+    Round 6: the pull needs ~70 us for its 1.6 MB (device-initiated reads over the host link) -- more than any idle window
+    of either stream -- so it is queued in TWO parts: the first MMVAE_RING_SPLIT per cent (50) behind the backward pass of the
+    decoder that does not share the fusion's stream (ops.StreamIdlePoint: that stream idles until the fusion's backward),
+    the rest at the tail as before: 0.4247 -> 0.4160 ms (25 / 35 / 50 / 65 %: 0.420 / 0.417 / 0.416 / 0.415; the WHOLE pull
+    at the early point: 0.44 - 0.51, it runs into the fusion's backward)."""
 
     def __init__(self, trainer, ring):
         assert len(ring) >= 1
@@ -592,16 +600,37 @@ class GraphInputRing:
             else:
                 ops.expand_text_tokens(m[1], m[2], m[3], m[4])
 
+    split = False
+    split_pct = 50
+    half_done = False
+
+    def _first_bytes(self):
+        return self.bytes * self.split_pct // 100 // 16 * 16
+
+    def pull_first_half(self, device):
+        """the first half of the next slot, without advancing the slot counter (ops.StreamIdlePoint: on the stream of the
+        decoder that finishes its backward pass early)"""
+        if self.done or self.half_done:
+            return
+        self.half_done = True
+        h = self._first_bytes()
+        rc = H.lib().mmvae_input_ring_pull(self.table.data_ptr(), len(self.ring), self.ctr.data_ptr(),
+                                           self.staging.data_ptr(), 0, h, 0, H.stream())
+        if rc:
+            raise RuntimeError(f"mmvae_input_ring_pull: {rc}")
+
     def pull_next(self, device, side_streams):
         """queue the pull of the next slot (once per recorded step): on the current stream -- the side tower's when its
-        last backward launch calls this --, or on the last of `side_streams`"""
+        last backward launch calls this --, or on the last of `side_streams`; only the second half when pull_first_half ran"""
         if self.done:
             return
         self.done = True
         st = side_streams[-1] if side_streams else None
+        off = self._first_bytes() if self.half_done else 0
+        self.half_done = False
         with torch.cuda.stream(st):
             rc = H.lib().mmvae_input_ring_pull(self.table.data_ptr(), len(self.ring), self.ctr.data_ptr(),
-                                               self.staging.data_ptr(), 0, self.bytes, 1, H.stream())
+                                               self.staging.data_ptr(), off, self.bytes - off, 1, H.stream())
         if rc:
             raise RuntimeError(f"mmvae_input_ring_pull: {rc}")
 

@@ -53,6 +53,7 @@ class GradReducer:
     # pass is submitted -- and starts -- late however long its stream has been idle (measured: the pull queued at the
     # join started ~30 us after the text stream went idle and delayed the optimiser by as much)
     side_tail = None
+    side_head = None      # fn(device): see StreamIdlePoint
     _arena = {}
     _state = {}
     _side = {}        # device key -> {"wgrad": Stream, "tower": Stream}: see StreamPlan below
@@ -1216,6 +1217,25 @@ class EarlyStepPoint(Function):
         if GradReducer.dw_at_fusion:
             GradReducer.flush_dw()
         GradReducer.run_early_step(g.device)
+        return g
+
+
+class StreamIdlePoint(Function):
+    """identity on the latent sample of a decoder that does NOT share the fusion's stream: its backward is the last node of
+    that decoder's backward pass, and its stream then idles until the fusion's backward has run on the other one (cfg2: the
+    text decoder is done ~50 us before the image decoder).  GradReducer.side_head -- the FIRST half of the in-graph input
+    ring's pull of the next batch over the host link -- is queued here; the second half stays behind the text encoder's last
+    backward launch (GradReducer.side_tail)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        return z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        fn, GradReducer.side_head = GradReducer.side_head, None
+        if fn is not None:
+            fn(g.device)
         return g
 
 
