@@ -211,7 +211,7 @@ class MoPOE(TorchMMVAE):
         else:
             torch.autograd.backward(recs + [kl], self._seeds)
         ops.GradReducer.tail = ops.GradReducer.early_step = None
-        ops.GradReducer.dw_open = False
+        ops.GradReducer.dw_open = ops.GradReducer.early_ready = False
         if tail is not None and tail["done"]:
             out = tail["args"][2].unbind(0)
         if out is None:

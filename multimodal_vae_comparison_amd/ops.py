@@ -77,6 +77,7 @@ class GradReducer:
             return
         _, st = cls._st(device)
         cls.early_step, cls.dw_jobs, cls.dw_open = None, [], False      # (per-step state: a backward pass that raised leaves them behind)
+        cls.tw_jobs, cls.early_ready = {}, False
         if cls.deferred is not None:
             cls.deferred = None
             raise RuntimeError("GradReducer: a deferred fold was never taken by an optimiser step: the split weight "
@@ -168,15 +169,51 @@ class GradReducer:
             j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, x_act, H.ACC_DEFER
         _call("mmvae_linear_bwd_weight_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
 
+    # tw_jobs: {stream: [(dy2, x2, w, b, gw, gb)]} -- weight gradients of TALL-SKINNY Linear layers (the action towers'
+    # attention projections: 12 800 rows, 32 .. 96 columns) whose backward only launched the data gradient.  Eight of them
+    # share one launch of the tall-skinny weight-gradient kernel (_txt_wgrad: csrc/twgrad.hip) on the stream they were
+    # parked from; what is left goes out at the end of the backward pass, in front of the join.  Alone, 12 800 x 96 x 32:
+    # grouped data + weight launch 11.5 us; data gradient 4.8 + 22.1 / 8 per job (tools/probe/skinny_time.py).
+    tw_jobs = {}
+    tw_enabled = os.environ.get("MMVAE_SKINNY_DW", "1") == "1"
+    TW_MIN_ROWS, TW_MAX_N, TW_MAX_K = 2048, 162, 128
+
+    @classmethod
+    def tw_ok(cls, M, N, K, in_act, has_b, dy, x):
+        return (cls.tw_enabled and M >= cls.TW_MIN_ROWS and N <= cls.TW_MAX_N and K <= cls.TW_MAX_K and in_act == H.ACT_NONE
+                and has_b and TXT_WGRAD and dy.is_contiguous() and x.is_contiguous()
+                and H.lib().mmvae_txt_wgrad_supported(M, N, K))
+
+    @classmethod
+    def tw_park(cls, job):
+        dev = job[0].device
+        st = torch.cuda.current_stream(dev)
+        lst = cls.tw_jobs.setdefault(st, [])
+        lst.append(job)
+        cls.note_stream(dev, st)
+        cls.ensure_flush(dev)
+        if len(lst) >= H.TXT_WGRAD_MAX:
+            cls.tw_jobs[st] = []
+            _txt_wgrad(lst)
+
+    @classmethod
+    def tw_flush(cls):
+        jobs, cls.tw_jobs = cls.tw_jobs, {}
+        for st, lst in jobs.items():
+            if lst:
+                with torch.cuda.stream(st):
+                    _txt_wgrad(lst)
+
     # WHERE on the fusion's stream the update is queued (MMVAE_EARLY_ADAM): 1 = right behind the fusion's backward
     # (EarlyStepPoint), 2 / 3 = in front of / behind the weight-gradient launch of the text encoder's layer, 4 = behind the
     # text encoder's last backward launch (EmbedPE.backward)
     early_at = int(os.environ.get("MMVAE_EARLY_ADAM", "2") or 0)
+    early_ready = False
 
     @classmethod
     def run_early_step(cls, device, at=1):
         es = cls.early_step
-        if es is None or at != cls.early_at:
+        if es is None or at != cls.early_at or not (cls.early_ready or at == 1):
             return
         fn, stream, lo, hi = es
         _, st = cls._st(device)
@@ -239,6 +276,7 @@ class GradReducer:
     @classmethod
     def flush(cls, device):
         cls.flush_dw()      # (no early optimiser launch took them with it: here, behind the whole backward pass)
+        cls.tw_flush()      # (each list on the stream it was parked from, in front of the join below)
         cls.launch_pending(device)
         _, st = cls._st(device)
         cur = torch.cuda.current_stream(device)
@@ -923,6 +961,13 @@ class Linear(Function):
             ep, aux, kadd, radd = H.EP_ADD_AUX, H.ptr(radd), radd, None
         defer = _defer(gw, gb if has_b else gw)
         nz = lib.mmvae_linear_bwd_splits(M, N, K) if need_dx else lib.mmvae_linear_bwd_weight_splits(M, N, K)
+        if need_dx and defer and radd is None and GradReducer.tw_ok(M, N, K, in_act, has_b, dy, x):
+            # tall-skinny layer: the data gradient now, the weight gradient with up to seven others in one launch of the
+            # tall-skinny kernel (GradReducer.tw_park)
+            _call("mmvae_linear_bwd_data", H.ptr(dy), H.ptr(w), aux, H.ptr(dx), M, N, K, ep, 0, H.stream())
+            GradReducer.tw_park((dy.view(M, N), x.view(M, K), w, True, gw, gb))
+            del kadd
+            return dx, ret_w, ret_b, None, None, None, None, None
         if need_dx and defer and nz == 1 and radd is None and GradReducer.dw_later(x.device) and \
                 lib.mmvae_linear_bwd_weight_splits(M, N, K) == 1:
             # the captured one-GPU MoPoE step, a Linear of the decoder that shares the fusion's stream: only the DATA
@@ -1213,6 +1258,8 @@ class EarlyStepPoint(Function):
 
     @staticmethod
     def backward(ctx, g):
+        GradReducer.early_ready = True   # (a weight-gradient launch on this stream IN FRONT of this point -- a decoder's --
+                                         # must not trigger the early optimiser launch: the fusion's backward has not run)
         GradReducer.dw_open = False      # (the encoders' Linear layers behind this point keep their grouped launches)
         if GradReducer.dw_at_fusion:
             GradReducer.flush_dw()
