@@ -141,6 +141,8 @@ class MoPOE(TorchMMVAE):
             _uses(z[i], st)
             with torch.cuda.stream(st):
                 zi = ops.mark_tensor(z[i], f"dec {n} z")
+                if seeds is not None and getattr(self, "early_adam", None) is not None and ops.GradReducer.defer_next:
+                    zi = ops.DecoderEnd.apply(zi)           # (parked weight gradients of this decoder: out before the fusion)
                 if seeds is not None and st != fuse0 and ops.GradReducer.side_head is not None:
                     zi = ops.StreamIdlePoint.apply(zi)      # (this decoder's stream idles behind its backward pass)
                 if seeds is not None:      # the term's upstream gradient is known: its kernel also writes its backward

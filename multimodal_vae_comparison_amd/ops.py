@@ -197,6 +197,12 @@ class GradReducer:
             _txt_wgrad(lst)
 
     @classmethod
+    def tw_flush_stream(cls, st):
+        lst = cls.tw_jobs.pop(st, None)
+        if lst:
+            _txt_wgrad(lst)      # (on the current stream == st)
+
+    @classmethod
     def tw_flush(cls):
         jobs, cls.tw_jobs = cls.tw_jobs, {}
         for st, lst in jobs.items():
@@ -1243,6 +1249,22 @@ class PoeReparamKL(Function):
               _poe_ticket(dev), E,
               int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, H.stream())
         return (ret, None, None, None, None, None, None, None, None, *dpacked, *([None] * ctx.n_eps_in))
+
+
+class DecoderEnd(Function):
+    """identity on a decoder's latent sample: its backward is the LAST node of that decoder's backward pass.  Parked
+    tall-skinny weight gradients of the decoder (GradReducer.tw_park: fewer than eight are left) are launched here, on the
+    decoder's stream and in front of the event the fusion's backward waits for -- the early optimiser launch folds and
+    updates the decoders' range and must find every decoder gradient final."""
+
+    @staticmethod
+    def forward(ctx, z):
+        return z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        GradReducer.tw_flush_stream(torch.cuda.current_stream(g.device))
+        return g
 
 
 class EarlyStepPoint(Function):
