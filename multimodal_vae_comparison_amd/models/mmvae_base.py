@@ -1,13 +1,11 @@
 """TorchMMVAE: base class of the multimodal mixers (reference: models/mmvae_base.py)."""
 import abc
-import os
 
 import numpy as np
 import torch
 import torch.distributions as dist
 import torch.nn as nn
 
-from .. import hipops as H
 from .. import ops
 from .nn_modules import DropoutState
 from .objectives import MultimodalObjective
@@ -16,7 +14,6 @@ from .output_storage import VAEOutput
 # the decoders' first dropout-counter advance rides on the first encoder's launch (DropoutState.link;
 # MMVAE_DROPOUT_LINK=0: one one-thread launch at the head of every tower's chain)
 LINK_DROPOUT_ADVANCE = True
-ADVANCE_PREFORK = os.environ.get("MMVAE_ADVANCE_PREFORK", "0") == "1"
 
 
 def normal(loc, scale):
@@ -104,16 +101,7 @@ class TorchMMVAE(nn.Module):
                     st.reset_calls()
                     if part.training:
                         groups[k].append(st)
-        if ADVANCE_PREFORK and groups[0] and all(s.state.is_cuda for g in groups for s in g) and \
-                len(groups[0]) + len(groups[1]) <= H.DROPOUT_ADVANCE_MAX:
-            # (experiment, MMVAE_ADVANCE_PREFORK=1) call 0 of EVERY tower in one launch on the caller's stream, in front of
-            # the fork: nothing at the head of any tower's chain, and the side branch of the captured graph hangs off a
-            # 2 us node instead of the image encoder's first convolution
-            states = [s for g in groups for s in g]
-            ops.dropout_advance_many([s.state for s in states])
-            for s in states:
-                s.pre = True
-        elif LINK_DROPOUT_ADVANCE:
+        if LINK_DROPOUT_ADVANCE:
             DropoutState.link(*groups)
 
     # ---- noise ----------------------------------------------------------------------------------
