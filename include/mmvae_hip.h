@@ -92,6 +92,13 @@ int mmvae_head_bcast_dropout_bwd(const float* dout, float* dv, int L, int N, int
  * by the caller (mmvae_reduce_rows / mmvae_reduce_segments).  ws may be NULL too (data gradient only): the data- and
  * the weight-gradient launch are independent and may go to different streams. */
 int mmvae_ffn32_supported(int d_model, int FF);
+/* out_proj + dropout + residual + LayerNorm of a d_model-32 layer in one launch (reference models/encoders.py:706-716:
+ * `src = norm1(src + dropout1(attn))`, the attention's out_proj being nn.Linear(32, 32)):
+ *   y = LayerNorm(dropout(x W^T + b) + r);  x, r, y, xhat (M, 32), w (32, 32) [out][in], rstd (M); all 16-byte aligned.
+ * Same saved tensors and dropout mask (element row * 32 + column) as mmvae_layernorm_residual_fwd on the Linear's output:
+ * the backward is mmvae_layernorm_residual_bwd followed by the Linear's backward. */
+int mmvae_proj32_ln_fwd(const float* x, const float* w, const float* b, const float* r, const float* gamma, const float* beta,
+                        float* y, float* xhat, float* rstd, int M, const mmvae_dropout_t* drop, mmvae_stream_t stream);
 int mmvae_ffn32_bwd_parts(int M, int FF);
 size_t mmvae_ffn32_bwd_rowlen(int FF);
 int mmvae_ffn32_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int M,

@@ -214,6 +214,7 @@ SIGNATURES = {
     "mmvae_ffn32_bwd_rowlen": (c_sz, [c_i]),
     "mmvae_ffn32_fwd": (c_i, [c_p] * 6 + [c_i, c_i, c_p, c_p]),
     "mmvae_ffn32_bwd": (c_i, [c_p] * 7 + [c_i, c_i, c_p, c_p]),
+    "mmvae_proj32_ln_fwd": (c_i, [c_p] * 9 + [c_i, c_dp, c_p]),
     "mmvae_ffn32_wsplit_bytes": (c_sz, [c_i]),
     "mmvae_ffn32_rsplit_bytes": (c_sz, [c_i]),
     "mmvae_ffn32_prep_weights": (c_i, [c_p, c_p, c_p, c_i, c_p]),

@@ -119,15 +119,17 @@ class HipTransformerDecoderLayer(nn.Module):
         # residual gradients of the self-attention and feed-forward blocks join those blocks' first backward kernels
         s1 = ops.residual_sink(x)
         if ds is None:
-            x = self.norm1(self.self_attn(x, mask_u8, res_sink=s1), x, res_sink=s1)
+            x = self.norm1(self.self_attn(x, mask_u8, res_sink=s1, lazy_out=self.self_attn.lazy_out(x)), x, res_sink=s1)
             x = self.norm2(x, self.multihead_attn.value_path(mem))     # (N,d) residual broadcast over time
             if fused_ffn:
                 s3 = ops.residual_sink(x)
                 return self.norm3(ffn(x, None, s3), x, res_sink=s3)
             return self.norm3(self.linear2(self.linear1(x)), x)
         L = x.shape[0]
-        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1), x, ds["drop1"], res_sink=s1)
-        ca = self.multihead_attn.value_path(mem, L, ds["xattn"])          # (L,N,d): weight dropout varies with l
+        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1, lazy_out=self.self_attn.lazy_out(x)), x, ds["drop1"],
+                       res_sink=s1)
+        ca = self.multihead_attn.value_path(mem, L, ds["xattn"],          # (L,N,d): weight dropout varies with l
+                                            lazy_out=self.multihead_attn.lazy_out(x))
         x = self.norm2(ca, x, ds["drop2"])
         if fused_ffn:
             s3 = ops.residual_sink(x)

@@ -319,12 +319,13 @@ class HipTransformerEncoderLayer(nn.Module):
         # the gradients of the two residual connections join their sub-layers' first backward kernels (ops.ResidualGrad)
         s1 = ops.residual_sink(x)
         if ds is None:
-            x = self.norm1(self.self_attn(x, mask_u8, res_sink=s1), x, res_sink=s1)
+            x = self.norm1(self.self_attn(x, mask_u8, res_sink=s1, lazy_out=self.self_attn.lazy_out(x)), x, res_sink=s1)
             if fused_ffn:
                 s2 = ops.residual_sink(x)
                 return self.norm2(self._ffn(x, None, s2), x, res_sink=s2)
             return self.norm2(self.linear2(self.linear1(x)), x)
-        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1), x, ds["drop1"], res_sink=s1)
+        x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1, lazy_out=self.self_attn.lazy_out(x)), x, ds["drop1"],
+                       res_sink=s1)
         if fused_ffn:      # the (L*N, ff) hidden activation never leaves the registers (csrc/ffn.hip)
             s2 = ops.residual_sink(x)
             return self.norm2(self._ffn(x, ds["ffn"], s2), x, ds["drop2"], res_sink=s2)

@@ -110,9 +110,9 @@ class HipLinear(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x, in_act=None, out_ep=H.EP_NONE):
+    def forward(self, x, in_act=None, out_ep=H.EP_NONE, lazy=False):
         return ops.linear(x, self.weight, self.bias, self.in_act if in_act is None else in_act, self.weight.grad,
-                          self.bias.grad, out_ep)
+                          self.bias.grad, out_ep, lazy=lazy)
 
 
 class HipLayerNorm(nn.Module):
@@ -149,15 +149,20 @@ class HipSelfAttention(nn.Module):
     def flat_groups(self):
         return [[self.in_proj_weight, self.in_proj_bias]]
 
-    def forward(self, x, mask_u8, drop=None, res_sink=None):
+    def lazy_out(self, x):
+        """may the caller's LayerNorm compute out_proj in its own launch (ops.PROJ32_LN: d_model 32 on the device)?"""
+        return ops.PROJ32_LN and self.d == 32 and x.is_cuda and x.dtype == torch.float32
+
+    def forward(self, x, mask_u8, drop=None, res_sink=None, lazy_out=False):
         """mask_u8: (N, L) validity bytes (1 = real token); padded keys are ignored; `drop`: attention-weight dropout;
-        res_sink: ops.ResidualGrad of the residual connection around this block (its gradient joins the in-projection's)"""
+        res_sink: ops.ResidualGrad of the residual connection around this block (its gradient joins the in-projection's);
+        lazy_out: the out-projection is left to the LayerNorm that consumes the result (ops.linear(..., lazy=True))"""
         qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, H.ACT_NONE, self.in_proj_weight.grad,
                          self.in_proj_bias.grad, res_sink=res_sink)
         a = ops.attention(qkv, mask_u8, self.nhead, mask_is_valid=True, drop=drop)
-        return self.out_proj(a)
+        return self.out_proj(a, lazy=lazy_out)
 
-    def value_path(self, mem, L=None, drop=None):
+    def value_path(self, mem, L=None, drop=None, lazy_out=False):
         """Cross-attention over a length-1 memory: softmax over one key == 1, so the output is
         out_proj(v_proj(mem)) for every query (q/k projections receive exactly zero gradient).  In train mode the
         attention-weight dropout acts on that single weight per (query, head): the value row is replicated over the
@@ -168,4 +173,5 @@ class HipSelfAttention(nn.Module):
                        gw[2 * d:] if gw is not None else None, gb[2 * d:] if gb is not None else None)
         if drop is not None:
             v = ops.head_bcast_dropout(v, L, self.nhead, drop)        # (L, N, d)
+            return self.out_proj(v, lazy=lazy_out)
         return self.out_proj(v)

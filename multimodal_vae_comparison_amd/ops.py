@@ -922,16 +922,19 @@ class Linear(Function):
     """y = act(x) W^T + b over the last dim   [nn.Linear / MHA projections / FFN]"""
 
     @staticmethod
-    def forward(ctx, x, w, b, in_act, gw, gb, out_ep=H.EP_NONE, res_sink=None):
+    def forward(ctx, x, w, b, in_act, gw, gb, out_ep=H.EP_NONE, res_sink=None, lazy=False):
         """out_ep: EP_NONE, or EP_SIGMOID -- y = sigmoid(.) in the GEMM's epilogue; the incoming gradient is then
-        taken as the gradient of the LOGITS (wrap the output in ops.sigmoid_out, see SigmoidOut).  res_sink: ResidualGrad"""
+        taken as the gradient of the LOGITS (wrap the output in ops.sigmoid_out, see SigmoidOut).  res_sink: ResidualGrad.
+        lazy: the output is a PLACEHOLDER (nothing is launched) -- its only consumer is a LayerNorm whose forward computes
+        the product itself (ops.layernorm_residual(..., proj=...): mmvae_proj32_ln_fwd); backward is unchanged"""
         ctx.res_sink = res_sink
         x = H.f32c(x)
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-        _call("mmvae_linear_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), M, N, K, K, in_act, out_ep, H.stream())
+        if not lazy:
+            _call("mmvae_linear_fwd", H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(y), M, N, K, K, in_act, out_ep, H.stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (in_act, gw, gb, b is not None)
         return y
@@ -973,7 +976,7 @@ class Linear(Function):
             _call("mmvae_linear_bwd_data", H.ptr(dy), H.ptr(w), aux, H.ptr(dx), M, N, K, ep, 0, H.stream())
             GradReducer.tw_park((dy.view(M, N), x.view(M, K), w, True, gw, gb))
             del kadd
-            return dx, ret_w, ret_b, None, None, None, None, None
+            return dx, ret_w, ret_b, None, None, None, None, None, None
         if need_dx and defer and nz == 1 and radd is None and GradReducer.dw_later(x.device) and \
                 lib.mmvae_linear_bwd_weight_splits(M, N, K) == 1:
             # the captured one-GPU MoPoE step, a Linear of the decoder that shares the fusion's stream: only the DATA
@@ -982,7 +985,7 @@ class Linear(Function):
             _call("mmvae_linear_bwd_data", H.ptr(dy), H.ptr(w), aux, H.ptr(dx), M, N, K, ep, 0, H.stream())
             GradReducer.dw_jobs.append((dy, x, dw, db, M, N, K, in_act))
             del kadd
-            return dx, ret_w, ret_b, None, None, None, None, None
+            return dx, ret_w, ret_b, None, None, None, None, None, None
         if defer:
             ws = GradReducer.alloc(nws, x.device) if nz > 1 else None
             acc = H.ACC_DEFER
@@ -1003,11 +1006,17 @@ class Linear(Function):
         del kadd
         if radd is not None and dx is not None:
             dx = dx + radd.view_as(dx)
-        return dx, ret_w, ret_b, None, None, None, None, None
+        return dx, ret_w, ret_b, None, None, None, None, None, None
 
 
-def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None, out_ep=H.EP_NONE, res_sink=None):
-    return Linear.apply(x, w, b, in_act, gw, gb, out_ep, res_sink)
+PROJ32_LN = os.environ.get("MMVAE_PROJ32_LN", "1") == "1"      # out_proj + dropout + residual + LayerNorm in one launch (d = 32)
+
+
+def linear(x, w, b, in_act=H.ACT_NONE, gw=None, gb=None, out_ep=H.EP_NONE, res_sink=None, lazy=False):
+    y = Linear.apply(x, w, b, in_act, gw, gb, out_ep, res_sink, lazy)
+    if lazy:
+        y._proj = (x, w, b)      # what the consuming LayerNorm needs to compute the product itself
+    return y
 
 
 class SigmoidOut(Function):
@@ -2343,7 +2352,9 @@ class LayerNormResidual(Function):
     """y = LayerNorm(x + r); r None, same shape, or (N,d) broadcast over the leading (time) axis"""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, gg, gb, drop, res_sink=None):
+    def forward(ctx, x, r, gamma, beta, gg, gb, drop, res_sink=None, proj=None):
+        """proj = (x_in, w, b): `x` is the placeholder output of a lazy Linear (ops.linear(..., lazy=True)) -- the product
+        x_in w^T + b is computed here, in the same launch as the LayerNorm (d = 32: mmvae_proj32_ln_fwd)"""
         x = H.f32c(x)
         d = x.shape[-1]
         rows = x.numel() // d
@@ -2355,8 +2366,22 @@ class LayerNormResidual(Function):
         y = torch.empty_like(x)
         xhat = torch.empty_like(x)
         rstd = torch.empty(rows, device=x.device)
-        _call("mmvae_layernorm_residual_fwd", H.ptr(x), H.ptr(r), H.ptr(gamma), H.ptr(beta), H.ptr(y), H.ptr(xhat),
-              H.ptr(rstd), rows, d, r_rows, _dp(drop, x.numel()), H.stream())
+        fused = False
+        if proj is not None:
+            xin, pw, pb = proj
+            xin = H.f32c(xin)
+            al = lambda t: t.data_ptr() % 16 == 0
+            fused = (d == 32 and xin.shape[-1] == 32 and r is not None and r_rows == 0 and pb is not None and pw.is_contiguous()
+                     and all(al(t) for t in (xin, pw, pb, r, gamma, beta, y, xhat)))
+            if fused:
+                _call("mmvae_proj32_ln_fwd", H.ptr(xin), H.ptr(pw), H.ptr(pb), H.ptr(r), H.ptr(gamma), H.ptr(beta), H.ptr(y),
+                      H.ptr(xhat), H.ptr(rstd), rows, _dp(drop, x.numel()), H.stream())
+            else:      # the Linear after all (its output was never computed), then the plain LayerNorm below
+                _call("mmvae_linear_fwd", H.ptr(xin), H.ptr(pw), H.ptr(pb), None, H.ptr(x), rows, d, xin.shape[-1],
+                      xin.shape[-1], H.ACT_NONE, H.EP_NONE, H.stream())
+        if not fused:
+            _call("mmvae_layernorm_residual_fwd", H.ptr(x), H.ptr(r), H.ptr(gamma), H.ptr(beta), H.ptr(y), H.ptr(xhat),
+                  H.ptr(rstd), rows, d, r_rows, _dp(drop, x.numel()), H.stream())
         ctx.save_for_backward(xhat, rstd, gamma)
         ctx.cfg = (gg, gb, r is not None, r_rows, tuple(x.shape), tuple(r.shape) if r is not None else None, drop)
         ctx.res_sink = res_sink if (r is not None and r_rows == 0) else None
@@ -2400,7 +2425,7 @@ class LayerNormResidual(Function):
             else:
                 dr = dsum
         dx = dxd if drop is not None else dsum
-        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None, None, None
 
 
 class MeanOverTime(Function):
@@ -2462,8 +2487,9 @@ def as_u8(mask):
 
 
 def layernorm_residual(x, r, gamma, beta, gg=None, gb=None, drop=None, res_sink=None):
-    """LayerNorm(dropout(x) + r); res_sink: the ResidualGrad that the op producing x from r also holds"""
-    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop, res_sink)
+    """LayerNorm(dropout(x) + r); res_sink: the ResidualGrad that the op producing x from r also holds.  An x that is the
+    placeholder of a lazy Linear (x._proj) has its product computed in the LayerNorm's launch"""
+    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop, res_sink, getattr(x, "_proj", None))
 
 
 class DropoutAct(Function):
