@@ -318,6 +318,46 @@ def test_linear_tiled_split_bf16_is_fp32_equivalent(ops, hip_lib, M, K, N, act):
         check(a_, b_.double(), 2e-5, f"{name}: split-bf16 vs fp32-MFMA")
 
 
+@pytest.mark.parametrize("M,p", [(12800, 0.1), (100, 0.0), (33, 0.3)])
+def test_proj32_layernorm_fused_matches_two_launches(ops, monkeypatch, M, p):
+    """mmvae_proj32_ln_fwd: LayerNorm(dropout(x W^T + b) + r) for d_model 32 in ONE launch (the Linear's output is a
+    placeholder that only the LayerNorm consumes) against the two launches it replaces -- same dropout mask, saved tensors
+    and backward -- and against torch in fp64 with the extracted mask; ragged row counts"""
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 32, generator=g).to(DEV)
+    r = torch.randn(M, 32, generator=g).to(DEV)
+    w = (torch.randn(32, 32, generator=g) * 0.3).to(DEV)
+    b = torch.randn(32, generator=g).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(32, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(32, generator=g)).to(DEV)
+    dy = torch.randn(M, 32, generator=g).to(DEV)
+    drop, mask = None, torch.ones(M, 32, dtype=torch.float64, device=DEV)
+    if p > 0:
+        st = DropoutState().to(DEV)
+        slot, call = st.begin()
+        drop = st.spec(slot, call, 2, p, "drop1")
+        mask = ops.dropout_mask(drop, M * 32).double().view(M, 32)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "PROJ32_LN", fused)
+        xs, rs, ws, bs, gs, bts = (t.clone().requires_grad_(True) for t in (x, r, w, b, gamma, beta))
+        calls0 = ops.CALLS[0]
+        y = ops.layernorm_residual(ops.linear(xs, ws, bs, lazy=fused), rs, gs, bts, None, None, drop)
+        n_fwd = ops.CALLS[0] - calls0
+        y.backward(dy)
+        outs.append((y.detach(), xs.grad, rs.grad, ws.grad, bs.grad, gs.grad, bts.grad, n_fwd))
+    assert outs[0][7] == 1 and outs[1][7] == 2
+    xr, rr, wr, br, gr, btr = (t.double().requires_grad_(True) for t in (x, r, w, b, gamma, beta))
+    ref = F.layer_norm((xr @ wr.t() + br) * mask + rr, (32,), gr, btr, 1e-5)
+    ref.backward(dy.double())
+    names = ("y", "dx", "dr", "dW", "db", "dgamma", "dbeta")
+    for k, name in enumerate(names):
+        check(outs[0][k], outs[1][k].double(), 3e-6, f"{name}: fused vs two launches")
+    for k, (name, t) in enumerate(zip(names, (ref.detach(), xr.grad, rr.grad, wr.grad, br.grad, gr.grad, btr.grad))):
+        check(outs[0][k], t, 2e-5, f"{name} vs fp64")
+
+
 def test_input_expansion_bit_exact(ops):
     """uint8 pixels / 255 and token ids -> one-hot + mask on the device, bit-identical to the
     reference's host preprocessing (torch.tensor(uint8) / 255; one_hot_encode + lengths_to_mask)"""
