@@ -119,6 +119,13 @@ int mmvae_ffn32_prep_weights_many(const float* const* w1, const float* const* w2
                                   mmvae_stream_t stream);
 int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const float* b1, const float* b2, float* y, int M, int FF,
                         const mmvae_dropout_t* drop, mmvae_stream_t stream);
+/* ... with the LayerNorm that consumes the block as the launch's epilogue: y = LayerNorm(dropout(ffn(x)) + r), xhat (M, 32)
+ * and rstd (M) saved as mmvae_layernorm_residual_fwd saves them (ln_drop: the dropout in front of the residual sum, mask of
+ * element row * 32 + column); backward = mmvae_layernorm_residual_bwd, then mmvae_ffn32_bwd_b16.
+ * (reference models/encoders.py:706-716: `src = norm2(src + dropout2(linear2(dropout(activation(linear1(src))))))`) */
+int mmvae_ffn32_fwd_b16_ln(const float* x, const void* wsplit, const float* b1, const float* b2, const float* r,
+                           const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int M, int FF,
+                           const mmvae_dropout_t* drop, const mmvae_dropout_t* ln_drop, mmvae_stream_t stream);
 int mmvae_ffn32_bwd_b16(const float* x, const float* dy, const void* wsplit, const float* b1, float* dx, float* ws,
                         void* rsplit, const float* dx_add, int M, int FF, const mmvae_dropout_t* drop,
                         mmvae_stream_t stream);

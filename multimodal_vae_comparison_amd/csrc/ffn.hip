@@ -97,6 +97,52 @@ __device__ __forceinline__ void ffn_reduce_store(const f32x16& acc, float* __res
   }
 }
 
+// The same reduction with the LayerNorm that consumes the block as its epilogue (round 6): out = LayerNorm(dropout(y) + r),
+// y = the summed tile + bias.  Thread (wave, li, lh) holds four rows' column li: a row's 32 columns are the 32 lanes of a
+// half-wave, so the row statistics are five xor-shuffles each; saves xhat / rstd as mmvae_layernorm_residual_fwd does (same
+// dropout mask: element row * 32 + column).
+struct FfnLn {
+  const float *r, *gamma, *beta;      // residual rows (M, 32), LayerNorm weight / bias
+  float *xhat, *rstd;
+  mmvae_dropout_t drop;
+};
+__device__ __forceinline__ float ffn_half_row_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+__device__ __forceinline__ void ffn_reduce_ln_store(const f32x16& acc, float* __restrict__ red, int wave, int lane,
+                                                    float* __restrict__ out, int R0, int M, const float* __restrict__ bias,
+                                                    const FfnLn& ln) {
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const float b = bias[li], g = ln.gamma[li], bt = ln.beta[li];
+  const DropKey dk = drop_key(ln.drop);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * wave + i;
+    const float s = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
+    const int row = R0 + ffn_i(r, lh);
+    const bool ok = row < M;
+    const size_t o = (size_t)(ok ? row : 0) * FFN_D + li;
+    const float v = ok ? (s + b) * drop_mul(dk, (uint32_t)o) + ln.r[o] : 0.f;
+    const float mean = ffn_half_row_sum(v) * (1.0f / 32.0f);
+    const float d = v - mean;
+    const float rs = rsqrtf(ffn_half_row_sum(d * d) * (1.0f / 32.0f) + 1e-5f);
+    const float xh = d * rs;
+    if (ok) {
+      ln.xhat[o] = xh;
+      out[o] = xh * g + bt;
+      if (li == 0) ln.rstd[row] = rs;
+    }
+  }
+}
+
 // ---- forward: workgroup = one 32-row block, wave w = FF chunks w, w + 4, ... ------------------------------------------
 __global__ __launch_bounds__(256) void ffn32_fwd_kernel(FfnArgs a) {
   __shared__ float red[4 * 16 * 64];
@@ -311,7 +357,20 @@ extern "C" int mmvae_ffn32_fwd_b16(const float* x, const void* wsplit, const flo
   if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
   if (!ffn_al16(x) || !ffn_al16(wsplit) || !ffn_al16(b1)) return MMVAE_ERR_ARG;
   FfnB16Args a{x, nullptr, b1, b2, (const unsigned short*)wsplit, nullptr, y, nullptr, nullptr, M, 0, FF, 0, 0, drop_arg(drop)};
-  hipLaunchKernelGGL(ffn32_fwd_b16_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ffn32_fwd_b16_kernel<false>, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a, FfnLn{});
+  return mmvae_launch_status();
+}
+// ... with the LayerNorm behind the block as the launch's epilogue: y = LayerNorm(dropout(ffn(x)) + r) (models/encoders.py:
+// 706-716: `src = norm2(src + dropout2(ff))`), xhat / rstd saved as mmvae_layernorm_residual_fwd saves them
+extern "C" int mmvae_ffn32_fwd_b16_ln(const float* x, const void* wsplit, const float* b1, const float* b2, const float* r,
+                                      const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int M, int FF,
+                                      const mmvae_dropout_t* drop, const mmvae_dropout_t* ln_drop, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && wsplit && b1 && b2 && r && gamma && beta && y && xhat && rstd && M > 0);
+  if (!mmvae_ffn32_supported(FFN_D, FF) || (long)M * FF >= (1L << 32)) return MMVAE_ERR_UNSUPPORTED;
+  if (!ffn_al16(x) || !ffn_al16(wsplit) || !ffn_al16(b1)) return MMVAE_ERR_ARG;
+  FfnB16Args a{x, nullptr, b1, b2, (const unsigned short*)wsplit, nullptr, y, nullptr, nullptr, M, 0, FF, 0, 0, drop_arg(drop)};
+  FfnLn ln{r, gamma, beta, xhat, rstd, drop_arg(ln_drop)};
+  hipLaunchKernelGGL(ffn32_fwd_b16_kernel<true>, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, a, ln);
   return mmvae_launch_status();
 }
 // as mmvae_ffn32_bwd; rsplit (mmvae_ffn32_rsplit_bytes(M) bytes, needed with ws) receives the split images of x and dy

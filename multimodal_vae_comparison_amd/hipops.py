@@ -220,6 +220,7 @@ SIGNATURES = {
     "mmvae_ffn32_prep_weights": (c_i, [c_p, c_p, c_p, c_i, c_p]),
     "mmvae_ffn32_prep_weights_many": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "mmvae_ffn32_fwd_b16": (c_i, [c_p] * 5 + [c_i, c_i, c_p, c_p]),
+    "mmvae_ffn32_fwd_b16_ln": (c_i, [c_p] * 10 + [c_i, c_i, c_dp, c_dp, c_p]),
     "mmvae_ffn32_bwd_b16": (c_i, [c_p] * 8 + [c_i, c_i, c_p, c_p]),
     "mmvae_adam_fold_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_p, c_f, c_i] + [c_p] * 4 + [c_i, c_i, c_i, c_p]),
     "mmvae_adam_fold_range": (c_i, [c_p] * 5 + [c_l, c_l, c_l, c_i] + [c_f] * 4 + [c_p, c_f, c_i] + [c_p] * 4

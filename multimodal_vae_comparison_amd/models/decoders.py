@@ -114,8 +114,9 @@ class HipTransformerDecoderLayer(nn.Module):
             return ops.txt_layer(x, mem, mask_u8, ops.TxtLayerMeta(d, ff, nh, True, ds), p,
                                  {k: v.grad for k, v in p.items()})
         fused_ffn = encoders.FUSED_FFN and x.is_cuda and ops.ffn32_supported(d, ff)
-        ffn = lambda t, drop, sink: ops.ffn32(t, self.linear1.weight, self.linear1.bias, self.linear2.weight,
-                                              self.linear2.bias, drop, encoders.stack_ffn_image(self), sink)
+        ffn = lambda t, drop, sink, ldrop=None: ops.ffn32(t, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                                          self.linear2.bias, drop, encoders.stack_ffn_image(self), sink,
+                                                          (t, self.norm3.weight, self.norm3.bias, ldrop))
         # residual gradients of the self-attention and feed-forward blocks join those blocks' first backward kernels
         s1 = ops.residual_sink(x)
         if ds is None:
@@ -133,7 +134,7 @@ class HipTransformerDecoderLayer(nn.Module):
         x = self.norm2(ca, x, ds["drop2"])
         if fused_ffn:
             s3 = ops.residual_sink(x)
-            return self.norm3(ffn(x, ds["ffn"], s3), x, ds["drop3"], res_sink=s3)
+            return self.norm3(ffn(x, ds["ffn"], s3, ds["drop3"]), x, ds["drop3"], res_sink=s3)
         h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])
         return self.norm3(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop3"])
 

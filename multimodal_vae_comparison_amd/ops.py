@@ -2352,7 +2352,7 @@ class LayerNormResidual(Function):
     """y = LayerNorm(x + r); r None, same shape, or (N,d) broadcast over the leading (time) axis"""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, gg, gb, drop, res_sink=None, proj=None):
+    def forward(ctx, x, r, gamma, beta, gg, gb, drop, res_sink=None, proj=None, pre=None):
         """proj = (x_in, w, b): `x` is the placeholder output of a lazy Linear (ops.linear(..., lazy=True)) -- the product
         x_in w^T + b is computed here, in the same launch as the LayerNorm (d = 32: mmvae_proj32_ln_fwd)"""
         x = H.f32c(x)
@@ -2367,7 +2367,10 @@ class LayerNormResidual(Function):
         xhat = torch.empty_like(x)
         rstd = torch.empty(rows, device=x.device)
         fused = False
-        if proj is not None:
+        if pre is not None:      # (y, xhat, rstd) computed by the producer's launch (ops.ffn32(..., ln=...)): nothing to launch
+            y, xhat, rstd = pre
+            fused = True
+        elif proj is not None:
             xin, pw, pb = proj
             xin = H.f32c(xin)
             al = lambda t: t.data_ptr() % 16 == 0
@@ -2425,7 +2428,7 @@ class LayerNormResidual(Function):
             else:
                 dr = dsum
         dx = dxd if drop is not None else dsum
-        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dr, ret_g, ret_b, None, None, None, None, None, None
 
 
 class MeanOverTime(Function):
@@ -2489,7 +2492,8 @@ def as_u8(mask):
 def layernorm_residual(x, r, gamma, beta, gg=None, gb=None, drop=None, res_sink=None):
     """LayerNorm(dropout(x) + r); res_sink: the ResidualGrad that the op producing x from r also holds.  An x that is the
     placeholder of a lazy Linear (x._proj) has its product computed in the LayerNorm's launch"""
-    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop, res_sink, getattr(x, "_proj", None))
+    return LayerNormResidual.apply(x, r, gamma, beta, gg, gb, drop, res_sink, getattr(x, "_proj", None),
+                                   getattr(x, "_ln_pre", None))
 
 
 class DropoutAct(Function):
@@ -2543,8 +2547,13 @@ class Ffn32(Function):
     (rows, FF) hidden activation stays in registers, backward recomputes it.  x (..., 32); w1 (FF,32), b1 (FF),
     w2 (32,FF), b2 (32); drop: DropSpec of the hidden dropout or None; g*: the parameters' flat gradient views."""
 
+    last_pre = None      # (y, xhat, rstd) of the LayerNorm epilogue of the forward that just ran (ops.ffn32 takes it)
+
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2, wsplit=None, res_sink=None):
+    def forward(ctx, x, w1, b1, w2, b2, drop, gw1, gb1, gw2, gb2, wsplit=None, res_sink=None, ln=None):
+        """ln = (r, gamma, beta, ln_drop): the LayerNorm that consumes the block runs as this launch's epilogue (split-bf16
+        path; mmvae_ffn32_fwd_b16_ln): the returned tensor is then a PLACEHOLDER carrying `_ln_pre = (y, xhat, rstd)`, which
+        ops.layernorm_residual picks up instead of launching"""
         ctx.res_sink = res_sink
         x = H.f32c(x)
         M, FF = x.numel() // 32, w1.shape[0]
@@ -2557,8 +2566,17 @@ class Ffn32(Function):
             if wsplit is None:
                 wsplit = torch.empty(H.lib().mmvae_ffn32_wsplit_bytes(FF), dtype=torch.uint8, device=x.device)
                 _call("mmvae_ffn32_prep_weights", H.ptr(w1), H.ptr(w2), H.ptr(wsplit), FF, H.stream())
-            _call("mmvae_ffn32_fwd_b16", H.ptr(x), H.ptr(wsplit), H.ptr(b1), H.ptr(b2), H.ptr(y), M, FF,
-                  _dp(drop, M * FF), H.stream())
+            if ln is not None:
+                r_, gamma_, beta_, ln_drop = ln
+                r_ = H.f32c(r_)
+                yln, xhat, rstd = torch.empty_like(x), torch.empty_like(x), torch.empty(M, device=x.device)
+                _call("mmvae_ffn32_fwd_b16_ln", H.ptr(x), H.ptr(wsplit), H.ptr(b1), H.ptr(b2), H.ptr(r_), H.ptr(gamma_),
+                      H.ptr(beta_), H.ptr(yln), H.ptr(xhat), H.ptr(rstd), M, FF, _dp(drop, M * FF), _dp(ln_drop, M * 32),
+                      H.stream())
+                Ffn32.last_pre = (yln, xhat, rstd)
+            else:
+                _call("mmvae_ffn32_fwd_b16", H.ptr(x), H.ptr(wsplit), H.ptr(b1), H.ptr(b2), H.ptr(y), M, FF,
+                      _dp(drop, M * FF), H.stream())
         else:
             _call("mmvae_ffn32_fwd", H.ptr(x), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(b2), H.ptr(y), M, FF,
                   _dp(drop, M * FF), H.stream())
@@ -2630,7 +2648,7 @@ class Ffn32(Function):
                 rets[i] = ret
         if radd is not None and dx is not None:
             dx = dx + radd.view_as(dx)
-        return (dx, *rets, None, None, None, None, None, None, None)
+        return (dx, *rets, None, None, None, None, None, None, None, None)
 
 
 # the fused feed-forward launches on split-bf16 MFMA (csrc/ffn_b16.inc) instead of fp32 MFMA (csrc/ffn.hip); both are tested
@@ -2643,8 +2661,18 @@ def ffn32_supported(d, ff):
     return bool(H.lib().mmvae_ffn32_supported(int(d), int(ff)))
 
 
-def ffn32(x, w1, b1, w2, b2, drop=None, wsplit=None, res_sink=None):
-    return Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad, wsplit, res_sink)
+FFN32_LN = os.environ.get("MMVAE_FFN32_LN", "1") == "1"      # the LayerNorm behind the block as the forward launch's epilogue
+
+
+def ffn32(x, w1, b1, w2, b2, drop=None, wsplit=None, res_sink=None, ln=None):
+    """ln = (r, gamma, beta, ln_drop) of the LayerNorm(dropout(.) + r) that consumes the result: computed in the same launch
+    when the split-bf16 core runs (the result is then a placeholder for ops.layernorm_residual, see Ffn32.forward)"""
+    fuse = (ln is not None and FFN32_LN and FFN32_SPLIT_BF16 and x.is_cuda and ln[0].numel() == x.numel()
+            and ln[0].is_contiguous() and ln[0].dtype == torch.float32)
+    y = Ffn32.apply(x, w1, b1, w2, b2, drop, w1.grad, b1.grad, w2.grad, b2.grad, wsplit, res_sink, ln if fuse else None)
+    if fuse:
+        y._ln_pre, Ffn32.last_pre = Ffn32.last_pre, None
+    return y
 
 
 def ffn32_prep_many(pairs):

@@ -358,6 +358,40 @@ def test_proj32_layernorm_fused_matches_two_launches(ops, monkeypatch, M, p):
         check(outs[0][k], t, 2e-5, f"{name} vs fp64")
 
 
+@pytest.mark.parametrize("M,FF,p", [(12800, 1024, 0.1), (70, 128, 0.0), (33, 96, 0.3)])
+def test_ffn32_layernorm_epilogue_matches_two_launches(ops, monkeypatch, M, FF, p):
+    """mmvae_ffn32_fwd_b16_ln: LayerNorm(dropout(ffn(x)) + x) with the LayerNorm as the feed-forward launch's epilogue
+    against the two launches (same masks, same saved tensors, same backward): outputs and every gradient"""
+    from multimodal_vae_comparison_amd.models.nn_modules import DropoutState
+    g = torch.Generator().manual_seed(M + FF)
+    x = torch.randn(M, 32, generator=g).to(DEV)
+    w1 = (torch.randn(FF, 32, generator=g) * 0.3).to(DEV)
+    b1 = (torch.randn(FF, generator=g) * 0.3).to(DEV)
+    w2 = (torch.randn(32, FF, generator=g) * 0.1).to(DEV)
+    b2 = torch.randn(32, generator=g).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(32, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(32, generator=g)).to(DEV)
+    dy = torch.randn(M, 32, generator=g).to(DEV)
+    d_ffn = d_ln = None
+    if p > 0:
+        st = DropoutState().to(DEV)
+        slot, call = st.begin()
+        d_ffn, d_ln = st.spec(slot, call, 3, p, "ffn"), st.spec(slot, call, 4, p, "drop2")
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FFN32_LN", fused)
+        xs, w1s, b1s, w2s, b2s, gs, bts = (t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gamma, beta))
+        calls0 = ops.CALLS[0]
+        h = ops.ffn32(xs, w1s, b1s, w2s, b2s, d_ffn, None, None, (xs, gs, bts, d_ln))
+        y = ops.layernorm_residual(h, xs, gs, bts, None, None, d_ln)
+        n_fwd = ops.CALLS[0] - calls0
+        y.backward(dy)
+        outs.append((y.detach(), xs.grad, w1s.grad, b1s.grad, w2s.grad, b2s.grad, gs.grad, bts.grad, n_fwd))
+    assert outs[1][8] == outs[0][8] + 1, (outs[0][8], outs[1][8])
+    for k, name in enumerate(("y", "dx", "dW1", "db1", "dW2", "db2", "dgamma", "dbeta")):
+        check(outs[0][k], outs[1][k].double(), 3e-6, f"{name}: epilogue vs two launches")
+
+
 def test_input_expansion_bit_exact(ops):
     """uint8 pixels / 255 and token ids -> one-hot + mask on the device, bit-identical to the
     reference's host preprocessing (torch.tensor(uint8) / 255; one_hot_encode + lengths_to_mask)"""
