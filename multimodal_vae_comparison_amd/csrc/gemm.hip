@@ -874,8 +874,13 @@ extern "C" int mmvae_gemm_f32(const float* A, const float* Bm, const float* bias
 }
 
 // ---- nn.Linear wrappers ---------------------------------------------------------------------------
+int mmvae_proj32_fwd_launch(const float* x, const float* w, const float* b, float* y, int M, int N, mmvae_stream_t stream);   // ffn.hip
 extern "C" int mmvae_linear_fwd(const float* x, const float* w, const float* b, float* aux, float* y, int M, int N,
                                 int K, long ldx, int x_act, int ep_mode, mmvae_stream_t stream) {
+  // many rows of a 32-wide input into 32 .. 128 outputs (the action towers' QKV projection): one wave per 32 rows
+  if (K == 32 && ldx == 32 && M >= 1024 && N >= 32 && N <= 128 && (N & 31) == 0 && x_act == MMVAE_ACT_NONE &&
+      ep_mode == MMVAE_EP_NONE && x && w && y && ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)b) & 15) == 0))
+    return mmvae_proj32_fwd_launch(x, w, b, y, M, N, stream);
   // y[m,n] = sum_k x[m,k] w[n,k]: A = x (sam = ldx, sak = 1), B(k,n) = w[n*K + k]
   return mmvae_gemm_f32(x, w, b, aux, y, nullptr, nullptr, M, N, K, ldx, 1, 1, K, N, x_act, MMVAE_ACT_NONE, ep_mode, 0,
                         1, stream);

@@ -235,7 +235,9 @@ def test_split_bf16_non_finite_inputs(ops, hip_lib, kind, B, C, Hin):
                                        (7680, 400, 400, 2), (7680, 400, 784, 2), (7680, 20, 400, 0), (6144, 576, 64, 2),
                                        (1000, 2048, 512, 2), (32000, 56, 160, 0), (520, 1024, 256, 3), (3844, 36, 132, 1),
                                        # 64 x 64 tiles (round 3): the 512-wide image-tower linears at batch 512 .. 1000
-                                       (1000, 512, 512, 2), (512, 512, 512, 0), (1000, 32, 512, 0), (996, 512, 64, 1), (300, 516, 100, 1)])
+                                       (1000, 512, 512, 2), (512, 512, 512, 0), (1000, 32, 512, 0), (996, 512, 64, 1), (300, 516, 100, 1),
+                                       # one wave per 32 rows (round 6): the action towers' 32 -> 96 / 32 projections at 12 800 rows
+                                       (12800, 32, 96, 0), (1030, 32, 32, 0), (3200, 32, 128, 0), (2049, 32, 64, 0)])
 def test_linear_fwd_bwd(ops, M, K, N, act):
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g)
