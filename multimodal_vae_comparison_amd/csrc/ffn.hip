@@ -478,32 +478,44 @@ extern "C" int mmvae_proj32_ln_fwd(const float* x, const float* w, const float* 
 // The action towers' packed QKV projection (12 800 x 32 -> 96: models/encoders.py:706-716 via nn.MultiheadAttention's in_proj)
 // ran 10.9 us on the generic 128 x 32-tile GEMM.  Same mapping as proj32_ln_fwd_kernel: a wave owns 32 rows (lane = row, the
 // tokens are the MFMA's B operand), one 32 x 32 x 32 product per 32 output columns, four float4 stores per lane and tile.
+template <int NT>      // NT = N / 32 output tiles; every tile's weight rows are in flight before the first MFMA (with the
+                        // loads inside the tile loop a wave paid the L2 round trip once per tile: 12.5 us whatever M)
 __global__ __launch_bounds__(256) void proj32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ y, int M, int N) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int row = (blockIdx.x * 4 + wave) * 32 + li;
+  const int rbase = (blockIdx.x * 4 + wave) * 32, row = rbase + li;
   const bool ok = row < M;
-  float xv[16];
+  float xv[16], wv[NT][16], bv[NT];
   ffn_row_pairs(x + (size_t)(ok ? row : 0) * FFN_D, ok, lh, xv);
-  for (int n0 = 0; n0 < N; n0 += 32) {
-    float wv[16];
-    ffn_row_pairs(W + (size_t)(n0 + li) * FFN_D, true, lh, wv);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ffn_row_pairs(W + (size_t)(32 * t + li) * FFN_D, true, lh, wv[t]);
+    bv[t] = b ? b[32 * t + li] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    // rows as the A operand: register r of lane (li, lh) = y[row ffn_i(r, lh)][column 32 t + li] -- a store instruction writes
+    // 32 consecutive floats of two rows
     f32x16 acc = ffn_zero();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[kk], xv[kk], acc, 0, 0, 0);
-    if (ok) {
+    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[kk], wv[t][kk], acc, 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 bq = b ? *reinterpret_cast<const float4*>(b + n0 + 8 * q + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(y + (size_t)row * N + n0 + 8 * q + 4 * lh) =
-            make_float4(acc[4 * q] + bq.x, acc[4 * q + 1] + bq.y, acc[4 * q + 2] + bq.z, acc[4 * q + 3] + bq.w);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int rr = rbase + ffn_i(r, lh);
+      if (rr < M) y[(size_t)rr * N + 32 * t + li] = acc[r] + bv[t];
     }
   }
 }
 // (called from mmvae_linear_fwd: csrc/gemm.hip)
 int mmvae_proj32_fwd_launch(const float* x, const float* w, const float* b, float* y, int M, int N, mmvae_stream_t stream) {
-  hipLaunchKernelGGL(proj32_fwd_kernel, dim3((M + 127) / 128), dim3(256), 0, (hipStream_t)stream, x, w, b, y, M, N);
+  const dim3 grid((M + 127) / 128);
+  hipStream_t st = (hipStream_t)stream;
+  switch (N / 32) {
+    case 1: hipLaunchKernelGGL(proj32_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, b, y, M, N); break;
+    case 2: hipLaunchKernelGGL(proj32_fwd_kernel<2>, grid, dim3(256), 0, st, x, w, b, y, M, N); break;
+    case 3: hipLaunchKernelGGL(proj32_fwd_kernel<3>, grid, dim3(256), 0, st, x, w, b, y, M, N); break;
+    default: hipLaunchKernelGGL(proj32_fwd_kernel<4>, grid, dim3(256), 0, st, x, w, b, y, M, N); break;
+  }
   return mmvae_launch_status();
 }
