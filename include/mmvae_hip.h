@@ -858,6 +858,10 @@ int mmvae_attn_fwd(const float* q, const float* k, const float* v, const uint8_t
 int mmvae_attn_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                    float* dq, float* dk, float* dv, int L, int S, int N, int H, int hd, long ldq, long ldk,
                    long ldv, const mmvae_dropout_t* drop, mmvae_stream_t stream);
+/* runtime switch between the two MFMA backward kernels of mmvae_attn_bwd for 32 < L, S <= 128: 0 (default) = the LDS-tile form,
+ * 1 = the register form (csrc/text.hip: attn_t_bwd_kernel, needs 16-byte aligned head slices; measured level in the step);
+ * returns the previous setting.  MMVAE_ATTN_T_BWD=1 in the environment starts with 1.  (nn.MultiheadAttention backward: reference models/encoders.py:706-716) */
+int mmvae_attn_t_bwd_set(int on);
 
 /* y = LayerNorm(x + r) * gamma + beta (eps 1e-5); r may be NULL, same-shape (r_rows = 0) or broadcast over time
  * (r_rows = N: row index = row % N).  xhat (rows,d) and rstd (rows) are saved for the backward.

@@ -811,12 +811,186 @@ __global__ __launch_bounds__(64) void attn_t_fwd_kernel(const float* __restrict_
     }
   }
 }
+// ---- backward, register form (round 6): the L x S tile never enters LDS --------------------------------------------------
+// attn_mfma_bwd_kernel stages Q, K, V, dO AND the 128 x 128 probability tile (92 KB of LDS: one workgroup per CU), rewrites
+// the tile in place between four barrier-separated phases and reads one LDS word per lane and MFMA out of it: 29.4 us at
+// 128 x 2 x 100 x 100 for 0.33 GFLOP.  Here the probabilities are read from global memory straight into the accumulator
+// layouts the products want and dP is computed twice, once per orientation:
+//   phase A, wave = 32 QUERIES (lane li = query): dP^T = V dO^T per 32-key tile (register r = key at_i(r, lh)), P^T read with
+//     four 16-byte loads per tile and lane, delta[query] = sum_key P dP.mask is in-lane adds + ONE exchange between the wave's
+//     halves (the tile form reduces 16 rows over 32 lanes: 80 shuffles), dS^T stays in registers and IS the B operand of
+//     dQ^T = K^T dS^T (accumulator-as-operand: reduction index = key at_i(s, lh), K read from LDS in that order);
+//   phase C, wave = 32 KEYS (lane li = key): per 32-query tile dP = dO V^T (register r = query), P read as 16 coalesced words,
+//     delta from LDS (128 floats), and the dropped probabilities / dS are the B operands of dV^T = dO^T P.mask and
+//     dK^T = Q^T dS with the reduction index = query at_i(s, lh); accumulated over the query tiles in registers, no cross-wave sum.
+// 35 KB of LDS (Q, K, V, dO rows + delta): four workgroups per CU; 256 MFMAs per wave, two barriers.
+__global__ __launch_bounds__(256) void attn_t_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ probs,
+                                                         const float* __restrict__ dout, float* __restrict__ dq,
+                                                         float* __restrict__ dk, float* __restrict__ dv, int L, int S, int N,
+                                                         int H, int hd, long ldq, long ldk, long ldv, mmvae_dropout_t drop) {
+  __shared__ float sq[128 * AT_HP], sk[128 * AT_HP], sv[128 * AT_HP], sdo[128 * AT_HP];
+  __shared__ float sdelta[128];
+  const int n = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+  const long E = (long)H * hd;
+  const float scale = 1.0f / sqrtf((float)hd);
+  at_stage(sq, q, L, N, n, ldq, h * hd, hd, 1.0f, tid);
+  at_stage(sk, k, S, N, n, ldk, h * hd, hd, 1.0f, tid);
+  at_stage(sv, v, S, N, n, ldv, h * hd, hd, 1.0f, tid);
+  at_stage(sdo, dout, L, N, n, E, h * hd, hd, 1.0f, tid);
+  const float* __restrict__ P = probs + ((size_t)n * H + h) * L * S;
+  const bool vec = (S & 3) == 0 && (((uintptr_t)P) & 15) == 0;
+  const float inv_keep = drop_key(drop).inv_keep;
+  const int b0 = wave * 32;
+  if (tid < 128) sdelta[tid] = 0.f;      // (rows >= L are read with a zero probability in front of them: keep them finite)
+  __syncthreads();
+  // ================= phase A: this wave's 32 queries =================
+  if (b0 < L) {
+    const int l = b0 + li;
+    const bool lok = l < L;
+    float da[AT_HD / 2];
+#pragma unroll
+    for (int kk = 0; kk < AT_HD / 2; ++kk) da[kk] = sdo[l * AT_HP + 2 * kk + lh];
+    f32x16 ds[4];                 // dP^T, then dS^T: register r <-> key 32 kb + at_i(r, lh), lane <-> query
+    float pa[4][16];              // |P^T|
+    float part = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ds[kb][r] = 0.f; pa[kb][r] = 0.f; }
+      if (kb * 32 < S) {
+#pragma unroll
+        for (int kk = 0; kk < AT_HD / 2; ++kk)
+          ds[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[(kb * 32 + li) * AT_HP + 2 * kk + lh], da[kk], ds[kb], 0, 0, 0);
+        const float* prow = P + (size_t)(lok ? l : 0) * S + kb * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int key0 = kb * 32 + 8 * g + 4 * lh;
+          float p4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (vec) {
+            if (lok && key0 < S) {
+              const float4 t = *reinterpret_cast<const float4*>(prow + 8 * g);
+              p4[0] = t.x; p4[1] = t.y; p4[2] = t.z; p4[3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (lok && key0 + j < S) p4[j] = prow[8 * g + j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const float dpm = ds[kb][r] * at_mask_of(p4[j], inv_keep);      // dP . mask
+            pa[kb][r] = fabsf(p4[j]);
+            ds[kb][r] = dpm;
+            part += pa[kb][r] * dpm;
+          }
+        }
+      }
+    }
+    const float delta = part + __shfl_xor(part, 32, 64);
+    if (lh == 0) sdelta[l] = delta;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[kb][r] = pa[kb][r] * (ds[kb][r] - delta);
+    // ---- dQ^T[d][query] = sum_key K[key][d] dS^T[key][query]: lane (d = li, lh) feeds K[32 kb + at_i(s, lh)][li] ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      if (kb * 32 < S) {
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+          const float a = li < AT_HD ? sk[(kb * 32 + at_i(s_, lh)) * AT_HP + li] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ds[kb][s_], acc, 0, 0, 0);
+        }
+      }
+    }
+    if (lok) {      // register r < 8 of lane (li, lh) = dQ[l][d = at_i(r, lh)]: two float4 per lane
+      float* o = dq + ((size_t)l * N + n) * ldq + h * hd;
+      if (4 * lh < hd) *reinterpret_cast<float4*>(o + 4 * lh) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+      if (8 + 4 * lh < hd)
+        *reinterpret_cast<float4*>(o + 8 + 4 * lh) = make_float4(acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale);
+    }
+  }
+  __syncthreads();
+  // ================= phase C: this wave's 32 keys =================
+  if (b0 < S) {
+    const int s_key = b0 + li;
+    const bool sok = s_key < S;
+    float vb[AT_HD / 2];
+#pragma unroll
+    for (int kk = 0; kk < AT_HD / 2; ++kk) vb[kk] = sv[s_key * AT_HP + 2 * kk + lh];
+    f32x16 accv, acck;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accv[r] = acck[r] = 0.f;
+#pragma unroll 1
+    for (int qt = 0; qt < 4; ++qt) {
+      if (qt * 32 >= L) break;
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < AT_HD / 2; ++kk)
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sdo[(qt * 32 + li) * AT_HP + 2 * kk + lh], vb[kk], dp, 0, 0, 0);
+      float pm[16], dsv[16];      // register r <-> query 32 qt + at_i(r, lh), lane <-> key
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int l = qt * 32 + at_i(r, lh);
+        const float pv = (sok && l < L) ? P[(size_t)l * S + s_key] : 0.f;
+        const float m = at_mask_of(pv, inv_keep), pabs = fabsf(pv);
+        pm[r] = pabs * m;
+        dsv[r] = pabs * (dp[r] * m - sdelta[l]);
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) {
+        const int l = qt * 32 + at_i(s_, lh);
+        const float ao = li < AT_HD ? sdo[l * AT_HP + li] : 0.f;
+        const float aq = li < AT_HD ? sq[l * AT_HP + li] : 0.f;
+        accv = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, pm[s_], accv, 0, 0, 0);
+        acck = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, dsv[s_], acck, 0, 0, 0);
+      }
+    }
+    if (sok) {
+      float* ov = dv + ((size_t)s_key * N + n) * ldv + h * hd;
+      float* ok_ = dk + ((size_t)s_key * N + n) * ldk + h * hd;
+      if (4 * lh < hd) {
+        *reinterpret_cast<float4*>(ov + 4 * lh) = make_float4(accv[0], accv[1], accv[2], accv[3]);
+        *reinterpret_cast<float4*>(ok_ + 4 * lh) = make_float4(acck[0] * scale, acck[1] * scale, acck[2] * scale, acck[3] * scale);
+      }
+      if (8 + 4 * lh < hd) {
+        *reinterpret_cast<float4*>(ov + 8 + 4 * lh) = make_float4(accv[4], accv[5], accv[6], accv[7]);
+        *reinterpret_cast<float4*>(ok_ + 8 + 4 * lh) = make_float4(acck[4] * scale, acck[5] * scale, acck[6] * scale, acck[7] * scale);
+      }
+    }
+  }
+}
 static inline bool attn_t_ok(const float* q, const float* k, const float* v, int hd, long ldq, long ldk, long ldv) {
   return hd <= AT_HD && (hd & 3) == 0 && ((ldq | ldk | ldv) & 3) == 0 &&
          ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0;
 }
 // the MFMA kernels take over from the thread-per-row ones past 32 rows (round 5: it was 64 -- the text decoder of a PoE
 // subset WITHOUT the text modality decodes all 45 positions of its modality: 20 / 33 us per call at 32 x 2 x 45 x 45)
+// runtime switch (the tests run both; MMVAE_ATTN_T_BWD=1 in the environment starts with the register form).  Measured, same
+// box (profiles/r06_attn_t_bwd.txt): alone 24.4 -> 22.8 us at 128 x 2 x 100 x 100, in the cfg5 step 2.932 -> 2.942 ms -- level,
+// so the tile form stays the default: both spend most of their time staging four strided operand matrices and waiting on
+// LDS operands, not in their 256 MFMAs (6.8 us)
+static int attn_t_bwd_flag = -1;
+static bool attn_t_bwd_enabled() {
+  if (attn_t_bwd_flag < 0) {
+    const char* e = getenv("MMVAE_ATTN_T_BWD");
+    attn_t_bwd_flag = (e && e[0] == '1') ? 1 : 0;
+  }
+  return attn_t_bwd_flag != 0;
+}
+extern "C" int mmvae_attn_t_bwd_set(int on) {
+  const int was = attn_t_bwd_enabled() ? 1 : 0;
+  attn_t_bwd_flag = on ? 1 : 0;
+  return was;
+}
 static inline bool attn_use_mfma(int L, int S, int hd) {
   return hd <= AT_HD && (L > 32 || S > 32) && L <= 128 && S <= 128;
 }
@@ -850,8 +1024,15 @@ extern "C" int mmvae_attn_bwd(const float* q, const float* k, const float* v, co
   MMVAE_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && L > 0 && S > 0 && N > 0 && H > 0 && hd > 0);
   if (L > ATT_MAX || S > ATT_MAX || hd > ATT_HD_MAX) return MMVAE_ERR_UNSUPPORTED;
   if (attn_use_mfma(L, S, hd)) {
-    hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk,
-                       dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
+    // the register form needs 16-byte aligned head slices (its dq / dk / dv stores are float4), as the transposed forward does
+    const bool t_ok = attn_t_bwd_enabled() && attn_t_ok(q, k, v, hd, ldq, ldk, ldv) && attn_t_ok(dq, dk, dv, hd, ldq, ldk, ldv) &&
+                      (((uintptr_t)dout) & 15) == 0;
+    if (t_ok)
+      hipLaunchKernelGGL(attn_t_bwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk, dv, L,
+                         S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
+    else
+      hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, q, k, v, probs, dout, dq, dk,
+                         dv, L, S, N, H, hd, ldq, ldk, ldv, drop_arg(drop));
     return mmvae_launch_status();
   }
 #define ATT_BWD(AM, HD)                                                                                              \

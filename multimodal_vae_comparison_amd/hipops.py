@@ -121,6 +121,7 @@ SIGNATURES = {
     "mmvae_bias_group_parts": (c_i, [c_i]),
     "mmvae_linear_fwd": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_gemm_b16_set": (c_i, [c_i]),
+    "mmvae_attn_t_bwd_set": (c_i, [c_i]),
     "mmvae_linear_bwd_data": (c_i, [c_p] * 4 + [c_i] * 5 + [c_p]),
     "mmvae_linear_bwd_weight": (c_i, [c_p] * 5 + [c_i] * 3 + [c_l] + [c_i] * 2 + [c_p]),
     "mmvae_linear_bwd_weight_ws_floats": (c_sz, [c_i] * 3),

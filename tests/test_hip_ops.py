@@ -830,6 +830,14 @@ def test_attention(ops, L, N, E, H_):
     out.backward(do.to(DEV))
     check(out, ref, 2e-5, "attn out")
     check(qg.grad, qr.grad, 5e-5, "attn dqkv")
+    from multimodal_vae_comparison_amd import hipops as H
+    was = H.lib().mmvae_attn_t_bwd_set(1)      # ... and the register-form backward
+    try:
+        qg2 = qkv.to(DEV).requires_grad_(True)
+        ops.attention(qg2, kpm.to(torch.uint8).to(DEV), H_).backward(do.to(DEV))
+        check(qg2.grad, qr.grad, 5e-5, "attn dqkv (register-form backward)")
+    finally:
+        H.lib().mmvae_attn_t_bwd_set(was)
 
 
 @pytest.mark.parametrize("L,N,E,H_,p", [(100, 9, 32, 2, 0.1), (128, 3, 32, 2, 0.3), (65, 4, 24, 2, 0.1), (70, 2, 16, 4, 0.2), (99, 3, 32, 2, 0.2), (67, 130, 32, 2, 0.1),
@@ -859,11 +867,18 @@ def test_attention_weight_dropout(ops, L, N, E, H_, p):
     att = F.softmax(att, -1).reshape(N * H_, L, L) * mask
     ref = torch.bmm(att, v).transpose(0, 1).reshape(L, N, E)
     ref.backward(do.double().to(DEV))
-    qg = qkv.to(DEV).requires_grad_(True)
-    out = ops.attention(qg, kpm.to(torch.uint8).to(DEV), H_, drop=drop)
-    out.backward(do.to(DEV))
-    check(out, ref, 2e-5, "attn out")
-    check(qg.grad, qr.grad, 5e-5, "attn dqkv")
+    from multimodal_vae_comparison_amd import hipops as H
+    was = H.lib().mmvae_attn_t_bwd_set(0)
+    try:
+        for form in (0, 1):      # the LDS-tile backward (default) and the register form (csrc/text.hip: attn_t_bwd_kernel)
+            H.lib().mmvae_attn_t_bwd_set(form)
+            qg = qkv.to(DEV).requires_grad_(True)
+            out = ops.attention(qg, kpm.to(torch.uint8).to(DEV), H_, drop=drop)
+            out.backward(do.to(DEV))
+            check(out, ref, 2e-5, "attn out")
+            check(qg.grad, qr.grad, 5e-5, f"attn dqkv (backward form {form})")
+    finally:
+        H.lib().mmvae_attn_t_bwd_set(was)
 
 
 @pytest.mark.parametrize("p", [0.0, 0.2])
