@@ -83,6 +83,20 @@ class Dec_CNN(VaeDecoder):
         return out, self._scale
 
 
+_ONES = {}
+
+
+def _ones_mask(bs, T, device):
+    """the `masks=None` decoder mask (every step valid), constant per shape: built once (read-only for every consumer)"""
+    key = (bs, T, str(device))
+    m = _ONES.get(key)
+    if m is None:
+        if len(_ONES) >= 16:
+            _ONES.clear()
+        m = _ONES[key] = torch.ones(bs, T, dtype=torch.bool, device=device)
+    return m
+
+
 class HipTransformerDecoderLayer(nn.Module):
     """torch.nn.TransformerDecoderLayer (post-norm, gelu) parameter layout.  Memory length 1 (K = 1 latent
     sample, decoders.py:718): the cross-attention softmax is identically 1."""
@@ -182,7 +196,9 @@ class Dec_TxtTransformer(VaeDecoder):
         if tq is None:
             pe = self.sequence_pos_encoder.module.pe[:T].to(device)          # (T,1,D)
             tq = pe.expand(T, bs, D).contiguous()
-            self._tq_cache = {key: tq}
+            if len(self._tq_cache) >= 8:      # (a PoE step decodes at two (T, bs) shapes: keep both, bound the rest)
+                self._tq_cache.clear()
+            self._tq_cache[key] = tq
         return tq
 
     def forward(self, batch):
@@ -191,7 +207,7 @@ class Dec_TxtTransformer(VaeDecoder):
         mask = batch["masks"]
         K, bs, D = z.shape
         if mask is None:
-            mask = torch.ones(bs, self.data_dim[0], dtype=torch.bool, device=z.device)
+            mask = _ones_mask(bs, self.data_dim[0], z.device)
         mask = mask.to(z.device)
         if K != 1:          # K-preserving extension (class docstring): K * B independent sequences
             mask = mask.repeat(K, 1)
@@ -203,7 +219,7 @@ class Dec_TxtTransformer(VaeDecoder):
         p = self.dropout
         nl = len(self.seqTransDecoder.layers)
         if self.training and p > 0:       # nn.Dropout sites of the reference: PE + 6 per layer
-            slot, call = self.drop_state.begin()
+            slot, call = batch.get("drop_begun") or self.drop_state.begin()      # (begun by the caller: POE._decoder_lanes)
             sp = lambda site, name: self.drop_state.spec(slot, call, site, p, name)
             x = ops.dropout_act(x, H.ACT_NONE, sp(0, "pe"))
             ds = [{"attn": sp(1 + 6 * i, f"l{i}.attn"), "drop1": sp(2 + 6 * i, f"l{i}.drop1"),
@@ -251,12 +267,12 @@ class Dec_Transformer(VaeDecoder):
                 mask = mask.repeat(int(bs / mask.shape[0]), 1)
             mask = mask.to(z.device)
         else:
-            mask = torch.ones(bs, self.data_dim[0], dtype=torch.bool, device=z.device)
+            mask = _ones_mask(bs, self.data_dim[0], z.device)
         T = mask.shape[1]
         mask_u8 = ops.as_u8(mask)
         nl = len(self.seqTransDecoder.layers)
         if self.training and self.dropout > 0:    # nn.Dropout sites: PE + 6 per layer
-            slot, call = self.drop_state.begin()
+            slot, call = batch.get("drop_begun") or self.drop_state.begin()      # (begun by the caller: POE._decoder_lanes)
             sp = lambda site, name: self.drop_state.spec(slot, call, site, self.dropout, name)
             d_pe = sp(0, "pe")
             ds = [{"attn": sp(1 + 6 * i, f"l{i}.attn"), "drop1": sp(2 + 6 * i, f"l{i}.drop1"),

@@ -267,6 +267,10 @@ class MoPOE(TorchMMVAE):
 class POE(TorchMMVAE):
     """MVAE, product of experts (mmvae_models.py:134-250)."""
 
+    # decoder calls of one step spread over the two streams by their launch counts (_decoder_lanes); MMVAE_POE_BALANCE=0:
+    # every call on its tower's stream
+    balance_decoder_calls = os.environ.get("MMVAE_POE_BALANCE", "1") != "0"
+
     def __init__(self, vaes, n_latents: int, obj_config: dict, model_config=None):
         super().__init__(vaes, n_latents, **obj_config)
         self.model_config = model_config
@@ -277,6 +281,7 @@ class POE(TorchMMVAE):
         # size depends on PYTHONHASHSEED; the default here is itertools order, `subset_order` pins another one.
         self.subset_order = None
         self.batch_dropout_towers = True      # decoders with dropout: all subset passes in one call (objective docstring)
+        self._job_calls = {}                  # launches of a decoder call the last time it ran (_decoder_lanes)
 
     @property
     def pz_params(self):
@@ -334,46 +339,69 @@ class POE(TorchMMVAE):
                     for s in member:
                         packed[s][n] = packed_head(*enc(mods[n]))
         self._join(streams, dev)
+        # Tensors that cross streams (a tower's heads -> the fusion; the latent samples -> decoder calls on the other stream;
+        # their row sums -> the ELBO assembly) are registered with the consuming stream.  Without it the allocator hands a
+        # block out again as soon as the host drops the last reference -- found in round 6 in the CAPTURED step: the
+        # image-only subset's z (capture stream) was re-used by the image decoder's backward while the text decoder's
+        # cross-attention weight gradient, queued long before on the side stream, had yet to read it.
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        for d_ in packed:
+            for t in d_.values():
+                _uses(t, cur)
         # ---- fusion per subset (one noise draw each, in subset order) ----
         zs, kl_blocks = [], []
         D = self.n_latents
+        B = next(iter(packed[0].values())).shape[0]
+        draws = self._draw_many(NS, B, D, dev)      # (one launch; `eps_override`: NS recorded draws in subset order)
         for s, S in enumerate(subsets):
             ps = [packed[s][n] for n in names if n in S]
-            B = ps[0].shape[0]
-            eps = [self._draw(B, D, ps[0].device)]
+            eps = [draws[s]]
             E = len(ps)
             _, kl, z = ops.poe_reparam_kl(theta, ps, eps, True, 1 << E, theta.grad)
             zs.append(z[0])
             kl_blocks.append(kl)             # (E + 1, B): the joint's KL is the last row
         # ---- decoders: one (passes, B) block of row sums per call ----
+        # One call for all passes of a decoder that run under the SAME mask: the B-row latent samples of those subsets are
+        # one batch (row k * B + b).  Subsets that contain the modality decode under its mask, the others under `masks=None`
+        # (the decoder's full-length all-ones mask, another sequence length for the text tower): two groups.
+        # optimal_sigma fits ONE sigma per call, so its passes cannot share one.  A decoder WITH dropout then draws its
+        # masks once per group instead of per pass (independent masks either way; the extracted-mask parity test splits
+        # them by pass).
+        jobs = []      # (modality index, name, subsets of the call, mask of the call, (slot, call) of its dropout state)
+        for i, n in enumerate(names):
+            vae = self.vaes[n]
+            mk = mods[n]["masks"]
+            share = vae.ltype != "optimal_sigma" and (one_call(vae.dec) or self.batch_dropout_towers)
+            groups = [[s_ for s_, S in enumerate(subsets) if n not in S], [s_ for s_, S in enumerate(subsets) if n in S]]
+            if mk is None:
+                groups = [list(range(NS))]
+            groups = sorted([g for g in groups if g], key=lambda g: g[0])          # call order = first member's order
+            for g in groups:
+                gm = mk if (mk is not None and n in subsets[g[0]]) else None
+                for part in ([g] if share and len(g) > 1 else [[s_] for s_ in g]):
+                    jobs.append((i, n, part, gm))
+        lanes = self._decoder_lanes(jobs, streams, B)
         rec_blocks = []
         self._fork(streams, dev, mods)
-        for i, (n, st) in enumerate(zip(names, streams)):
+        for (i, n, g, gm), (st, begun) in zip(jobs, lanes):
             vae = self.vaes[n]
             with torch.cuda.stream(st):
-                # One call for all passes of a decoder that run under the SAME mask: the B-row latent samples of those
-                # subsets are one batch (row k * B + b).  Subsets that contain the modality decode under its mask, the
-                # others under `masks=None` (the decoder's full-length all-ones mask, another sequence length for the text
-                # tower): two groups.  optimal_sigma fits ONE sigma per call, so its passes cannot share one.  A decoder
-                # WITH dropout then draws its masks once per group instead of per pass (independent masks either way;
-                # the extracted-mask parity test splits them by pass).
-                mk = mods[n]["masks"]
-                share = vae.ltype != "optimal_sigma" and (one_call(vae.dec) or self.batch_dropout_towers)
-                groups = [[s_ for s_, S in enumerate(subsets) if n not in S], [s_ for s_, S in enumerate(subsets) if n in S]]
-                if mk is None:
-                    groups = [list(range(NS))]
-                groups = sorted([g for g in groups if g], key=lambda g: g[0])          # call order = first member's order
-                for g in groups:
-                    gm = mk if (mk is not None and n in subsets[g[0]]) else None
-                    if share and len(g) > 1:
-                        z_all = torch.cat([zs[s_] for s_ in g], 0)
-                        out, _ = vae.dec({"latents": z_all.unsqueeze(0), "masks": None if gm is None else gm.repeat(len(g), 1)})
-                        r = recon_rowsum(vae.ltype, out, mods[n])                # target row = output row % B
-                        rec_blocks.append((r.view(len(g), B), i, list(g)))       # the call's rows as ONE (passes, B) block
-                    else:
-                        for s_ in g:
-                            out, _ = vae.dec({"latents": zs[s_].unsqueeze(0), "masks": gm})
-                            rec_blocks.append((recon_rowsum(vae.ltype, out, mods[n]).view(1, B), i, [s_]))
+                c0 = ops.CALLS[0]
+                for s_ in g:
+                    _uses(zs[s_], st)
+                if len(g) > 1:
+                    z_in = torch.cat([zs[s_] for s_ in g], 0)
+                    m_in = None if gm is None else gm.repeat(len(g), 1)
+                else:
+                    z_in, m_in = zs[g[0]], gm
+                job = {"latents": z_in.unsqueeze(0), "masks": m_in}
+                if begun is not None:
+                    job["drop_begun"] = begun
+                out, _ = vae.dec(job)
+                r = recon_rowsum(vae.ltype, out, mods[n])                    # target row = output row % B
+                _uses(r, cur)
+                rec_blocks.append((r.view(len(g), B), i, list(g)))           # the call's rows as ONE (passes, B) block
+                self._job_calls[(n, len(g), gm is None, B)] = ops.CALLS[0] - c0
         self._join(streams, dev)
         # ELBO assembly straight on the calls' row BLOCKS (round 5: slicing the batched row sums and selecting the joint KL
         # row cost ~40 ATen fill / copy / add launches per step in forward + autograd): every block is addressed in place,
@@ -415,6 +443,40 @@ class POE(TorchMMVAE):
                     if s_ == i:
                         ind[i] = blk[k].detach().sum()
         return {"loss": out[0], "reconstruction_loss": ind, "kld": out[1]}
+
+    def _decoder_lanes(self, jobs, streams, B):
+        """Stream of every decoder call of a step, [(stream, (slot, call) | None)] in call order.
+
+        By default a call runs on its tower's stream.  Two streams, several calls: the calls are spread over the two by the
+        number of launches each one took the last time it ran (longest first onto the shorter lane) -- BASELINE configs[0]
+        decodes the text once at full length for the image-only subset (45 steps: the layer's launch-per-op form, ~20
+        launches each way) and once under the mask for the other two (one launch per layer); behind one another on the text
+        tower's stream they are the step's critical chain while the image decoder's stream idles.  A decoder with dropout
+        whose calls leave its tower's stream gets its per-call counter advances up front, in call order, on the caller's
+        stream (DropoutState.begin launches on the current stream: two lanes would race on the counter)."""
+        own = [(streams[i], None) for i, _, _, _ in jobs]
+        self.decoder_calls_moved = 0      # (tests: calls of the last step that left their tower's stream)
+        lanes = sorted(set(streams), key=lambda s: s is not None)
+        if not POE.balance_decoder_calls or len(lanes) != 2 or len(jobs) < 3:
+            return own
+        cost = [self._job_calls.get((n, len(g), gm is None, B)) for i, n, g, gm in jobs]
+        if any(c is None for c in cost):
+            return own
+        load = {lanes[0]: 0, lanes[1]: 0}
+        pick = [None] * len(jobs)
+        for k in sorted(range(len(jobs)), key=lambda k: -cost[k]):
+            st = min(lanes, key=lambda s: (load[s], s is not None))
+            pick[k] = st
+            load[st] += cost[k]
+        out = []
+        for k, (i, n, g, gm) in enumerate(jobs):
+            dec = self.vaes[n].dec
+            ds = getattr(dec, "drop_state", None)
+            moved = any(pick[j] is not streams[i] for j, job in enumerate(jobs) if job[0] == i)
+            begun = ds.begin() if (ds is not None and dec.training and moved) else None
+            out.append((pick[k], begun))
+            self.decoder_calls_moved += pick[k] is not streams[i]
+        return out
 
     def modality_mixing(self, x):
         """mmvae_models.py:210-232: prior expert + present encoders -> product"""

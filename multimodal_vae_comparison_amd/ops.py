@@ -78,6 +78,7 @@ class GradReducer:
         _, st = cls._st(device)
         cls.early_step, cls.dw_jobs, cls.dw_open = None, [], False      # (per-step state: a backward pass that raised leaves them behind)
         cls.tw_jobs, cls.early_ready = {}, False
+        cls.last_writer.clear()
         if cls.deferred is not None:
             cls.deferred = None
             raise RuntimeError("GradReducer: a deferred fold was never taken by an optimiser step: the split weight "
@@ -151,6 +152,28 @@ class GradReducer:
     # launch it lands, with that launch, on the image encoder's conv2 backward: 383.2 vs 389.4 us (same box, 3 pairs)
     dw_at_fusion = os.environ.get("MMVAE_LINEAR_DW_LATER_AT", "fusion") == "fusion"
 
+    # data_ptr of a preset gradient view -> stream of the launch that last accumulated into it IN PLACE this step
+    last_writer = {}
+
+    @classmethod
+    def writes(cls, device, *grads):
+        """The launch the caller queues next on the current stream accumulates in place (read-modify-write, no atomics)
+        into these preset gradient views -- the small layers whose weight gradient needs no split partials.  Two calls of
+        ONE module on different streams (POE._decoder_lanes: the text decoder at full length beside the same decoder under
+        the mask) would race on them: the later launch (host order = autograd order) first waits for the stream of the
+        earlier one.  No-op while a parameter is only ever written from one stream (every other step of this package)."""
+        if device.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(device)
+        for g in grads:
+            if g is None:
+                continue
+            k = g.data_ptr()
+            last = cls.last_writer.get(k)
+            if last is not None and last != cur:
+                cur.wait_stream(last)
+            cls.last_writer[k] = cur
+
     @classmethod
     def dw_later(cls, device):
         es = cls.early_step
@@ -164,6 +187,7 @@ class GradReducer:
         if not jobs:
             return
         arr = (H.WgradJob * len(jobs))()
+        cls.writes(jobs[0][0].device, *[t for job in jobs for t in job[2:4]])
         for j, (dy, x, dw, db, M, N, K, x_act) in zip(arr, jobs):
             j.dy, j.x, j.dw, j.db, j.ws = H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), None
             j.M, j.N, j.K, j.ldx, j.x_act, j.accumulate = M, N, K, K, x_act, H.ACC_DEFER
@@ -992,11 +1016,14 @@ class Linear(Function):
         else:
             ws, acc = H.workspace(nws, x.device), acc_w
         side = None if need_dx else (_wgrad_side(x.device, dy, x) if (defer and StreamPlan.wgrad_linear) else None)
+        direct = (gw, gb) if (gw is not None and not (defer and nz > 1)) else ()      # accumulated in place by the launch
         if need_dx:   # data and weight gradients in ONE grouped launch
+            GradReducer.writes(x.device, *direct)
             _call("mmvae_linear_bwd", H.ptr(dy), H.ptr(x), H.ptr(w), aux, H.ptr(dx), H.ptr(dw), H.ptr(db), H.ptr(ws),
                   M, N, K, K, in_act, ep, acc, H.stream())
         else:
             with torch.cuda.stream(side):
+                GradReducer.writes(x.device, *direct)
                 _call("mmvae_linear_bwd_weight", H.ptr(dy), H.ptr(x), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K,
                       in_act, acc, H.stream())
         if defer and nz > 1:
@@ -1090,6 +1117,8 @@ class LinearKN(Function):
         if nz > 1:
             nws = lib.mmvae_gemm_ws_floats(K, N, nz)
             ws = GradReducer.alloc(nws, x.device) if defer else H.workspace(nws, x.device)
+        if gw is not None and not defer:
+            GradReducer.writes(x.device, gw)
         _call("mmvae_gemm_f32", H.ptr(x), H.ptr(dy), None, None, H.ptr(dw), None, H.ptr(ws), K, N, M, 1, K, N, 1, N,
               in_act, H.ACT_NONE, H.EP_NONE, H.ACC_DEFER if defer else acc_w, want, H.stream())
         if defer:
@@ -1103,6 +1132,7 @@ class LinearKN(Function):
                 GradReducer.add(bws.data_ptr(), gb, lib.mmvae_bias_group_parts(M), C, C)
             elif gb is not None:
                 bws = torch.empty(nbw, device=x.device)
+                GradReducer.writes(x.device, gb)
                 _call("mmvae_bias_group_grad", H.ptr(dy), H.ptr(gb), H.ptr(bws), M, C, G, 1, H.stream())
             else:
                 ret_b = torch.empty(C, device=x.device)
@@ -1250,6 +1280,7 @@ class PoeReparamKL(Function):
             a.dz[i] = dz[i].data_ptr()
         if gtheta is not None:
             dth, acc, ret = gtheta, 1, None
+            GradReducer.writes(dev, gtheta)
         else:
             dth = ret = torch.empty_like(theta)
             acc = 0
@@ -2126,6 +2157,8 @@ def _linear_wgrad(dy2, x2, w, b, gw, gb, x_act=H.ACT_NONE):
         acc = H.ACC_DEFER
     else:
         ws, acc = H.workspace(nws, dy2.device), acc_w
+    if gw is not None and not (defer and nz > 1):
+        GradReducer.writes(dy2.device, gw, gb)
     _call("mmvae_linear_bwd_weight", H.ptr(dy2), H.ptr(x2), H.ptr(dw), H.ptr(db), H.ptr(ws), M, N, K, K, x_act, acc,
           H.stream())
     if defer and nz > 1:

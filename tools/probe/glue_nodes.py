@@ -36,7 +36,7 @@ def main():
         tr._fwd_bwd(batch)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         tr._fwd_bwd(batch)
         torch.cuda.synchronize()
     glue = collections.Counter()
@@ -51,7 +51,14 @@ def main():
         if any(c.kernels for c in ev.cpu_children):
             continue
         frames = [f for f in (ev.stack or []) if "multimodal_vae_comparison_amd" in f or "multimodal-vae" in f]
-        where = " <- ".join(f.split("multimodal_vae_comparison_amd/")[-1] for f in frames[:3]) or "(autograd engine / torch)"
+        where = " <- ".join(f.split("multimodal_vae_comparison_amd/")[-1] for f in frames[:3])
+        if not where:      # no Python frames (autograd thread): the chain of parent ops / autograd nodes instead
+            chain, p = [], ev.cpu_parent
+            while p is not None and len(chain) < 4:
+                chain.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd of "))
+                p = p.cpu_parent
+            where = " <- ".join(chain) or "(top level)"
+        where += "  " + str([tuple(s) for s in (ev.input_shapes or []) if s][:3])
         glue[(ev.name, ks[0][:60], where)] += 1
         kernels[ks[0][:60]] += 1
     print(desc)
