@@ -757,26 +757,38 @@ class DMVAE(TorchMMVAE):
         B = packed[0].shape[0]
         P = [self.vaes[n].private_latents for n in names]
         # noise in the reference's draw order (mmvae_models.py:486-502)
-        e_joint = self._draw(B, D, dev)
         e_sh, e_pr, e_cross = {}, {}, {}
-        for i in range(M):
-            e_sh[i] = self._draw(B, D, dev)
-            e_pr[i] = self._draw(B, P[i], dev)
-            for m in range(M):
-                if m != i:
-                    e_cross[(i, m)] = self._draw(B, D, dev)        # target i, fresh draw of q_shared(m)
+        if self.eps_override is None and len(set(P)) == 1:
+            # two launches instead of 1 + M (M + 1): every D-wide draw of the step from one (n, B, D) block, the private
+            # ones from one (M, B, P) block (independent standard normals either way; recorded noise keeps the order below)
+            wide = self._draw_many(1 + M * M, B, D, dev)
+            priv = self._draw_many(M, B, P[0], dev)
+            e_joint, k = wide[0], 1
+            for i in range(M):
+                e_sh[i], e_pr[i], k = wide[k], priv[i], k + 1
+                for m in range(M):
+                    if m != i:
+                        e_cross[(i, m)], k = wide[k], k + 1
+        else:
+            e_joint = self._draw(B, D, dev)
+            for i in range(M):
+                e_sh[i] = self._draw(B, D, dev)
+                e_pr[i] = self._draw(B, P[i], dev)
+                for m in range(M):
+                    if m != i:
+                        e_cross[(i, m)] = self._draw(B, D, dev)        # target i, fresh draw of q_shared(m)
         _, klj, zj = ops.poe_reparam_kl(theta, packed, [e_joint], 0, 1 << M, theta.grad, cols=(0, D))
         z_sh, z_cr, kl_sh, z_pr, kl_pr = {}, {}, {}, {}, {}
         for m in range(M):
             targets = [i for i in range(M) if i != m]
             _, kl, z = ops.poe_reparam_kl(theta, [packed[m]], [e_sh[m]] + [e_cross[(i, m)] for i in targets], 2, 0b10,
                                           theta.grad, cols=(0, D))
-            z_sh[m], kl_sh[m] = z[0], kl[1]
+            z_sh[m], kl_sh[m] = z[0], kl                    # (kl: (2, B), the posterior's KL is row 1)
             for i, zc in zip(targets, z[1:]):
                 z_cr[(i, m)] = zc
             _, klp, zp = ops.poe_reparam_kl(self._theta0[:, :P[m]].contiguous(), [packed[m]], [e_pr[m]], 2, 0b10, None,
                                             cols=(D, P[m]))
-            z_pr[m], kl_pr[m] = zp[0], klp[1]
+            z_pr[m], kl_pr[m] = zp[0], klp
         for t in [zj[0]] + list(z_sh.values()) + list(z_cr.values()) + list(z_pr.values()):
             for st in real:
                 _uses(t, st)
@@ -792,25 +804,55 @@ class DMVAE(TorchMMVAE):
                     lat = torch.cat([torch.cat(zs_i, 0), z_pr[i].repeat(NP, 1)], -1)
                     out, _ = vae.dec({"latents": lat.unsqueeze(0), "masks": None if mk is None else mk.repeat(NP, 1)})
                     rs = recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
-                    per[i] = list(rs.view(NP, B).unbind(0))
+                    per[i] = [rs.view(NP, B)]                  # ONE (passes, B) block: rows own, joint, cross...
                 else:
                     per[i] = []
                     for z in zs_i:
                         out, _ = vae.dec({"latents": torch.cat([z, z_pr[i]], -1).unsqueeze(0), "masks": mk})
-                        per[i].append(recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae)))
+                        per[i].append(recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae)).view(1, B))
             for t in per[i]:
                 _uses(t, cur)
         self._join(streams, dev)
-        rows, W_loss, W_kld, ind = [], [], [], []
+        # ELBO assembly on the calls' row BLOCKS (as POE.objective: selecting rows out of the batched row sums / the KL
+        # blocks cost a zero-fill and a copy per row in autograd's select / unbind backward -- 15 launches per step at
+        # M = 2): every block is addressed in place, a row that does not enter an output has weight 0
+        blocks, W_loss, W_kld = [], [], []
+        W_ind = [[] for _ in range(M)]
+
+        def put(blk, wl, wk, ind_of=None):
+            blocks.append(blk)
+            W_loss.extend(wl)
+            W_kld.extend(wk)
+            for j in range(M):
+                W_ind[j].extend([1.0 if (j == ind_of and r == 0) else 0.0 for r in range(len(wl))])
         for i, n in enumerate(names):
             lam = float(self.vaes[n].llik_scaling)
-            own, joint, cross = per[i][0], per[i][1], per[i][2:]
-            ind.append(own)
-            rows += [own, kl_sh[i], joint, klj[M]] + cross + [kl_pr[i]]
-            W_loss += [lam, beta, lam, beta] + [lam] * len(cross) + [beta * len(cross)]
-            W_kld += [0.0, 1.0 / M, 0.0, 0.0] + [0.0] * len(cross) + [0.0]
-        out = ops.lincomb_rows(rows, [W_loss, W_kld])
-        return {"loss": out[0], "reconstruction_loss": [r.sum() for r in ind], "kld": out[1]}
+            first = True
+            for blk in per[i]:                                  # rows in decode order: own, joint, cross...
+                r = blk.shape[0]
+                put(blk, [lam] * r, [0.0] * r, i if first else None)
+                first = False
+            put(kl_sh[i], [0.0, beta], [0.0, 1.0 / M])
+            put(kl_pr[i], [0.0, beta * (M - 1)], [0.0, 0.0])
+        put(klj, [0.0] * M + [beta * M], [0.0] * (M + 1))       # the joint's KL (last row) enters every modality's joint ELBO
+        if len(W_loss) <= 32 and M <= 2:
+            out = ops.lincomb_rows(blocks, [W_loss, W_kld] + W_ind)
+            ind = [o.detach() for o in out[2:]]
+        elif len(W_loss) <= 32:
+            out = ops.lincomb_rows(blocks, [W_loss, W_kld])
+            ind = [per[i][0][0].detach().sum() for i in range(M)]
+        else:       # (more rows than one assembly launch addresses: the selected rows only)
+            rows, W_loss, W_kld = [], [], []
+            for i, n in enumerate(names):
+                lam = float(self.vaes[n].llik_scaling)
+                flat_rows = [r_ for blk in per[i] for r_ in blk.unbind(0)]
+                own, joint, cross = flat_rows[0], flat_rows[1], flat_rows[2:]
+                rows += [own, kl_sh[i][1], joint, klj[M]] + cross + [kl_pr[i][1]]
+                W_loss += [lam, beta, lam, beta] + [lam] * len(cross) + [beta * len(cross)]
+                W_kld += [0.0, 1.0 / M, 0.0, 0.0] + [0.0] * len(cross) + [0.0]
+            out = ops.lincomb_rows(rows, [W_loss, W_kld])
+            ind = [per[i][0][0].detach().sum() for i in range(M)]
+        return {"loss": out[0], "reconstruction_loss": ind, "kld": out[1]}
 
     def modality_mixing(self, mods):
         return self.encode(mods)

@@ -10,7 +10,7 @@ def call(name, *a):
     names.append(name)
     return _c(name, *a)
 dev = torch.device("cuda", 0)
-desc, cfg, dims, data, meta = workload("cfg2", 128, device=dev, seed=1)
+desc, cfg, dims, data, meta = workload(sys.argv[1] if len(sys.argv) > 1 else "cfg2", int(sys.argv[2]) if len(sys.argv) > 2 else None, device=dev, seed=1)
 tr = MultimodalVAE(cfg, feature_dims=dims, device=dev); tr.model.train(); tr.configure_optimizers()
 tr.capture(data, 1)
 ops._call = call
