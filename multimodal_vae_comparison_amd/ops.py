@@ -9,6 +9,7 @@ Conventions used by every layer op
   the flat gradient buffer, see flat.py) the kernels ACCUMULATE into it and autograd gets None for that
   input -- no AccumulateGrad kernels, no copies.  Without it, fresh tensors are returned to autograd.
 """
+import bisect
 import ctypes
 import os
 
@@ -127,6 +128,56 @@ class GradReducer:
             torch.autograd.Variable._execution_engine.queue_callback(lambda: cls.flush(dev))
 
     @classmethod
+    def _merged(cls, segs):
+        """Fewer table entries for the same fold.  A segment that CONTINUES the one registered before it -- its source columns
+        follow in the same partial rows, its destination follows in the flat gradient: LayerNorm's gamma | beta, the
+        feed-forward block's w1 | b1 | w2 | b2, a fused text layer's three LayerNorm pairs -- is the same sum with a longer
+        row.  Two ops may reach one parameter through runs of different length (PoE's text decoder: the fused layer registers
+        its six LayerNorm tensors as one run, the launch-per-op form of the same layer as three pairs), and the fold needs
+        destination ranges that are EQUAL (chained) or DISJOINT: every run is therefore cut at each other run's end points
+        (which are boundaries of its own pieces, since the registered pieces are equal-or-disjoint themselves).  Per element
+        the same sum in the same order: bit-identical training (test_merged_fold_segments_train_bit_identically).
+        cfg1: 67 -> 51 entries (<= 64: the step closes with the ONE fold + Adam launch); cfg5: 213 -> 133, 61 of them in the
+        decoders' range (the early optimiser launch takes <= 64)."""
+        if not cls.merge_adjacent or len(segs) < 2:
+            return list(segs)
+        runs = []      # [src, dst, rows, stride, [piece lengths]]
+        for sp, dp, r, ln, sd in segs:
+            if runs:
+                q = runs[-1]
+                tot = sum(q[4])
+                if sp == q[0] + 4 * tot and dp == q[1] + 4 * tot and r == q[2] and sd == q[3]:
+                    q[4].append(ln)
+                    continue
+            runs.append([sp, dp, r, sd, [ln]])
+        ends = sorted({e for q in runs for e in (q[1], q[1] + 4 * sum(q[4]))})
+        out = []
+        for sp, dp, r, sd, lens in runs:
+            end = dp + 4 * sum(lens)
+            need = [c for c in ends[bisect.bisect_right(ends, dp):bisect.bisect_left(ends, end)]]
+            offs, o = [], 0
+            for ln in lens:
+                offs.append(o)
+                o += ln
+            bounds = {dp + 4 * o_ for o_ in offs}
+            if any(c not in bounds for c in need):      # (cannot happen for equal-or-disjoint pieces: keep them as registered)
+                out.extend((sp + 4 * o_, dp + 4 * o_, r, ln, sd) for o_, ln in zip(offs, lens))
+                continue
+            cuts = sorted({dp, *need})
+            for a, b in zip(cuts, cuts[1:] + [end]):
+                out.append((sp + (a - dp), a, r, (b - a) // 4, sd))
+        return out
+
+    @staticmethod
+    def _check_disjoint(segs):
+        """destination ranges of one fold are equal (chained) or disjoint: a partial overlap would be two workgroups adding
+        into the same elements (the fused fold + Adam launch refuses it; the plain fold launches would race)"""
+        spans = sorted({(dp, dp + 4 * ln) for _, dp, _, ln, _ in segs})
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            if b0 < a1:
+                raise RuntimeError(f"GradReducer: fold segments overlap partially: [{a0:#x}, {a1:#x}) and [{b0:#x}, {b1:#x})")
+
+    @classmethod
     def run_side_tail(cls, device):
         fn, cls.side_tail = cls.side_tail, None
         if fn is not None:
@@ -140,6 +191,7 @@ class GradReducer:
     # (Round 6, measured: queued behind the text encoder's LAST backward launch instead, the 65 MB the update moves landed
     # on the image encoder's first-layer weight gradient -- 14 -> 26 us -- and gave back what the shorter closing launch won.)
     early_step = None
+    merge_adjacent = True      # (module switch for the tests: False = one table entry per registered segment)
 
     # dw_jobs: weight gradients of Linear layers whose backward only launched the data gradient (Linear.backward, while
     # `early_step` is armed, on the fusion's stream): (dy, x, dw, db, M, N, K, x_act), tensors held until flush_dw queues them
@@ -252,7 +304,7 @@ class GradReducer:
         cls.early_step = None
         if st["pending"] or st["spill"] or not cls.defer_next:
             return
-        inside = [sg for sg in st["segs"] if lo <= sg[1] < hi]
+        inside = cls._merged([sg for sg in st["segs"] if lo <= sg[1] < hi])
         if len(inside) > H.MAX_SEGMENTS or any(sg[1] + 4 * sg[3] > hi for sg in inside):
             return
         st["segs"] = [sg for sg in st["segs"] if not (lo <= sg[1] < hi)]
@@ -317,7 +369,8 @@ class GradReducer:
                 cur.wait_stream(side)
         st["used"] = set()
         st["keep"] = []
-        segs, st["segs"], st["armed"] = st["segs"], [], False
+        segs, st["segs"], st["armed"] = cls._merged(st["segs"]), [], False
+        cls._check_disjoint(segs)
         need, st["off"] = st["spilled"] + st["off"], 0
         tail, cls.tail = cls.tail, None
         defer, cls.defer_next = cls.defer_next, False
