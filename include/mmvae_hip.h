@@ -889,6 +889,13 @@ int mmvae_permute_mask_fwd(const float* x, const uint8_t* mask, float* y, int T,
                            mmvae_stream_t stream);
 int mmvae_permute_mask_bwd(const float* dy, const uint8_t* mask, float* dx, int T, int B, int V,
                            mmvae_stream_t stream);
+/* ... the first Tk <= T steps only: out (B,Tk,V); mask stays (B,T).  bwd: dy (B,Tk,V) -> dx (T,B,V), exact zeros from step
+ * Tk on.  The reference slices the permuted, masked decoder output to the target's mask length (BaseObjective.recon_loss_fn,
+ * models/objectives.py:30-52, behind models/decoders.py:720-722): the two as one launch per direction. */
+int mmvae_permute_mask_head_fwd(const float* x, const uint8_t* mask, float* y, int T, int B, int V, int Tk,
+                                mmvae_stream_t stream);
+int mmvae_permute_mask_head_bwd(const float* dy, const uint8_t* mask, float* dx, int T, int B, int V, int Tk,
+                                mmvae_stream_t stream);
 
 /* Standard-normal noise for the reparameterised samples (the reference draws it with torch.distributions rsample:
  * models/mmvae_models.py:363-369).  state = {seed, call counter, ticket} (three uint32 on the device, ticket 0); the

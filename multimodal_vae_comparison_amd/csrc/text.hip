@@ -1358,6 +1358,49 @@ __global__ __launch_bounds__(256) void permute_mask_kernel(const float* __restri
     if (fwd) y[i] = keep ? x[j] : 0.f; else y[j] = keep ? x[i] : 0.f;
   }
 }
+// ... the first Tk of the T steps only: y (B,Tk,V) = x[:Tk] permuted and masked (mask (B,T)); the transpose writes the
+// gradient of ALL T steps, zero from step Tk on (a PoE subset without the text modality decodes at full length and compares
+// the first `mask length` steps: objectives.py:30-52 slice after decoders.py:722 -- slicing the permuted output instead cost
+// a copy forward and a zero-fill + copy backward)
+__global__ __launch_bounds__(256) void permute_mask_head_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                                float* __restrict__ y, int T, int B, int V, int Tk,
+                                                                int fwd) {
+  if (fwd) {
+    const long n = (long)Tk * B * V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {   // i: (B,Tk,V) side
+      const int v = (int)(i % V);
+      const long bt = i / V;
+      const int t = (int)(bt % Tk), b = (int)(bt / Tk);
+      y[i] = m[(long)b * T + t] != 0 ? x[((long)t * B + b) * V + v] : 0.f;
+    }
+  } else {
+    const long n = (long)T * B * V;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long)gridDim.x * 256) {   // j: (T,B,V) side
+      const int v = (int)(j % V);
+      const long tb = j / V;
+      const int b = (int)(tb % B), t = (int)(tb / B);
+      y[j] = (t < Tk && m[(long)b * T + t] != 0) ? x[((long)b * Tk + t) * V + v] : 0.f;
+    }
+  }
+}
+extern "C" int mmvae_permute_mask_head_fwd(const float* x, const uint8_t* mask, float* y, int T, int B, int V, int Tk,
+                                           mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(x && mask && y && T > 0 && B > 0 && V > 0 && Tk > 0 && Tk <= T);
+  long blocks = ((long)Tk * B * V + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(permute_mask_head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mask, y, T,
+                     B, V, Tk, 1);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_permute_mask_head_bwd(const float* dy, const uint8_t* mask, float* dx, int T, int B, int V, int Tk,
+                                           mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(dy && mask && dx && T > 0 && B > 0 && V > 0 && Tk > 0 && Tk <= T);
+  long blocks = ((long)T * B * V + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(permute_mask_head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, mask, dx, T,
+                     B, V, Tk, 0);
+  return mmvae_launch_status();
+}
 extern "C" int mmvae_permute_mask_fwd(const float* x, const uint8_t* mask, float* y, int T, int B, int V,
                                       mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && mask && y && T > 0 && B > 0 && V > 0);

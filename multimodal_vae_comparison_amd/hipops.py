@@ -203,6 +203,8 @@ SIGNATURES = {
     "mmvae_sum_over_time": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "mmvae_permute_mask_fwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
     "mmvae_permute_mask_bwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
+    "mmvae_permute_mask_head_fwd": (c_i, [c_p] * 3 + [c_i] * 4 + [c_p]),
+    "mmvae_permute_mask_head_bwd": (c_i, [c_p] * 3 + [c_i] * 4 + [c_p]),
     "mmvae_adam_amsgrad_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_i, c_p, c_f, c_i, c_p]),
     "mmvae_adabelief_flat": (c_i, [c_p] * 4 + [c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_i, c_p, c_f, c_i, c_p]),
     "mmvae_step_inc": (c_i, [c_p, c_p]),

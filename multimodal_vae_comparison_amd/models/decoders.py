@@ -169,6 +169,8 @@ class Dec_TxtTransformer(VaeDecoder):
     in oracle/mmvae_oracle.py: dec_txt_transformer keep_k): every sample is decoded on its own, (K,B) flattened into
     the batch axis exactly as Dec_CNN does (decoders.py:73-76): output (K*B, T, V), row k*B + b."""
 
+    takes_keep_steps = True      # forward() honours batch["keep_steps"] (POE.objective)
+
     def __init__(self, latent_dim, data_dim, latent_private, ff_size=128, num_layers=1, num_heads=2, dropout=0.1,
                  activation="gelu"):
         super().__init__(latent_dim, data_dim, latent_private, net_type=NetworkTypes.TXTTRANSFORMER)
@@ -230,7 +232,10 @@ class Dec_TxtTransformer(VaeDecoder):
         for layer, d in zip(self.seqTransDecoder.layers, ds):
             x = layer(x, mem, mask_u8, d)
         out = self.finallayer(x)                                              # (T, bs, V)
-        out = ops.permute_mask(out, mask_u8)                                  # (bs, T, V), zero at padding
+        # (bs, T, V), zero at padding; "keep_steps": the caller compares the first steps only (a PoE subset without this
+        # modality decodes at full length against a target that carries a shorter mask: objectives.py:30-52)
+        keep = batch.get("keep_steps")
+        out = ops.permute_mask(out, mask_u8, keep if (keep is not None and keep < T) else None)
         return out, self._scale
 
 

@@ -397,6 +397,8 @@ class POE(TorchMMVAE):
                 job = {"latents": z_in.unsqueeze(0), "masks": m_in}
                 if begun is not None:
                     job["drop_begun"] = begun
+                if gm is None and mods[n]["masks"] is not None and getattr(vae.dec, "takes_keep_steps", False):
+                    job["keep_steps"] = int(mods[n]["masks"].shape[1])      # (recon_rowsum slices to the target's mask length)
                 out, _ = vae.dec(job)
                 r = recon_rowsum(vae.ltype, out, mods[n])                    # target row = output row % B
                 _uses(r, cur)

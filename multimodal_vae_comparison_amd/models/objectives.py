@@ -79,7 +79,7 @@ def recon_rowsum(ltype, out, target, laplace=False):
     if getattr(out, "_bce_rows", False):      # Dec_CNN already produced the bce row sums with its last layer (ops.convT3_bce)
         return out
     masked = target["masks"] is not None
-    if masked:
+    if masked and out.shape[1] != target["masks"].shape[1]:      # (a decoder told `keep_steps` has sliced already)
         out = out[:, : target["masks"].shape[1]]
     data = target["data"]
     if ltype == "lprob":

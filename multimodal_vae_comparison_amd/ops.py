@@ -2537,26 +2537,35 @@ class MeanOverTime(Function):
 
 
 class PermuteMask(Function):
-    """(T,B,V) -> (B,T,V) * mask[b,t]   (models/decoders.py:722)"""
+    """(T,B,V) -> (B,T,V) * mask[b,t]   (models/decoders.py:722); keep = Tk: the first Tk steps only, (B,Tk,V) -- the slice
+    BaseObjective.recon_loss_fn takes afterwards (objectives.py:30-52) folded into the launch, zeros beyond Tk in backward"""
 
     @staticmethod
-    def forward(ctx, x, mask_u8):
+    def forward(ctx, x, mask_u8, keep=None):
         x = H.f32c(x)
         T, B, V = x.shape
-        y = torch.empty(B, T, V, device=x.device)
-        _call("mmvae_permute_mask_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(y), T, B, V, H.stream())
+        Tk = T if keep is None else int(keep)
+        assert 0 < Tk <= T and tuple(mask_u8.shape) == (B, T)
+        y = torch.empty(B, Tk, V, device=x.device)
+        if Tk == T:
+            _call("mmvae_permute_mask_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(y), T, B, V, H.stream())
+        else:
+            _call("mmvae_permute_mask_head_fwd", H.ptr(x), H.ptr(mask_u8), H.ptr(y), T, B, V, Tk, H.stream())
         ctx.save_for_backward(mask_u8)
-        ctx.shape = (T, B, V)
+        ctx.shape = (T, B, V, Tk)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (mask_u8,) = ctx.saved_tensors
-        T, B, V = ctx.shape
+        T, B, V, Tk = ctx.shape
         dy = H.f32c(dy)
         dx = torch.empty(T, B, V, device=dy.device)
-        _call("mmvae_permute_mask_bwd", H.ptr(dy), H.ptr(mask_u8), H.ptr(dx), T, B, V, H.stream())
-        return dx, None
+        if Tk == T:
+            _call("mmvae_permute_mask_bwd", H.ptr(dy), H.ptr(mask_u8), H.ptr(dx), T, B, V, H.stream())
+        else:
+            _call("mmvae_permute_mask_head_bwd", H.ptr(dy), H.ptr(mask_u8), H.ptr(dx), T, B, V, Tk, H.stream())
+        return dx, None, None
 
 
 def embed_pe(onehot, emb, pe, mode, gemb=None, drop=None, repeat=1):
@@ -2787,8 +2796,8 @@ def mean_over_time(x):
     return MeanOverTime.apply(x)
 
 
-def permute_mask(x, mask_u8):
-    return PermuteMask.apply(x, mask_u8)
+def permute_mask(x, mask_u8, keep=None):
+    return PermuteMask.apply(x, mask_u8, keep)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1395,3 +1395,28 @@ def test_dropout_advance_many(ops, hip_lib):
         assert int(y[1]) == 10 * i + 1 and int(y[2]) == 10 * i + 1 and int(y[3]) == 5 and int(y[0]) == 7 + i
     arr = (ctypes.c_void_p * 2)(b[0].data_ptr(), b[0].data_ptr())
     assert hip_lib.mmvae_dropout_advance_many(ctypes.cast(arr, ctypes.c_void_p), 2, H.stream()) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,V,Tk", [(45, 32, 27, 8), (32, 7, 5, 31), (9, 3, 4, 1)])
+def test_permute_mask_head_is_permute_mask_then_slice(hip_lib, T, B, V, Tk):
+    """mmvae_permute_mask_head_fwd / _bwd (the decoder's permute(1,0,2) * mask, decoders.py:720-722, and the slice to the
+    target's mask length, objectives.py:30-52, as one launch): bit-equal to the two steps; the gradient of the steps
+    beyond Tk is an exact zero, and a padded step stays a masked WRITE (no NaN leaks through)."""
+    from multimodal_vae_comparison_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(T, B, V, device=DEV)
+    x[0, 0, 0] = float("nan")
+    mask = torch.rand(B, T, device=DEV) > 0.3
+    mask[0, 0] = False
+    mask_u8 = ops.as_u8(mask)
+    x1 = x.clone().requires_grad_(True)
+    y = ops.permute_mask(x1, mask_u8, Tk)
+    ref_in = x.clone().requires_grad_(True)
+    ref = torch.where(mask.unsqueeze(-1), ref_in.permute(1, 0, 2), torch.zeros((), device=DEV))[:, :Tk]
+    assert y.shape == (B, Tk, V) and torch.equal(y, ref)
+    g = torch.randn(B, Tk, V, device=DEV)
+    y.backward(g)
+    ref.backward(g)
+    assert torch.equal(x1.grad, ref_in.grad)
+    assert float(x1.grad[Tk:].abs().sum()) == 0.0
