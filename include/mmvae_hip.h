@@ -253,8 +253,10 @@ int mmvae_linear_bwd_weight_batch(const mmvae_wgrad_job_t* jobs, int n_jobs, mmv
 /* All weight gradients behind one fused text layer in ONE launch (csrc/twgrad.hip; round 4): dW_j = dy_j^T x_j and
  * db_j = colsum(dy_j) of torch.nn.TransformerEncoderLayer / TransformerDecoderLayer's linears
  * (models/encoders.py:828-837, models/decoders.py:708-723), each operand row fetched once.  Every job writes
- * mmvae_txt_wgrad_splits(M, N, K) partial rows to ws: [nz][N * K] then [nz][N], to be folded by
- * mmvae_reduce_segments / mmvae_adam_fold_flat.  N (K) must be even when > 32. */
+ * nz = mmvae_txt_wgrad_splits(M, N, K) partial rows to ws, row z at ws + z * pitch = [N * K weight sums | N bias sums]
+ * with pitch = mmvae_txt_wgrad_ws_floats(M, N, K) / nz (N * K + N rounded up to even), to be folded by
+ * mmvae_reduce_segments / mmvae_adam_fold_flat -- as ONE segment of length N * K + N when weight and bias are adjacent in
+ * the gradient buffer.  N (K) must be even when > 32. */
 typedef struct {
   const float* dy; const float* x; float* ws;
   int M, N, K;

@@ -31,6 +31,7 @@ struct Job {
   int aw, bw;          // floats per lane on the dY / X side (1 | 2)
   int n_sk;            // units along K
   int wg0;             // first workgroup of this job
+  int pitch;           // floats per partial row: [N * K weight sums | N bias sums], rounded up to even
 };
 struct Args {
   Job job[MAXJ];
@@ -169,7 +170,7 @@ __device__ __forceinline__ void unit_body(const Job& jb, const int unit, const i
 #pragma unroll
       for (int a = 0; a < AW; ++a) bsum[a] += o[(AW * BW * 16 + a) * 64];
     }
-    float* pw = jb.ws + (size_t)split * N * K;
+    float* pw = jb.ws + (size_t)split * jb.pitch;
     if (okB) {
 #pragma unroll
       for (int a = 0; a < AW; ++a)
@@ -187,7 +188,7 @@ __device__ __forceinline__ void unit_body(const Job& jb, const int unit, const i
 #pragma unroll
       for (int a = 0; a < AW; ++a) bsum[a] += __shfl_xor(bsum[a], 32, 64);
       if (lh == 0 && okA) {
-        float* pb = jb.ws + (size_t)jb.nz * N * K + (size_t)split * N + colA;
+        float* pb = pw + (size_t)N * K + colA;
 #pragma unroll
         for (int a = 0; a < AW; ++a) pb[a] = bsum[a];
       }
@@ -211,6 +212,9 @@ __global__ __launch_bounds__(256, 2) void txt_wgrad_kernel(const Args args) {
   else unit_body<1, 1>(jb, unit, split, red);
 }
 
+// one partial row of a job = its N * K weight sums followed by its N bias sums: ONE fold segment per job (weight and bias
+// are adjacent in the flat gradient buffer) instead of two -- the step's closing fold + Adam launch takes 64 entries
+static inline int row_pitch(int N, int K) { return (N * K + N + 1) & ~1; }
 static inline int plan_splits(int M) {
   int nz = M / 128;
   if (nz < 1) nz = 1;
@@ -226,7 +230,7 @@ extern "C" int mmvae_txt_wgrad_splits(int M, int N, int K) {
   return tw::plan_splits(M);
 }
 extern "C" size_t mmvae_txt_wgrad_ws_floats(int M, int N, int K) {
-  return (size_t)tw::plan_splits(M) * ((size_t)N * K + N);
+  return (size_t)tw::plan_splits(M) * (size_t)tw::row_pitch(N, K);
 }
 extern "C" int mmvae_txt_wgrad_supported(int M, int N, int K) {
   if (M < 1 || N < 1 || K < 1) return 0;
@@ -245,6 +249,7 @@ extern "C" int mmvae_txt_wgrad(const mmvae_txt_wgrad_job_t* jobs, int n_jobs, mm
     tw::Job& d = a.job[j];
     d.dy = s.dy; d.x = s.x; d.ws = s.ws;
     d.M = s.M; d.N = s.N; d.K = s.K;
+    d.pitch = tw::row_pitch(s.N, s.K);
     d.aw = s.N > 32 ? 2 : 1;
     d.bw = s.K > 32 ? 2 : 1;
     if (d.aw == 2 && ((uintptr_t)s.dy & 7)) return MMVAE_ERR_ARG;

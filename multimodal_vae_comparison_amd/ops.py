@@ -2242,16 +2242,17 @@ def _txt_wgrad(jobs):
         M, N = dy2.shape
         K = x2.shape[1]
         nz = lib.mmvae_txt_wgrad_splits(M, N, K)
-        ws = GradReducer.alloc(lib.mmvae_txt_wgrad_ws_floats(M, N, K), dy2.device)
+        nws = lib.mmvae_txt_wgrad_ws_floats(M, N, K)
+        ws = GradReducer.alloc(nws, dy2.device)
         j = arr[i]
         j.dy, j.x, j.ws, j.M, j.N, j.K = H.ptr(dy2), H.ptr(x2), H.ptr(ws), M, N, K
-        segs.append((ws, nz, gw, gb, N, K))
+        segs.append((ws, nz, gw, gb, N, K, nws // nz))
     GradReducer.run_early_step(jobs[0][0].device, 2)
     _call("mmvae_txt_wgrad", ctypes.cast(arr, ctypes.c_void_p), len(jobs), H.stream())
     GradReducer.run_early_step(jobs[0][0].device, 3)
-    for ws, nz, gw, gb, N, K in segs:
-        GradReducer.add(ws.data_ptr(), gw, nz, N * K, N * K)
-        GradReducer.add(ws.data_ptr() + 4 * nz * N * K, gb, nz, N, N)
+    for ws, nz, gw, gb, N, K, pitch in segs:      # (partial row z: [N * K weight sums | N bias sums] at ws + z * pitch)
+        GradReducer.add(ws.data_ptr(), gw, nz, N * K, pitch)
+        GradReducer.add(ws.data_ptr() + 4 * N * K, gb, nz, N, pitch)
     return [(None, None)] * len(jobs)
 
 

@@ -1362,7 +1362,7 @@ def test_txt_wgrad_matches_float64(hip_lib, rows, D, FF, small):
         assert lib.mmvae_txt_wgrad_supported(M, N, K) == 1
         nz = lib.mmvae_txt_wgrad_splits(M, N, K)
         nws = lib.mmvae_txt_wgrad_ws_floats(M, N, K)
-        assert nws == nz * (N * K + N)
+        assert nws == nz * ((N * K + N + 1) // 2 * 2)      # (row pitch: N * K + N rounded up to even)
         ws = torch.full((nws + 64,), float("nan"), device=DEV)
         ws[nws:] = 7.0
         wss.append((ws, nz, nws))
@@ -1370,11 +1370,12 @@ def test_txt_wgrad_matches_float64(hip_lib, rows, D, FF, small):
     assert lib.mmvae_txt_wgrad(ctypes.cast(arr, ctypes.c_void_p), len(shapes), st) == 0
     torch.cuda.synchronize()
     for (dy, x), (ws, nz, nws), (M, N, K) in zip(prob, wss, shapes):
-        assert bool(torch.isfinite(ws[:nws]).all()), (M, N, K)      # every partial row written
+        part = ws[:nws].view(nz, nws // nz)                         # row z: [N * K weight sums | N bias sums | pad]
+        assert bool(torch.isfinite(part[:, :N * K + N]).all()), (M, N, K)      # every partial row written
         assert bool((ws[nws:] == 7.0).all()), (M, N, K)
         ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
-        got_w = ws[:nz * N * K].view(nz, N, K).double().sum(0)
-        got_b = ws[nz * N * K:nws].view(nz, N).double().sum(0)
+        got_w = part[:, :N * K].reshape(nz, N, K).double().sum(0)
+        got_b = part[:, N * K:N * K + N].double().sum(0)
         check(got_w, ref_w, 5e-5, f"dw {M, N, K}")
         check(got_b, ref_b, 5e-5, f"db {M, N, K}")
     assert lib.mmvae_txt_wgrad_supported(64, 35, 32) == 0 and lib.mmvae_txt_wgrad_supported(64, 31, 33) == 0
