@@ -1302,40 +1302,71 @@ extern "C" int mmvae_layernorm_residual_bwd(const float* dy, const float* xhat, 
 // ---------------------------------------------------------------------------------------------
 // time reductions over x (L,N,d): y[n,c] = scale * sum_l x[l,n,c];  and the broadcast backward
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void time_sum_kernel(const float* __restrict__ x, float* __restrict__ y, int L,
-                                                       long nd, float scale) {
+__global__ __launch_bounds__(256) void time_sum_serial_kernel(const float* __restrict__ x, float* __restrict__ y, int L,
+                                                              long nd, float scale) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nd) return;
   float a = 0.f;
   for (int l = 0; l < L; ++l) a += x[(size_t)l * nd + i];
   y[i] = a * scale;
 }
+// (round 6: from TIME_SUM_WIDE_L steps on -- a thread per column walking all L rows left 16 workgroups with 100
+// dependent-latency loads each at the action encoder's pooling: 28 us for 1.6 MB -- 64 columns x 4 row groups per workgroup,
+// two accumulators per thread, the four partial sums added in a fixed order; short sequences keep the serial sum)
+#define TIME_SUM_WIDE_L 32
+__global__ __launch_bounds__(256) void time_sum_kernel(const float* __restrict__ x, float* __restrict__ y, int L,
+                                                       long nd, float scale) {
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < nd) {
+    int l = r;
+    for (; l + 4 < L; l += 8) {
+      a0 += x[(size_t)l * nd + i];
+      a1 += x[(size_t)(l + 4) * nd + i];
+    }
+    if (l < L) a0 += x[(size_t)l * nd + i];
+  }
+  part[r][c] = a0 + a1;
+  __syncthreads();
+  if (r == 0 && i < nd) y[i] = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) * scale;
+}
 __global__ __launch_bounds__(256) void time_bcast_kernel(const float* __restrict__ dy, float* __restrict__ dx, int L,
                                                          long nd, float scale) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
   if (i >= nd) return;
   const float g = dy[i] * scale;
-  for (int l = 0; l < L; ++l) dx[(size_t)l * nd + i] = g;
+  for (int l = r; l < L; l += 4) dx[(size_t)l * nd + i] = g;
 }
 extern "C" int mmvae_mean_over_time_fwd(const float* x, float* y, int L, int N, int d, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && y && L > 0 && N > 0 && d > 0);
   const long nd = (long)N * d;
-  hipLaunchKernelGGL(time_sum_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, L,
-                     nd, 1.0f / (float)L);
+  if (L < TIME_SUM_WIDE_L)
+    hipLaunchKernelGGL(time_sum_serial_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       L, nd, 1.0f / (float)L);
+  else
+    hipLaunchKernelGGL(time_sum_kernel, dim3((unsigned)((nd + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, y, L,
+                       nd, 1.0f / (float)L);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_mean_over_time_bwd(const float* dy, float* dx, int L, int N, int d, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(dy && dx && L > 0 && N > 0 && d > 0);
   const long nd = (long)N * d;
-  hipLaunchKernelGGL(time_bcast_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+  hipLaunchKernelGGL(time_bcast_kernel, dim3((unsigned)((nd + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dy, dx,
                      L, nd, 1.0f / (float)L);
   return mmvae_launch_status();
 }
 extern "C" int mmvae_sum_over_time(const float* x, float* y, int L, int N, int d, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(x && y && L > 0 && N > 0 && d > 0);
   const long nd = (long)N * d;
-  hipLaunchKernelGGL(time_sum_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, L,
-                     nd, 1.0f);
+  if (L < TIME_SUM_WIDE_L)
+    hipLaunchKernelGGL(time_sum_serial_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       L, nd, 1.0f);
+  else
+    hipLaunchKernelGGL(time_sum_kernel, dim3((unsigned)((nd + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, y, L,
+                       nd, 1.0f);
   return mmvae_launch_status();
 }
 

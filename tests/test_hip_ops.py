@@ -915,15 +915,17 @@ def test_layernorm_residual(ops, L, N, d, bcast, p):
 
 def test_time_reduce_and_permute_mask(ops):
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(7, 5, 54, generator=g)
-    dy = torch.randn(5, 54, generator=g)
-    xr = x.double().requires_grad_(True)
-    xr.mean(0).backward(dy.double())
-    xg = x.to(DEV).requires_grad_(True)
-    out = ops.mean_over_time(xg)
-    out.backward(dy.to(DEV))
-    check(out, x.double().mean(0), 1e-6, "mean")
-    check(xg.grad, xr.grad, 1e-6, "mean dx")
+    # (7 steps: the serial sum; 100 / 33 / 37 steps: four row groups per workgroup, ragged column counts)
+    for L, N, d in ((7, 5, 54), (100, 128, 32), (33, 3, 27), (37, 1, 70)):
+        x = torch.randn(L, N, d, generator=g)
+        dy = torch.randn(N, d, generator=g)
+        xr = x.double().requires_grad_(True)
+        xr.mean(0).backward(dy.double())
+        xg = x.to(DEV).requires_grad_(True)
+        out = ops.mean_over_time(xg)
+        out.backward(dy.to(DEV))
+        check(out, x.double().mean(0), 1e-6, f"mean {L, N, d}")
+        check(xg.grad, xr.grad, 1e-6, f"mean dx {L, N, d}")
     T, B, V = 6, 4, 27
     y = torch.randn(T, B, V, generator=g)
     m = torch.rand(B, T, generator=g) > 0.3
