@@ -331,6 +331,31 @@ int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, co
                              int ld_in, int raw_heads, int accumulate, mmvae_stream_t stream);
 size_t mmvae_poe_ws_floats(int B, int D);
 
+/* Latent samples -> decoder inputs, and the transpose (round 6).  The reference decodes every subset's sample in a call of its
+ * own (POE.objective, models/mmvae_models.py:159-187) and builds DMVAE's decoder inputs with torch.cat([z_shared, z_private], -1)
+ * per pass (:494-502); here a decoder's passes are one batch, and the batches of ALL decoders are written by one launch:
+ * block k copies B rows of `width[k]` floats, dst[k][b * ld_dst[k] + d] = src[k][b * ld_src[k] + d] (dst already points at the
+ * block's first row / column of its output).  bwd: out[s] (B, width[s]) = sum_j g[s][j][b * ld[s][j] + d] over the n_g[s] <= 4
+ * blocks that read source s, in that order. */
+#define MMVAE_FAN_MAX_BLOCKS 16
+#define MMVAE_FAN_MAX_SRC 8
+#define MMVAE_FAN_MAX_USES 4
+typedef struct {
+  const float* src[MMVAE_FAN_MAX_BLOCKS];
+  float* dst[MMVAE_FAN_MAX_BLOCKS];
+  int width[MMVAE_FAN_MAX_BLOCKS], ld_src[MMVAE_FAN_MAX_BLOCKS], ld_dst[MMVAE_FAN_MAX_BLOCKS];
+  int n, B;
+} mmvae_fan_blocks_t;
+typedef struct {
+  float* out[MMVAE_FAN_MAX_SRC];
+  const float* g[MMVAE_FAN_MAX_SRC][MMVAE_FAN_MAX_USES];
+  int ld[MMVAE_FAN_MAX_SRC][MMVAE_FAN_MAX_USES];
+  int n_g[MMVAE_FAN_MAX_SRC], width[MMVAE_FAN_MAX_SRC];
+  int n, B;
+} mmvae_fan_sum_t;
+int mmvae_rows_fan_fwd(const mmvae_fan_blocks_t* blocks, mmvae_stream_t stream);
+int mmvae_rows_fan_bwd(const mmvae_fan_sum_t* sums, mmvae_stream_t stream);
+
 /* MoE importance weights, models/mmvae_models.py:56-62:  lw[b] = sum_d [log N(z; mu_r, s_r) - log N(z; mu_o, s_o)]
  * with z and the source posterior detached; packed_* = (B,2D) [mu | sigma].  bwd: dpacked_r (B,2D) = g[b] * d lw. */
 int mmvae_normal_logratio_fwd(const float* packed_r, const float* packed_o, const float* z, float* lw, int B, int D,

@@ -791,4 +791,61 @@ extern "C" int mmvae_debug_spin(long long* slot, long long ticks, mmvae_stream_t
   return mmvae_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// latent samples -> decoder inputs (PoE: one decoder call decodes the samples of several subsets as one batch; DMVAE: a
+// decoder's own / joint / cross passes as one batch of [shared | private] rows) and the transpose.  Forward: up to 16 strided
+// 2-D copies in one launch.  Backward: the gradient of every SOURCE = the sum of the blocks that read it, in block order.
+// (torch.cat / repeat for the inputs and autograd's per-consumer additions for the gradients were 5 .. 13 launches per step.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_fan_fwd_kernel(mmvae_fan_blocks_t t) {
+  const int k = blockIdx.y;
+  const int W = t.width[k];
+  const long n = (long)t.B * W;
+  const float* __restrict__ src = t.src[k];
+  float* __restrict__ dst = t.dst[k];
+  const int ls = t.ld_src[k], ld = t.ld_dst[k];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / W), d = (int)(i - (long)b * W);
+    dst[(size_t)b * ld + d] = src[(size_t)b * ls + d];
+  }
+}
+__global__ __launch_bounds__(256) void rows_fan_bwd_kernel(mmvae_fan_sum_t t) {
+  const int s = blockIdx.y;
+  const int W = t.width[s], ng = t.n_g[s];
+  const long n = (long)t.B * W;
+  float* __restrict__ out = t.out[s];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / W), d = (int)(i - (long)b * W);
+    float a = t.g[s][0][(size_t)b * t.ld[s][0] + d];
+    for (int j = 1; j < ng; ++j) a += t.g[s][j][(size_t)b * t.ld[s][j] + d];
+    out[i] = a;
+  }
+}
+extern "C" int mmvae_rows_fan_fwd(const mmvae_fan_blocks_t* blocks, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(blocks && blocks->n >= 1 && blocks->n <= MMVAE_FAN_MAX_BLOCKS && blocks->B > 0);
+  int wmax = 0;
+  for (int k = 0; k < blocks->n; ++k) {
+    MMVAE_CHECK_ARG(blocks->src[k] && blocks->dst[k] && blocks->width[k] > 0 && blocks->ld_src[k] >= blocks->width[k] &&
+                    blocks->ld_dst[k] >= blocks->width[k]);
+    wmax = blocks->width[k] > wmax ? blocks->width[k] : wmax;
+  }
+  long bx = ((long)blocks->B * wmax + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(rows_fan_fwd_kernel, dim3((unsigned)bx, blocks->n), dim3(256), 0, (hipStream_t)stream, *blocks);
+  return mmvae_launch_status();
+}
+extern "C" int mmvae_rows_fan_bwd(const mmvae_fan_sum_t* sums, mmvae_stream_t stream) {
+  MMVAE_CHECK_ARG(sums && sums->n >= 1 && sums->n <= MMVAE_FAN_MAX_SRC && sums->B > 0);
+  int wmax = 0;
+  for (int s = 0; s < sums->n; ++s) {
+    MMVAE_CHECK_ARG(sums->out[s] && sums->width[s] > 0 && sums->n_g[s] >= 1 && sums->n_g[s] <= MMVAE_FAN_MAX_USES);
+    for (int j = 0; j < sums->n_g[s]; ++j) MMVAE_CHECK_ARG(sums->g[s][j] && sums->ld[s][j] >= sums->width[s]);
+    wmax = sums->width[s] > wmax ? sums->width[s] : wmax;
+  }
+  long bx = ((long)sums->B * wmax + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(rows_fan_bwd_kernel, dim3((unsigned)bx, sums->n), dim3(256), 0, (hipStream_t)stream, *sums);
+  return mmvae_launch_status();
+}
+
 MMVAE_TRACE_SETTER(latent)

@@ -38,6 +38,19 @@ class PoeBwdArgs(ctypes.Structure):
                 ("dz", c_p * MAX_EXPERTS), ("dmu", c_p * MAX_EXPERTS), ("dlv", c_p * MAX_EXPERTS)]
 
 
+FAN_MAX_BLOCKS, FAN_MAX_SRC, FAN_MAX_USES = 16, 8, 4
+
+
+class FanBlocks(ctypes.Structure):
+    _fields_ = [("src", c_p * FAN_MAX_BLOCKS), ("dst", c_p * FAN_MAX_BLOCKS), ("width", c_i * FAN_MAX_BLOCKS),
+                ("ld_src", c_i * FAN_MAX_BLOCKS), ("ld_dst", c_i * FAN_MAX_BLOCKS), ("n", c_i), ("B", c_i)]
+
+
+class FanSum(ctypes.Structure):
+    _fields_ = [("out", c_p * FAN_MAX_SRC), ("g", (c_p * FAN_MAX_USES) * FAN_MAX_SRC), ("ld", (c_i * FAN_MAX_USES) * FAN_MAX_SRC),
+                ("n_g", c_i * FAN_MAX_SRC), ("width", c_i * FAN_MAX_SRC), ("n", c_i), ("B", c_i)]
+
+
 class Dropout(ctypes.Structure):
     _fields_ = [("state", c_p), ("slot", c_u), ("site", c_u), ("p", c_f)]
 
@@ -228,6 +241,8 @@ SIGNATURES = {
     "mmvae_adam_fold_flat": (c_i, [c_p] * 5 + [c_l] + [c_f] * 4 + [c_p, c_f, c_i] + [c_p] * 4 + [c_i, c_i, c_i, c_p]),
     "mmvae_adam_fold_range": (c_i, [c_p] * 5 + [c_l, c_l, c_l, c_i] + [c_f] * 4 + [c_p, c_f, c_i] + [c_p] * 4
                               + [c_i, c_i, c_i, c_p]),
+    "mmvae_rows_fan_fwd": (c_i, [c_p, c_p]),
+    "mmvae_rows_fan_bwd": (c_i, [c_p, c_p]),
     "mmvae_normal_logratio_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_normal_logratio_bwd": (c_i, [c_p] * 4 + [c_i, c_i, c_p]),
     "mmvae_expmul_fwd": (c_i, [c_p] * 3 + [c_i, c_p]),

@@ -318,26 +318,33 @@ class POE(TorchMMVAE):
 
         # ---- encoders: packed[s][n] for n in subset s ----
         packed = [dict() for _ in subsets]
+        raw_heads = dev.type == "cuda" and all(hasattr(v.enc, "raw_heads") and v.enc.enc_mu_logvar for v in self.vaes.values())
         self._fork(streams, dev, mods)
         for n, st in zip(names, streams):
             member = [s for s, S in enumerate(subsets) if n in S]
             with torch.cuda.stream(st):
                 enc = self.vaes[n].enc
-                if one_call(enc):
-                    p = packed_head(*enc(mods[n]))
-                    for s in member:
-                        packed[s][n] = p
-                elif self.batch_dropout_towers and len(member) > 1 and getattr(enc, "takes_repeat", False) and \
-                        enc.repeat_ok(mods[n]):
-                    # an encoder WITH dropout whose passes differ only in their masks: all of them as one call over
-                    # len(member) * B sequences (round 5: the text encoder's positional term follows the sample's position
-                    # in the ORIGINAL batch, ops.embed_pe), rows k * B + b
-                    p = packed_head(*enc(dict(mods[n], repeat=len(member))))
-                    for s, part in zip(member, ops.split_rows(p, len(member))):      # (row blocks; ONE cat in backward)
-                        packed[s][n] = part
-                else:
-                    for s in member:
-                        packed[s][n] = packed_head(*enc(mods[n]))
+                # lv = softmax(u) + eta is applied by the fusion kernels (as MoPOE._elbo_terms does): no softmax launch
+                # behind the heads, none in front of their backward
+                enc.raw_heads = raw_heads
+                try:
+                    if one_call(enc):
+                        p = packed_head(*enc(mods[n]))
+                        for s in member:
+                            packed[s][n] = p
+                    elif self.batch_dropout_towers and len(member) > 1 and getattr(enc, "takes_repeat", False) and \
+                            enc.repeat_ok(mods[n]):
+                        # an encoder WITH dropout whose passes differ only in their masks: all of them as one call over
+                        # len(member) * B sequences (round 5: the text encoder's positional term follows the sample's
+                        # position in the ORIGINAL batch, ops.embed_pe), rows k * B + b
+                        p = packed_head(*enc(dict(mods[n], repeat=len(member))))
+                        for s, part in zip(member, ops.split_rows(p, len(member))):      # (row blocks; ONE cat in backward)
+                            packed[s][n] = part
+                    else:
+                        for s in member:
+                            packed[s][n] = packed_head(*enc(mods[n]))
+                finally:
+                    enc.raw_heads = False
         self._join(streams, dev)
         # Tensors that cross streams (a tower's heads -> the fusion; the latent samples -> decoder calls on the other stream;
         # their row sums -> the ELBO assembly) are registered with the consuming stream.  Without it the allocator hands a
@@ -357,7 +364,7 @@ class POE(TorchMMVAE):
             ps = [packed[s][n] for n in names if n in S]
             eps = [draws[s]]
             E = len(ps)
-            _, kl, z = ops.poe_reparam_kl(theta, ps, eps, True, 1 << E, theta.grad)
+            _, kl, z = ops.poe_reparam_kl(theta, ps, eps, True, 1 << E, theta.grad, raw=raw_heads)
             zs.append(z[0])
             kl_blocks.append(kl)             # (E + 1, B): the joint's KL is the last row
         # ---- decoders: one (passes, B) block of row sums per call ----
@@ -381,19 +388,25 @@ class POE(TorchMMVAE):
                 for part in ([g] if share and len(g) > 1 else [[s_] for s_ in g]):
                     jobs.append((i, n, part, gm))
         lanes = self._decoder_lanes(jobs, streams, B)
+        # every call's input batch -- the samples of its subsets as row blocks -- from ONE launch, and in backward every
+        # sample's gradient as one sum over the calls that decoded it (ops.RowsFan), instead of a torch.cat per call and an
+        # addition per sample
+        plan = [(len(g), D, [(s_, k, 0) for k, s_ in enumerate(g)]) for _, _, g, _ in jobs]
+        z_ins = ops.rows_fan(plan, zs) if (zs[0].is_cuda and ops.RowsFan.supported(plan, zs)) else None
         rec_blocks = []
         self._fork(streams, dev, mods)
-        for (i, n, g, gm), (st, begun) in zip(jobs, lanes):
+        for j_, ((i, n, g, gm), (st, begun)) in enumerate(zip(jobs, lanes)):
             vae = self.vaes[n]
             with torch.cuda.stream(st):
                 c0 = ops.CALLS[0]
-                for s_ in g:
-                    _uses(zs[s_], st)
-                if len(g) > 1:
-                    z_in = torch.cat([zs[s_] for s_ in g], 0)
-                    m_in = None if gm is None else gm.repeat(len(g), 1)
+                m_in = gm if (gm is None or len(g) == 1) else gm.repeat(len(g), 1)
+                if z_ins is not None:
+                    z_in = z_ins[j_]
+                    _uses(z_in, st)
                 else:
-                    z_in, m_in = zs[g[0]], gm
+                    for s_ in g:
+                        _uses(zs[s_], st)
+                    z_in = torch.cat([zs[s_] for s_ in g], 0) if len(g) > 1 else zs[g[0]]
                 job = {"latents": z_in.unsqueeze(0), "masks": m_in}
                 if begun is not None:
                     job["drop_begun"] = begun
@@ -795,6 +808,25 @@ class DMVAE(TorchMMVAE):
             for st in real:
                 _uses(t, st)
         per = [None] * M
+        # every decoder's input batch -- rows [own | joint | cross...] x columns [shared | private] -- from ONE launch for all
+        # modalities, and every sample's gradient as one sum in backward (ops.RowsFan): 2 cat + 1 repeat per modality forward,
+        # a repeat-sum, the strided slices' copies and an addition per shared sample backward before
+        batched = [self.vaes[n].ltype != "optimal_sigma" and self.batch_passes for n in names]
+        lats = None
+        if all(batched) and zj[0].is_cuda:
+            srcs, index, plan = [], {}, []
+
+            def src(t):
+                if id(t) not in index:
+                    index[id(t)] = len(srcs)
+                    srcs.append(t)
+                return index[id(t)]
+            for i in range(M):
+                zs_i = [z_sh[i], zj[0]] + [z_cr[(i, m)] for m in range(M) if m != i]
+                plan.append((len(zs_i), D + P[i], [(src(z), k, 0) for k, z in enumerate(zs_i)] +
+                             [(src(z_pr[i]), k, D) for k in range(len(zs_i))]))
+            if ops.RowsFan.supported(plan, srcs):
+                lats = ops.rows_fan(plan, srcs)
         self._fork(streams, dev, mods)
         for i, (n, st) in enumerate(zip(names, streams)):
             vae = self.vaes[n]
@@ -803,7 +835,11 @@ class DMVAE(TorchMMVAE):
                 mk = mods[n]["masks"]                                                  # (mmvae_models.py:494-502)
                 if vae.ltype != "optimal_sigma" and self.batch_passes:
                     NP = len(zs_i)
-                    lat = torch.cat([torch.cat(zs_i, 0), z_pr[i].repeat(NP, 1)], -1)
+                    if lats is not None:
+                        lat = lats[i]
+                        _uses(lat, st)
+                    else:
+                        lat = torch.cat([torch.cat(zs_i, 0), z_pr[i].repeat(NP, 1)], -1)
                     out, _ = vae.dec({"latents": lat.unsqueeze(0), "masks": None if mk is None else mk.repeat(NP, 1)})
                     rs = recon_rowsum(vae.ltype, out, mods[n], laplace=self._lap(vae))
                     per[i] = [rs.view(NP, B)]                  # ONE (passes, B) block: rows own, joint, cross...

@@ -1344,6 +1344,74 @@ class PoeReparamKL(Function):
         return (ret, None, None, None, None, None, None, None, None, *dpacked, *([None] * ctx.n_eps_in))
 
 
+class RowsFan(Function):
+    """Latent samples -> the decoders' input batches in ONE launch, and every sample's gradient as ONE sum in backward
+    (csrc/latent.hip: mmvae_rows_fan_fwd / _bwd).  plan = [(R, W, [(source index, row block r, first column c0), ...]), ...]:
+    output o is (R * B, W), block (i, r, c0) writes source i (B, w_i) to rows [r * B, (r + 1) * B), columns [c0, c0 + w_i).
+    Replaces torch.cat / repeat per decoder call and autograd's addition per extra consumer of a sample
+    (POE.objective / DMVAE.objective; reference: models/mmvae_models.py:159-187, :494-502)."""
+
+    @staticmethod
+    def supported(plan, srcs):
+        nb = sum(len(bl) for _, _, bl in plan)
+        uses = [0] * len(srcs)
+        for _, _, bl in plan:
+            for i, _, _ in bl:
+                uses[i] += 1
+        return (nb <= H.FAN_MAX_BLOCKS and len(srcs) <= H.FAN_MAX_SRC and max(uses) <= H.FAN_MAX_USES and min(uses) >= 1
+                and all(t.is_cuda and t.dim() == 2 and t.shape[0] == srcs[0].shape[0] for t in srcs))
+
+    @staticmethod
+    def forward(ctx, plan, *srcs):
+        srcs = [H.f32c(t) for t in srcs]
+        B, dev = srcs[0].shape[0], srcs[0].device
+        outs = [torch.empty(R * B, W, device=dev) for R, W, _ in plan]
+        t = H.FanBlocks()
+        k = 0
+        for (R, W, bl), out in zip(plan, outs):
+            for i, r, c0 in bl:
+                w = srcs[i].shape[1]
+                assert 0 <= r < R and c0 + w <= W
+                t.src[k], t.dst[k] = srcs[i].data_ptr(), out.data_ptr() + 4 * (r * B * W + c0)
+                t.width[k], t.ld_src[k], t.ld_dst[k] = w, w, W
+                k += 1
+        t.n, t.B = k, B
+        _call("mmvae_rows_fan_fwd", ctypes.byref(t), H.stream())
+        ctx.plan, ctx.B, ctx.widths = plan, B, [t_.shape[1] for t_ in srcs]
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        plan, B, widths = ctx.plan, ctx.B, ctx.widths
+        gs = [H.f32c(g) if g is not None else None for g in gs]
+        dev = next(g.device for g in gs if g is not None)
+        t = H.FanSum()
+        outs, n = [None] * len(widths), 0
+        slot = {}
+        for (R, W, bl), g in zip(plan, gs):
+            if g is None:
+                continue
+            for i, r, c0 in bl:
+                if i not in slot:
+                    slot[i] = n
+                    outs[i] = torch.empty(B, widths[i], device=dev)
+                    t.out[n], t.width[n], t.n_g[n] = outs[i].data_ptr(), widths[i], 0
+                    n += 1
+                s_, j = slot[i], t.n_g[slot[i]]
+                t.g[s_][j], t.ld[s_][j] = g.data_ptr() + 4 * (r * B * W + c0), W
+                t.n_g[s_] = j + 1
+        t.n, t.B = n, B
+        if n:
+            _call("mmvae_rows_fan_bwd", ctypes.byref(t), H.stream())
+        return (None, *outs)
+
+
+def rows_fan(plan, srcs):
+    """[output tensors] of RowsFan for `plan` over the source tensors `srcs` (see RowsFan)"""
+    return list(RowsFan.apply(plan, *srcs))
+
+
 class DecoderEnd(Function):
     """identity on a decoder's latent sample: its backward is the LAST node of that decoder's backward pass.  Parked
     tall-skinny weight gradients of the decoder (GradReducer.tw_park: fewer than eight are left) are launched here, on the
