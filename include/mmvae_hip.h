@@ -329,6 +329,13 @@ int mmvae_poe_reparam_kl_fwd(const mmvae_poe_fwd_args* a, const float* theta, fl
 int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl, float* dtheta,
                              float* ws, int* ticket, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D,
                              int ld_in, int raw_heads, int accumulate, mmvae_stream_t stream);
+/* ... acc_packed bit e: dmu[e] / dlv[e] already hold another call's contribution to these columns and this one is ADDED (the
+ * same head output read by several fusion calls -- DMVAE's joint, shared and private posteriors, models/mmvae_models.py:
+ * 480-502 -- accumulates its gradient in one tensor instead of one tensor per call plus autograd's addition launches).
+ * Not with raw_heads. */
+int mmvae_poe_reparam_kl_bwd_acc(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl, float* dtheta,
+                                 float* ws, int* ticket, int E, int with_prior, int n_z, unsigned kl_mask, int B, int D,
+                                 int ld_in, int raw_heads, int accumulate, unsigned acc_packed, mmvae_stream_t stream);
 size_t mmvae_poe_ws_floats(int B, int D);
 
 /* Latent samples -> decoder inputs, and the transpose (round 6).  The reference decodes every subset's sample in a call of its

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
                                                       const float* __restrict__ dkl, float* __restrict__ ws, int E,
                                                       int with_prior, int n_z, unsigned kl_mask, int B, int D, int ld,
                                                       int raw, float* __restrict__ dtheta, int* __restrict__ ticket,
-                                                      int accumulate) {
+                                                      int accumulate, unsigned acc_packed) {
   MMVAE_TRACE_STAMP(23);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -323,8 +323,11 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(mmvae_poe_bwd_args a, cons
           dlv += gk[e] * (lv[e] * isp2 - 1.0f / lv[e]);
           dspe += gk[e] * (1.0f - (lv[e] * lv[e] + mu[e] * mu[e]) * isp2) / sp[s];
         }
-        a.dmu[e][oi] = dmu;
-        a.dlv[e][oi] = dlv;
+        // (acc_packed bit e: expert e's gradient tensor already holds another call's contribution to these columns -- the
+        // same head output read by several fusion calls, DMVAE's joint / shared / private: add instead of an addition launch)
+        const bool acc_e = (acc_packed >> e) & 1u;
+        a.dmu[e][oi] = acc_e ? a.dmu[e][oi] + dmu : dmu;
+        a.dlv[e][oi] = acc_e ? a.dlv[e][oi] + dlv : dlv;
         udot[e] += (lv[e] - 1e-6f) * dlv;
       }
       dsp[s] += dspe;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void poe_bwd_fast_kernel(mmvae_poe_bwd_args a,
                                                            const float* __restrict__ dkl, float* __restrict__ ws,
                                                            int with_prior, unsigned kl_mask, int B, int D, int ld,
                                                            int raw, float* __restrict__ dtheta,
-                                                           int* __restrict__ ticket, int accumulate) {
+                                                           int* __restrict__ ticket, int accumulate, unsigned acc_packed) {
   MMVAE_TRACE_STAMP(23);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(256) void poe_bwd_fast_kernel(mmvae_poe_bwd_args a,
         dlv[e] += gk[e] * (lv[e] * isp2 - 1.0f / lv[e]);
         dspe += gk[e] * (1.0f - (lv[e] * lv[e] + mu[e] * mu[e]) * isp2) / sp;
       }
-      if (live) a.dmu[e][oi] = dmu;
+      if (live) a.dmu[e][oi] = ((acc_packed >> e) & 1u) ? a.dmu[e][oi] + dmu : dmu;
     }
     if (live) dsp += dspe;
 #pragma unroll
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void poe_bwd_fast_kernel(mmvae_poe_bwd_args a,
         const float dot = wave_sum(live ? (lv[e] - 1e-6f) * dlv[e] : 0.f);
         dlv[e] = sv[e] * (dlv[e] - dot);
       }
-      if (live) a.dlv[e][oi] = dlv[e];
+      if (live) a.dlv[e][oi] = ((acc_packed >> e) & 1u) ? a.dlv[e][oi] + dlv[e] : dlv[e];
     }
   }
   if (live) {
@@ -665,18 +668,26 @@ extern "C" int mmvae_poe_reparam_kl_bwd(const mmvae_poe_bwd_args* a, const float
                                         float* dtheta, float* ws, int* ticket, int E, int with_prior, int n_z,
                                         unsigned kl_mask, int B, int D, int ld_in, int raw_heads, int accumulate,
                                         mmvae_stream_t stream) {
+  return mmvae_poe_reparam_kl_bwd_acc(a, theta, dkl, dtheta, ws, ticket, E, with_prior, n_z, kl_mask, B, D, ld_in, raw_heads,
+                                      accumulate, 0u, stream);
+}
+extern "C" int mmvae_poe_reparam_kl_bwd_acc(const mmvae_poe_bwd_args* a, const float* theta, const float* dkl,
+                                            float* dtheta, float* ws, int* ticket, int E, int with_prior, int n_z,
+                                            unsigned kl_mask, int B, int D, int ld_in, int raw_heads, int accumulate,
+                                            unsigned acc_packed, mmvae_stream_t stream) {
   MMVAE_CHECK_ARG(a && theta && ws && B > 0 && D > 0 && E > 0 && ld_in >= D);
+  if (acc_packed && raw_heads) return MMVAE_ERR_ARG;      // (the raw-head form uses the gradient tensor as scratch)
   if (E > MMVAE_MAX_EXPERTS || n_z > MMVAE_MAX_EXPERTS || D > 64 * POE_SLOTS) return MMVAE_ERR_UNSUPPORTED;
   const int nb = poe_blocks(B);
   const bool one_launch = dtheta && ticket;
   if (!poe_fast_visit(E, n_z, D, [&](auto e, auto z) {
         hipLaunchKernelGGL((poe_bwd_fast_kernel<decltype(e)::value, decltype(z)::value>), dim3(nb), dim3(256), 0,
                            (hipStream_t)stream, *a, theta, dkl, ws, with_prior, kl_mask, B, D, ld_in, raw_heads ? 1 : 0,
-                           one_launch ? dtheta : nullptr, one_launch ? ticket : nullptr, accumulate);
+                           one_launch ? dtheta : nullptr, one_launch ? ticket : nullptr, accumulate, acc_packed);
       }))
     hipLaunchKernelGGL(poe_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, theta, dkl, ws, E, with_prior,
                        n_z, kl_mask, B, D, ld_in, raw_heads ? 1 : 0, one_launch ? dtheta : nullptr,
-                       one_launch ? ticket : nullptr, accumulate);
+                       one_launch ? ticket : nullptr, accumulate, acc_packed);
   if (dtheta && !one_launch)
     hipLaunchKernelGGL(poe_theta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, theta, ws, dtheta, nb * 4, D,
                        accumulate);

@@ -159,6 +159,8 @@ SIGNATURES = {
                                        c_i, c_p, c_p]),
     "mmvae_poe_reparam_kl_bwd": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i, c_i,
                                        c_i, c_i, c_i, c_p]),
+    "mmvae_poe_reparam_kl_bwd_acc": (c_i, [ctypes.POINTER(PoeBwdArgs), c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_i,
+                                           c_i, c_i, c_i, c_i, c_u, c_p]),
     "mmvae_poe_ws_floats": (c_sz, [c_i, c_i]),
     "mmvae_bce_rowsum_fwd": (c_i, [c_p] * 3 + [c_i] * 3 + [c_p]),
     "mmvae_bce_sigmoid_clamp_bwd": (c_i, [c_p] * 4 + [c_i] * 3 + [c_p]),

@@ -80,6 +80,8 @@ class GradReducer:
         cls.early_step, cls.dw_jobs, cls.dw_open = None, [], False      # (per-step state: a backward pass that raised leaves them behind)
         cls.tw_jobs, cls.early_ready = {}, False
         cls.last_writer.clear()
+        cls.packed_grads.clear()
+        cls.packed_uses.clear()
         if cls.deferred is not None:
             cls.deferred = None
             raise RuntimeError("GradReducer: a deferred fold was never taken by an optimiser step: the split weight "
@@ -191,6 +193,22 @@ class GradReducer:
     # (Round 6, measured: queued behind the text encoder's LAST backward launch instead, the 65 MB the update moves landed
     # on the image encoder's first-layer weight gradient -- 14 -> 26 us -- and gave back what the shorter closing launch won.)
     early_step = None
+    # data_ptr of a head output -> [its ONE gradient tensor of this backward pass, fusion calls whose backward is still to
+    # come]; packed_uses: how many column-range fusion calls read it in this step's forward pass (PoeReparamKL)
+    packed_grads, packed_uses = {}, {}
+    share_packed_grads = True     # (module switch for the tests)
+
+    @classmethod
+    def packed_grads_done(cls):
+        """end of a backward pass: every shared gradient tensor must have been handed over by its last reader"""
+        left = [k for k, (_, n) in cls.packed_grads.items() if n > 0]
+        for k in cls.packed_grads:
+            cls.packed_uses.pop(k, None)
+        cls.packed_grads.clear()
+        if left:
+            raise RuntimeError(f"PoeReparamKL: {len(left)} head output(s) were read by more column-range fusion calls than "
+                               f"took part in this backward pass; their gradient was not delivered "
+                               f"(ops.GradReducer.share_packed_grads = False restores one gradient tensor per call)")
     merge_adjacent = True      # (module switch for the tests: False = one table entry per registered segment)
 
     # dw_jobs: weight gradients of Linear layers whose backward only launched the data gradient (Linear.backward, while
@@ -1298,6 +1316,10 @@ class PoeReparamKL(Function):
             a.z[i] = zs[i].data_ptr()
         _call("mmvae_poe_reparam_kl_fwd", ctypes.byref(a), H.ptr(theta), H.ptr(joint), H.ptr(kl), E, int(with_prior),
               n_z, kl_mask, B, D, D2, int(bool(raw)), H.ptr(rng), H.stream())
+        if cols is not None and not raw and GradReducer.share_packed_grads:
+            for e, t in enumerate(packed):      # (backward: one gradient tensor per head output, handed over by its last reader)
+                if ctx.needs_input_grad[9 + e]:
+                    GradReducer.packed_uses[t.data_ptr()] = GradReducer.packed_uses.get(t.data_ptr(), 0) + 1
         ctx.save_for_backward(theta, *packed, *eps)
         ctx.n_eps_in = 0 if rng is not None else n_z
         ctx.cfg = (gtheta, with_prior, n_z, kl_mask, E, B, D, Dtot, col0, int(bool(raw)))
@@ -1318,7 +1340,32 @@ class PoeReparamKL(Function):
         dkl = H.f32c(dkl) if dkl is not None else torch.zeros(E + 1, B, device=dev)
         dz = [H.f32c(g) if g is not None else torch.zeros(B, D, device=dev) for g in dzs] if n_z else None
         sub = D != Dtot
-        if sub and all(p.shape == packed[0].shape for p in packed):
+        acc_packed, ret_packed = 0, None
+        if sub and not raw and GradReducer.share_packed_grads:
+            # a head output whose column ranges are read by several fusion calls (DMVAE: joint, shared, private) gets ONE
+            # gradient tensor per backward pass: the first call to run zero-fills it and hands it to autograd, the later ones
+            # add their columns in place (mmvae_poe_reparam_kl_bwd_acc) and hand back nothing -- instead of a zero-filled
+            # tensor per call and autograd's addition per extra call.  (All of them run on the fusion's stream, and the
+            # head's own backward node waits for every consumer before it reads the tensor.)
+            reg = GradReducer.packed_grads
+            if not reg:      # (entries live for ONE backward pass: an address may belong to another tensor in the next)
+                torch.autograd.Variable._execution_engine.queue_callback(GradReducer.packed_grads_done)
+            fresh = [p for p in packed if p.data_ptr() not in reg]
+            new = iter(torch.zeros(len(fresh), *fresh[0].shape, device=dev).unbind(0)) if fresh and all(
+                p.shape == fresh[0].shape for p in fresh) else iter([torch.zeros_like(p) for p in fresh])
+            dpacked, ret_packed = [], []
+            for e, p in enumerate(packed):
+                ent = reg.get(p.data_ptr())
+                if ent is None:      # [tensor, calls still to come]: the forward pass counted this output's readers
+                    ent = reg[p.data_ptr()] = [next(new), GradReducer.packed_uses.get(p.data_ptr(), 1)]
+                else:
+                    acc_packed |= 1 << e
+                ent[1] -= 1
+                # the LAST reader's backward hands the tensor to autograd: every addition is then queued in front of the
+                # point at which the engine records the gradient as produced (the head's backward may run on another stream)
+                ret_packed.append(ent[0] if ent[1] == 0 else None)
+                dpacked.append(ent[0])
+        elif sub and all(p.shape == packed[0].shape for p in packed):
             dpacked = list(torch.zeros(len(packed), *packed[0].shape, device=dev).unbind(0))     # ONE fill for all experts
         else:
             dpacked = [(torch.zeros_like(p) if sub else torch.empty_like(p)) for p in packed]
@@ -1338,10 +1385,11 @@ class PoeReparamKL(Function):
             dth = ret = torch.empty_like(theta)
             acc = 0
         ws = H.workspace(H.lib().mmvae_poe_ws_floats(B, D), dev)
-        _call("mmvae_poe_reparam_kl_bwd", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws),
+        _call("mmvae_poe_reparam_kl_bwd_acc", ctypes.byref(a), H.ptr(theta), H.ptr(dkl), H.ptr(dth), H.ptr(ws),
               _poe_ticket(dev), E,
-              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, H.stream())
-        return (ret, None, None, None, None, None, None, None, None, *dpacked, *([None] * ctx.n_eps_in))
+              int(with_prior), n_z if dz is not None else 0, kl_mask, B, D, 2 * Dtot, raw, acc, acc_packed, H.stream())
+        return (ret, None, None, None, None, None, None, None, None, *(dpacked if ret_packed is None else ret_packed),
+                *([None] * ctx.n_eps_in))
 
 
 class RowsFan(Function):

@@ -1457,3 +1457,42 @@ def test_rows_fan_is_cat_and_repeat_with_summed_gradients(hip_lib):
         check(x.grad, y.grad.double(), 1e-6, f"d source {i}")
     too_many = [(1, D, [(0, 0, 0)])] * 17
     assert not ops.RowsFan.supported(too_many, srcs[:1])
+
+
+@pytest.mark.gpu
+def test_poe_column_ranges_share_one_gradient_tensor(hip_lib, monkeypatch):
+    """Several fusion calls over column ranges of ONE head output (DMVAE: joint over the shared columns, each modality's
+    shared and private posteriors): with ops.GradReducer.share_packed_grads the calls' backward passes accumulate into one
+    gradient tensor (mmvae_poe_reparam_kl_bwd_acc) instead of a zero-filled tensor per call + autograd's additions -- the head
+    output's gradient equal to the per-call form (2e-7: the order of two additions), twice in a row (the registry of
+    shared tensors lives for one backward pass only)."""
+    from multimodal_vae_comparison_amd import ops
+    torch.manual_seed(11)
+    B, D, P = 33, 20, 10
+    theta = torch.randn(1, D, device=DEV, requires_grad=True)
+    theta0 = torch.zeros(1, P, device=DEV)
+
+    def run(share):
+        monkeypatch.setattr(ops.GradReducer, "share_packed_grads", share)
+        outs = []
+        for rep in range(2):
+            g = torch.Generator(device="cpu").manual_seed(100 + rep)
+            heads = [torch.randn(B, 2 * (D + P), generator=g).to(DEV) for _ in range(2)]
+            for h in heads:
+                h[:, D + P:] = h[:, D + P:].abs() * 0.5 + 0.1       # (positive scales)
+            heads = [h.requires_grad_(True) for h in heads]
+            eps = [torch.randn(B, D, generator=g).to(DEV) for _ in range(5)] + [torch.randn(B, P, generator=g).to(DEV) for _ in range(2)]
+            _, klj, zj = ops.poe_reparam_kl(theta, heads, [eps[0]], 0, 1 << 2, None, cols=(0, D))
+            terms = [klj.sum(), (zj[0] * eps[0]).sum()]
+            for m in range(2):
+                _, kl, z = ops.poe_reparam_kl(theta, [heads[m]], [eps[1 + 2 * m], eps[2 + 2 * m]], 2, 0b10, None, cols=(0, D))
+                _, klp, zp = ops.poe_reparam_kl(theta0, [heads[m]], [eps[5 + m]], 2, 0b10, None, cols=(D, P))
+                terms += [kl[1].sum(), (z[0] * z[1]).sum(), klp[1].sum(), (zp[0] ** 2).sum()]
+            torch.stack(terms).sum().backward()
+            outs.append([h.grad.clone() for h in heads])
+        return outs
+    a, b = run(False), run(True)
+    for rep in range(2):
+        for m in range(2):
+            check(b[rep][m], a[rep][m].double(), 2e-7, f"d head {m} (pass {rep})")
+    assert not ops.GradReducer.packed_grads
