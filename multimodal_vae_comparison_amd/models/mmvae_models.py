@@ -597,7 +597,7 @@ class MOE(TorchMMVAE):
                 kls.append(ops.kl_laplace_normal(packed[i]))
             else:
                 _, kl, z = ops.poe_reparam_kl(self._theta0, [packed[i]], [eps], 2, 0b10)
-                kls.append(kl[1])
+                kls.append(ops.kl_row(kl, 1))      # (kl_mask 0b10: row 1 is the only one the backward reads)
             zs.append(z[0])
         for t in packed + zs:         # read by both towers' decoder sides
             for st in real:

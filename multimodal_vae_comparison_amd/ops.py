@@ -1460,6 +1460,27 @@ def rows_fan(plan, srcs):
     return list(RowsFan.apply(plan, *srcs))
 
 
+class KlRow(Function):
+    """row j of a fusion call's KL block (E + 1, B) as its own tensor's view.  Its backward hands the block's gradient back
+    with ONLY row j written -- PoeReparamKL.backward reads the rows of its kl_mask and nothing else -- where autograd's select
+    backward zero-fills the block first (a launch per KL term on the chain decoders -> fusion -> encoders)."""
+
+    @staticmethod
+    def forward(ctx, kl, j):
+        ctx.shape, ctx.j = tuple(kl.shape), int(j)
+        return kl[int(j)]
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.empty(ctx.shape, device=g.device, dtype=g.dtype)
+        out[ctx.j].copy_(g)
+        return out, None
+
+
+def kl_row(kl, j):
+    return KlRow.apply(kl, j)
+
+
 class DecoderEnd(Function):
     """identity on a decoder's latent sample: its backward is the LAST node of that decoder's backward pass.  Parked
     tall-skinny weight gradients of the decoder (GradReducer.tw_park: fewer than eight are left) are launched here, on the
