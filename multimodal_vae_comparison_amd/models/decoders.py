@@ -139,7 +139,8 @@ class HipTransformerDecoderLayer(nn.Module):
             if fused_ffn:
                 s3 = ops.residual_sink(x)
                 return self.norm3(ffn(x, None, s3), x, res_sink=s3)
-            return self.norm3(self.linear2(self.linear1(x)), x)
+            s3 = ops.residual_sink(x)      # (the launch-per-op form: the residual's gradient joins linear1's data gradient)
+            return self.norm3(self.linear2(self.linear1(x, res_sink=s3)), x, res_sink=s3)
         L = x.shape[0]
         x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1, lazy_out=self.self_attn.lazy_out(x)), x, ds["drop1"],
                        res_sink=s1)
@@ -149,8 +150,9 @@ class HipTransformerDecoderLayer(nn.Module):
         if fused_ffn:
             s3 = ops.residual_sink(x)
             return self.norm3(ffn(x, ds["ffn"], s3, ds["drop3"]), x, ds["drop3"], res_sink=s3)
-        h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])
-        return self.norm3(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop3"])
+        s3 = ops.residual_sink(x)
+        h = ops.dropout_act(self.linear1(x, res_sink=s3), H.ACT_GELU, ds["ffn"])
+        return self.norm3(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop3"], res_sink=s3)
 
 
 class HipTransformerDecoderStack(nn.Module):

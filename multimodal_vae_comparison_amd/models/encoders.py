@@ -323,15 +323,17 @@ class HipTransformerEncoderLayer(nn.Module):
             if fused_ffn:
                 s2 = ops.residual_sink(x)
                 return self.norm2(self._ffn(x, None, s2, (x, self.norm2.weight, self.norm2.bias, None)), x, res_sink=s2)
-            return self.norm2(self.linear2(self.linear1(x)), x)
+            s2 = ops.residual_sink(x)
+            return self.norm2(self.linear2(self.linear1(x, res_sink=s2)), x, res_sink=s2)
         x = self.norm1(self.self_attn(x, mask_u8, ds["attn"], res_sink=s1, lazy_out=self.self_attn.lazy_out(x)), x, ds["drop1"],
                        res_sink=s1)
         if fused_ffn:      # the (L*N, ff) hidden activation never leaves the registers (csrc/ffn.hip)
             s2 = ops.residual_sink(x)
             return self.norm2(self._ffn(x, ds["ffn"], s2, (x, self.norm2.weight, self.norm2.bias, ds["drop2"])), x, ds["drop2"],
                               res_sink=s2)
-        h = ops.dropout_act(self.linear1(x), H.ACT_GELU, ds["ffn"])           # dropout(gelu(.)) materialised
-        return self.norm2(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop2"])
+        s2 = ops.residual_sink(x)
+        h = ops.dropout_act(self.linear1(x, res_sink=s2), H.ACT_GELU, ds["ffn"])           # dropout(gelu(.)) materialised
+        return self.norm2(self.linear2(h, in_act=H.ACT_NONE), x, ds["drop2"], res_sink=s2)
 
     def _ffn(self, x, drop, res_sink=None, ln=None):
         return ops.ffn32(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop,

@@ -110,9 +110,11 @@ class HipLinear(nn.Module):
     def flat_groups(self):
         return [[self.weight, self.bias]]
 
-    def forward(self, x, in_act=None, out_ep=H.EP_NONE, lazy=False):
+    def forward(self, x, in_act=None, out_ep=H.EP_NONE, lazy=False, res_sink=None):
+        """res_sink: ops.ResidualGrad of a residual connection around the block this layer opens (its gradient joins this
+        layer's data-gradient launch instead of an addition of its own)"""
         return ops.linear(x, self.weight, self.bias, self.in_act if in_act is None else in_act, self.weight.grad,
-                          self.bias.grad, out_ep, lazy=lazy)
+                          self.bias.grad, out_ep, res_sink=res_sink, lazy=lazy)
 
 
 class HipLayerNorm(nn.Module):
